@@ -1,0 +1,143 @@
+/* sgx.h -- C ABI of libsgx_hip.so: the MI355X (gfx950) kernels behind the StyleGAN G+D training hot path.
+ *
+ * The reference (huangzh13/StyleGAN.pytorch) is pure Python and has no FFI: its seam for this path is the
+ * nn.Module surface of models/CustomLayers.py, models/Blocks.py and models/GAN.py.  Every entry point below
+ * replaces one composition of PyTorch ops that those modules issue; the comment above each one cites it
+ * (file:line relative to the reference root).  stylegan/pytorch_amd/native.py binds them with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers.
+ *   - activations are NHWC ("channels last"): x[b][h][w][c].  dtype: SGX_F32 or SGX_BF16 storage
+ *     (accumulation is always fp32).  Parameters, statistics, RGB images and gradients of parameters are fp32.
+ *   - `stream` is a hipStream_t passed as void*; the library never allocates, frees or synchronises.
+ *     Scratch memory is supplied by the caller (`ws`, `ws_bytes`; query with the *_ws_bytes functions).
+ *   - every function returns 0 on success, a negative SGX_E* code for argument errors, or a positive
+ *     hipError_t; sgx_last_error() returns a thread-local message.  Nothing throws or aborts.
+ *   - re-entrant: no global mutable state (backward runs on autograd worker threads).
+ */
+#ifndef SGX_H
+#define SGX_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SGX_F32 = 0, SGX_BF16 = 1 };
+enum { SGX_ACT_NONE = 0, SGX_ACT_LRELU = 1 };          /* LeakyReLU(0.2): models/GAN.py:67-68,150-151,346-347 */
+enum { SGX_EINVAL = -1, SGX_EUNSUPPORTED = -2, SGX_EWORKSPACE = -3 };
+
+int sgx_version(void);
+const char* sgx_last_error(void);
+
+/* ---------------------------------------------------------------- convolutions (MFMA implicit GEMM)
+ * Packed weight layout for all three: w[tap][n][k], n = output channel of THIS launch, k = reduction
+ * channel, k contiguous; dtype = activation dtype.  bias (fp32, may be NULL) and act are fused in the store.
+ *
+ * sgx_conv3x3: EqualizedConv2d plain path, F.conv2d(x, W*w_mul, b, padding=1) -- models/CustomLayers.py:170-171;
+ *   also its data gradient (call with the flipped/transposed pack).
+ *   y[b,h,w,n] = act(bias[n] + sum_{ty,tx,k} x[b,h+ty-1,w+tx-1,k] * w[ty*3+tx][n][k])                              */
+int sgx_conv3x3(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                int act, int dtype, void* stream);
+/* sgx_conv4x4s2_down: fused conv+downscale, F.conv2d(x, W4, stride=2, padding=1) -- models/CustomLayers.py:158-165
+ *   (== conv3x3 -> avg_pool2 of :166-168); also the data gradient of sgx_conv4x4s2_up.
+ *   H,W = input size.  y[b,oy,ox,n] = act(bias[n] + sum_{ky,kx,k} x[b,2oy+ky-1,2ox+kx-1,k] * w[ky*4+kx][n][k])    */
+int sgx_conv4x4s2_down(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin,
+                       int Cout, int act, int dtype, void* stream);
+/* sgx_conv4x4s2_up: fused upscale+conv, F.conv_transpose2d(x, W4, stride=2, padding=1) -- models/CustomLayers.py:143-152
+ *   (== nearest-up -> conv3x3 of :153-154 with the kernel flipped); also the data gradient of
+ *   sgx_conv4x4s2_down.  H,W = input (coarse) size, output is 2H x 2W.
+ *   y[b,iy,ix,n] = sum over (oy,ky),(ox,kx) with 2oy+ky-1=iy, 2ox+kx-1=ix of x[b,oy,ox,k] * w[ky*4+kx][n][k]      */
+int sgx_conv4x4s2_up(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int dtype,
+                     void* stream);
+/* weight gradients (fp32 out, same [tap][n][k] pack as the forward weight):
+ *   sgx_wgrad3x3:   dw[t][n][k]        = sum_{b,h,w} dy[b,h,w,n] * x[b,h+ty-1,w+tx-1,k]
+ *   sgx_wgrad4x4s2: dw[ky*4+kx][n][k]  = sum_{b,oy,ox} coarse[b,oy,ox,n] * fine[b,2oy+ky-1,2ox+kx-1,k]   (H,W = fine size)
+ * (autograd of F.conv2d / F.conv_transpose2d w.r.t. weight in the reference)                                      */
+size_t sgx_wgrad_ws_bytes(int taps, int B, int H, int W, int Ck, int Cn);
+int sgx_wgrad3x3(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, int B, int H, int W, int Cin,
+                 int Cout, int dtype, void* stream);
+int sgx_wgrad4x4s2(const void* fine, const void* coarse, float* dw, void* ws, size_t ws_bytes, int B, int H, int W,
+                   int Cfine, int Ccoarse, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- memory-bound layer pieces
+ * y = act(x + bias[c])                      bias after blur / avgpool: models/CustomLayers.py:178-179; Blocks.py:142,146 */
+int sgx_bias_act(const void* x, const float* bias, void* y, size_t npix, int C, int act, int dtype, void* stream);
+/* dx = dy * (y > 0 ? 1 : 0.2)               autograd of nn.LeakyReLU(0.2); y is the activation OUTPUT               */
+int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, int dtype, void* stream);
+/* out = alpha*a + beta*b (b may be NULL)    fade-in lerp: models/GAN.py:202,427,586                                 */
+int sgx_axpby(const void* a, const void* b, void* out, float alpha, float beta, size_t n, int dtype, void* stream);
+/* depthwise [1,2,1]x[1,2,1]/16 blur, zero pad   BlurLayer: models/CustomLayers.py:251-276 (self-adjoint)           */
+int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+/* y = scale * (2x2 block sum)   scale .25: AvgPool2d(2) models/GAN.py:382,423; Downscale2d CustomLayers.py:60-64   */
+int sgx_pool2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream);
+/* y = scale * nearest_up2(x)    Upscale2d CustomLayers.py:27-36; F.interpolate(scale_factor=2) models/GAN.py:173     */
+int sgx_up2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream);
+/* out[c] = sum_p x[p][c]  (fp32 out)        bias gradient                                                            */
+size_t sgx_colsum_ws_bytes(size_t npix, int C);
+int sgx_colsum(const void* x, float* out, void* ws, size_t ws_bytes, size_t npix, int C, int dtype, void* stream);
+
+/* 1x1 RGB convolutions; images are fp32 [p][3]; w is fp32 [3][C] (already multiplied by w_mul)
+ *   sgx_rgb_in : y[p][c] = bias[c] + sum_j img[p][j]*w[j][c]      from_rgb: models/GAN.py:358-359,377-378,425-426
+ *   sgx_rgb_out: img[p][j] = bias[j] + sum_c x[p][c]*w[j][c]      to_rgb:   models/GAN.py:157,167,199-200
+ *   sgx_rgb_wgrad: dw[j][c] = sum_p img[p][j]*f[p][c]                                                               */
+int sgx_rgb_in(const float* img, const float* w, const float* bias, void* y, size_t npix, int C, int dtype, void* stream);
+int sgx_rgb_out(const void* x, const float* w, const float* bias, float* img, size_t npix, int C, int dtype, void* stream);
+size_t sgx_rgb_wgrad_ws_bytes(size_t npix, int C);
+int sgx_rgb_wgrad(const float* img, const void* f, float* dw, void* ws, size_t ws_bytes, size_t npix, int C, int dtype,
+                  void* stream);
+
+/* ---------------------------------------------------------------- generator layer epilogue
+ * LayerEpilogue (models/CustomLayers.py:219-248) = NoiseLayer (:191-200) -> LeakyReLU -> nn.InstanceNorm2d (:233,
+ * eps 1e-5, biased variance) -> StyleMod (:210-216), with the conv's post-blur bias (:178-179) folded in:
+ *   p = x + bias[c] + nw[c]*noise[b,hw];  a = lrelu(p);  xh = (a - mean[b,c]) * rstd[b,c]
+ *   y = xh * (style[b,c] + 1) + style[b,C+c]
+ * bias may be NULL.  mean/rstd ([B][C] fp32) are outputs of fwd and inputs of bwd.
+ * bwd returns dx, dstyle[B][2C], dnw[C], dbias[C] (dbias may be NULL).                                               */
+size_t sgx_gepi_ws_bytes(int B, int HW, int C);
+int sgx_gepi_fwd(const void* x, const float* bias, const float* noise, const float* nw, const float* style, void* y,
+                 float* mean, float* rstd, void* ws, size_t ws_bytes, int B, int HW, int C, int dtype, void* stream);
+int sgx_gepi_bwd(const void* dy, const void* x, const float* bias, const float* noise, const float* nw,
+                 const float* style, const float* mean, const float* rstd, void* dx, float* dstyle, float* dnw,
+                 float* dbias, void* ws, size_t ws_bytes, int B, int HW, int C, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- small fp32 pieces
+ * PixelNormLayer on [B][C] rows: y = x * rsqrt(mean_c(x^2) + 1e-8)      models/CustomLayers.py:22-23                 */
+int sgx_pixelnorm_fwd(const float* x, float* y, int B, int C, void* stream);
+int sgx_pixelnorm_bwd(const float* dy, const float* x, float* dx, int B, int C, void* stream);
+/* StddevLayer (models/CustomLayers.py:294-305), group = min(4,B), strided groups (sample i with i+M, i+2M, i+3M).
+ *   fwd: y[b][hw][0..C) = x, y[b][hw][C] = stat[b % M], y[..][C+1..Cpad) = 0;   stat[m] = mean_{c,hw} sqrt(var_g + 1e-8)
+ *   bwd: dx = dy[..][0..C) + (sum_{g,hw} dy[g*M+m][hw][C]) / (C*HW) * d / (G * s)
+ *   bwd2 (second order, for R1): given ggx = cotangent of dx, returns its contribution to grad wrt dy (ddy) and x (gx) */
+int sgx_mbstd_fwd(const void* x, void* y, int B, int HW, int C, int Cpad, int dtype, void* stream);
+int sgx_mbstd_bwd(const void* dy, const void* x, void* dx, int B, int HW, int C, int Cpad, int dtype, void* stream);
+int sgx_mbstd_bwd2(const void* ggx, const void* dy, const void* x, void* ddy, void* gx, int B, int HW, int C, int Cpad,
+                   int dtype, void* stream);
+/* C[M][N] = alpha * op(A) * op(B) (+ beta*C), row-major fp32, MFMA f32 16x16x4.  EqualizedLinear
+ * (models/CustomLayers.py:99-103: F.linear(x, W*w_mul)) and its gradients.  ta/tb: 0 = as stored, 1 = transposed:
+ *   ta=0: A is [M][K], ta=1: A is [K][M];  tb=0: B is [K][N], tb=1: B is [N][K].                                      */
+size_t sgx_gemm_ws_bytes(int M, int N, int K);
+int sgx_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, int ta, int tb, float alpha,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- optimizer step (multi-tensor, fp32)
+ * torch.optim.Adam step (models/GAN.py:529-533, 616-618, 652) over n tensors described by DEVICE arrays of
+ * pointers/sizes.  Per tensor t (torch keeps a step count per parameter; parameters of inactive resolutions have
+ * no gradient and are not listed): step_sizes[t] = lr / (1 - beta1^step_t), bc2_sqrts[t] = sqrt(1 - beta2^step_t).
+ *   g = grad*grad_scale[0];  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= step_size * m / (sqrt(v)/bc2_sqrt + eps)
+ * grad_scale (device scalar, may be NULL) is the global-norm clip coefficient (models/GAN.py:651).
+ * update_average EMA (models/__init__.py:31-36): tgt = beta*tgt + (1-beta)*src.                                      */
+int sgx_adam_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                   const int64_t* sizes, int n, float beta1, float beta2, float eps, const float* step_sizes,
+                   const float* bc2_sqrts, const float* grad_scale, void* stream);
+int sgx_ema_multi(float* const* tgt, const float* const* src, const int64_t* sizes, int n, float beta, void* stream);
+/* nn.utils.clip_grad_norm_ (models/GAN.py:651) without a host sync: out[0] = sum over all tensors of sum(g^2),
+ * out[1] = min(1, max_norm / (sqrt(out[0]) + 1e-6)); pass out+1 as grad_scale of sgx_adam_multi.
+ * partial: caller scratch of n*32 doubles.                                                                            */
+int sgx_gradnorm_clip_coef(const float* const* grads, const int64_t* sizes, int n, float max_norm, double* partial,
+                           float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGX_H */

@@ -1,0 +1,137 @@
+"""Per-resolution blocks with the reference's names and ``state_dict`` keys (reference models/Blocks.py).
+
+``forward`` keeps the reference contract (logical NCHW fp32); the networks call ``forward_nhwc`` and stay in the
+kernels' NHWC layout / compute dtype from the first layer to the last.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from .CustomLayers import (BlurLayer, EqualizedConv2d, EqualizedLinear, LayerEpilogue, StddevLayer, View)
+from .native import ACT_LRELU, ACT_NONE
+
+
+def _is_lrelu02(act):
+    return isinstance(act, nn.LeakyReLU) and abs(act.negative_slope - 0.2) < 1e-12
+
+
+class InputBlock(nn.Module):
+    """The 4x4 block: learned constant (+bias) -> epilogue -> conv3x3 -> epilogue -- reference models/Blocks.py:17-60."""
+
+    def __init__(self, nf, dlatent_size, const_input_layer, gain, use_wscale, use_noise, use_pixel_norm,
+                 use_instance_norm, use_styles, activation_layer):
+        super().__init__()
+        self.const_input_layer = const_input_layer
+        self.nf = nf
+        if self.const_input_layer:
+            self.const = nn.Parameter(torch.ones(1, nf, 4, 4))
+            self.bias = nn.Parameter(torch.ones(nf))
+        else:
+            self.dense = EqualizedLinear(dlatent_size, nf * 16, gain=gain / 4, use_wscale=use_wscale)
+        self.epi1 = LayerEpilogue(nf, dlatent_size, use_wscale, use_noise, use_pixel_norm, use_instance_norm,
+                                  use_styles, activation_layer)
+        self.conv = EqualizedConv2d(nf, nf, 3, gain=gain, use_wscale=use_wscale)
+        self.epi2 = LayerEpilogue(nf, dlatent_size, use_wscale, use_noise, use_pixel_norm, use_instance_norm,
+                                  use_styles, activation_layer)
+
+    def forward_nhwc(self, dlatents_in_range, dtype=torch.float32):
+        b = dlatents_in_range.size(0)
+        if self.const_input_layer:
+            # const [1,C,4,4] -> NHWC [B,4,4,C]; its bias is folded into the epilogue kernel (Blocks.py:51-52)
+            x = self.const.permute(0, 2, 3, 1).to(dtype).expand(b, -1, -1, -1).contiguous()
+            bias = self.bias
+        else:
+            x = self.dense(dlatents_in_range[:, 0]).view(b, self.nf, 4, 4).permute(0, 2, 3, 1).to(dtype).contiguous()
+            bias = None
+        x = self.epi1.forward_nhwc(x, dlatents_in_range[:, 0], conv_bias=bias)
+        x = self.conv.forward_nhwc(x, skip_bias=True)
+        return self.epi2.forward_nhwc(x, dlatents_in_range[:, 1], conv_bias=self.conv.scaled_bias())
+
+    def forward(self, dlatents_in_range):
+        return F.nchw_view(self.forward_nhwc(dlatents_in_range))
+
+
+class GSynthesisBlock(nn.Module):
+    """upscale-conv (+blur) -> epilogue -> conv3x3 -> epilogue -- reference models/Blocks.py:63-88."""
+
+    def __init__(self, in_channels, out_channels, blur_filter, dlatent_size, gain, use_wscale, use_noise,
+                 use_pixel_norm, use_instance_norm, use_styles, activation_layer):
+        super().__init__()
+        blur = BlurLayer(blur_filter) if blur_filter else None
+        self.conv0_up = EqualizedConv2d(in_channels, out_channels, kernel_size=3, gain=gain, use_wscale=use_wscale,
+                                        intermediate=blur, upscale=True)
+        self.epi1 = LayerEpilogue(out_channels, dlatent_size, use_wscale, use_noise, use_pixel_norm,
+                                  use_instance_norm, use_styles, activation_layer)
+        self.conv1 = EqualizedConv2d(out_channels, out_channels, kernel_size=3, gain=gain, use_wscale=use_wscale)
+        self.epi2 = LayerEpilogue(out_channels, dlatent_size, use_wscale, use_noise, use_pixel_norm,
+                                  use_instance_norm, use_styles, activation_layer)
+
+    def forward_nhwc(self, x, dlatents_in_range):
+        x = self.conv0_up.forward_nhwc(x, skip_bias=True)                 # transposed conv + blur; bias folded below
+        x = self.epi1.forward_nhwc(x, dlatents_in_range[:, 0], conv_bias=self.conv0_up.scaled_bias())
+        x = self.conv1.forward_nhwc(x, skip_bias=True)
+        return self.epi2.forward_nhwc(x, dlatents_in_range[:, 1], conv_bias=self.conv1.scaled_bias())
+
+    def forward(self, x, dlatents_in_range):
+        return F.nchw_view(self.forward_nhwc(F.nhwc(x), dlatents_in_range))
+
+
+class DiscriminatorTop(nn.Module):
+    """stddev -> conv3x3 -> lrelu -> flatten -> dense -> lrelu -> dense -- reference models/Blocks.py:91-134
+    (an nn.Sequential there; same child names, hence the same state_dict keys)."""
+
+    def __init__(self, mbstd_group_size, mbstd_num_features, in_channels, intermediate_channels, gain, use_wscale,
+                 activation_layer, resolution=4, in_channels2=None, output_features=1, last_gain=1):
+        super().__init__()
+        if mbstd_group_size > 1:
+            self.stddev_layer = StddevLayer(mbstd_group_size, mbstd_num_features)
+        else:
+            self.stddev_layer = None
+        if in_channels2 is None:
+            in_channels2 = in_channels
+        nfeat = mbstd_num_features if mbstd_group_size > 1 else 0
+        self.conv = EqualizedConv2d(in_channels + nfeat, in_channels2, kernel_size=3, gain=gain, use_wscale=use_wscale)
+        self.act0 = activation_layer
+        self.view = View(-1)
+        self.dense0 = EqualizedLinear(in_channels2 * resolution * resolution, intermediate_channels, gain=gain,
+                                      use_wscale=use_wscale)
+        self.act1 = activation_layer
+        self.dense1 = EqualizedLinear(intermediate_channels, output_features, gain=last_gain, use_wscale=use_wscale)
+        self.resolution = resolution
+        assert _is_lrelu02(activation_layer), "the kernels fuse LeakyReLU(0.2)"
+
+    def forward_nhwc(self, x):
+        if self.stddev_layer is not None:
+            x = self.stddev_layer.forward_nhwc(x)
+        x = self.conv.forward_nhwc(x, act=ACT_LRELU)                      # [B,4,4,C]
+        b, h, w, c = x.shape
+        flat = x.reshape(b, h * w * c).float()
+        # the reference flattens NCHW (View(-1), index c*16+h*4+w); permute dense0's K axis to the NHWC order instead
+        w0 = self.dense0.weight.view(-1, c, h * w).transpose(1, 2).reshape(-1, h * w * c)
+        y = self.dense0(flat, act=ACT_LRELU, weight=w0)
+        return self.dense1(y)
+
+    def forward(self, x):
+        return self.forward_nhwc(F.nhwc(x))
+
+
+class DiscriminatorBlock(nn.Module):
+    """conv3x3 -> lrelu -> blur -> conv-downscale -> lrelu -- reference models/Blocks.py:137-146."""
+
+    def __init__(self, in_channels, out_channels, gain, use_wscale, activation_layer, blur_kernel):
+        super().__init__()
+        self.conv0 = EqualizedConv2d(in_channels, in_channels, kernel_size=3, gain=gain, use_wscale=use_wscale)
+        self.act0 = activation_layer
+        self.blur = BlurLayer(kernel=blur_kernel)
+        self.conv1_down = EqualizedConv2d(in_channels, out_channels, kernel_size=3, gain=gain, use_wscale=use_wscale,
+                                          downscale=True)
+        self.act1 = activation_layer
+        assert _is_lrelu02(activation_layer), "the kernels fuse LeakyReLU(0.2)"
+
+    def forward_nhwc(self, x):
+        x = self.conv0.forward_nhwc(x, act=ACT_LRELU)                     # bias + LeakyReLU fused in the conv store
+        x = self.blur.forward_nhwc(x)
+        return self.conv1_down.forward_nhwc(x, act=ACT_LRELU)
+
+    def forward(self, x):
+        return F.nchw_view(self.forward_nhwc(F.nhwc(x)))

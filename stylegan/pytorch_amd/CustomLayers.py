@@ -1,0 +1,361 @@
+"""Primitive layers with the reference's class names, constructor arguments and ``state_dict`` keys
+(reference models/CustomLayers.py), computed by the gfx950 kernels of libsgx_hip.so.
+
+Every ``forward`` keeps the reference contract: logical NCHW fp32 tensors in and out.  Blocks call the
+``*_nhwc`` methods instead, which stay in the library's native NHWC layout (and compute dtype) between kernels.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from . import functional as F
+from .native import ACT_LRELU, ACT_NONE
+
+MBSTD_CPAD = 32          # the stddev channel is appended in a zero-padded group of 32 channels (MFMA K granularity)
+
+
+class PixelNormLayer(nn.Module):
+    """x * rsqrt(mean(x^2, dim=1) + eps) -- reference models/CustomLayers.py:17-23.  The training path applies it
+    to the latent z [B, C] (models/GAN.py:75-76); 4-D inputs are normalised over the channel dim as well."""
+
+    def __init__(self, epsilon=1e-8):
+        super().__init__()
+        self.epsilon = epsilon
+
+    def forward(self, x):
+        assert abs(self.epsilon - 1e-8) < 1e-20, "kernel is built for the reference's epsilon"
+        if x.dim() == 2:
+            return F.PixelNormFn.apply(x)
+        shape = x.shape                                         # [B, C, ...] -> rows of C
+        y = F.PixelNormFn.apply(x.movedim(1, -1).reshape(-1, shape[1]))
+        return y.reshape(shape[0], *shape[2:], shape[1]).movedim(-1, 1)
+
+
+class Upscale2d(nn.Module):
+    """Nearest-neighbour replicate -- reference models/CustomLayers.py:26-45."""
+
+    def __init__(self, factor=2, gain=1):
+        super().__init__()
+        assert isinstance(factor, int) and factor >= 1
+        self.gain = gain
+        self.factor = factor
+
+    @staticmethod
+    def upscale2d(x, factor=2, gain=1):
+        assert x.dim() == 4
+        if factor == 1:
+            return x * gain if gain != 1 else x
+        assert factor == 2, "the kernel implements the factor-2 case the networks use"
+        return F.nchw_view(F.Up2Fn.apply(F.nhwc(x), float(gain)))
+
+    def forward(self, x):
+        return self.upscale2d(x, factor=self.factor, gain=self.gain)
+
+
+class BlurLayer(nn.Module):
+    """Depthwise separable blur, zero padded -- reference models/CustomLayers.py:251-276.  The kernel buffer keeps
+    the reference's name/shape; the HIP kernel implements the default normalised [1,2,1] filter (stride 1)."""
+
+    def __init__(self, kernel=None, normalize=True, flip=False, stride=1):
+        super().__init__()
+        if kernel is None:
+            kernel = [1, 2, 1]
+        k = torch.tensor(kernel, dtype=torch.float32)
+        k = k[:, None] * k[None, :]
+        k = k[None, None]
+        if normalize:
+            k = k / k.sum()
+        if flip:
+            k = k.flip(2, 3)
+        self.register_buffer('kernel', k)
+        self.stride = stride
+        self._is_121 = (list(kernel) == [1, 2, 1]) and normalize and stride == 1
+        self._is_box2 = (len(kernel) == 2 and stride == 2 and abs(float(k.sum()) - 1.0) < 1e-6
+                         and float((k - k.mean()).abs().max()) < 1e-7)
+
+    def forward_nhwc(self, x):
+        if self._is_121:
+            return F.BlurFn.apply(x)
+        if self._is_box2:
+            return F.Pool2Fn.apply(x, 0.25)
+        raise NotImplementedError("BlurLayer: only the [1,2,1] blur and the 2x2 box (Downscale2d) are built")
+
+    def forward(self, x):
+        return F.nchw_view(self.forward_nhwc(F.nhwc(x)))
+
+
+class Downscale2d(nn.Module):
+    """2x2 mean -- reference models/CustomLayers.py:48-76 (both of its branches are this arithmetic)."""
+
+    def __init__(self, factor=2, gain=1):
+        super().__init__()
+        assert isinstance(factor, int) and factor >= 1
+        self.factor = factor
+        self.gain = gain
+        if factor == 2:
+            f = [np.sqrt(gain) / factor] * factor
+            self.blur = BlurLayer(kernel=f, normalize=False, stride=factor)
+        else:
+            self.blur = None
+
+    def forward_nhwc(self, x):
+        assert self.factor == 2, "the kernel implements the factor-2 case the networks use"
+        return F.Pool2Fn.apply(x, 0.25 * float(self.gain))
+
+    def forward(self, x):
+        assert x.dim() == 4
+        return F.nchw_view(self.forward_nhwc(F.nhwc(x)))
+
+
+class EqualizedLinear(nn.Module):
+    """Linear layer with equalized learning rate -- reference models/CustomLayers.py:79-103."""
+
+    def __init__(self, input_size, output_size, gain=2 ** 0.5, use_wscale=False, lrmul=1, bias=True):
+        super().__init__()
+        he_std = gain * input_size ** (-0.5)
+        if use_wscale:
+            init_std = 1.0 / lrmul
+            self.w_mul = he_std * lrmul
+        else:
+            init_std = he_std / lrmul
+            self.w_mul = lrmul
+        self.weight = nn.Parameter(torch.randn(output_size, input_size) * init_std)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(output_size))
+            self.b_mul = lrmul
+        else:
+            self.bias = None
+            self.b_mul = 1
+
+    def forward(self, x, act=ACT_NONE, weight=None):
+        """``act`` fuses the LeakyReLU that follows the layer in the mapping network / D head; ``weight``
+        substitutes a re-ordered view of the weight (D dense0 consumes NHWC-flattened features)."""
+        w = self.weight if weight is None else weight
+        return F.linear(x.float(), w, self.bias, self.w_mul, self.b_mul, act)
+
+
+class EqualizedConv2d(nn.Module):
+    """Conv layer with equalized learning rate -- reference models/CustomLayers.py:106-180.
+
+    All of the reference's paths are served by three MFMA kernels: plain 3x3; 4x4 stride-2 (the fused
+    conv+downscale, which is also exactly conv3x3 -> avg_pool2 of the non-fused branch); 4x4 stride-2 transposed
+    (the fused upscale+conv; the non-fused nearest-up -> conv3x3 branch is the same operator with the 3x3 kernel
+    flipped).  The fused/non-fused *semantics* still switch on the input size exactly where the
+    reference switches (:143), because the two up paths differ by that flip.
+    """
+
+    def __init__(self, input_channels, output_channels, kernel_size, stride=1, gain=2 ** 0.5, use_wscale=False,
+                 lrmul=1, bias=True, intermediate=None, upscale=False, downscale=False):
+        super().__init__()
+        self.upscale = Upscale2d() if upscale else None
+        self.downscale = Downscale2d() if downscale else None
+        he_std = gain * (input_channels * kernel_size ** 2) ** (-0.5)
+        self.kernel_size = kernel_size
+        if use_wscale:
+            init_std = 1.0 / lrmul
+            self.w_mul = he_std * lrmul
+        else:
+            init_std = he_std / lrmul
+            self.w_mul = lrmul
+        self.weight = nn.Parameter(torch.randn(output_channels, input_channels, kernel_size, kernel_size) * init_std)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(output_channels))
+            self.b_mul = lrmul
+        else:
+            self.bias = None
+            self.b_mul = 1
+        self.intermediate = intermediate
+        assert stride == 1
+
+    # ---- packed weights [taps][n][k], fp32, differentiable w.r.t. self.weight (tiny tensors: torch ops)
+    def scaled_bias(self):
+        if self.bias is None:
+            return None
+        return self.bias * self.b_mul if self.b_mul != 1 else self.bias
+
+    def pack_plain(self, pad_in_to=None):
+        w = self.weight * self.w_mul                                     # [O, I, 3, 3]
+        if pad_in_to is not None and pad_in_to > w.shape[1]:
+            w = TF.pad(w, [0, 0, 0, 0, 0, pad_in_to - w.shape[1]])
+        return w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).contiguous()
+
+    def pack_down(self):
+        w = TF.pad(self.weight * self.w_mul, [1, 1, 1, 1])                # reference :159-162
+        w = (w[:, :, 1:, 1:] + w[:, :, :-1, 1:] + w[:, :, 1:, :-1] + w[:, :, :-1, :-1]) * 0.25
+        return w.permute(2, 3, 0, 1).reshape(16, w.shape[0], w.shape[1]).contiguous()
+
+    def pack_up(self, fused_semantics):
+        w = self.weight * self.w_mul
+        if not fused_semantics:
+            w = w.flip(2, 3)                                             # nearest-up -> conv3x3 == fused form of the flipped kernel
+        w = TF.pad(w.permute(1, 0, 2, 3), [1, 1, 1, 1])                   # reference :146-150  -> [I, O, 4, 4]
+        w = w[:, :, 1:, 1:] + w[:, :, :-1, 1:] + w[:, :, 1:, :-1] + w[:, :, :-1, :-1]
+        return w.permute(2, 3, 1, 0).reshape(16, w.shape[1], w.shape[0]).contiguous()
+
+    def rgb_weight(self):
+        """[3][C] fp32 for the 1x1 RGB convolutions."""
+        w = (self.weight * self.w_mul)[:, :, 0, 0]
+        return w.t().contiguous() if w.shape[1] == 3 else w.contiguous()
+
+    def forward_nhwc(self, x, act=ACT_NONE, skip_bias=False, out_dtype=None):
+        """x: NHWC.  ``skip_bias``: the caller folds the bias into the next kernel (generator epilogue)."""
+        bias = None if skip_bias else self.scaled_bias()
+        cin, cout = self.weight.shape[1], self.weight.shape[0]
+        if self.kernel_size == 1:
+            assert self.upscale is None and self.downscale is None and self.intermediate is None
+            if cin == 3 and x.dtype == torch.float32 and x.shape[3] == 3:
+                y = F.RgbInFn.apply(x, self.rgb_weight(), bias, out_dtype or torch.float32)
+            elif cout == 3:
+                y = F.RgbOutFn.apply(x, self.rgb_weight(), bias)
+            else:
+                raise NotImplementedError("1x1 EqualizedConv2d is built for the to_rgb / from_rgb layers (3 channels on one side)")
+            return F.BiasActFn.apply(y, None, act) if act else y
+        assert self.kernel_size == 3
+        if self.upscale is not None:
+            fused = min(x.shape[1], x.shape[2]) * 2 >= 128                # reference :143
+            y = F.conv(x, self.pack_up(fused), None, "U")
+            if self.intermediate is not None:
+                y = self.intermediate.forward_nhwc(y)
+            if bias is not None or act:
+                y = F.BiasActFn.apply(y, bias, act)                       # bias after the blur (:178-179)
+            return y
+        if self.downscale is not None:
+            assert self.intermediate is None                              # reference :167
+            return F.conv(x, self.pack_down(), bias, "D", act)            # bias after the 2x2 mean == bias in the fused store
+        if self.intermediate is None:
+            pad = x.shape[3] if x.shape[3] != cin else None
+            return F.conv(x, self.pack_plain(pad), bias, "S", act)
+        y = self.intermediate.forward_nhwc(F.conv(x, self.pack_plain(), None, "S"))
+        return F.BiasActFn.apply(y, bias, act) if (bias is not None or act) else y
+
+    def forward(self, x):
+        if self.kernel_size == 1 and self.weight.shape[0] == 3:
+            return F.nchw_view(self.forward_nhwc(F.nhwc(x)))
+        xin = F.nhwc(x, torch.float32)
+        return F.nchw_view(self.forward_nhwc(xin))
+
+
+class NoiseLayer(nn.Module):
+    """Per-pixel noise with a per-channel weight -- reference models/CustomLayers.py:183-200.  Inside the networks
+    the addition is fused into the layer-epilogue kernel; this standalone forward is the reference formula."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(channels))
+        self.noise = None
+
+    def sample(self, x_nhwc_shape, device):
+        """Noise for one layer, [B,1,H,W] fp32: the preset ``.noise`` if set (reference :194-198), else a fresh draw
+        from the device generator in the reference's order (:193)."""
+        if self.noise is not None:
+            return self.noise
+        b, h, w, _ = x_nhwc_shape
+        return torch.randn(b, 1, h, w, device=device, dtype=torch.float32)
+
+    def forward(self, x, noise=None):
+        if noise is None:
+            noise = self.sample((x.size(0), x.size(2), x.size(3), x.size(1)), x.device)
+        return x + self.weight.view(1, -1, 1, 1).to(x.dtype) * noise.to(x.dtype)   # standalone use only (not the hot path)
+
+
+class StyleMod(nn.Module):
+    """x * (style0 + 1) + style1 with style = EqualizedLinear(w) -- reference models/CustomLayers.py:203-216."""
+
+    def __init__(self, latent_size, channels, use_wscale):
+        super().__init__()
+        self.lin = EqualizedLinear(latent_size, channels * 2, gain=1.0, use_wscale=use_wscale)
+
+    def style(self, latent):
+        return self.lin(latent)                                           # [B, 2C] fp32
+
+    def forward(self, x, latent):
+        s = self.style(latent).view(-1, 2, x.size(1), *([1] * (x.dim() - 2))).to(x.dtype)
+        return x * (s[:, 0] + 1.) + s[:, 1]
+
+
+class LayerEpilogue(nn.Module):
+    """Things to do at the end of each generator layer -- reference models/CustomLayers.py:219-248.
+    noise -> LeakyReLU -> InstanceNorm -> StyleMod run as ONE fused HIP op (two passes over the tensor)."""
+
+    def __init__(self, channels, dlatent_size, use_wscale, use_noise, use_pixel_norm, use_instance_norm, use_styles,
+                 activation_layer):
+        super().__init__()
+        from collections import OrderedDict
+        layers = []
+        if use_noise:
+            layers.append(('noise', NoiseLayer(channels)))
+        layers.append(('activation', activation_layer))
+        if use_pixel_norm:
+            layers.append(('pixel_norm', PixelNormLayer()))
+        if use_instance_norm:
+            layers.append(('instance_norm', nn.InstanceNorm2d(channels)))
+        self.top_epi = nn.Sequential(OrderedDict(layers))
+        self.style_mod = StyleMod(dlatent_size, channels, use_wscale=use_wscale) if use_styles else None
+        self._fusable = use_noise and use_instance_norm and use_styles and not use_pixel_norm \
+            and isinstance(activation_layer, nn.LeakyReLU) and abs(activation_layer.negative_slope - 0.2) < 1e-12
+
+    def forward_nhwc(self, x, dlatents_in_slice, conv_bias=None):
+        if not self._fusable:
+            raise NotImplementedError("LayerEpilogue: the fused kernel implements the reference's default flags "
+                                      "(noise + LeakyReLU(0.2) + instance norm + styles, no pixel norm)")
+        noise_layer = self.top_epi.noise
+        noise = noise_layer.sample(x.shape, x.device)
+        style = self.style_mod.style(dlatents_in_slice)
+        return F.GEpilogueFn.apply(x, conv_bias, noise, noise_layer.weight, style)
+
+    def forward(self, x, dlatents_in_slice=None):
+        return F.nchw_view(self.forward_nhwc(F.nhwc(x), dlatents_in_slice))
+
+
+class View(nn.Module):
+    """reference models/CustomLayers.py:279-285."""
+
+    def __init__(self, *shape):
+        super().__init__()
+        self.shape = shape
+
+    def forward(self, x):
+        return x.reshape(x.size(0), *self.shape)
+
+
+class StddevLayer(nn.Module):
+    """Minibatch standard deviation -- reference models/CustomLayers.py:288-305 (group_size 4, one new feature)."""
+
+    def __init__(self, group_size=4, num_new_features=1):
+        super().__init__()
+        self.group_size = group_size
+        self.num_new_features = num_new_features
+
+    def forward_nhwc(self, x):
+        """[B,H,W,C] -> [B,H,W,C+MBSTD_CPAD]; channel C is the statistic, the rest is zero padding."""
+        if self.group_size != 4 or self.num_new_features != 1:
+            raise NotImplementedError("StddevLayer: the kernel implements group_size=4, num_new_features=1")
+        return F.MbstdFn.apply(x, x.shape[3] + MBSTD_CPAD)
+
+    def forward(self, x):
+        y = self.forward_nhwc(F.nhwc(x))
+        return F.nchw_view(y)[:, :x.size(1) + 1]
+
+
+class Truncation(nn.Module):
+    """W-space truncation trick + moving average of W -- reference models/CustomLayers.py:308-323.
+    [B, layers, 512] fp32 bookkeeping, two tiny elementwise ops."""
+
+    def __init__(self, avg_latent, max_layer=8, threshold=0.7, beta=0.995):
+        super().__init__()
+        self.max_layer = max_layer
+        self.threshold = threshold
+        self.beta = beta
+        self.register_buffer('avg_latent', avg_latent)
+
+    def update(self, last_avg):
+        self.avg_latent.copy_(self.beta * self.avg_latent + (1. - self.beta) * last_avg)
+
+    def forward(self, x):
+        assert x.dim() == 3
+        interp = torch.lerp(self.avg_latent.expand_as(x), x, self.threshold)
+        do_trunc = (torch.arange(x.size(1), device=x.device) < self.max_layer).view(1, -1, 1)
+        return torch.where(do_trunc, interp, x)

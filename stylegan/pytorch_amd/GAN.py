@@ -1,0 +1,352 @@
+"""Networks and the training-step wrapper with the reference's surface (reference models/GAN.py):
+``GMapping``, ``GSynthesis``, ``Generator``, ``Discriminator``, ``StyleGAN`` -- same constructor kwargs, forward
+signatures, attribute names and ``state_dict`` keys, so ``train.py``-style drivers, the generate scripts and
+checkpoints interchange.  All arithmetic of the forward/backward hot path runs in libsgx_hip.so.
+
+Extra (non-reference) knobs are keyword-only and default to the reference behaviour:
+``act_dtype`` (torch.float32 | torch.bfloat16 storage of activations between kernels; accumulation stays fp32).
+"""
+import copy
+import random
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import Losses
+from . import functional as F
+from .Blocks import DiscriminatorBlock, DiscriminatorTop, GSynthesisBlock, InputBlock
+from .CustomLayers import EqualizedConv2d, EqualizedLinear, PixelNormLayer, Truncation
+from .native import ACT_LRELU
+from .optim import FusedAdam, clip_and_step, ema_update
+
+
+def update_average(model_tgt, model_src, beta):
+    """EMA of the generator weights into the shadow copy -- reference models/__init__.py:13-40."""
+    ema_update(model_tgt, model_src, beta)
+
+
+class GMapping(nn.Module):
+    """Mapping network -- reference models/GAN.py:37-100: PixelNorm, then ``mapping_layers`` x
+    (EqualizedLinear lrmul 0.01 -> LeakyReLU 0.2), broadcast to [B, dlatent_broadcast, dlatent_size]."""
+
+    def __init__(self, latent_size=512, dlatent_size=512, dlatent_broadcast=None, mapping_layers=8, mapping_fmaps=512,
+                 mapping_lrmul=0.01, mapping_nonlinearity='lrelu', use_wscale=True, normalize_latents=True, **kwargs):
+        super().__init__()
+        self.latent_size = latent_size
+        self.mapping_fmaps = mapping_fmaps
+        self.dlatent_size = dlatent_size
+        self.dlatent_broadcast = dlatent_broadcast
+        assert mapping_nonlinearity == 'lrelu', "the kernels fuse LeakyReLU(0.2)"
+        act, gain = nn.LeakyReLU(negative_slope=0.2), np.sqrt(2)
+        layers = []
+        if normalize_latents:
+            layers.append(('pixel_norm', PixelNormLayer()))
+        layers.append(('dense0', EqualizedLinear(self.latent_size, self.mapping_fmaps, gain=gain, lrmul=mapping_lrmul,
+                                                 use_wscale=use_wscale)))
+        layers.append(('dense0_act', act))
+        for layer_idx in range(1, mapping_layers):
+            fmaps_in = self.mapping_fmaps
+            fmaps_out = self.dlatent_size if layer_idx == mapping_layers - 1 else self.mapping_fmaps
+            layers.append(('dense{:d}'.format(layer_idx),
+                           EqualizedLinear(fmaps_in, fmaps_out, gain=gain, lrmul=mapping_lrmul, use_wscale=use_wscale)))
+            layers.append(('dense{:d}_act'.format(layer_idx), act))
+        self.map = nn.Sequential(OrderedDict(layers))
+        self.mapping_layers = mapping_layers
+
+    def forward(self, x):
+        x = x.float()
+        if hasattr(self.map, 'pixel_norm'):
+            x = self.map.pixel_norm(x)
+        for i in range(self.mapping_layers):
+            x = getattr(self.map, 'dense{:d}'.format(i))(x, act=ACT_LRELU)   # bias + LeakyReLU fused after the GEMM
+        if self.dlatent_broadcast is not None:
+            x = x.unsqueeze(1).expand(-1, self.dlatent_broadcast, -1)
+        return x
+
+
+class GSynthesis(nn.Module):
+    """Synthesis network with progressive growing -- reference models/GAN.py:103-208."""
+
+    def __init__(self, dlatent_size=512, num_channels=3, resolution=1024, fmap_base=8192, fmap_decay=1.0, fmap_max=512,
+                 use_styles=True, const_input_layer=True, use_noise=True, nonlinearity='lrelu', use_wscale=True,
+                 use_pixel_norm=False, use_instance_norm=True, blur_filter=None, structure='linear', act_dtype=torch.float32,
+                 **kwargs):
+        super().__init__()
+
+        def nf(stage):
+            return min(int(fmap_base / (2.0 ** (stage * fmap_decay))), fmap_max)
+
+        self.structure = structure
+        resolution_log2 = int(np.log2(resolution))
+        assert resolution == 2 ** resolution_log2 and resolution >= 4
+        self.depth = resolution_log2 - 1
+        self.num_layers = resolution_log2 * 2 - 2
+        self.num_styles = self.num_layers if use_styles else 1
+        self.act_dtype = act_dtype
+        assert nonlinearity == 'lrelu', "the kernels fuse LeakyReLU(0.2)"
+        act, gain = nn.LeakyReLU(negative_slope=0.2), np.sqrt(2)
+
+        self.init_block = InputBlock(nf(1), dlatent_size, const_input_layer, gain, use_wscale, use_noise, use_pixel_norm,
+                                     use_instance_norm, use_styles, act)
+        rgb_converters = [EqualizedConv2d(nf(1), num_channels, 1, gain=1, use_wscale=use_wscale)]
+        blocks = []
+        for res in range(3, resolution_log2 + 1):
+            last_channels = nf(res - 2)
+            channels = nf(res - 1)
+            blocks.append(GSynthesisBlock(last_channels, channels, blur_filter, dlatent_size, gain, use_wscale, use_noise,
+                                          use_pixel_norm, use_instance_norm, use_styles, act))
+            rgb_converters.append(EqualizedConv2d(channels, num_channels, 1, gain=1, use_wscale=use_wscale))
+        self.blocks = nn.ModuleList(blocks)
+        self.to_rgb = nn.ModuleList(rgb_converters)
+        self.temporaryUpsampler = lambda x: F.nchw_view(F.Up2Fn.apply(F.nhwc(x), 1.0))
+
+    def forward(self, dlatents_in, depth=0, alpha=0., labels_in=None):
+        assert depth < self.depth, "Requested output depth cannot be produced"
+        dl = dlatents_in.float()
+        dt = self.act_dtype
+        if self.structure == 'fixed':
+            x = self.init_block.forward_nhwc(dl[:, 0:2], dt)
+            for i, block in enumerate(self.blocks):
+                x = block.forward_nhwc(x, dl[:, 2 * (i + 1):2 * (i + 2)])
+            images = self.to_rgb[-1].forward_nhwc(x)
+        elif self.structure == 'linear':
+            x = self.init_block.forward_nhwc(dl[:, 0:2], dt)
+            if depth > 0:
+                for i, block in enumerate(self.blocks[:depth - 1]):
+                    x = block.forward_nhwc(x, dl[:, 2 * (i + 1):2 * (i + 2)])
+                # reference GAN.py:199 applies to_rgb AFTER the nearest upsample; a 1x1 conv commutes with
+                # replication, so convert at the low resolution (4x fewer bytes) and upsample the RGB image.
+                residual = F.Up2Fn.apply(self.to_rgb[depth - 1].forward_nhwc(x), 1.0)
+                straight = self.to_rgb[depth].forward_nhwc(
+                    self.blocks[depth - 1].forward_nhwc(x, dl[:, 2 * depth:2 * (depth + 1)]))
+                images = F.AxpbyFn.apply(straight, residual, float(alpha), float(1 - alpha))     # GAN.py:202
+            else:
+                images = self.to_rgb[0].forward_nhwc(x)
+        else:
+            raise KeyError("Unknown structure: ", self.structure)
+        return F.nchw_view(images)
+
+
+class Generator(nn.Module):
+    """Style-based generator -- reference models/GAN.py:211-297 (mapping, W moving average, style mixing,
+    truncation, synthesis).  The RNG draws of the mixing step happen in the reference's order (:282-288)."""
+
+    def __init__(self, resolution, latent_size=512, dlatent_size=512, conditional=False, n_classes=0, truncation_psi=0.7,
+                 truncation_cutoff=8, dlatent_avg_beta=0.995, style_mixing_prob=0.9, **kwargs):
+        super().__init__()
+        if conditional:
+            assert n_classes > 0, "Conditional generation requires n_class > 0"
+            self.class_embedding = nn.Embedding(n_classes, latent_size)
+            latent_size *= 2
+        self.conditional = conditional
+        self.style_mixing_prob = style_mixing_prob
+        self.num_layers = (int(np.log2(resolution)) - 1) * 2
+        self.g_mapping = GMapping(latent_size, dlatent_size, dlatent_broadcast=self.num_layers, **kwargs)
+        self.g_synthesis = GSynthesis(resolution=resolution, **kwargs)
+        if truncation_psi > 0:
+            self.truncation = Truncation(avg_latent=torch.zeros(dlatent_size), max_layer=truncation_cutoff,
+                                         threshold=truncation_psi, beta=dlatent_avg_beta)
+        else:
+            self.truncation = None
+
+    def forward(self, latents_in, depth, alpha, labels_in=None):
+        if self.conditional:
+            assert labels_in is not None, "Conditional discriminatin requires labels"
+            latents_in = torch.cat([latents_in, self.class_embedding(labels_in)], 1)
+        dlatents_in = self.g_mapping(latents_in)
+        if self.training:
+            if self.truncation is not None:
+                self.truncation.update(dlatents_in[0, 0].detach())                       # sample 0 only (:278)
+            if self.style_mixing_prob is not None and self.style_mixing_prob > 0:
+                latents2 = torch.randn(latents_in.shape).to(latents_in.device)           # CPU RNG first (:282)
+                dlatents2 = self.g_mapping(latents2)
+                layer_idx = torch.arange(self.num_layers, device=latents_in.device).view(1, -1, 1)
+                cur_layers = 2 * (depth + 1)
+                mixing_cutoff = random.randint(1, cur_layers) if random.random() < self.style_mixing_prob else cur_layers
+                dlatents_in = torch.where(layer_idx < mixing_cutoff, dlatents_in, dlatents2)
+            if self.truncation is not None:
+                dlatents_in = self.truncation(dlatents_in)
+        return self.g_synthesis(dlatents_in, depth, alpha)
+
+
+class Discriminator(nn.Module):
+    """Progressive discriminator -- reference models/GAN.py:300-444."""
+
+    def __init__(self, resolution, num_channels=3, conditional=False, n_classes=0, fmap_base=8192, fmap_decay=1.0,
+                 fmap_max=512, nonlinearity='lrelu', use_wscale=True, mbstd_group_size=4, mbstd_num_features=1,
+                 blur_filter=None, structure='linear', act_dtype=torch.float32, **kwargs):
+        super().__init__()
+        if conditional:
+            raise NotImplementedError("conditional discriminator (label embeddings as image channels) is outside the "
+                                      "accelerated path")
+
+        def nf(stage):
+            return min(int(fmap_base / (2.0 ** (stage * fmap_decay))), fmap_max)
+
+        self.conditional = conditional
+        self.mbstd_num_features = mbstd_num_features
+        self.mbstd_group_size = mbstd_group_size
+        self.structure = structure
+        self.act_dtype = act_dtype
+        resolution_log2 = int(np.log2(resolution))
+        assert resolution == 2 ** resolution_log2 and resolution >= 4
+        self.depth = resolution_log2 - 1
+        assert nonlinearity == 'lrelu', "the kernels fuse LeakyReLU(0.2)"
+        act, gain = nn.LeakyReLU(negative_slope=0.2), np.sqrt(2)
+
+        blocks, from_rgb = [], []
+        for res in range(resolution_log2, 2, -1):
+            blocks.append(DiscriminatorBlock(nf(res - 1), nf(res - 2), gain=gain, use_wscale=use_wscale,
+                                             activation_layer=act, blur_kernel=blur_filter))
+            from_rgb.append(EqualizedConv2d(num_channels, nf(res - 1), kernel_size=1, gain=gain, use_wscale=use_wscale))
+        self.blocks = nn.ModuleList(blocks)
+        self.final_block = DiscriminatorTop(self.mbstd_group_size, self.mbstd_num_features, in_channels=nf(2),
+                                            intermediate_channels=nf(2), gain=gain, use_wscale=use_wscale,
+                                            activation_layer=act)
+        from_rgb.append(EqualizedConv2d(num_channels, nf(2), kernel_size=1, gain=gain, use_wscale=use_wscale))
+        self.from_rgb = nn.ModuleList(from_rgb)
+        self.temporaryDownsampler = lambda x: F.nchw_view(F.Pool2Fn.apply(F.nhwc(x), 0.25))
+
+    def forward(self, images_in, depth, alpha=1., labels_in=None):
+        assert depth < self.depth, "Requested output depth cannot be produced"
+        img = F.nhwc(images_in, torch.float32)                              # [B,R,R,3] fp32
+        dt = self.act_dtype
+        if self.structure == 'fixed':
+            x = self.from_rgb[0].forward_nhwc(img, out_dtype=dt)
+            for block in self.blocks:
+                x = block.forward_nhwc(x)
+        elif self.structure == 'linear':
+            if depth > 0:
+                residual = self.from_rgb[self.depth - depth].forward_nhwc(F.Pool2Fn.apply(img, 0.25), out_dtype=dt)
+                straight = self.blocks[self.depth - depth - 1].forward_nhwc(
+                    self.from_rgb[self.depth - depth - 1].forward_nhwc(img, out_dtype=dt))
+                x = F.AxpbyFn.apply(straight, residual, float(alpha), float(1 - alpha))   # GAN.py:427
+                for block in self.blocks[(self.depth - depth):]:
+                    x = block.forward_nhwc(x)
+            else:
+                x = self.from_rgb[-1].forward_nhwc(img, out_dtype=dt)
+        else:
+            raise KeyError("Unknown structure: ", self.structure)
+        return self.final_block.forward_nhwc(x)
+
+
+class StyleGAN:
+    """Wrapper around the Generator and the Discriminator: optimizers, loss, EMA and the two optimisation steps --
+    reference models/GAN.py:447-659.  ``train`` (the progressive schedule loop) lives in train_loop.py."""
+
+    def __init__(self, structure, resolution, num_channels, latent_size, g_args, d_args, g_opt_args, d_opt_args,
+                 conditional=False, n_classes=0, loss="relativistic-hinge", drift=0.001, d_repeats=1, use_ema=False,
+                 ema_decay=0.999, device=torch.device("cpu"), act_dtype=torch.float32, data_parallel=None):
+        assert structure in ['fixed', 'linear']
+        if conditional:
+            assert n_classes > 0, "Conditional GANs require n_classes > 0"
+        self.structure = structure
+        self.depth = int(np.log2(resolution)) - 1
+        self.latent_size = latent_size
+        self.device = torch.device(device)
+        self.d_repeats = d_repeats
+        self.conditional = conditional
+        self.n_classes = n_classes
+        self.use_ema = use_ema
+        self.ema_decay = ema_decay
+        self.dp = data_parallel                       # parallel.DataParallelGroup or None
+        if self.device.type != "cuda":
+            raise RuntimeError("stylegan.pytorch_amd runs on MI355X only: device must be a cuda (ROCm) device; the "
+                               "reference's CPU path is the oracle, not a fallback of this package")
+
+        self.gen = Generator(num_channels=num_channels, resolution=resolution, structure=self.structure,
+                             conditional=self.conditional, n_classes=self.n_classes, act_dtype=act_dtype,
+                             **g_args).to(self.device)
+        self.dis = Discriminator(num_channels=num_channels, resolution=resolution, structure=self.structure,
+                                 conditional=self.conditional, n_classes=self.n_classes, act_dtype=act_dtype,
+                                 **d_args).to(self.device)
+        self.__setup_gen_optim(**g_opt_args)
+        self.__setup_dis_optim(**d_opt_args)
+        self.drift = drift
+        self.loss = self.__setup_loss(loss)
+        if self.use_ema:
+            self.gen_shadow = copy.deepcopy(self.gen)
+            self.ema_updater = update_average
+            self.ema_updater(self.gen_shadow, self.gen, beta=0)
+
+    def __setup_gen_optim(self, learning_rate, beta_1, beta_2, eps):
+        self.gen_optim = FusedAdam(self.gen.parameters(), lr=learning_rate, betas=(float(beta_1), float(beta_2)), eps=eps)
+
+    def __setup_dis_optim(self, learning_rate, beta_1, beta_2, eps):
+        self.dis_optim = FusedAdam(self.dis.parameters(), lr=learning_rate, betas=(float(beta_1), float(beta_2)), eps=eps)
+
+    def __setup_loss(self, loss):
+        if isinstance(loss, str):
+            loss = loss.lower()
+            assert not self.conditional, "conditional losses are outside the accelerated path"
+            assert loss in ["logistic", "hinge", "relativistic-hinge"], "Unknown loss function"
+            mean_scale = 1.0 / self.dp.world_size if self.dp is not None else 1.0
+            if loss == "logistic":
+                return Losses.LogisticGAN(self.dis, mean_scale=mean_scale)
+            if loss == "hinge":
+                assert self.dp is None, "data parallel is wired for the logistic loss"
+                return Losses.HingeGAN(self.dis)
+            assert self.dp is None, "data parallel is wired for the logistic loss"
+            return Losses.RelativisticAverageHingeGAN(self.dis)
+        return loss
+
+    def progressive_down_sampling(self, real_batch, depth, alpha):
+        """Real images at the current depth with the fade-in blend -- reference models/GAN.py:557-589."""
+        if self.structure == 'fixed':
+            return real_batch
+        x = F.nhwc(real_batch, torch.float32)
+        levels = self.depth - depth - 1                         # AvgPool2d(2**levels) == levels x (2x2 mean)
+        for _ in range(levels):
+            x = F.Pool2Fn.apply(x, 0.25)
+        if depth > 0:
+            prior = F.Up2Fn.apply(F.Pool2Fn.apply(x, 0.25), 1.0)
+            x = F.AxpbyFn.apply(x, prior, float(alpha), float(1 - alpha))
+        else:
+            x = F.AxpbyFn.apply(x, x, float(alpha), float(1 - alpha))    # prior == current at depth 0 (:583-584)
+        return F.nchw_view(x)
+
+    # name-mangled alias so code written against the reference's private helper keeps working
+    _StyleGAN__progressive_down_sampling = progressive_down_sampling
+
+    def optimize_discriminator(self, noise, real_batch, depth, alpha, labels=None):
+        """One discriminator update -- reference models/GAN.py:591-622."""
+        real_samples = self.progressive_down_sampling(real_batch, depth, alpha)
+        loss_val = 0
+        for _ in range(self.d_repeats):
+            with torch.no_grad():                     # the reference builds and drops this graph (.detach(), :607)
+                fake_samples = self.gen(noise, depth, alpha, labels)
+            loss = self.loss.dis_loss(real_samples, fake_samples, depth, alpha)
+            self.dis_optim.zero_grad()
+            loss.backward()
+            if self.dp is not None:
+                self.dp.all_reduce_grads(self.dis.parameters())
+            self.dis_optim.step()
+            loss_val += loss.item()
+        return loss_val / self.d_repeats
+
+    def optimize_generator(self, noise, real_batch, depth, alpha, labels=None):
+        """One generator update incl. gradient clipping and EMA -- reference models/GAN.py:624-659."""
+        real_samples = None
+        if not isinstance(self.loss, (Losses.LogisticGAN, Losses.HingeGAN)):
+            real_samples = self.progressive_down_sampling(real_batch, depth, alpha)   # only the relativistic loss reads it
+        fake_samples = self.gen(noise, depth, alpha, labels)
+        # the reference also back-propagates into D's parameters here and discards the result at the next
+        # dis_optim.zero_grad(); skipping those weight gradients changes no observable value
+        d_params = [p for p in self.dis.parameters() if p.requires_grad]
+        for p in d_params:
+            p.requires_grad_(False)
+        try:
+            loss = self.loss.gen_loss(real_samples, fake_samples, depth, alpha)
+            self.gen_optim.zero_grad()
+            loss.backward()
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
+        if self.dp is not None:
+            self.dp.all_reduce_grads(self.gen.parameters())
+        clip_and_step(self.gen_optim, max_norm=10.)                                   # :651-652 without a host sync
+        if self.use_ema:
+            self.ema_updater(self.gen_shadow, self.gen, self.ema_decay)
+        return loss.item()

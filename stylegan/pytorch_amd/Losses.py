@@ -1,0 +1,86 @@
+"""GAN losses with the reference's class names and call signatures (reference models/Losses.py).
+
+The loss heads are [B,1] scalars; what matters here is how they drive the discriminator: LogisticGAN's R1 penalty
+differentiates D twice (``create_graph=True``), which the kernels support because every D op's backward is itself
+built from differentiable ops (functional.py).
+"""
+import torch
+import torch.nn.functional as TF
+
+from . import functional as F
+
+
+class GANLoss:
+    """Base class -- reference models/Losses.py:20-51."""
+
+    def __init__(self, dis):
+        self.dis = dis
+
+    def dis_loss(self, real_samps, fake_samps, height, alpha):
+        raise NotImplementedError("dis_loss method has not been implemented")
+
+    def gen_loss(self, real_samps, fake_samps, height, alpha):
+        raise NotImplementedError("gen_loss method has not been implemented")
+
+
+class HingeGAN(GANLoss):
+    """reference models/Losses.py:136-151."""
+
+    def dis_loss(self, real_samps, fake_samps, height, alpha):
+        r_preds = self.dis(real_samps, height, alpha)
+        f_preds = self.dis(fake_samps, height, alpha)
+        return torch.mean(TF.relu(1 - r_preds)) + torch.mean(TF.relu(1 + f_preds))
+
+    def gen_loss(self, _, fake_samps, height, alpha):
+        return -torch.mean(self.dis(fake_samps, height, alpha))
+
+
+class RelativisticAverageHingeGAN(GANLoss):
+    """reference models/Losses.py:154-189."""
+
+    def dis_loss(self, real_samps, fake_samps, height, alpha):
+        r_preds = self.dis(real_samps, height, alpha)
+        f_preds = self.dis(fake_samps, height, alpha)
+        r_f_diff = r_preds - torch.mean(f_preds)
+        f_r_diff = f_preds - torch.mean(r_preds)
+        return torch.mean(TF.relu(1 - r_f_diff)) + torch.mean(TF.relu(1 + f_r_diff))
+
+    def gen_loss(self, real_samps, fake_samps, height, alpha):
+        r_preds = self.dis(real_samps, height, alpha)
+        f_preds = self.dis(fake_samps, height, alpha)
+        r_f_diff = r_preds - torch.mean(f_preds)
+        f_r_diff = f_preds - torch.mean(r_preds)
+        return torch.mean(TF.relu(1 + r_f_diff)) + torch.mean(TF.relu(1 - f_r_diff))
+
+
+class LogisticGAN(GANLoss):
+    """Non-saturating logistic loss with the R1 gradient penalty -- reference models/Losses.py:192-229.
+
+    ``r1_scale`` / ``mean_scale`` exist for data parallelism: the softplus terms are batch MEANS,
+    the R1 term is a batch SUM (:210), so under a gradient all-reduce(SUM) over N ranks the mean terms carry 1/N.
+    """
+
+    def __init__(self, dis, mean_scale=1.0):
+        super().__init__(dis)
+        self.mean_scale = float(mean_scale)
+
+    def R1Penalty(self, real_img, height, alpha):
+        real_img = real_img.detach().requires_grad_(True)
+        real_logit = self.dis(real_img, height, alpha)
+        with F.data_grad_only():                      # only d(logit)/d(image) is needed here, not the parameter grads
+            real_grads = torch.autograd.grad(outputs=real_logit, inputs=real_img,
+                                             grad_outputs=torch.ones_like(real_logit),
+                                             create_graph=True, retain_graph=True)[0]
+        return torch.sum(real_grads * real_grads)     # SUM over batch and pixels (:210)
+
+    def dis_loss(self, real_samps, fake_samps, height, alpha, r1_gamma=10.0):
+        r_preds = self.dis(real_samps, height, alpha)
+        f_preds = self.dis(fake_samps, height, alpha)
+        loss = (torch.mean(TF.softplus(f_preds)) + torch.mean(TF.softplus(-r_preds))) * self.mean_scale
+        if r1_gamma != 0.0:
+            loss = loss + self.R1Penalty(real_samps.detach(), height, alpha) * (r1_gamma * 0.5)
+        return loss
+
+    def gen_loss(self, _, fake_samps, height, alpha):
+        f_preds = self.dis(fake_samps, height, alpha)
+        return torch.mean(TF.softplus(-f_preds)) * self.mean_scale

@@ -1,0 +1,88 @@
+// Internal helpers shared by the gfx950 kernels of libsgx_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "sgx.h"
+
+typedef unsigned short bf16_t;                                       // raw bf16 storage
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define SGX_LRELU 0.2f
+#define WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {                    // round to nearest even
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : SGX_LRELU * v; }
+__device__ __forceinline__ float lrelu_slope(float out_or_in) { return out_or_in > 0.f ? 1.f : SGX_LRELU; }
+
+// 16-byte vector access, VE elements of T per vector
+template <typename T> struct VecTraits;
+template <> struct VecTraits<float> {
+    static constexpr int VE = 4;
+    __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
+        float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    __device__ static __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct VecTraits<bf16_t> {
+    static constexpr int VE = 8;
+    __device__ static __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        uint4 t = *reinterpret_cast<const uint4*>(p);
+        unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    __device__ static __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- host side error plumbing -------------------------------------------------------------
+void sgx_set_error(const char* fmt, ...);
+#define SGX_REQUIRE(cond, code, ...)                 \
+    do {                                             \
+        if (!(cond)) {                               \
+            sgx_set_error(__VA_ARGS__);              \
+            return (code);                           \
+        }                                            \
+    } while (0)
+#define SGX_LAUNCH_CHECK(name)                                                         \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) {                                                        \
+            sgx_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \
+            return (int)e_;                                                            \
+        }                                                                              \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -1,0 +1,261 @@
+// Generator layer epilogue (models/CustomLayers.py:219-248) as four HBM passes instead of ~12:
+//   p = x + bias[c] + nw[c]*noise[b,hw];  a = lrelu(p);  xh = (a - mean[b,c]) * rstd[b,c];  y = xh*(s0+1) + s1
+// forward : stats pass (per-(b,c) sum / sum of squares; fp32 per lane over <= 64 elements, double across lanes,
+//           chunks and the final mean/variance: no float atomics, bit-reproducible) + apply pass.
+// backward: reduction pass (sum dy, sum dy*xh per (b,c)) + apply pass that writes dx and the per-channel partials
+//           of d(noise weight) and d(bias).
+// Layout per block: image b, pixel chunk; thread = (pixel row tr, channel vector tc); channel vectors are 16 bytes.
+#include "common.h"
+
+#define GEPI_EPS 1e-5f
+#define GEPI_ROWS_PER_THREAD 64
+
+struct GepiGeom { int cvt, rows, chunk, nchunk; };
+static GepiGeom gepi_geom(int HW, int C, int ve) {
+    GepiGeom g;
+    int cv = C / ve;
+    g.cvt = cv < 256 ? cv : 256;
+    g.rows = 256 / g.cvt;
+    g.chunk = g.rows * GEPI_ROWS_PER_THREAD;
+    g.nchunk = (HW + g.chunk - 1) / g.chunk;
+    return g;
+}
+
+extern "C" size_t sgx_gepi_ws_bytes(int B, int HW, int C) {
+    GepiGeom g4 = gepi_geom(HW, C, 4), g8 = gepi_geom(HW, C, 8);
+    int nchunk = g4.nchunk > g8.nchunk ? g4.nchunk : g8.nchunk;
+    return (size_t)2 * B * nchunk * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float) + 256;
+}
+
+// mode 0: (sum a, sum a^2)                       [forward statistics]
+// mode 1: (sum dy, sum dy*xh)                    [backward reduction]
+// mode 2: writes dx, (sum dp*noise, sum dp)      [backward apply]
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                 const float* __restrict__ bias, const float* __restrict__ noise,
+                                                 const float* __restrict__ nw, const float* __restrict__ style,
+                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                 const float* __restrict__ coef, double* __restrict__ part, int HW, int C,
+                                                 int cvt, int rows, int chunk) {
+    constexpr int VE = VecTraits<T>::VE;
+    extern __shared__ double sh[];                                 // [256][2*VE]
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int tc = threadIdx.x % cvt, tr = threadIdx.x / cvt;
+    const int cv = C / VE;
+    const int p0 = ch * chunk, p1 = (p0 + chunk < HW) ? p0 + chunk : HW;
+    for (int vb = 0; vb < cv; vb += cvt) {                         // uniform trip count (cv is a multiple of cvt)
+        const int v = vb + tc, c0 = v * VE;
+        float s0[VE], s1[VE], kb[VE], kw[VE], km[VE], kr[VE], ks[VE], k1[VE], k2[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+            s0[j] = 0.f; s1[j] = 0.f;
+            kb[j] = bias ? bias[c0 + j] : 0.f;
+            kw[j] = nw[c0 + j];
+            if (MODE >= 1) {
+                km[j] = mean[(size_t)b * C + c0 + j]; kr[j] = rstd[(size_t)b * C + c0 + j];
+                ks[j] = style[(size_t)b * 2 * C + c0 + j] + 1.f;
+            }
+            if (MODE == 2) { k1[j] = coef[((size_t)b * C + c0 + j) * 2]; k2[j] = coef[((size_t)b * C + c0 + j) * 2 + 1]; }
+        }
+        if (tr < rows) {
+            for (int p = p0 + tr; p < p1; p += rows) {
+                const size_t off = (((size_t)b * HW + p) * cv + v) * VE;
+                const float nz = noise[(size_t)b * HW + p];
+                float xv[VE];
+                VecTraits<T>::load(x + off, xv);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int j = 0; j < VE; ++j) {
+                        const float a = lrelu(xv[j] + kb[j] + kw[j] * nz);
+                        s0[j] += a; s1[j] += a * a;
+                    }
+                } else {
+                    float gv[VE];
+                    VecTraits<T>::load(dy + off, gv);
+                    if (MODE == 1) {
+#pragma unroll
+                        for (int j = 0; j < VE; ++j) {
+                            const float xh = (lrelu(xv[j] + kb[j] + kw[j] * nz) - km[j]) * kr[j];
+                            s0[j] += gv[j]; s1[j] += gv[j] * xh;
+                        }
+                    } else {
+                        float ov[VE];
+#pragma unroll
+                        for (int j = 0; j < VE; ++j) {
+                            const float pp = xv[j] + kb[j] + kw[j] * nz;
+                            const float xh = (lrelu(pp) - km[j]) * kr[j];
+                            const float da = kr[j] * (gv[j] * ks[j] - k1[j] - xh * k2[j]);
+                            const float dp = da * lrelu_slope(pp);
+                            ov[j] = dp;
+                            s0[j] += dp * nz; s1[j] += dp;
+                        }
+                        VecTraits<T>::store(dx + off, ov);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VE; ++j) { sh[threadIdx.x * 2 * VE + j] = (double)s0[j]; sh[threadIdx.x * 2 * VE + VE + j] = (double)s1[j]; }
+        __syncthreads();
+        if (tr == 0) {
+            double* o = part + (((size_t)b * gridDim.x + ch) * C + c0) * 2;
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {
+                double a0 = 0.0, a1 = 0.0;
+                for (int r = 0; r < rows; ++r) {
+                    a0 += sh[(r * cvt + tc) * 2 * VE + j];
+                    a1 += sh[(r * cvt + tc) * 2 * VE + VE + j];
+                }
+                o[j * 2] = a0; o[j * 2 + 1] = a1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// forward finalize: mean / rstd per (b,c)
+__global__ void gepi_fin_stats(const double* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd, int B, int C,
+                               int nchunk, int HW) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        const double* p = part + (((size_t)b * nchunk + k) * C + c) * 2;
+        s += p[0]; ss += p[1];
+    }
+    const double m = s / HW;
+    double var = ss / HW - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)GEPI_EPS));
+}
+
+// backward finalize 1: dstyle and the two per-(b,c) coefficients of the apply pass
+__global__ void gepi_fin_bwd1(const double* __restrict__ part, const float* __restrict__ style, float* __restrict__ dstyle,
+                              float* __restrict__ coef, int B, int C, int nchunk, int HW) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    double s1 = 0.0, s0 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        const double* p = part + (((size_t)b * nchunk + k) * C + c) * 2;
+        s1 += p[0]; s0 += p[1];
+    }
+    dstyle[(size_t)b * 2 * C + c] = (float)s0;              // d/d style[:,0] = sum dy*xh
+    dstyle[(size_t)b * 2 * C + C + c] = (float)s1;          // d/d style[:,1] = sum dy
+    const double sc = (double)style[(size_t)b * 2 * C + c] + 1.0;
+    coef[(size_t)i * 2] = (float)(sc * s1 / HW);
+    coef[(size_t)i * 2 + 1] = (float)(sc * s0 / HW);
+}
+
+// backward finalize 2: d noise-weight and d bias per channel (sum over images and chunks)
+__global__ void gepi_fin_bwd2(const double* __restrict__ part, float* __restrict__ dnw, float* __restrict__ dbias, int B, int C,
+                              int nchunk) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, d = 0.0;
+    for (int k = 0; k < B * nchunk; ++k) {
+        const double* p = part + ((size_t)k * C + c) * 2;
+        a += p[0]; d += p[1];
+    }
+    dnw[c] = (float)a;
+    if (dbias) dbias[c] = (float)d;
+}
+
+template <typename T>
+__global__ void gepi_apply(const T* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ noise,
+                           const float* __restrict__ nw, const float* __restrict__ style, const float* __restrict__ mean,
+                           const float* __restrict__ rstd, T* __restrict__ y, size_t nvec, int HW, int C) {
+    constexpr int VE = VecTraits<T>::VE;
+    const int cv = C / VE;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cv) * VE;
+        const size_t p = i / cv;
+        const int b = (int)(p / HW);
+        const float nz = noise[p];
+        float v[VE];
+        VecTraits<T>::load(x + i * VE, v);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+            const int c = c0 + j;
+            const float a = lrelu(v[j] + (bias ? bias[c] : 0.f) + nw[c] * nz);
+            const float xh = (a - mean[(size_t)b * C + c]) * rstd[(size_t)b * C + c];
+            v[j] = xh * (style[(size_t)b * 2 * C + c] + 1.f) + style[(size_t)b * 2 * C + C + c];
+        }
+        VecTraits<T>::store(y + i * VE, v);
+    }
+}
+
+template <typename T>
+static int gepi_fwd_t(const void* x, const float* bias, const float* noise, const float* nw, const float* style, void* y,
+                      float* mean, float* rstd, void* ws, int B, int HW, int C, hipStream_t st) {
+    constexpr int VE = VecTraits<T>::VE;
+    GepiGeom g = gepi_geom(HW, C, VE);
+    double* part = static_cast<double*>(ws);
+    hipLaunchKernelGGL((gepi_pass<T, 0>), dim3(g.nchunk, B), dim3(256), 256 * 2 * VE * sizeof(double), st, (const T*)x,
+                       (const T*)nullptr, (T*)nullptr, bias, noise, nw, style, mean, rstd, (const float*)nullptr, part, HW, C,
+                       g.cvt, g.rows, g.chunk);
+    SGX_LAUNCH_CHECK("gepi_stats");
+    hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 255) / 256), dim3(256), 0, st, part, mean, rstd, B, C, g.nchunk, HW);
+    SGX_LAUNCH_CHECK("gepi_fin_stats");
+    const size_t nvec = (size_t)B * HW * C / VE;
+    size_t grid = (nvec + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(gepi_apply<T>, dim3((unsigned)grid), dim3(256), 0, st, (const T*)x, bias, noise, nw, style, mean, rstd,
+                       (T*)y, nvec, HW, C);
+    SGX_LAUNCH_CHECK("gepi_apply");
+    return 0;
+}
+
+template <typename T>
+static int gepi_bwd_t(const void* dy, const void* x, const float* bias, const float* noise, const float* nw,
+                      const float* style, const float* mean, const float* rstd, void* dx, float* dstyle, float* dnw,
+                      float* dbias, void* ws, int B, int HW, int C, hipStream_t st) {
+    constexpr int VE = VecTraits<T>::VE;
+    GepiGeom g = gepi_geom(HW, C, VE);
+    double* partA = static_cast<double*>(ws);
+    double* partB = partA + (size_t)B * g.nchunk * C * 2;
+    float* coef = reinterpret_cast<float*>(partB + (size_t)B * g.nchunk * C * 2);
+    const size_t shb = 256 * 2 * VE * sizeof(double);
+    hipLaunchKernelGGL((gepi_pass<T, 1>), dim3(g.nchunk, B), dim3(256), shb, st, (const T*)x, (const T*)dy, (T*)nullptr, bias,
+                       noise, nw, style, mean, rstd, (const float*)nullptr, partA, HW, C, g.cvt, g.rows, g.chunk);
+    SGX_LAUNCH_CHECK("gepi_bwd1");
+    hipLaunchKernelGGL(gepi_fin_bwd1, dim3((B * C + 255) / 256), dim3(256), 0, st, partA, style, dstyle, coef, B, C, g.nchunk, HW);
+    SGX_LAUNCH_CHECK("gepi_fin_bwd1");
+    hipLaunchKernelGGL((gepi_pass<T, 2>), dim3(g.nchunk, B), dim3(256), shb, st, (const T*)x, (const T*)dy, (T*)dx, bias, noise,
+                       nw, style, mean, rstd, (const float*)coef, partB, HW, C, g.cvt, g.rows, g.chunk);
+    SGX_LAUNCH_CHECK("gepi_bwd2");
+    hipLaunchKernelGGL(gepi_fin_bwd2, dim3((C + 255) / 256), dim3(256), 0, st, partB, dnw, dbias, B, C, g.nchunk);
+    SGX_LAUNCH_CHECK("gepi_fin_bwd2");
+    return 0;
+}
+
+static int gepi_check(int B, int HW, int C, int dtype, size_t ws_bytes) {
+    const int ve = dtype == SGX_F32 ? 4 : 8;
+    SGX_REQUIRE(dtype == SGX_F32 || dtype == SGX_BF16, SGX_EINVAL, "gepi: bad dtype");
+    SGX_REQUIRE(C % ve == 0, SGX_EUNSUPPORTED, "gepi: C=%d", C);
+    const int cv = C / ve;
+    SGX_REQUIRE(cv <= 256 ? (256 % cv == 0) : (cv % 256 == 0), SGX_EUNSUPPORTED, "gepi: C=%d", C);
+    SGX_REQUIRE(ws_bytes >= sgx_gepi_ws_bytes(B, HW, C), SGX_EWORKSPACE, "gepi: workspace %zu < %zu", ws_bytes,
+                sgx_gepi_ws_bytes(B, HW, C));
+    return 0;
+}
+
+extern "C" int sgx_gepi_fwd(const void* x, const float* bias, const float* noise, const float* nw, const float* style, void* y,
+                            float* mean, float* rstd, void* ws, size_t ws_bytes, int B, int HW, int C, int dtype, void* stream) {
+    int rc = gepi_check(B, HW, C, dtype, ws_bytes);
+    if (rc) return rc;
+    if (dtype == SGX_F32) return gepi_fwd_t<float>(x, bias, noise, nw, style, y, mean, rstd, ws, B, HW, C, (hipStream_t)stream);
+    return gepi_fwd_t<bf16_t>(x, bias, noise, nw, style, y, mean, rstd, ws, B, HW, C, (hipStream_t)stream);
+}
+
+extern "C" int sgx_gepi_bwd(const void* dy, const void* x, const float* bias, const float* noise, const float* nw,
+                            const float* style, const float* mean, const float* rstd, void* dx, float* dstyle, float* dnw,
+                            float* dbias, void* ws, size_t ws_bytes, int B, int HW, int C, int dtype, void* stream) {
+    int rc = gepi_check(B, HW, C, dtype, ws_bytes);
+    if (rc) return rc;
+    if (dtype == SGX_F32)
+        return gepi_bwd_t<float>(dy, x, bias, noise, nw, style, mean, rstd, dx, dstyle, dnw, dbias, ws, B, HW, C, (hipStream_t)stream);
+    return gepi_bwd_t<bf16_t>(dy, x, bias, noise, nw, style, mean, rstd, dx, dstyle, dnw, dbias, ws, B, HW, C, (hipStream_t)stream);
+}

@@ -1,0 +1,420 @@
+// HBM-bound pieces of the StyleGAN layers (NHWC): bias/activation, LeakyReLU backward, fade-in lerp, depthwise blur,
+// 2x2 pooling, nearest upsample, per-channel sums, 1x1 RGB convolutions.  One 16-byte vector per lane per access;
+// grid-stride loops capped at 256 CUs x 8 blocks.
+#include "common.h"
+
+static inline unsigned grid_for(size_t nvec, int block = 256) {
+    size_t g = (nvec + block - 1) / block;
+    if (g > 2048 * 4) g = 2048 * 4;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// ---------------------------------------------------------------- y = act(x + bias[c])
+template <typename T>
+__global__ void bias_act_kernel(const T* __restrict__ x, const float* __restrict__ bias, T* __restrict__ y, size_t nvec,
+                                int C, int act) {
+    constexpr int VE = VecTraits<T>::VE;
+    const int cv = C / VE;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        float v[VE];
+        VecTraits<T>::load(x + i * VE, v);
+        const int c0 = (int)(i % cv) * VE;
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+            float t = v[j] + (bias ? bias[c0 + j] : 0.f);
+            v[j] = act == SGX_ACT_LRELU ? lrelu(t) : t;
+        }
+        VecTraits<T>::store(y + i * VE, v);
+    }
+}
+extern "C" int sgx_bias_act(const void* x, const float* bias, void* y, size_t npix, int C, int act, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SGX_F32) {
+        SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "bias_act: C %% 4");
+        size_t nvec = npix * C / 4;
+        hipLaunchKernelGGL(bias_act_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, st, (const float*)x, bias, (float*)y, nvec, C, act);
+    } else {
+        SGX_REQUIRE(C % 8 == 0, SGX_EUNSUPPORTED, "bias_act: C %% 8");
+        size_t nvec = npix * C / 8;
+        hipLaunchKernelGGL(bias_act_kernel<bf16_t>, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)x, bias, (bf16_t*)y, nvec, C, act);
+    }
+    SGX_LAUNCH_CHECK("bias_act");
+    return 0;
+}
+
+// ---------------------------------------------------------------- dx = dy * slope(y)
+template <typename T>
+__global__ void lrelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, size_t nvec) {
+    constexpr int VE = VecTraits<T>::VE;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        float g[VE], a[VE];
+        VecTraits<T>::load(dy + i * VE, g);
+        VecTraits<T>::load(y + i * VE, a);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) g[j] *= lrelu_slope(a[j]);
+        VecTraits<T>::store(dx + i * VE, g);
+    }
+}
+extern "C" int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SGX_F32) {
+        SGX_REQUIRE(n % 4 == 0, SGX_EUNSUPPORTED, "lrelu_bwd: n %% 4");
+        hipLaunchKernelGGL(lrelu_bwd_kernel<float>, dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)dx, n / 4);
+    } else {
+        SGX_REQUIRE(n % 8 == 0, SGX_EUNSUPPORTED, "lrelu_bwd: n %% 8");
+        hipLaunchKernelGGL(lrelu_bwd_kernel<bf16_t>, dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n / 8);
+    }
+    SGX_LAUNCH_CHECK("lrelu_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------- out = alpha*a + beta*b
+template <typename T>
+__global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, float alpha, float beta,
+                             size_t nvec, size_t n) {
+    constexpr int VE = VecTraits<T>::VE;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        if ((i + 1) * VE <= n) {
+            float va[VE], vb[VE];
+            VecTraits<T>::load(a + i * VE, va);
+            if (b) {
+                VecTraits<T>::load(b + i * VE, vb);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) va[j] = alpha * va[j] + beta * vb[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < VE; ++j) va[j] = alpha * va[j];
+            }
+            VecTraits<T>::store(out + i * VE, va);
+        } else {
+            for (size_t k = i * VE; k < n; ++k) {
+                float t = alpha * to_f(a[k]) + (b ? beta * to_f(b[k]) : 0.f);
+                out[k] = from_f<T>(t);
+            }
+        }
+    }
+}
+extern "C" int sgx_axpby(const void* a, const void* b, void* out, float alpha, float beta, size_t n, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return 0;
+    if (dtype == SGX_F32) {
+        size_t nvec = (n + 3) / 4;
+        hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, alpha, beta, nvec, n);
+    } else {
+        size_t nvec = (n + 7) / 8;
+        hipLaunchKernelGGL(axpby_kernel<bf16_t>, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, alpha, beta, nvec, n);
+    }
+    SGX_LAUNCH_CHECK("axpby");
+    return 0;
+}
+
+// ---------------------------------------------------------------- depthwise blur [1,2,1]x[1,2,1]/16, zero pad
+template <typename T>
+__global__ void blur3x3_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+    constexpr int VE = VecTraits<T>::VE;
+    const int cv = C / VE;
+    const size_t nvec = (size_t)B * H * W * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        size_t p = i / cv;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int b = (int)(p / H);
+        float acc[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int hh = h + dy;
+            if ((unsigned)hh >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ww = w + dx;
+                if ((unsigned)ww >= (unsigned)W) continue;
+                const float k = (dy == 0 ? 2.f : 1.f) * (dx == 0 ? 2.f : 1.f) * (1.f / 16.f);
+                float v[VE];
+                VecTraits<T>::load(x + ((((size_t)b * H + hh) * W + ww) * cv + c) * VE, v);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) acc[j] += k * v[j];
+            }
+        }
+        VecTraits<T>::store(y + i * VE, acc);
+    }
+}
+extern "C" int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SGX_F32) {
+        SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "blur: C %% 4");
+        hipLaunchKernelGGL(blur3x3_kernel<float>, dim3(grid_for((size_t)B * H * W * C / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C);
+    } else {
+        SGX_REQUIRE(C % 8 == 0, SGX_EUNSUPPORTED, "blur: C %% 8");
+        hipLaunchKernelGGL(blur3x3_kernel<bf16_t>, dim3(grid_for((size_t)B * H * W * C / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+    }
+    SGX_LAUNCH_CHECK("blur3x3");
+    return 0;
+}
+
+// ---------------------------------------------------------------- 2x2 pooling / nearest upsample.  C generic (RGB has C=3):
+// scalar-per-lane variant used when C is not a multiple of the vector width.
+template <typename T, bool VECT>
+__global__ void pool2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, float scale) {
+    constexpr int VE = VECT ? VecTraits<T>::VE : 1;
+    const int cv = C / VE, OH = H / 2, OW = W / 2;
+    const size_t n = (size_t)B * OH * OW * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        size_t p = i / cv;
+        const int ow = (int)(p % OW); p /= OW;
+        const int oh = (int)(p % OH);
+        const int b = (int)(p / OH);
+        const size_t base = ((((size_t)b * H + 2 * oh) * W + 2 * ow) * cv + c) * VE;
+        if (VECT) {
+            float a0[VecTraits<T>::VE], a1[VecTraits<T>::VE], a2[VecTraits<T>::VE], a3[VecTraits<T>::VE];
+            VecTraits<T>::load(x + base, a0);
+            VecTraits<T>::load(x + base + C, a1);
+            VecTraits<T>::load(x + base + (size_t)W * C, a2);
+            VecTraits<T>::load(x + base + (size_t)W * C + C, a3);
+#pragma unroll
+            for (int j = 0; j < VecTraits<T>::VE; ++j) a0[j] = scale * ((a0[j] + a1[j]) + (a2[j] + a3[j]));
+            VecTraits<T>::store(y + i * VE, a0);
+        } else {
+            float s = (to_f(x[base]) + to_f(x[base + C])) + (to_f(x[base + (size_t)W * C]) + to_f(x[base + (size_t)W * C + C]));
+            y[i] = from_f<T>(scale * s);
+        }
+    }
+}
+extern "C" int sgx_pool2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SGX_REQUIRE(H % 2 == 0 && W % 2 == 0, SGX_EINVAL, "pool2: odd size");
+    const size_t nout = (size_t)B * (H / 2) * (W / 2) * C;
+    if (dtype == SGX_F32) {
+        if (C % 4 == 0) hipLaunchKernelGGL((pool2_kernel<float, true>), dim3(grid_for(nout / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
+        else hipLaunchKernelGGL((pool2_kernel<float, false>), dim3(grid_for(nout)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
+    } else {
+        if (C % 8 == 0) hipLaunchKernelGGL((pool2_kernel<bf16_t, true>), dim3(grid_for(nout / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, scale);
+        else hipLaunchKernelGGL((pool2_kernel<bf16_t, false>), dim3(grid_for(nout)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, scale);
+    }
+    SGX_LAUNCH_CHECK("pool2");
+    return 0;
+}
+
+template <typename T, bool VECT>
+__global__ void up2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, float scale) {
+    constexpr int VE = VECT ? VecTraits<T>::VE : 1;
+    const int cv = C / VE, OH = 2 * H, OW = 2 * W;
+    const size_t n = (size_t)B * OH * OW * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        size_t p = i / cv;
+        const int ow = (int)(p % OW); p /= OW;
+        const int oh = (int)(p % OH);
+        const int b = (int)(p / OH);
+        const size_t src = ((((size_t)b * H + (oh >> 1)) * W + (ow >> 1)) * cv + c) * VE;
+        if (VECT) {
+            float v[VecTraits<T>::VE];
+            VecTraits<T>::load(x + src, v);
+#pragma unroll
+            for (int j = 0; j < VecTraits<T>::VE; ++j) v[j] *= scale;
+            VecTraits<T>::store(y + i * VE, v);
+        } else {
+            y[i] = from_f<T>(scale * to_f(x[src]));
+        }
+    }
+}
+extern "C" int sgx_up2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nout = (size_t)B * H * W * 4 * C;
+    if (dtype == SGX_F32) {
+        if (C % 4 == 0) hipLaunchKernelGGL((up2_kernel<float, true>), dim3(grid_for(nout / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
+        else hipLaunchKernelGGL((up2_kernel<float, false>), dim3(grid_for(nout)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
+    } else {
+        if (C % 8 == 0) hipLaunchKernelGGL((up2_kernel<bf16_t, true>), dim3(grid_for(nout / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, scale);
+        else hipLaunchKernelGGL((up2_kernel<bf16_t, false>), dim3(grid_for(nout)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, scale);
+    }
+    SGX_LAUNCH_CHECK("up2");
+    return 0;
+}
+
+// ---------------------------------------------------------------- out[c] = sum_p x[p][c]
+// stage 1: each block sums a pixel range into ws[block][C] (fp32 per-thread, double across the block);
+// stage 2: one block sums the partials in double.  Deterministic.
+#define COLSUM_BLOCKS 512
+template <typename T>
+__global__ void colsum_stage1(const T* __restrict__ x, double* __restrict__ ws, size_t npix, int C) {
+    // thread t handles channel (t % C') of pixel rows t / C' ... generic scalar layout: C <= 1024
+    extern __shared__ double sh[];
+    const int tpr = C < 256 ? C : 256;                 // threads per pixel row
+    const int rows = 256 / tpr;                        // pixel rows per iteration
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const size_t p0 = (size_t)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
+    for (int cb = 0; cb < C; cb += tpr) {                  // uniform trip count (barriers inside)
+        const int c = cb + tc;
+        double acc = 0.0;
+        if (tr < rows && c < C) {
+            float part = 0.f; int cnt = 0;
+            for (size_t p = p0 + tr; p < p1; p += rows) {
+                part += to_f(x[p * C + c]);
+                if (++cnt == 64) { acc += (double)part; part = 0.f; cnt = 0; }
+            }
+            acc += (double)part;
+        }
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        if (tr == 0 && c < C) {
+            double s = 0.0;
+            for (int r = 0; r < rows; ++r) s += sh[r * tpr + tc];
+            ws[(size_t)blockIdx.x * C + c] = s;
+        }
+        __syncthreads();
+    }
+}
+__global__ void colsum_stage2(const double* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * C + c];
+    out[c] = (float)s;
+}
+extern "C" size_t sgx_colsum_ws_bytes(size_t npix, int C) { (void)npix; return (size_t)COLSUM_BLOCKS * C * sizeof(double); }
+extern "C" int sgx_colsum(const void* x, float* out, void* ws, size_t ws_bytes, size_t npix, int C, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SGX_REQUIRE(ws_bytes >= sgx_colsum_ws_bytes(npix, C), SGX_EWORKSPACE, "colsum: workspace");
+    SGX_REQUIRE(C <= 256 ? (256 % C == 0) : true, SGX_EUNSUPPORTED, "colsum: C=%d", C);
+    int nblk = (int)((npix + 63) / 64);
+    if (nblk > COLSUM_BLOCKS) nblk = COLSUM_BLOCKS;
+    if (nblk < 1) nblk = 1;
+    if (dtype == SGX_F32) hipLaunchKernelGGL(colsum_stage1<float>, dim3(nblk), dim3(256), 256 * sizeof(double), st, (const float*)x, (double*)ws, npix, C);
+    else hipLaunchKernelGGL(colsum_stage1<bf16_t>, dim3(nblk), dim3(256), 256 * sizeof(double), st, (const bf16_t*)x, (double*)ws, npix, C);
+    SGX_LAUNCH_CHECK("colsum_stage1");
+    hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, out, nblk, C);
+    SGX_LAUNCH_CHECK("colsum_stage2");
+    return 0;
+}
+
+// ---------------------------------------------------------------- 1x1 RGB convolutions (3 <-> C), images fp32 [p][3]
+template <typename T>
+__global__ void rgb_in_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                              T* __restrict__ y, size_t npix, int C) {
+    constexpr int VE = VecTraits<T>::VE;
+    const int cv = C / VE;
+    const size_t nvec = npix * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cv;
+        const int c0 = (int)(i % cv) * VE;
+        const float r = img[p * 3], g = img[p * 3 + 1], b = img[p * 3 + 2];
+        float v[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j)
+            v[j] = (bias ? bias[c0 + j] : 0.f) + r * w[c0 + j] + g * w[C + c0 + j] + b * w[2 * C + c0 + j];
+        VecTraits<T>::store(y + i * VE, v);
+    }
+}
+extern "C" int sgx_rgb_in(const float* img, const float* w, const float* bias, void* y, size_t npix, int C, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SGX_F32) {
+        SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "rgb_in: C %% 4");
+        hipLaunchKernelGGL(rgb_in_kernel<float>, dim3(grid_for(npix * C / 4)), dim3(256), 0, st, img, w, bias, (float*)y, npix, C);
+    } else {
+        SGX_REQUIRE(C % 8 == 0, SGX_EUNSUPPORTED, "rgb_in: C %% 8");
+        hipLaunchKernelGGL(rgb_in_kernel<bf16_t>, dim3(grid_for(npix * C / 8)), dim3(256), 0, st, img, w, bias, (bf16_t*)y, npix, C);
+    }
+    SGX_LAUNCH_CHECK("rgb_in");
+    return 0;
+}
+
+// one pixel per group of LPP lanes (LPP = C/VE capped at 16); partial dot products reduced with shuffles
+template <typename T>
+__global__ void rgb_out_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                               float* __restrict__ img, size_t npix, int C, int lpp) {
+    constexpr int VE = VecTraits<T>::VE;
+    const int cv = C / VE;
+    const int sub = threadIdx.x % lpp;
+    const size_t gid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / lpp;
+    const size_t gstride = ((size_t)gridDim.x * blockDim.x) / lpp;
+    const size_t niter = (npix + gstride - 1) / gstride;
+    for (size_t it = 0; it < niter; ++it) {
+        const size_t p = gid + it * gstride;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        if (p < npix) {
+            for (int v = sub; v < cv; v += lpp) {
+                float t[VE];
+                VecTraits<T>::load(x + (p * cv + v) * VE, t);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) {
+                    const int c = v * VE + j;
+                    s0 += t[j] * w[c]; s1 += t[j] * w[C + c]; s2 += t[j] * w[2 * C + c];
+                }
+            }
+        }
+        for (int o = lpp >> 1; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64);
+        }
+        if (p < npix && sub == 0) {
+            img[p * 3] = s0 + (bias ? bias[0] : 0.f);
+            img[p * 3 + 1] = s1 + (bias ? bias[1] : 0.f);
+            img[p * 3 + 2] = s2 + (bias ? bias[2] : 0.f);
+        }
+    }
+}
+extern "C" int sgx_rgb_out(const void* x, const float* w, const float* bias, float* img, size_t npix, int C, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int ve = dtype == SGX_F32 ? 4 : 8;
+    SGX_REQUIRE(C % ve == 0, SGX_EUNSUPPORTED, "rgb_out: C=%d", C);
+    int lpp = C / ve;
+    if (lpp > 16) lpp = 16;
+    SGX_REQUIRE((lpp & (lpp - 1)) == 0, SGX_EUNSUPPORTED, "rgb_out: C=%d", C);
+    const unsigned g = grid_for(npix * lpp);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_out_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, w, bias, img, npix, C, lpp);
+    else hipLaunchKernelGGL(rgb_out_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, w, bias, img, npix, C, lpp);
+    SGX_LAUNCH_CHECK("rgb_out");
+    return 0;
+}
+
+// dw[j][c] = sum_p img[p][j] * f[p][c]: stage 1 partials per block in double, stage 2 sums them.
+template <typename T>
+__global__ void rgb_wgrad_stage1(const float* __restrict__ img, const T* __restrict__ f, double* __restrict__ ws, size_t npix, int C) {
+    extern __shared__ double sh[];                        // [256][3]
+    const int tpr = C < 256 ? C : 256, rows = 256 / tpr;
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const size_t p0 = (size_t)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
+    for (int cb = 0; cb < C; cb += tpr) {
+        const int c = cb + tc;
+        double a0 = 0, a1 = 0, a2 = 0;
+        if (tr < rows && c < C) {
+            float q0 = 0.f, q1 = 0.f, q2 = 0.f; int cnt = 0;
+            for (size_t p = p0 + tr; p < p1; p += rows) {
+                const float v = to_f(f[p * C + c]);
+                q0 += v * img[p * 3]; q1 += v * img[p * 3 + 1]; q2 += v * img[p * 3 + 2];
+                if (++cnt == 64) { a0 += q0; a1 += q1; a2 += q2; q0 = q1 = q2 = 0.f; cnt = 0; }
+            }
+            a0 += q0; a1 += q1; a2 += q2;
+        }
+        sh[threadIdx.x * 3] = a0; sh[threadIdx.x * 3 + 1] = a1; sh[threadIdx.x * 3 + 2] = a2;
+        __syncthreads();
+        if (tr == 0 && c < C) {
+            double s0 = 0, s1 = 0, s2 = 0;
+            for (int r = 0; r < rows; ++r) { s0 += sh[(r * tpr + tc) * 3]; s1 += sh[(r * tpr + tc) * 3 + 1]; s2 += sh[(r * tpr + tc) * 3 + 2]; }
+            double* o = ws + (size_t)blockIdx.x * 3 * C;
+            o[c] = s0; o[C + c] = s1; o[2 * C + c] = s2;
+        }
+        __syncthreads();
+    }
+}
+extern "C" size_t sgx_rgb_wgrad_ws_bytes(size_t npix, int C) { (void)npix; return (size_t)COLSUM_BLOCKS * 3 * C * sizeof(double); }
+extern "C" int sgx_rgb_wgrad(const float* img, const void* f, float* dw, void* ws, size_t ws_bytes, size_t npix, int C, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SGX_REQUIRE(ws_bytes >= sgx_rgb_wgrad_ws_bytes(npix, C), SGX_EWORKSPACE, "rgb_wgrad: workspace");
+    SGX_REQUIRE(C <= 256 ? (256 % C == 0) : true, SGX_EUNSUPPORTED, "rgb_wgrad: C=%d", C);
+    int nblk = (int)((npix + 63) / 64);
+    if (nblk > COLSUM_BLOCKS) nblk = COLSUM_BLOCKS;
+    if (nblk < 1) nblk = 1;
+    if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_wgrad_stage1<float>, dim3(nblk), dim3(256), 768 * sizeof(double), st, img, (const float*)f, (double*)ws, npix, C);
+    else hipLaunchKernelGGL(rgb_wgrad_stage1<bf16_t>, dim3(nblk), dim3(256), 768 * sizeof(double), st, img, (const bf16_t*)f, (double*)ws, npix, C);
+    SGX_LAUNCH_CHECK("rgb_wgrad_stage1");
+    hipLaunchKernelGGL(colsum_stage2, dim3((3 * C + 255) / 256), dim3(256), 0, st, (const double*)ws, dw, nblk, 3 * C);
+    SGX_LAUNCH_CHECK("rgb_wgrad_stage2");
+    return 0;
+}

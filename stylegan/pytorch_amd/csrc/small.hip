@@ -1,0 +1,223 @@
+// Small fp32 pieces: PixelNorm rows, minibatch-stddev (forward / backward / second-order backward for R1),
+// and the MFMA fp32 GEMM behind EqualizedLinear (mapping network, style affine maps, discriminator head).
+#include "common.h"
+
+// ---------------------------------------------------------------- PixelNorm over the feature dim of [B][C]
+__global__ void pixelnorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C) {
+    const int row = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float ss = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = x[(size_t)row * C + c]; ss += v * v; }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / C + 1e-8f);
+    for (int c = lane; c < C; c += 64) y[(size_t)row * C + c] = x[(size_t)row * C + c] * r;
+}
+__global__ void pixelnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int B, int C) {
+    const int row = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = x[(size_t)row * C + c];
+        ss += v * v; dot += v * dy[(size_t)row * C + c];
+    }
+    ss = wave_sum(ss); dot = wave_sum(dot);
+    const float r = rsqrtf(ss / C + 1e-8f);
+    const float k = r * r * r * dot / C;
+    for (int c = lane; c < C; c += 64) dx[(size_t)row * C + c] = dy[(size_t)row * C + c] * r - x[(size_t)row * C + c] * k;
+}
+extern "C" int sgx_pixelnorm_fwd(const float* x, float* y, int B, int C, void* stream) {
+    hipLaunchKernelGGL(pixelnorm_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, B, C);
+    SGX_LAUNCH_CHECK("pixelnorm_fwd");
+    return 0;
+}
+extern "C" int sgx_pixelnorm_bwd(const float* dy, const float* x, float* dx, int B, int C, void* stream) {
+    hipLaunchKernelGGL(pixelnorm_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, dx, B, C);
+    SGX_LAUNCH_CHECK("pixelnorm_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------- minibatch stddev
+// x [B][HW][C], y/dy [B][HW][Cpad].  Group g, slot m: sample g*M+m.  One block per slot m.
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sh[i];
+    return s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mbstd_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int HW, int C, int Cpad) {
+    __shared__ double sh[4];
+    const int G = B < 4 ? B : 4, M = B / G, m = blockIdx.x, n = HW * C;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float v[4], mu = 0.f;
+        for (int g = 0; g < G; ++g) { v[g] = to_f(x[(size_t)(g * M + m) * n + i]); mu += v[g]; }
+        mu /= G;
+        float var = 0.f;
+        for (int g = 0; g < G; ++g) { const float d = v[g] - mu; var += d * d; }
+        acc += (double)sqrtf(var / G + 1e-8f);
+    }
+    const float stat = (float)(block_sum_d(acc, sh) / n);
+    for (int g = 0; g < G; ++g) {
+        const size_t b = (size_t)(g * M + m);
+        for (int i = threadIdx.x; i < HW * Cpad; i += blockDim.x) {
+            const int p = i / Cpad, c = i % Cpad;
+            float v = 0.f;
+            if (c < C) v = to_f(x[(b * HW + p) * C + c]);
+            else if (c == C) v = stat;
+            y[(b * HW + p) * Cpad + c] = from_f<T>(v);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, int B,
+                                                        int HW, int C, int Cpad) {
+    __shared__ double sh[4];
+    const int G = B < 4 ? B : 4, M = B / G, m = blockIdx.x, n = HW * C;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < G * HW; i += blockDim.x) {
+        const int g = i / HW, p = i % HW;
+        acc += (double)to_f(dy[((size_t)(g * M + m) * HW + p) * Cpad + C]);
+    }
+    const float k = (float)(block_sum_d(acc, sh) / n) / G;              // gy / (C*HW*G)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int p = i / C, c = i % C;
+        float v[4], mu = 0.f;
+        for (int g = 0; g < G; ++g) { v[g] = to_f(x[(size_t)(g * M + m) * n + i]); mu += v[g]; }
+        mu /= G;
+        float var = 0.f;
+        for (int g = 0; g < G; ++g) { const float d = v[g] - mu; var += d * d; }
+        const float s = sqrtf(var / G + 1e-8f);
+        for (int g = 0; g < G; ++g) {
+            const size_t b = (size_t)(g * M + m);
+            dx[b * n + i] = from_f<T>(to_f(dy[(b * HW + p) * Cpad + c]) + k * (v[g] - mu) / s);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mbstd_bwd2_kernel(const T* __restrict__ ggx, const T* __restrict__ dy, const T* __restrict__ x,
+                                                         T* __restrict__ ddy, T* __restrict__ gx, int B, int HW, int C, int Cpad) {
+    __shared__ double sh[4];
+    const int G = B < 4 ? B : 4, M = B / G, m = blockIdx.x, n = HW * C;
+    double a_gy = 0.0, a_dd = 0.0;
+    for (int i = threadIdx.x; i < G * HW; i += blockDim.x) {
+        const int g = i / HW, p = i % HW;
+        a_gy += (double)to_f(dy[((size_t)(g * M + m) * HW + p) * Cpad + C]);
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float v[4], mu = 0.f;
+        for (int g = 0; g < G; ++g) { v[g] = to_f(x[(size_t)(g * M + m) * n + i]); mu += v[g]; }
+        mu /= G;
+        float var = 0.f, dot = 0.f;
+        for (int g = 0; g < G; ++g) {
+            const float d = v[g] - mu;
+            var += d * d;
+            dot += d * to_f(ggx[(size_t)(g * M + m) * n + i]);
+        }
+        a_dd += (double)(dot / sqrtf(var / G + 1e-8f));
+    }
+    const float k = (float)(block_sum_d(a_gy, sh) / n) / G;             // gy / (C*HW*G)
+    const float dstat = (float)(block_sum_d(a_dd, sh) / n) / G;         // d L / d gy[m]
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float v[4], gg[4], mu = 0.f;
+        for (int g = 0; g < G; ++g) {
+            v[g] = to_f(x[(size_t)(g * M + m) * n + i]); mu += v[g];
+            gg[g] = to_f(ggx[(size_t)(g * M + m) * n + i]);
+        }
+        mu /= G;
+        float var = 0.f, dot = 0.f;
+        for (int g = 0; g < G; ++g) { const float d = v[g] - mu; var += d * d; dot += d * gg[g]; }
+        const float s = sqrtf(var / G + 1e-8f);
+        float u[4], um = 0.f;
+        for (int g = 0; g < G; ++g) { u[g] = gg[g] / s - dot * (v[g] - mu) / (G * s * s * s); um += u[g]; }
+        um /= G;
+        for (int g = 0; g < G; ++g) gx[(size_t)(g * M + m) * n + i] = from_f<T>(k * (u[g] - um));
+    }
+    for (int g = 0; g < G; ++g) {
+        const size_t b = (size_t)(g * M + m);
+        for (int i = threadIdx.x; i < HW * Cpad; i += blockDim.x) {
+            const int p = i / Cpad, c = i % Cpad;
+            float v = 0.f;
+            if (c < C) v = to_f(ggx[(b * HW + p) * C + c]);
+            else if (c == C) v = dstat;
+            ddy[(b * HW + p) * Cpad + c] = from_f<T>(v);
+        }
+    }
+}
+
+static int mbstd_check(int B, int C, int Cpad) {
+    SGX_REQUIRE(B > 0 && (B < 4 || B % 4 == 0), SGX_EINVAL, "mbstd: batch %d not divisible by group size", B);
+    SGX_REQUIRE(Cpad > C, SGX_EINVAL, "mbstd: Cpad must exceed C");
+    return 0;
+}
+extern "C" int sgx_mbstd_fwd(const void* x, void* y, int B, int HW, int C, int Cpad, int dtype, void* stream) {
+    int rc = mbstd_check(B, C, Cpad); if (rc) return rc;
+    const int M = B / (B < 4 ? B : 4);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_fwd_kernel<float>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, HW, C, Cpad);
+    else hipLaunchKernelGGL(mbstd_fwd_kernel<bf16_t>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, HW, C, Cpad);
+    SGX_LAUNCH_CHECK("mbstd_fwd");
+    return 0;
+}
+extern "C" int sgx_mbstd_bwd(const void* dy, const void* x, void* dx, int B, int HW, int C, int Cpad, int dtype, void* stream) {
+    int rc = mbstd_check(B, C, Cpad); if (rc) return rc;
+    const int M = B / (B < 4 ? B : 4);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_bwd_kernel<float>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, (float*)dx, B, HW, C, Cpad);
+    else hipLaunchKernelGGL(mbstd_bwd_kernel<bf16_t>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, B, HW, C, Cpad);
+    SGX_LAUNCH_CHECK("mbstd_bwd");
+    return 0;
+}
+extern "C" int sgx_mbstd_bwd2(const void* ggx, const void* dy, const void* x, void* ddy, void* gx, int B, int HW, int C, int Cpad,
+                              int dtype, void* stream) {
+    int rc = mbstd_check(B, C, Cpad); if (rc) return rc;
+    const int M = B / (B < 4 ? B : 4);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_bwd2_kernel<float>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)ggx, (const float*)dy, (const float*)x, (float*)ddy, (float*)gx, B, HW, C, Cpad);
+    else hipLaunchKernelGGL(mbstd_bwd2_kernel<bf16_t>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ggx, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)ddy, (bf16_t*)gx, B, HW, C, Cpad);
+    SGX_LAUNCH_CHECK("mbstd_bwd2");
+    return 0;
+}
+
+// ---------------------------------------------------------------- fp32 GEMM on v_mfma_f32_16x16x4_f32
+// C[M][N] = alpha * op(A)[M][K] * op(B)[K][N].  One 16x16 output tile per block; the block's 4 waves split K and
+// reduce through LDS (fixed order: deterministic).  Operand fragments are read straight from global memory: these
+// GEMMs have M = batch (4..64) and are weight-bandwidth/latency bound.
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ Cm,
+                                                       int M, int N, int K, int ta, int tb, float alpha) {
+    __shared__ float red[4][16][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, l15 = lane & 15;
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    const int i = i0 + l15, j = j0 + l15;
+    const int kper = ((K + 3) / 4 + 3) / 4 * 4;                    // K slice per wave, multiple of 4
+    const int kb = wave * kper, ke = (kb + kper < K) ? kb + kper : K;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const size_t sa_i = ta ? 1 : (size_t)K, sa_k = ta ? (size_t)M : 1;
+    const size_t sb_k = tb ? 1 : (size_t)N, sb_j = tb ? (size_t)K : 1;
+    for (int k = kb; k < ke; k += 4) {
+        const int kk = k + q;
+        const float a = (i < M && kk < ke) ? A[i * sa_i + kk * sa_k] : 0.f;
+        const float b = (j < N && kk < ke) ? Bm[kk * sb_k + j * sb_j] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][q * 4 + r][l15] = acc[r];
+    __syncthreads();
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+    if (threadIdx.x < 256 && i0 + r < M && j0 + c < N) {
+        const float s = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
+        Cm[(size_t)(i0 + r) * N + j0 + c] = alpha * s;
+    }
+}
+extern "C" size_t sgx_gemm_ws_bytes(int M, int N, int K) { (void)M; (void)N; (void)K; return 0; }
+extern "C" int sgx_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, int ta, int tb, float alpha, void* ws,
+                            size_t ws_bytes, void* stream) {
+    (void)ws; (void)ws_bytes;
+    SGX_REQUIRE(M > 0 && N > 0 && K > 0, SGX_EINVAL, "gemm: bad shape %d %d %d", M, N, K);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, A, Bm, C, M, N, K, ta, tb, alpha);
+    SGX_LAUNCH_CHECK("gemm_f32");
+    return 0;
+}

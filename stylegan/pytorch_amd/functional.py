@@ -1,0 +1,538 @@
+"""torch.autograd wrappers around the libsgx_hip.so kernels.
+
+Activations inside this module are contiguous NHWC tensors ``[B, H, W, C]`` (fp32 or bf16); the nn.Modules in
+CustomLayers.py / Blocks.py / GAN.py convert at their boundary (a logical-NCHW view with channels_last strides
+is the same memory).  Parameters, statistics, RGB images and parameter gradients are fp32.
+
+Differentiation structure: every discriminator op is closed under differentiation -- the
+backward of each Function is built from other Functions of this file -- so ``create_graph=True`` (the R1 penalty,
+reference models/Losses.py:197-211) works through autograd composition.  Generator-only ops (the fused layer
+epilogue, PixelNorm) are first order.
+"""
+import contextlib
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import native as N
+
+# ---------------------------------------------------------------------------------------------------
+# "data gradient only" mode: inside torch.autograd.grad(logit, image, create_graph=True) (the R1 penalty) only
+# the chain to the image is needed, but a Python Function cannot see which of its input gradients the engine
+# wants.  The flag is process-global (backward runs on autograd worker threads; one process drives one GPU).
+_DATA_GRAD_ONLY = 0
+
+
+@contextlib.contextmanager
+def data_grad_only():
+    global _DATA_GRAD_ONLY
+    _DATA_GRAD_ONLY += 1
+    try:
+        yield
+    finally:
+        _DATA_GRAD_ONLY -= 1
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------
+# convolutions.  geo: 'S' 3x3 stride 1, 'D' 4x4 stride-2 down, 'U' 4x4 stride-2 transposed (up).
+# wp: packed fp32 weight [taps][n][k] (n = output channels, k = input channels).
+ADJOINT = {"S": "S", "D": "U", "U": "D"}
+
+
+def transpose_pack(wp, geo):
+    """Pack of the adjoint (data-gradient) convolution: swap n/k; the 3x3 kernel is also spatially flipped."""
+    if geo == "S":
+        return wp.flip(0).transpose(1, 2).contiguous()
+    return wp.transpose(1, 2).contiguous()
+
+
+def _conv_raw(geo, x, wq, bias, act):
+    B, H, W, Cin = x.shape
+    taps, Cout, K = wq.shape
+    if K != Cin:
+        raise N.SgxError(f"conv: weight expects {K} input channels, activation has {Cin}")
+    L = N.lib()
+    if geo == "S":
+        y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
+        N.check(L.sgx_conv3x3(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv3x3")
+    elif geo == "D":
+        y = torch.empty((B, H // 2, W // 2, Cout), dtype=x.dtype, device=x.device)
+        N.check(L.sgx_conv4x4s2_down(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv4x4s2_down")
+    elif geo == "U":
+        assert bias is None and act == 0
+        y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
+        N.check(L.sgx_conv4x4s2_up(N.ptr(x), N.ptr(wq), N.ptr(y), B, H, W, Cin, Cout, N.dt(x), N.stream()), "sgx_conv4x4s2_up")
+    else:
+        raise ValueError(geo)
+    return y
+
+
+def _wgrad_raw(geo, x, gy):
+    """dwp [taps][n][k] fp32 for y = conv_geo(x, wp)."""
+    L = N.lib()
+    B = x.shape[0]
+    if geo == "S":
+        _, H, W, Ck = x.shape
+        Cn = gy.shape[3]
+        dw = torch.empty((9, Cn, Ck), dtype=torch.float32, device=x.device)
+        ws = N.workspace(L.sgx_wgrad_ws_bytes(9, B, H, W, Ck, Cn), x.device)
+        N.check(L.sgx_wgrad3x3(N.ptr(x), N.ptr(gy), N.ptr(dw), N.ptr(ws), ws.numel(), B, H, W, Ck, Cn, N.dt(x), N.stream()), "sgx_wgrad3x3")
+        return dw
+    fine, coarse = (x, gy) if geo == "D" else (gy, x)
+    _, H, W, Cf = fine.shape
+    Cc = coarse.shape[3]
+    dw = torch.empty((16, Cc, Cf), dtype=torch.float32, device=x.device)
+    ws = N.workspace(L.sgx_wgrad_ws_bytes(16, B, H, W, Cf, Cc), x.device)
+    N.check(L.sgx_wgrad4x4s2(N.ptr(fine), N.ptr(coarse), N.ptr(dw), N.ptr(ws), ws.numel(), B, H, W, Cf, Cc, N.dt(x), N.stream()), "sgx_wgrad4x4s2")
+    if geo == "U":                       # kernel returns [t][coarse=k][fine=n]
+        dw = dw.transpose(1, 2).contiguous()
+    return dw
+
+
+class ConvFn(Function):
+    """y = act(conv_geo(x, wp) + bias).  Twice differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, wp, bias, geo, act):
+        x = _c(x)
+        wq = _c(wp.detach().to(x.dtype))
+        y = _conv_raw(geo, x, wq, None if bias is None else _c(bias.detach()), act)
+        ctx.geo, ctx.act, ctx.has_bias = geo, act, bias is not None
+        ctx.save_for_backward(x, wp, y if act else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wp, y = ctx.saved_tensors
+        gy = _c(gy)
+        if ctx.act:
+            gy = LReluBwdFn.apply(gy, y)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ConvFn.apply(gy, transpose_pack(wp, ctx.geo), None, ADJOINT[ctx.geo], 0)
+        if not _DATA_GRAD_ONLY:
+            if ctx.needs_input_grad[1]:
+                gw = WgradFn.apply(x, gy, ctx.geo)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = ColSumFn.apply(gy)
+        return gx, gw, gb, None, None
+
+
+class WgradFn(Function):
+    """dwp = d<gy, conv_geo(x, wp)>/dwp.  Bilinear in (x, gy): its backward is two convolutions."""
+
+    @staticmethod
+    def forward(ctx, x, gy, geo):
+        x, gy = _c(x), _c(gy)
+        ctx.geo = geo
+        ctx.save_for_backward(x, gy)
+        return _wgrad_raw(geo, x, gy)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, gy = ctx.saved_tensors
+        gx = ggy = None
+        if ctx.needs_input_grad[0]:
+            gx = ConvFn.apply(gy, transpose_pack(ggw, ctx.geo), None, ADJOINT[ctx.geo], 0)
+        if ctx.needs_input_grad[1]:
+            ggy = ConvFn.apply(x, ggw, None, ctx.geo, 0)
+        return gx, ggy, None
+
+
+# ---------------------------------------------------------------------------------------------------
+class LReluBwdFn(Function):
+    """g * (y > 0 ? 1 : 0.2), y = LeakyReLU output.  Linear in g; no second derivative w.r.t. y."""
+
+    @staticmethod
+    def forward(ctx, g, y):
+        g = _c(g)
+        out = torch.empty_like(g)
+        N.check(N.lib().sgx_lrelu_bwd(N.ptr(g), N.ptr(y), N.ptr(out), g.numel(), N.dt(g), N.stream()), "sgx_lrelu_bwd")
+        ctx.save_for_backward(y)
+        return out
+
+    @staticmethod
+    def backward(ctx, gg):
+        (y,) = ctx.saved_tensors
+        return LReluBwdFn.apply(gg, y), None
+
+
+class ColSumFn(Function):
+    """[..., C] -> fp32 [C] (bias gradient)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        C = x.shape[-1]
+        npix = x.numel() // C
+        out = torch.empty((C,), dtype=torch.float32, device=x.device)
+        L = N.lib()
+        ws = N.workspace(L.sgx_colsum_ws_bytes(npix, C), x.device)
+        N.check(L.sgx_colsum(N.ptr(x), N.ptr(out), N.ptr(ws), ws.numel(), npix, C, N.dt(x), N.stream()), "sgx_colsum")
+        ctx.shape, ctx.dtype = x.shape, x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).expand(ctx.shape)
+
+
+class BiasActFn(Function):
+    """y = act(x + bias[c]) on [..., C]."""
+
+    @staticmethod
+    def forward(ctx, x, bias, act):
+        x = _c(x)
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        N.check(N.lib().sgx_bias_act(N.ptr(x), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(y), x.numel() // C, C, act,
+                                     N.dt(x), N.stream()), "sgx_bias_act")
+        ctx.act, ctx.has_bias = act, bias is not None
+        ctx.save_for_backward(y if act else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = _c(g)
+        if ctx.act:
+            g = LReluBwdFn.apply(g, y)
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[1] and not _DATA_GRAD_ONLY:
+            gb = ColSumFn.apply(g)
+        return g, gb, None
+
+
+class ScaleFn(Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        x = _c(x)
+        out = torch.empty_like(x)
+        N.check(N.lib().sgx_axpby(N.ptr(x), None, N.ptr(out), float(s), 0.0, x.numel(), N.dt(x), N.stream()), "sgx_axpby")
+        ctx.s = float(s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return ScaleFn.apply(g, ctx.s), None
+
+
+class AxpbyFn(Function):
+    """alpha*a + beta*b (fade-in lerp)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha, beta):
+        a, b = _c(a), _c(b)
+        assert a.shape == b.shape and a.dtype == b.dtype
+        out = torch.empty_like(a)
+        N.check(N.lib().sgx_axpby(N.ptr(a), N.ptr(b), N.ptr(out), float(alpha), float(beta), a.numel(), N.dt(a), N.stream()), "sgx_axpby")
+        ctx.alpha, ctx.beta = float(alpha), float(beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ga = ScaleFn.apply(g, ctx.alpha) if ctx.needs_input_grad[0] else None
+        gb = ScaleFn.apply(g, ctx.beta) if ctx.needs_input_grad[1] else None
+        return ga, gb, None, None
+
+
+class BlurFn(Function):
+    """Depthwise [1,2,1]x[1,2,1]/16 blur with zero padding; self-adjoint."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        B, H, W, C = x.shape
+        y = torch.empty_like(x)
+        N.check(N.lib().sgx_blur3x3(N.ptr(x), N.ptr(y), B, H, W, C, N.dt(x), N.stream()), "sgx_blur3x3")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return BlurFn.apply(g)
+
+
+class Pool2Fn(Function):
+    """scale * (2x2 block sum); adjoint = scale * nearest-up."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _c(x)
+        B, H, W, C = x.shape
+        y = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+        N.check(N.lib().sgx_pool2(N.ptr(x), N.ptr(y), B, H, W, C, float(scale), N.dt(x), N.stream()), "sgx_pool2")
+        ctx.scale = float(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return Up2Fn.apply(g, ctx.scale), None
+
+
+class Up2Fn(Function):
+    """scale * nearest-neighbour x2; adjoint = scale * (2x2 block sum)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _c(x)
+        B, H, W, C = x.shape
+        y = torch.empty((B, 2 * H, 2 * W, C), dtype=x.dtype, device=x.device)
+        N.check(N.lib().sgx_up2(N.ptr(x), N.ptr(y), B, H, W, C, float(scale), N.dt(x), N.stream()), "sgx_up2")
+        ctx.scale = float(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return Pool2Fn.apply(g, ctx.scale), None
+
+
+# ---------------------------------------------------------------------------------------------------
+# 1x1 RGB convolutions.  Images are fp32 [B,H,W,3]; w3c is fp32 [3][C] (w_mul already applied).
+def _dtype_code(dtype):
+    return N.F32 if dtype == torch.float32 else N.BF16
+
+
+class RgbInFn(Function):
+    """from_rgb: f[p][c] = bias[c] + sum_j img[p][j] * w3c[j][c]."""
+
+    @staticmethod
+    def forward(ctx, img, w3c, bias, out_dtype):
+        img, w = _c(img), _c(w3c.detach())
+        B, H, W, _ = img.shape
+        C = w.shape[1]
+        y = torch.empty((B, H, W, C), dtype=out_dtype, device=img.device)
+        N.check(N.lib().sgx_rgb_in(N.ptr(img), N.ptr(w), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(y), B * H * W, C,
+                                   _dtype_code(out_dtype), N.stream()), "sgx_rgb_in")
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(img, w3c)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        img, w3c = ctx.saved_tensors
+        g = _c(g)
+        gi = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gi = RgbOutFn.apply(g, w3c, None)
+        if not _DATA_GRAD_ONLY:
+            if ctx.needs_input_grad[1]:
+                gw = RgbWgradFn.apply(img, g)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = ColSumFn.apply(g)
+        return gi, gw, gb, None
+
+
+class RgbOutFn(Function):
+    """to_rgb: img[p][j] = bias[j] + sum_c x[p][c] * w3c[j][c]."""
+
+    @staticmethod
+    def forward(ctx, x, w3c, bias):
+        x, w = _c(x), _c(w3c.detach())
+        B, H, W, C = x.shape
+        img = torch.empty((B, H, W, 3), dtype=torch.float32, device=x.device)
+        N.check(N.lib().sgx_rgb_out(N.ptr(x), N.ptr(w), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(img), B * H * W, C,
+                                    N.dt(x), N.stream()), "sgx_rgb_out")
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w3c)
+        return img
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w3c = ctx.saved_tensors
+        g = _c(g)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = RgbInFn.apply(g, w3c, None, x.dtype)
+        if not _DATA_GRAD_ONLY:
+            if ctx.needs_input_grad[1]:
+                gw = RgbWgradFn.apply(g, x)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = g.sum(dim=(0, 1, 2))                     # 3 numbers
+        return gx, gw, gb
+
+
+class RgbWgradFn(Function):
+    """dw3c[j][c] = sum_p img[p][j] * f[p][c]."""
+
+    @staticmethod
+    def forward(ctx, img, f):
+        img, f = _c(img), _c(f)
+        C = f.shape[-1]
+        npix = img.numel() // 3
+        dw = torch.empty((3, C), dtype=torch.float32, device=f.device)
+        L = N.lib()
+        ws = N.workspace(L.sgx_rgb_wgrad_ws_bytes(npix, C), f.device)
+        N.check(L.sgx_rgb_wgrad(N.ptr(img), N.ptr(f), N.ptr(dw), N.ptr(ws), ws.numel(), npix, C, N.dt(f), N.stream()), "sgx_rgb_wgrad")
+        ctx.save_for_backward(img, f)
+        return dw
+
+    @staticmethod
+    def backward(ctx, ggw):
+        img, f = ctx.saved_tensors
+        gi = RgbOutFn.apply(f, ggw, None) if ctx.needs_input_grad[0] else None
+        gf = RgbInFn.apply(img, ggw, None, f.dtype) if ctx.needs_input_grad[1] else None
+        return gi, gf
+
+
+# ---------------------------------------------------------------------------------------------------
+class GEpilogueFn(Function):
+    """noise + LeakyReLU + InstanceNorm + StyleMod (reference LayerEpilogue), conv bias folded in.  First order."""
+
+    @staticmethod
+    def forward(ctx, x, bias, noise, nw, style):
+        x = _c(x)
+        B, H, W, C = x.shape
+        noise = _c(noise.detach().reshape(B, H * W).float())
+        nw_c, style_c = _c(nw.detach().float()), _c(style.detach().float())
+        bias_c = None if bias is None else _c(bias.detach().float())
+        y = torch.empty_like(x)
+        mean = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        L = N.lib()
+        ws = N.workspace(L.sgx_gepi_ws_bytes(B, H * W, C), x.device)
+        N.check(L.sgx_gepi_fwd(N.ptr(x), N.ptr(bias_c), N.ptr(noise), N.ptr(nw_c), N.ptr(style_c), N.ptr(y), N.ptr(mean), N.ptr(rstd),
+                               N.ptr(ws), ws.numel(), B, H * W, C, N.dt(x), N.stream()), "sgx_gepi_fwd")
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, bias_c, noise, nw_c, style_c, mean, rstd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, bias_c, noise, nw_c, style_c, mean, rstd = ctx.saved_tensors
+        gy = _c(gy)
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        dstyle = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)
+        dnw = torch.empty((C,), dtype=torch.float32, device=x.device)
+        dbias = torch.empty((C,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        L = N.lib()
+        ws = N.workspace(L.sgx_gepi_ws_bytes(B, H * W, C), x.device)
+        N.check(L.sgx_gepi_bwd(N.ptr(gy), N.ptr(x), N.ptr(bias_c), N.ptr(noise), N.ptr(nw_c), N.ptr(style_c), N.ptr(mean), N.ptr(rstd),
+                               N.ptr(dx), N.ptr(dstyle), N.ptr(dnw), N.ptr(dbias), N.ptr(ws), ws.numel(), B, H * W, C, N.dt(x),
+                               N.stream()), "sgx_gepi_bwd")
+        return dx, dbias, None, dnw, dstyle
+
+
+class PixelNormFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x.float())
+        y = torch.empty_like(x)
+        N.check(N.lib().sgx_pixelnorm_fwd(N.ptr(x), N.ptr(y), x.shape[0], x.shape[1], N.stream()), "sgx_pixelnorm_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _c(g)
+        dx = torch.empty_like(x)
+        N.check(N.lib().sgx_pixelnorm_bwd(N.ptr(g), N.ptr(x), N.ptr(dx), x.shape[0], x.shape[1], N.stream()), "sgx_pixelnorm_bwd")
+        return dx
+
+
+class MbstdFn(Function):
+    """Minibatch stddev: [B,H,W,C] -> [B,H,W,Cpad] (channel C = group statistic, the rest zero padding)."""
+
+    @staticmethod
+    def forward(ctx, x, cpad):
+        x = _c(x)
+        B, H, W, C = x.shape
+        y = torch.empty((B, H, W, cpad), dtype=x.dtype, device=x.device)
+        N.check(N.lib().sgx_mbstd_fwd(N.ptr(x), N.ptr(y), B, H * W, C, cpad, N.dt(x), N.stream()), "sgx_mbstd_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return MbstdBwdFn.apply(gy, x), None
+
+
+class MbstdBwdFn(Function):
+    @staticmethod
+    def forward(ctx, gy, x):
+        gy = _c(gy)
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        N.check(N.lib().sgx_mbstd_bwd(N.ptr(gy), N.ptr(x), N.ptr(dx), B, H * W, C, gy.shape[3], N.dt(x), N.stream()), "sgx_mbstd_bwd")
+        ctx.save_for_backward(gy, x)
+        return dx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggx):
+        gy, x = ctx.saved_tensors
+        ggx = _c(ggx)
+        B, H, W, C = x.shape
+        ddy = torch.empty_like(gy)
+        gx = torch.empty_like(x)
+        N.check(N.lib().sgx_mbstd_bwd2(N.ptr(ggx), N.ptr(gy), N.ptr(x), N.ptr(ddy), N.ptr(gx), B, H * W, C, gy.shape[3], N.dt(x),
+                                       N.stream()), "sgx_mbstd_bwd2")
+        return ddy, gx
+
+
+class MatMulFn(Function):
+    """C = alpha * op(A) @ op(B), fp32 row-major.  ta/tb as in sgx_gemm_f32.  Closed under differentiation."""
+
+    @staticmethod
+    def forward(ctx, A, Bm, ta, tb, alpha):
+        A, Bm = _c(A), _c(Bm)
+        assert A.dtype == torch.float32 and Bm.dtype == torch.float32
+        M, K = (A.shape[1], A.shape[0]) if ta else (A.shape[0], A.shape[1])
+        K2, Nn = (Bm.shape[1], Bm.shape[0]) if tb else (Bm.shape[0], Bm.shape[1])
+        assert K == K2, (A.shape, Bm.shape, ta, tb)
+        C = torch.empty((M, Nn), dtype=torch.float32, device=A.device)
+        N.check(N.lib().sgx_gemm_f32(N.ptr(A), N.ptr(Bm), N.ptr(C), M, Nn, K, int(ta), int(tb), float(alpha), None, 0, N.stream()), "sgx_gemm_f32")
+        ctx.ta, ctx.tb, ctx.alpha = int(ta), int(tb), float(alpha)
+        ctx.save_for_backward(A, Bm)
+        return C
+
+    @staticmethod
+    def backward(ctx, gC):
+        A, Bm = ctx.saved_tensors
+        ta, tb, al = ctx.ta, ctx.tb, ctx.alpha
+        gA = gB = None
+        if ctx.needs_input_grad[0]:
+            gA = MatMulFn.apply(gC, Bm, 0, 1 - tb, al) if not ta else MatMulFn.apply(Bm, gC, tb, 1, al)
+        if ctx.needs_input_grad[1] and not _DATA_GRAD_ONLY:
+            gB = MatMulFn.apply(A, gC, 1 - ta, 0, al) if not tb else MatMulFn.apply(gC, A, 1, ta, al)
+        return gA, gB, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# functional conveniences used by the modules
+def conv(x, wp, bias=None, geo="S", act=N.ACT_NONE):
+    return ConvFn.apply(x, wp, bias, geo, act)
+
+
+def linear(x, weight, bias, w_mul, b_mul, act=N.ACT_NONE):
+    """EqualizedLinear: F.linear(x, W*w_mul, b*b_mul) (+ LeakyReLU).  x fp32 [B, in]."""
+    y = MatMulFn.apply(x, weight, 0, 1, w_mul)
+    if bias is None and act == N.ACT_NONE:
+        return y
+    b = None if bias is None else (bias * b_mul if b_mul != 1 else bias)
+    if y.shape[1] % 4 != 0:                                   # [B,1] discriminator output: one bias value, no activation
+        assert act == N.ACT_NONE
+        return y + b
+    return BiasActFn.apply(y, b, act)
+
+
+def nhwc(x_nchw, dtype=None):
+    """Logical NCHW tensor (any strides) -> contiguous NHWC."""
+    t = x_nchw.permute(0, 2, 3, 1)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def nchw_view(x_nhwc):
+    """Contiguous NHWC -> logical NCHW view (channels_last strides, zero copy)."""
+    return x_nhwc.permute(0, 3, 1, 2)

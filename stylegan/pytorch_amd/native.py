@@ -1,0 +1,129 @@
+"""ctypes binding of libsgx_hip.so (C ABI: include/sgx.h).
+
+The reference has no FFI -- its seam is the nn.Module surface -- so this file *is* the binding a maintainer
+would add.  Tensors are passed as raw device pointers + sizes; the stream is read from
+``torch.cuda.current_stream()`` at call time (backward runs on autograd worker threads).
+
+There is NO fallback: if the shared library is missing or a tensor is not on a GPU the call raises.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsgx_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_LRELU = 0, 1
+
+_lib = None
+_lock = threading.Lock()
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+P, I, F, Z = c_void_p, c_int, c_float, c_size_t
+
+# name -> (restype, argtypes); mirrors include/sgx.h one to one
+SIGNATURES = {
+    "sgx_version": (I, []),
+    "sgx_last_error": (ctypes.c_char_p, []),
+    "sgx_conv3x3": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+    "sgx_conv4x4s2_down": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+    "sgx_conv4x4s2_up": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "sgx_wgrad_ws_bytes": (Z, [I, I, I, I, I, I]),
+    "sgx_wgrad3x3": (I, [P, P, P, P, Z, I, I, I, I, I, I, P]),
+    "sgx_wgrad4x4s2": (I, [P, P, P, P, Z, I, I, I, I, I, I, P]),
+    "sgx_bias_act": (I, [P, P, P, Z, I, I, I, P]),
+    "sgx_lrelu_bwd": (I, [P, P, P, Z, I, P]),
+    "sgx_axpby": (I, [P, P, P, F, F, Z, I, P]),
+    "sgx_blur3x3": (I, [P, P, I, I, I, I, I, P]),
+    "sgx_pool2": (I, [P, P, I, I, I, I, F, I, P]),
+    "sgx_up2": (I, [P, P, I, I, I, I, F, I, P]),
+    "sgx_colsum_ws_bytes": (Z, [Z, I]),
+    "sgx_colsum": (I, [P, P, P, Z, Z, I, I, P]),
+    "sgx_rgb_in": (I, [P, P, P, P, Z, I, I, P]),
+    "sgx_rgb_out": (I, [P, P, P, P, Z, I, I, P]),
+    "sgx_rgb_wgrad_ws_bytes": (Z, [Z, I]),
+    "sgx_rgb_wgrad": (I, [P, P, P, P, Z, Z, I, I, P]),
+    "sgx_gepi_ws_bytes": (Z, [I, I, I]),
+    "sgx_gepi_fwd": (I, [P, P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),
+    "sgx_gepi_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),
+    "sgx_pixelnorm_fwd": (I, [P, P, I, I, P]),
+    "sgx_pixelnorm_bwd": (I, [P, P, P, I, I, P]),
+    "sgx_mbstd_fwd": (I, [P, P, I, I, I, I, I, P]),
+    "sgx_mbstd_bwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "sgx_mbstd_bwd2": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "sgx_gemm_ws_bytes": (Z, [I, I, I]),
+    "sgx_gemm_f32": (I, [P, P, P, I, I, I, I, I, F, P, Z, P]),
+    "sgx_adam_multi": (I, [P, P, P, P, P, I, F, F, F, P, P, P, P]),
+    "sgx_ema_multi": (I, [P, P, P, I, F, P]),
+    "sgx_gradnorm_clip_coef": (I, [P, P, I, F, P, P, P]),
+}
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the gfx950 kernels in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libsgx_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return LIB_PATH
+
+
+def lib():
+    """Load libsgx_hip.so (after torch, so the HIP runtime torch already loaded is the one it binds to)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                       "(there is no non-HIP fallback for this path)")
+                l = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(l, name)
+                    fn.restype, fn.argtypes = res, args
+                _lib = l
+    return _lib
+
+
+class SgxError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().sgx_last_error().decode(errors="replace")
+        raise SgxError(f"{what} failed (code {rc}): {msg}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SgxError("libsgx_hip kernels need GPU tensors (no CPU fallback exists for this path)")
+    if not t.is_contiguous():
+        raise SgxError("internal: non-contiguous tensor passed to a kernel")
+    return t.data_ptr()
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)

@@ -194,6 +194,76 @@ def step():
     npz("step.npz", **out)
 
 
+# ------------------------------------------------------------------ "mid" fixtures: channel counts the HIP kernels take
+# (multiples of 16), so the GPU path can be checked against reference OUTPUTS directly, not only via the oracle.
+MID = dict(resolution=128, fmap_base=1024, fmap_max=32, mapping_layers=2)
+GM_KW = dict(resolution=128, latent_size=512, mapping_layers=2, blur_filter=[1, 2, 1], truncation_psi=0.7,
+             truncation_cutoff=8, fmap_base=1024, fmap_max=32, structure="linear")
+DM_KW = dict(resolution=128, num_channels=3, use_wscale=True, blur_filter=[1, 2, 1], fmap_base=1024, fmap_max=32,
+             structure="linear")
+
+
+def networks_mid():
+    out = {}
+    B = 4
+    gen = fill_module(Generator(**GM_KW)); dis = fill_module(Discriminator(**DM_KW))
+    gen.train(); dis.train()
+    pin_noise(gen, B)
+    z = gu.seeded((B, 512), 11)
+    gen.style_mixing_prob = None
+    for depth, alpha in [(0, 1), (3, 0.25), (5, 0.6)]:
+        gen.truncation.avg_latent.copy_(gu.fill_value("truncation.avg_latent", (512,)))
+        img = gen(z, depth, alpha)
+        out[f"g_d{depth}_img"] = img.to(torch.float16) if depth == 5 else img       # 128x128: store compactly
+        out[f"g_d{depth}_img_stats"] = np.array(gu.tensor_stats(img))
+        real = gu.seeded((B, 3, 4 * 2 ** depth, 4 * 2 ** depth), 60 + depth)
+        out[f"d_d{depth}_score"] = dis(real, depth, alpha)
+    npz("networks_mid.npz", **out)
+
+
+def step_mid():
+    """Losses and per-tensor gradient norms of one reference iteration (fp32 and fp64) on the mid networks:
+    ||g64||, ||g32 - g64|| per tensor -- the yardstick for the HIP path's gradient error."""
+    out = {}
+    B, depth, alpha = 4, 5, 0.5
+    grads = {}
+    for tag, dtype in [("f32", torch.float32), ("f64", torch.float64)]:
+        torch.manual_seed(0)
+        sg = StyleGAN(structure="linear", resolution=128, num_channels=3, latent_size=512,
+                      g_args={k: v for k, v in GM_KW.items() if k not in ("resolution", "structure")},
+                      d_args={k: v for k, v in DM_KW.items() if k not in ("resolution", "structure", "num_channels")},
+                      g_opt_args=dict(learning_rate=0.003, beta_1=0.0, beta_2=0.99, eps=1e-8),
+                      d_opt_args=dict(learning_rate=0.003, beta_1=0.0, beta_2=0.99, eps=1e-8),
+                      loss="logistic", d_repeats=1, use_ema=True, ema_decay=0.999, device=torch.device("cpu"))
+        if dtype == torch.float64:
+            sg.gen.double(); sg.dis.double(); sg.gen_shadow.double()
+        fill_module(sg.gen, dtype=dtype); fill_module(sg.dis, dtype=dtype)
+        sg.gen_shadow.load_state_dict(sg.gen.state_dict())
+        sg.gen.train(); sg.dis.train(); sg.gen_shadow.train()
+        pin_noise(sg.gen, B, dtype=dtype)
+        z = gu.seeded((B, 512), 21, dtype); real = gu.seeded((B, 3, 128, 128), 22, dtype)
+        _randn = torch.randn
+        if dtype == torch.float64:
+            torch.randn = lambda *a, **k: _randn(*a, **k).double()
+        torch.manual_seed(77); random.seed(77)
+        out[f"{tag}_d_loss"] = sg.optimize_discriminator(z, real, depth, alpha)
+        grads[tag, "d"] = {k: p.grad.clone().double() for k, p in sg.dis.named_parameters() if p.grad is not None}
+        torch.manual_seed(78); random.seed(78)
+        out[f"{tag}_g_loss"] = sg.optimize_generator(z, real, depth, alpha)
+        torch.randn = _randn
+        grads[tag, "g"] = {k: p.grad.clone().double() for k, p in sg.gen.named_parameters() if p.grad is not None}
+    for net in ("d", "g"):
+        names = sorted(grads["f64", net])
+        out[f"{net}_grad_names"] = np.array(names)
+        out[f"{net}_grad_norm64"] = np.array([float(torch.linalg.vector_norm(grads["f64", net][k])) for k in names])
+        out[f"{net}_grad_err32"] = np.array([float(torch.linalg.vector_norm(grads["f32", net][k] - grads["f64", net][k]))
+                                             for k in names])
+        for k in names:
+            if grads["f64", net][k].numel() <= 1024:
+                out[f"{net}_grad64::{k}"] = grads["f64", net][k]
+    npz("step_mid.npz", **out)
+
+
 # ------------------------------------------------------------------ schedule (bit-exact bookkeeping)
 def schedule():
     """Replays the loop bookkeeping of StyleGAN.train (models/GAN.py:730-803) by running the
@@ -271,5 +341,7 @@ if __name__ == "__main__":
     with torch.no_grad():
         layers()
         networks()
+        networks_mid()
     step()
+    step_mid()
     schedule()

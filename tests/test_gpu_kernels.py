@@ -1,0 +1,275 @@
+"""-m gpu: every HIP kernel of libsgx_hip.so, called through the module / autograd surface, against the CPU oracle
+(fp64) on the same seeded inputs.  fp32 bar: rel-L2 <= 1e-3 per tensor (BASELINE north_star); observed ~1e-6."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+import golden_util as gu
+from gpu_util import DEV, assert_close
+from oracle import stylegan_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3          # north_star tolerance, fp32
+TIGHT = 2e-5        # what fp32 MFMA (exact fma chain) actually achieves
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    from stylegan.pytorch_amd import native
+    assert torch.cuda.is_available()
+    native.lib()
+
+
+def conv_module(cin, cout, k=3, **kw):
+    from stylegan.pytorch_amd.CustomLayers import BlurLayer, EqualizedConv2d
+    if kw.pop("blur", False):
+        kw["intermediate"] = BlurLayer([1, 2, 1])
+    m = EqualizedConv2d(cin, cout, k, use_wscale=True, **kw)
+    with torch.no_grad():
+        m.weight.copy_(gu.seeded(m.weight.shape, 5))
+        m.bias.copy_(0.1 * gu.seeded(m.bias.shape, 6))
+    return m.to(DEV)
+
+
+CONV_CASES = [
+    # (mode, cin, cout, B, H)
+    ("plain", 16, 16, 2, 32), ("plain", 32, 64, 3, 16), ("plain", 64, 32, 5, 8), ("plain", 48, 16, 4, 4),
+    ("plain", 16, 32, 1, 64), ("plain", 128, 128, 2, 8),
+    ("up", 32, 16, 2, 8), ("up", 16, 32, 1, 64), ("up", 64, 64, 3, 4), ("up", 32, 32, 2, 16),
+    ("down", 16, 32, 2, 16), ("down", 32, 16, 1, 128), ("down", 64, 64, 5, 8), ("down", 32, 32, 3, 32),
+]
+
+
+@pytest.mark.parametrize("mode,cin,cout,B,H", CONV_CASES)
+def test_conv_forward_backward(mode, cin, cout, B, H):
+    """EqualizedConv2d plain / up (fused + non-fused semantics, with blur) / down: y, dx, dW, db."""
+    m = conv_module(cin, cout, upscale=(mode == "up"), downscale=(mode == "down"), blur=(mode == "up"))
+    x = gu.seeded((B, cin, H, H), 7)
+    xg = x.to(DEV).requires_grad_(True)
+    y = m(xg)
+    w64 = m.weight.detach().double().cpu().requires_grad_(True)
+    b64 = m.bias.detach().double().cpu().requires_grad_(True)
+    x64 = x.double().requires_grad_(True)
+    y64 = O.eq_conv2d(x64, w64, b64, up=(mode == "up"), down=(mode == "down"), blur_after=(mode == "up"))
+    assert_close(y, y64, TIGHT, "y")
+    gy = gu.seeded(y64.shape, 8)
+    y.backward(gy.to(DEV))
+    y64.backward(gy.double())
+    assert_close(xg.grad, x64.grad, TIGHT, "dx")
+    assert_close(m.weight.grad, w64.grad, TIGHT, "dW")
+    assert_close(m.bias.grad, b64.grad, TIGHT, "db")
+
+
+def test_conv_edge_shapes():
+    """Ragged sizes: non-power-of-two spatial extent and batch not filling the per-block image group."""
+    for (B, H, W) in [(1, 4, 4), (3, 12, 20), (7, 8, 8), (2, 24, 40)]:
+        m = conv_module(16, 32)
+        x = gu.seeded((B, 16, H, W), 9)
+        y = m(x.to(DEV))
+        y64 = O.eq_conv2d(x.double(), m.weight.detach().double().cpu(), m.bias.detach().double().cpu())
+        assert_close(y, y64, TIGHT, f"plain {B}x{H}x{W}")
+
+
+def test_conv_final_block_513():
+    """DiscriminatorTop conv: 513 input channels (512 + stddev) handled through the zero-padded channel group."""
+    from stylegan.pytorch_amd.Blocks import DiscriminatorTop
+    top = DiscriminatorTop(4, 1, in_channels=32, intermediate_channels=32, gain=math.sqrt(2), use_wscale=True,
+                           activation_layer=torch.nn.LeakyReLU(0.2)).to(DEV)
+    names = dict(top.named_parameters())
+    with torch.no_grad():
+        for k, p in names.items():
+            p.copy_(gu.fill_value("final_block." + k, p.shape))
+    x = gu.seeded((8, 32, 4, 4), 10)
+    xg = x.to(DEV).requires_grad_(True)
+    out = top(xg)
+    p64 = {"final_block." + k: v.detach().double().cpu().requires_grad_(True) for k, v in names.items()}
+    x64 = x.double().requires_grad_(True)
+    h = O.minibatch_stddev(x64)
+    h = O.leaky_relu(O.eq_conv2d(h, p64["final_block.conv.weight"], p64["final_block.conv.bias"]))
+    h = h.reshape(8, -1)
+    h = O.leaky_relu(O.eq_linear(h, p64["final_block.dense0.weight"], p64["final_block.dense0.bias"], gain=O.SQRT2))
+    ref = O.eq_linear(h, p64["final_block.dense1.weight"], p64["final_block.dense1.bias"], gain=1.0)
+    assert_close(out, ref, TIGHT, "scores")
+    g = gu.seeded((8, 1), 11)
+    out.backward(g.to(DEV)); ref.backward(g.double())
+    assert_close(xg.grad, x64.grad, 1e-4, "dx")
+    for k, p in names.items():
+        assert_close(p.grad, p64["final_block." + k].grad, 1e-4, k)
+
+
+def test_second_order_block():
+    """R1-style double backward through a DiscriminatorBlock (+from_rgb): d/dtheta sum((d out / d img)^2)."""
+    from stylegan.pytorch_amd import functional as F
+    from stylegan.pytorch_amd.Blocks import DiscriminatorBlock
+    from stylegan.pytorch_amd.CustomLayers import EqualizedConv2d
+    act = torch.nn.LeakyReLU(0.2)
+    rgb = EqualizedConv2d(3, 16, 1, gain=math.sqrt(2), use_wscale=True).to(DEV)
+    blk = DiscriminatorBlock(16, 32, gain=math.sqrt(2), use_wscale=True, activation_layer=act, blur_kernel=[1, 2, 1]).to(DEV)
+    params = dict(list({"from_rgb.0." + k: v for k, v in rgb.named_parameters()}.items())
+                  + list({"blocks.0." + k: v for k, v in blk.named_parameters()}.items()))
+    with torch.no_grad():
+        for k, p in params.items():
+            p.copy_(gu.fill_value(k, p.shape))
+    img = gu.seeded((2, 3, 32, 32), 12)
+
+    def ours(img_t):
+        x = rgb.forward_nhwc(F.nhwc(img_t))
+        return F.nchw_view(blk.forward_nhwc(x))
+
+    ig = img.to(DEV).requires_grad_(True)
+    out = ours(ig)
+    wsum = gu.seeded(out.shape, 13)
+    with F.data_grad_only():
+        (g1,) = torch.autograd.grad((out * wsum.to(DEV)).sum(), ig, create_graph=True)
+    pen = (g1 * g1).sum()
+    pen.backward()
+
+    p64 = {k: v.detach().double().cpu().requires_grad_(True) for k, v in params.items()}
+    i64 = img.double().requires_grad_(True)
+    h = O.eq_conv2d(i64, p64["from_rgb.0.weight"], p64["from_rgb.0.bias"])
+    h = O.leaky_relu(O.eq_conv2d(h, p64["blocks.0.conv0.weight"], p64["blocks.0.conv0.bias"]))
+    h = O.blur3(h)
+    o64 = O.leaky_relu(O.eq_conv2d(h, p64["blocks.0.conv1_down.weight"], p64["blocks.0.conv1_down.bias"], down=True))
+    (g64,) = torch.autograd.grad((o64 * wsum.double()).sum(), i64, create_graph=True)
+    pen64 = (g64 * g64).sum()
+    pen64.backward()
+    assert_close(g1, g64, TIGHT, "d out / d img")
+    assert_close(pen, pen64, TIGHT, "penalty")
+    for k, p in params.items():
+        if k.endswith("weight"):
+            assert_close(p.grad, p64[k].grad, 1e-4, "R1 grad " + k)
+
+
+@pytest.mark.parametrize("B,C,H", [(2, 16, 32), (3, 32, 8), (4, 64, 4), (1, 16, 128), (2, 512, 4)])
+def test_layer_epilogue(B, C, H):
+    from stylegan.pytorch_amd.CustomLayers import LayerEpilogue
+    epi = LayerEpilogue(C, 512, True, True, False, True, True, torch.nn.LeakyReLU(0.2)).to(DEV)
+    names = dict(epi.named_parameters())
+    with torch.no_grad():
+        for k, p in names.items():
+            p.copy_(gu.fill_value("epi." + k, p.shape))
+    x = gu.seeded((B, C, H, H), 14); noise = gu.seeded((B, 1, H, H), 15); dl = gu.seeded((B, 512), 16)
+    epi.top_epi.noise.noise = noise.to(DEV)
+    xg = x.to(DEV).requires_grad_(True); dg = dl.to(DEV).requires_grad_(True)
+    y = epi(xg, dg)
+    p64 = {k: v.detach().double().cpu().requires_grad_(True) for k, v in names.items()}
+    x64 = x.double().requires_grad_(True); d64 = dl.double().requires_grad_(True)
+    y64 = O.layer_epilogue(x64, noise.double(), p64["top_epi.noise.weight"], p64["style_mod.lin.weight"],
+                           p64["style_mod.lin.bias"], d64)
+    assert_close(y, y64, TIGHT, "y")
+    gy = gu.seeded(y64.shape, 17)
+    y.backward(gy.to(DEV)); y64.backward(gy.double())
+    assert_close(xg.grad, x64.grad, 2e-4, "dx")
+    assert_close(dg.grad, d64.grad, 2e-4, "d dlatent")
+    for k, p in names.items():
+        assert_close(p.grad, p64[k].grad, 2e-4, k)
+
+
+def test_pointwise_ops():
+    from stylegan.pytorch_amd import functional as F
+    x = gu.seeded((2, 8, 8, 32), 20); y = gu.seeded((2, 8, 8, 32), 21)
+    xd, yd = x.to(DEV), y.to(DEV)
+    assert_close(F.AxpbyFn.apply(xd, yd, 0.3, 0.7), 0.3 * x + 0.7 * y, 1e-6, "axpby")
+    assert_close(F.ScaleFn.apply(xd, 4.0), 4.0 * x, 1e-7, "scale")
+    xn = x.permute(0, 3, 1, 2)
+    assert_close(F.nchw_view(F.BlurFn.apply(xd)), O.blur3(xn.double()), 1e-6, "blur")
+    assert_close(F.nchw_view(F.Pool2Fn.apply(xd, 0.25)), TF.avg_pool2d(xn, 2), 1e-6, "avgpool")
+    assert_close(F.nchw_view(F.Up2Fn.apply(xd, 1.0)), O.upscale2d(xn), 0, "up2")
+    img = gu.seeded((2, 16, 16, 3), 22).to(DEV)                       # RGB images: C = 3 scalar path
+    assert_close(F.nchw_view(F.Pool2Fn.apply(img, 0.25)), TF.avg_pool2d(img.cpu().permute(0, 3, 1, 2), 2), 1e-6, "avgpool rgb")
+    assert_close(F.nchw_view(F.Up2Fn.apply(img, 1.0)), O.upscale2d(img.cpu().permute(0, 3, 1, 2)), 0, "up2 rgb")
+    b = 0.1 * gu.seeded((32,), 23)
+    assert_close(F.BiasActFn.apply(xd, b.to(DEV), 1), TF.leaky_relu(x + b, 0.2), 1e-6, "bias+lrelu")
+    assert_close(F.ColSumFn.apply(xd), x.double().sum(dim=(0, 1, 2)), 1e-6, "colsum")
+    odd = gu.seeded((1037,), 24)                                       # ragged length: vector tail
+    assert_close(F.ScaleFn.apply(odd.to(DEV), -2.0), -2.0 * odd, 1e-7, "scale tail")
+
+
+def test_rgb_convs():
+    from stylegan.pytorch_amd.CustomLayers import EqualizedConv2d
+    for C in (16, 32, 128, 512):
+        fr = EqualizedConv2d(3, C, 1, gain=math.sqrt(2), use_wscale=True).to(DEV)
+        to = EqualizedConv2d(C, 3, 1, gain=1, use_wscale=True).to(DEV)
+        with torch.no_grad():
+            fr.bias.copy_(0.1 * gu.seeded((C,), 30)); to.bias.copy_(0.1 * gu.seeded((3,), 31))
+        img = gu.seeded((2, 3, 8, 8), 32)
+        ig = img.to(DEV).requires_grad_(True)
+        out = to(fr(ig))
+        i64 = img.double().requires_grad_(True)
+        p = [t.detach().double().cpu().requires_grad_(True) for t in (fr.weight, fr.bias, to.weight, to.bias)]
+        ref = O.eq_conv2d(O.eq_conv2d(i64, p[0], p[1]), p[2], p[3], gain=1.0)
+        assert_close(out, ref, TIGHT, "rgb roundtrip")
+        g = gu.seeded(ref.shape, 33)
+        out.backward(g.to(DEV)); ref.backward(g.double())
+        assert_close(ig.grad, i64.grad, TIGHT, "d img")
+        for ours, r in zip((fr.weight, fr.bias, to.weight, to.bias), p):
+            assert_close(ours.grad, r.grad, 1e-4, "rgb param grad")
+
+
+@pytest.mark.parametrize("B", [2, 4, 8, 16])
+def test_minibatch_stddev(B):
+    from stylegan.pytorch_amd.CustomLayers import StddevLayer
+    x = gu.seeded((B, 32, 4, 4), 40)
+    xg = x.to(DEV).requires_grad_(True)
+    y = StddevLayer(4, 1)(xg)
+    x64 = x.double().requires_grad_(True)
+    y64 = O.minibatch_stddev(x64)
+    assert_close(y, y64, 1e-6, "y")
+    # first and second order: L = sum(w * y); g = dL/dx (create_graph); pen = sum(g^2); d pen / dx
+    w = gu.seeded(y64.shape, 41)
+    (g1,) = torch.autograd.grad((y * w.to(DEV)).sum(), xg, create_graph=True)
+    (g64,) = torch.autograd.grad((y64 * w.double()).sum(), x64, create_graph=True)
+    assert_close(g1, g64, 1e-5, "dx")
+    (g1 * g1).sum().backward(); (g64 * g64).sum().backward()
+    assert_close(xg.grad, x64.grad, 1e-4, "second order")
+
+
+def test_mapping_and_linear():
+    from stylegan.pytorch_amd.GAN import GMapping
+    gm = GMapping(512, 512, dlatent_broadcast=None, mapping_layers=3).to(DEV)
+    names = dict(gm.named_parameters())
+    with torch.no_grad():
+        for k, p in names.items():
+            p.copy_(gu.fill_value("g_mapping." + k, p.shape))
+    z = gu.seeded((5, 512), 50)
+    zg = z.to(DEV).requires_grad_(True)
+    w = gm(zg)
+    p64 = {"g_mapping." + k: v.detach().double().cpu().requires_grad_(True) for k, v in names.items()}
+    z64 = z.double().requires_grad_(True)
+    w64 = O.g_mapping(p64, z64, 3)
+    assert_close(w, w64, TIGHT, "w")
+    g = gu.seeded(w64.shape, 51)
+    w.backward(g.to(DEV)); w64.backward(g.double())
+    assert_close(zg.grad, z64.grad, 1e-4, "dz")
+    for k, p in names.items():
+        assert_close(p.grad, p64["g_mapping." + k].grad, 1e-4, k)
+
+
+def test_fused_adam_clip_ema():
+    from stylegan.pytorch_amd.optim import FusedAdam, clip_and_step, ema_update
+    torch.manual_seed(0)
+    shapes = [(7,), (33, 5), (4, 4, 3, 3), (1,), (257, 129)]
+    ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    a = FusedAdam(ps, lr=0.003, betas=(0.0, 0.99), eps=1e-8)
+    b = torch.optim.Adam(qs, lr=0.003, betas=(0.0, 0.99), eps=1e-8)
+    for it in range(3):
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            if it == 0 and i == 1:
+                p.grad = None; q.grad = None                       # inactive parameter: skipped, own step count
+                continue
+            g = torch.randn_like(p) * 20
+            p.grad = g.clone(); q.grad = g.clone()
+        out = clip_and_step(a, 10.0)
+        tot = torch.nn.utils.clip_grad_norm_(qs, 10.0)
+        b.step()
+        assert abs(math.sqrt(float(out[0])) - float(tot)) <= 1e-5 * float(tot)
+        for p, q in zip(ps, qs):
+            assert_close(p, q, 1e-6, f"adam it{it}")
+    m_t = torch.nn.Linear(8, 8).to(DEV); m_s = torch.nn.Linear(8, 8).to(DEV)
+    ref = {k: 0.999 * v.detach().clone() + 0.001 * dict(m_s.named_parameters())[k].detach() for k, v in m_t.named_parameters()}
+    ema_update(m_t, m_s, 0.999)
+    for k, v in m_t.named_parameters():
+        assert_close(v, ref[k], 1e-6, "ema")

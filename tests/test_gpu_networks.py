@@ -1,0 +1,171 @@
+"""-m gpu: whole networks and one full training iteration on the HIP path vs (a) reference outputs committed as
+golden fixtures (tests/golden/*_mid.npz) and (b) the CPU oracle in fp64 on the same weights / noise / seeds.
+Bar (BASELINE north_star): fp32 rel-L2 <= 1e-3 per tensor; gradients are judged against fp64 with the reference's
+own fp32 error as the floor."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from gpu_util import DEV, MID, MID_DEPTH, assert_close, build_mid, load_into, mid_noises, mid_params, pin_noise, rel_err
+from oracle import stylegan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dtype=torch.float64):
+    return torch.from_numpy(np.asarray(a)).to(dtype)
+
+
+@pytest.fixture(scope="module")
+def nets():
+    gp, dp = mid_params(torch.float64)
+    gen, dis = build_mid()
+    load_into(gen, gp); load_into(dis, dp)
+    gen.train(); dis.train()
+    return gp, dp, gen, dis
+
+
+def test_forward_vs_golden_and_oracle(nets, golden_dir):
+    gp, dp, gen, dis = nets
+    g = np.load(os.path.join(golden_dir, "networks_mid.npz"))
+    B = 4
+    noises = mid_noises(B)
+    pin_noise(gen, noises)
+    z = gu.seeded((B, 512), 11)
+    gen.style_mixing_prob = None
+    with torch.no_grad():
+        for depth, alpha in [(0, 1), (3, 0.25), (5, 0.6)]:
+            gen.truncation.avg_latent.copy_(gu.fill_value("truncation.avg_latent", (512,)).to(DEV))
+            img = gen(z.to(DEV), depth, alpha)
+            assert img.shape == (B, 3, 4 * 2 ** depth, 4 * 2 ** depth)
+            gold = T(g[f"g_d{depth}_img"])
+            assert_close(img, gold, 1e-3, f"G depth {depth} vs reference")          # (fp16-stored fixture at depth 5)
+            gp["truncation.avg_latent"] = gu.fill_value("truncation.avg_latent", (512,), torch.float64)
+            ref, _ = O.generator(gp, z.double(), depth, alpha, noises, mapping_layers=MID["mapping_layers"],
+                                 num_layers=2 * MID_DEPTH)
+            assert_close(img, ref, 2e-5, f"G depth {depth} vs oracle fp64")
+            real = gu.seeded((B, 3, 4 * 2 ** depth, 4 * 2 ** depth), 60 + depth)
+            score = dis(real.to(DEV), depth, alpha)
+            assert_close(score, T(g[f"d_d{depth}_score"]), 1e-3, f"D depth {depth} vs reference")
+            assert_close(score, O.discriminator(dp, real.double(), depth, alpha, MID_DEPTH), 2e-5, f"D depth {depth} vs oracle")
+
+
+def test_style_mixing_rng_order(nets):
+    """Seeding python `random` + torch CPU RNG reproduces the reference's mixing draws (models/GAN.py:282-288)."""
+    gp, dp, gen, dis = nets
+    B, depth = 4, 3
+    noises = mid_noises(B)
+    pin_noise(gen, noises)
+    z = gu.seeded((B, 512), 11)
+    gen.style_mixing_prob = 0.9
+    with torch.no_grad():
+        gen.truncation.avg_latent.copy_(gu.fill_value("truncation.avg_latent", (512,)).to(DEV))
+        torch.manual_seed(1234); random.seed(1234)
+        img = gen(z.to(DEV), depth, 0.5)
+        torch.manual_seed(1234); random.seed(1234)
+        l2, cut = O.draw_mixing(z.shape, depth)
+        gp["truncation.avg_latent"] = gu.fill_value("truncation.avg_latent", (512,), torch.float64)
+        ref, avg = O.generator(gp, z.double(), depth, 0.5, noises, mapping_layers=MID["mapping_layers"],
+                               num_layers=2 * MID_DEPTH, latents2=l2.double(), mixing_cutoff=cut)
+    assert_close(img, ref, 2e-5, "mixed image")
+    assert_close(gen.truncation.avg_latent, avg, 1e-6, "avg_latent")
+    gen.style_mixing_prob = None
+
+
+def make_stylegan(act_dtype=torch.float32):
+    from stylegan.pytorch_amd.GAN import StyleGAN
+    kw = dict(learning_rate=0.003, beta_1=0, beta_2=0.99, eps=1e-8)      # int beta_1 as in reference config.py:81
+    sg = StyleGAN(structure="linear", resolution=128, num_channels=3, latent_size=512,
+                  g_args=dict(latent_size=512, mapping_layers=MID["mapping_layers"], blur_filter=[1, 2, 1], truncation_psi=0.7,
+                              truncation_cutoff=8, fmap_base=MID["fmap_base"], fmap_max=MID["fmap_max"]),
+                  d_args=dict(use_wscale=True, blur_filter=[1, 2, 1], fmap_base=MID["fmap_base"], fmap_max=MID["fmap_max"]),
+                  g_opt_args=kw, d_opt_args=kw, loss="logistic", d_repeats=1, use_ema=True, ema_decay=0.999,
+                  device=torch.device(DEV), act_dtype=act_dtype)
+    return sg
+
+
+def test_full_step_vs_oracle_and_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "step_mid.npz"))
+    B, depth, alpha = 4, 5, 0.5
+    sg = make_stylegan()
+    gp, dp = mid_params(torch.float64)
+    load_into(sg.gen, gp); load_into(sg.dis, dp); load_into(sg.gen_shadow, gp)
+    sg.gen.train(); sg.dis.train()
+    noises = mid_noises(B)
+    pin_noise(sg.gen, noises)
+    z = gu.seeded((B, 512), 21); real = gu.seeded((B, 3, 128, 128), 22)
+
+    # ---- HIP path
+    torch.manual_seed(77); random.seed(77)
+    d_loss = sg.optimize_discriminator(z.to(DEV), real.to(DEV), depth, alpha)
+    d_grads = {k: p.grad.detach().clone() for k, p in sg.dis.named_parameters() if p.grad is not None}
+    torch.manual_seed(78); random.seed(78)
+    g_loss = sg.optimize_generator(z.to(DEV), real.to(DEV), depth, alpha)
+    g_grads = {k: p.grad.detach().clone() for k, p in sg.gen.named_parameters() if p.grad is not None}
+
+    # ---- oracle fp64
+    shadow = {k: v.detach().clone() for k, v in gp.items()}
+    kw = dict(total_depth=MID_DEPTH, mapping_layers=MID["mapping_layers"], noises=noises)
+    d_opt, g_opt = O.AdamState(), O.AdamState()
+    torch.manual_seed(77); random.seed(77)
+    l2, cut = O.draw_mixing(z.shape, depth)
+    od_loss, od_grads = O.d_step(gp, dp, d_opt, z.double(), real.double(), depth, alpha, latents2=l2.double(), mixing_cutoff=cut, **kw)
+    torch.manual_seed(78); random.seed(78)
+    l2, cut = O.draw_mixing(z.shape, depth)
+    og_loss, og_grads = O.g_step(gp, dp, g_opt, z.double(), depth, alpha, latents2=l2.double(), mixing_cutoff=cut, shadow=shadow, **kw)
+
+    # losses: vs the reference (fixture) and vs the oracle
+    assert abs(d_loss - float(g["f64_d_loss"])) <= 1e-4 * abs(float(g["f64_d_loss"]))
+    assert abs(g_loss - float(g["f64_g_loss"])) <= 1e-4 * abs(float(g["f64_g_loss"]))
+    assert abs(d_loss - od_loss) <= 1e-4 * abs(od_loss)
+    assert abs(g_loss - og_loss) <= 1e-4 * abs(og_loss)
+
+    # gradients: same active set; error vs fp64 bounded by 1e-3 or 4x the reference's own fp32 error
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(v.double()) for v in g_grads.values()])).item()
+    coef = min(1.0, 10.0 / (total + 1e-6))                       # oracle grads are post-clip, ours pre-clip
+    worst = {}
+    for net, ours, ref, scale in (("d", d_grads, od_grads, 1.0), ("g", g_grads, og_grads, coef)):
+        names = [str(n) for n in g[f"{net}_grad_names"]]
+        assert sorted(ours) == names == sorted(k for k, v in ref.items() if v is not None)
+        norm64 = dict(zip(names, g[f"{net}_grad_norm64"])); err32 = dict(zip(names, g[f"{net}_grad_err32"]))
+        net_scale = max(norm64.values())
+        for k in names:
+            a = ours[k].double().cpu() * scale
+            err = torch.linalg.vector_norm(a - ref[k]).item()
+            tol = max(1e-3 * norm64[k], 4 * err32[k], 1e-7 * net_scale)
+            worst[net + ":" + k] = err / (norm64[k] + 1e-30)
+            assert err <= tol, f"{net} grad {k}: err {err:.3e} > tol {tol:.3e} (|g|={norm64[k]:.3e}, ref fp32 err {err32[k]:.3e})"
+            key = f"{net}_grad64::{k}"
+            if key in g.files:                                     # direct check against the reference's fp64 gradient
+                assert torch.linalg.vector_norm(a - T(g[key])).item() <= tol, key
+    med = float(np.median([v for k, v in worst.items() if "init_block.bias" not in k]))
+    assert med <= 1e-4, med
+
+    # parameters after the Adam steps (lr 0.003, beta1 0: each element moves ~lr*sign(g)) and the EMA shadow
+    for name, mod, ref in (("dis", sg.dis, dp), ("gen", sg.gen, gp), ("shadow", sg.gen_shadow, shadow)):
+        for k, p in mod.named_parameters():
+            d = (p.detach().double().cpu() - ref[k].detach()).abs()
+            frac_bad = float((d > 1e-5 * (1 + ref[k].detach().abs())).double().mean())
+            assert frac_bad <= 2e-3, (name, k, frac_bad)          # sign flips of ~zero gradients only
+    assert_close(sg.gen.truncation.avg_latent, gp["truncation.avg_latent"], 1e-5, "avg_latent")
+
+
+def test_progressive_down_sampling():
+    sg = make_stylegan()
+    real = gu.seeded((4, 3, 128, 128), 70)
+    for depth, alpha in [(0, 0.25), (2, 0.5), (5, 1)]:
+        out = sg.progressive_down_sampling(real.to(DEV), depth, alpha)
+        ref = O.progressive_down_sampling(real.double(), depth, alpha, MID_DEPTH)
+        assert_close(out, ref, 1e-6, f"downsample depth {depth}")
+
+
+def test_fails_loudly_without_gpu_tensors():
+    from stylegan.pytorch_amd import native
+    from stylegan.pytorch_amd.CustomLayers import EqualizedConv2d
+    m = EqualizedConv2d(16, 16, 3, use_wscale=True)
+    with pytest.raises(native.SgxError):
+        m(torch.zeros(1, 16, 8, 8))
