@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: img/s of the full G+D StyleGAN training iteration (optimize_discriminator +
+optimize_generator: logistic loss + R1, both Adam steps, grad clip, EMA) on synthetic data, on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json `metric` / configs[2..3]): FFHQ-1024 model (8 mapping layers, no truncation), progressive
+depth index 8 (1024x1024), batch 4 per GPU, alpha 0.5 (fade-in active: both branches live), bf16 activations with
+fp32 accumulation / parameters.  Random-init weights, synthetic N(0,1) latents and images.
+
+Prints ONE JSON line.  `roofline` is measured live with HIP events around the dominant kernel (kernel
+instantiation with the largest total time) on the launch stream; `cpu_baseline` times the CPU oracle (a port of
+the reference step, oracle/stylegan_oracle.py) on this host's cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: (resolution, mapping_layers, truncation_psi, depth index)
+    "ffhq1024": dict(resolution=1024, mapping_layers=8, truncation_psi=-1.0, depth=8, flops_per_img=1223.27e9),
+    "ffhq128": dict(resolution=128, mapping_layers=4, truncation_psi=0.7, depth=5, flops_per_img=692.85e9),
+}
+PEAK = {"bf16": 2500e12, "fp32": 157.3e12}      # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="ffhq1024", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch-per-gpu", type=int, default=4)
+    ap.add_argument("--alpha", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, batch=2):
+    """One iteration of the CPU oracle (fp32, torch CPU ops on all host cores) at a reduced batch."""
+    import random
+    from oracle import stylegan_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    res, depth = cfg["resolution"], cfg["depth"]
+    total_depth = int(torch.log2(torch.tensor(float(res))).item()) - 1
+    torch.manual_seed(0)
+    gp = O.make_generator_params(res, cfg["mapping_layers"], truncation=cfg["truncation_psi"] > 0)
+    dp = O.make_discriminator_params(res)
+    shadow = {k: v.detach().clone() for k, v in gp.items()}
+    noises = [torch.randn(s) for s in O.noise_shapes(batch, total_depth - 1)]
+    z = torch.randn(batch, 512); real = torch.randn(batch, 3, res, res)
+    kw = dict(total_depth=total_depth, mapping_layers=cfg["mapping_layers"], noises=noises,
+              truncation_psi=cfg["truncation_psi"])
+    random.seed(0)
+    t0 = time.time()
+    l2, cut = O.draw_mixing(z.shape, depth)
+    O.d_step(gp, dp, O.AdamState(), z, real, depth, 0.5, latents2=l2, mixing_cutoff=cut, **kw)
+    l2, cut = O.draw_mixing(z.shape, depth)
+    O.g_step(gp, dp, O.AdamState(), z, depth, 0.5, latents2=l2, mixing_cutoff=cut, shadow=shadow, **kw)
+    dt = time.time() - t0
+    return {"value": batch / dt, "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"1 full G+D iteration, batch {batch}, {res}x{res} depth index {depth}, fp32 torch-CPU oracle "
+                      f"(oracle/stylegan_oracle.py), {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    cfg = CONFIGS[a.config]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE {world} (launch N>1 with torch.distributed.run)"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from stylegan.pytorch_amd import functional as F
+    from stylegan.pytorch_amd import native
+    from stylegan.pytorch_amd.GAN import StyleGAN
+    native.lib()
+    dp = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        from stylegan.pytorch_amd.dist import DataParallelGroup
+        dp = DataParallelGroup()
+
+    act_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)                                    # identical random-init weights on every rank
+    opt = dict(learning_rate=0.003, beta_1=0, beta_2=0.99, eps=1e-8)
+    sg = StyleGAN("linear", cfg["resolution"], 3, 512,
+                  g_args=dict(latent_size=512, mapping_layers=cfg["mapping_layers"], blur_filter=[1, 2, 1],
+                              truncation_psi=cfg["truncation_psi"], truncation_cutoff=8),
+                  d_args=dict(use_wscale=True, blur_filter=[1, 2, 1]),
+                  g_opt_args=opt, d_opt_args=opt, loss="logistic", d_repeats=1, use_ema=True, ema_decay=0.999,
+                  device=dev, act_dtype=act_dtype, data_parallel=dp)
+    sg.gen.train(); sg.dis.train(); sg.gen_shadow.train()
+
+    B, res, depth = a.batch_per_gpu, cfg["resolution"], cfg["depth"]
+    gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
+    ring = 2                                                 # ring of pre-generated synthetic batches, resident in HBM
+    reals = [torch.randn(B, res, res, 3, device=dev, generator=gen).permute(0, 3, 1, 2) for _ in range(ring)]  # NHWC storage
+    lats = [torch.randn(B, 512, device=dev, generator=gen) for _ in range(ring)]
+    import random
+    random.seed(1234)                                        # same mixing cutoffs on every rank
+
+    def step(i):
+        z, x = lats[i % ring], reals[i % ring]
+        sg.optimize_discriminator(z, x, depth, a.alpha)
+        sg.optimize_generator(z, x, depth, a.alpha)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(a.warmup):
+        step(i)
+    if not a.no_kernel_timing:
+        F.KERNEL_TIMES = {}
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roof = None
+    if F.KERNEL_TIMES:
+        agg = {}
+        for name, evs in F.KERNEL_TIMES.items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+            agg[name] = (ms, len(evs), sum(f for _, _, f in evs))
+        F.KERNEL_TIMES = None
+        name, (ms, n, flops) = max(agg.items(), key=lambda kv: kv[1][0])
+        achieved = flops / (ms * 1e-3) / 1e12
+        peak = PEAK[a.dtype] / 1e12
+        roof = {"bound": "mfma", "kernel": name, "launches": n, "avg_us": ms * 1e3 / n, "achieved": achieved, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "all_kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]}}
+
+    if rank == 0:
+        imgs = B * world * a.steps
+        value = imgs / dt
+        out = {"metric": "img/s full G+D train step, 1024x1024 depth-9 bf16" if a.config == "ffhq1024" and a.dtype == "bf16"
+               else f"img/s full G+D train step, {a.config} {a.dtype}",
+               "value": value, "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": f"{a.config}: StyleGAN {res}x{res}, progressive depth index {depth}, logistic+R1, "
+                                      f"alpha {a.alpha}, batch {B}/GPU, global batch {B * world}",
+                          "global_batch": B * world, "parallelism": f"dp{world}"},
+               "useful_tflops": value * cfg["flops_per_img"] / 1e12,
+               "mfma_frac_of_step": value * cfg["flops_per_img"] / (PEAK[a.dtype] * world)}
+        if roof:
+            out["roofline"] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg)
+            except Exception as e:                           # never lose the GPU number to a host-side problem
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -310,6 +310,11 @@ class StyleGAN:
     # name-mangled alias so code written against the reference's private helper keeps working
     _StyleGAN__progressive_down_sampling = progressive_down_sampling
 
+    def _sync_w_avg(self):
+        """Data parallel: the W moving average follows GLOBAL sample 0 = rank 0's local sample 0 (GAN.py:278)."""
+        if self.dp is not None and self.gen.truncation is not None:
+            self.dp.broadcast(self.gen.truncation.avg_latent, src=0)
+
     def optimize_discriminator(self, noise, real_batch, depth, alpha, labels=None):
         """One discriminator update -- reference models/GAN.py:591-622."""
         real_samples = self.progressive_down_sampling(real_batch, depth, alpha)
@@ -317,6 +322,7 @@ class StyleGAN:
         for _ in range(self.d_repeats):
             with torch.no_grad():                     # the reference builds and drops this graph (.detach(), :607)
                 fake_samples = self.gen(noise, depth, alpha, labels)
+            self._sync_w_avg()
             loss = self.loss.dis_loss(real_samples, fake_samples, depth, alpha)
             self.dis_optim.zero_grad()
             loss.backward()
@@ -332,6 +338,7 @@ class StyleGAN:
         if not isinstance(self.loss, (Losses.LogisticGAN, Losses.HingeGAN)):
             real_samples = self.progressive_down_sampling(real_batch, depth, alpha)   # only the relativistic loss reads it
         fake_samples = self.gen(noise, depth, alpha, labels)
+        self._sync_w_avg()
         # the reference also back-propagates into D's parameters here and discards the result at the next
         # dis_optim.zero_grad(); skipping those weight gradients changes no observable value
         d_params = [p for p in self.dis.parameters() if p.requires_grad]

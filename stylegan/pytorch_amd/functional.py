@@ -51,12 +51,76 @@ def transpose_pack(wp, geo):
     return wp.transpose(1, 2).contiguous()
 
 
+# ---------------------------------------------------------------------------------------------------
+# optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  KERNEL_TIMES maps
+# the kernel instantiation name (as rocprofv3 prints it) to a list of (start_event, end_event, flops).
+KERNEL_TIMES = None
+
+
+def conv_kernel_name(geo, H, W, Cin, Cout, dtype):
+    """Mirror of dispatch_conv() in csrc/conv.hip: the template instantiation a launch resolves to."""
+    f32 = dtype == torch.float32
+    kc = 16 if f32 else (32 if Cin % 32 == 0 else 16)
+    g = {"S": 0, "D": 1, "U": 2}[geo]
+    bp = 128 if geo == "D" else 256
+    oh, ow = (H // 2, W // 2) if geo == "D" else (H, W)
+    if oh >= 16 and ow >= 16:
+        th, tw = bp // 16, 16
+    elif oh >= 8 and ow >= 8:
+        th, tw = 8, 8
+    else:
+        th, tw = 4, 4
+    max_ct = 2 if geo == "D" else 4
+    ct = 4 if (max_ct >= 4 and Cout % 64 == 0) else (2 if (max_ct >= 2 and Cout % 32 == 0) else 1)
+    return f"void conv_kernel<{'float' if f32 else 'unsigned short'}, {kc}, {g}, {th}, {tw}, {bp}, {ct}>(ConvArgs)"
+
+
+def wgrad_kernel_name(geo, Hn, Wn, Ck, Cn, dtype):
+    """Mirror of wgrad_ch()/wgrad_tile() in csrc/conv.hip.  geo 'S' or 'D' (4x4 stride 2, n side = coarse grid)."""
+    f32 = dtype == torch.float32
+    g = 0 if geo == "S" else 1
+    bp = 128 if geo == "S" else 64
+    if Hn >= 16 and Wn >= 16:
+        th, tw = bp // 16, 16
+    elif Hn >= 8 and Wn >= 8:
+        th, tw = (8 if bp >= 64 else bp // 8), 8
+    else:
+        th, tw = (4 if bp >= 16 else bp // 4), 4
+    nsub = 2 if Cn % 32 == 0 else 1
+    ksub = 1 if geo == "D" else (2 if Ck % 32 == 0 else 1)
+    return f"void wgrad_kernel<{'float' if f32 else 'unsigned short'}, {g}, {th}, {tw}, {bp}, {nsub}, {ksub}>(WgradArgs)"
+
+
+class _Timed:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if KERNEL_TIMES is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if KERNEL_TIMES is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            KERNEL_TIMES.setdefault(self.name, []).append((self.e0, e1, self.flops))
+
+
 def _conv_raw(geo, x, wq, bias, act):
     B, H, W, Cin = x.shape
     taps, Cout, K = wq.shape
     if K != Cin:
         raise N.SgxError(f"conv: weight expects {K} input channels, activation has {Cin}")
     L = N.lib()
+    if KERNEL_TIMES is not None:
+        npix = B * H * W * (1 if geo == "S" else (0.25 if geo == "D" else 1.0))   # class-grid pixels x taps below
+        with _Timed(conv_kernel_name(geo, H, W, Cin, Cout, x.dtype), 2.0 * taps * Cin * Cout * npix):
+            return _conv_launch(L, geo, x, wq, bias, act, B, H, W, Cin, Cout)
+    return _conv_launch(L, geo, x, wq, bias, act, B, H, W, Cin, Cout)
+
+
+def _conv_launch(L, geo, x, wq, bias, act, B, H, W, Cin, Cout):
     if geo == "S":
         y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
         N.check(L.sgx_conv3x3(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv3x3")
@@ -81,14 +145,16 @@ def _wgrad_raw(geo, x, gy):
         Cn = gy.shape[3]
         dw = torch.empty((9, Cn, Ck), dtype=torch.float32, device=x.device)
         ws = N.workspace(L.sgx_wgrad_ws_bytes(9, B, H, W, Ck, Cn), x.device)
-        N.check(L.sgx_wgrad3x3(N.ptr(x), N.ptr(gy), N.ptr(dw), N.ptr(ws), ws.numel(), B, H, W, Ck, Cn, N.dt(x), N.stream()), "sgx_wgrad3x3")
+        with _Timed(wgrad_kernel_name("S", H, W, Ck, Cn, x.dtype), 2.0 * 9 * Ck * Cn * B * H * W):
+            N.check(L.sgx_wgrad3x3(N.ptr(x), N.ptr(gy), N.ptr(dw), N.ptr(ws), ws.numel(), B, H, W, Ck, Cn, N.dt(x), N.stream()), "sgx_wgrad3x3")
         return dw
     fine, coarse = (x, gy) if geo == "D" else (gy, x)
     _, H, W, Cf = fine.shape
     Cc = coarse.shape[3]
     dw = torch.empty((16, Cc, Cf), dtype=torch.float32, device=x.device)
     ws = N.workspace(L.sgx_wgrad_ws_bytes(16, B, H, W, Cf, Cc), x.device)
-    N.check(L.sgx_wgrad4x4s2(N.ptr(fine), N.ptr(coarse), N.ptr(dw), N.ptr(ws), ws.numel(), B, H, W, Cf, Cc, N.dt(x), N.stream()), "sgx_wgrad4x4s2")
+    with _Timed(wgrad_kernel_name("D", H // 2, W // 2, Cf, Cc, x.dtype), 2.0 * 16 * Cf * Cc * B * (H // 2) * (W // 2)):
+        N.check(L.sgx_wgrad4x4s2(N.ptr(fine), N.ptr(coarse), N.ptr(dw), N.ptr(ws), ws.numel(), B, H, W, Cf, Cc, N.dt(x), N.stream()), "sgx_wgrad4x4s2")
     if geo == "U":                       # kernel returns [t][coarse=k][fine=n]
         dw = dw.transpose(1, 2).contiguous()
     return dw
