@@ -42,15 +42,33 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=4)
     ap.add_argument("--alpha", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-timeout", type=float, default=150.0)
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, batch=2):
-    """One iteration of the CPU oracle (fp32, torch CPU ops on all host cores) at a reduced batch."""
+def cpu_baseline_subprocess(config, timeout_s):
+    """Run the CPU-oracle leg in a child process with a hard time limit, so a slow host cannot eat the run."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--config", config]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "error": (r.stderr or r.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": f"CPU oracle leg exceeded {timeout_s} s on this host; see BASELINE.md section 2 for "
+                                         "the reference's own CPU numbers"}
+
+
+def cpu_baseline(cfg, batch=1):
+    """One iteration of the CPU oracle (fp32, torch CPU ops) at a reduced batch.  Threads are capped: the step is
+    thousands of small ATen ops, and a 256-thread fork/join per op is slower than 16 threads."""
     import random
     from oracle import stylegan_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     res, depth = cfg["resolution"], cfg["depth"]
     total_depth = int(torch.log2(torch.tensor(float(res))).item()) - 1
@@ -77,6 +95,9 @@ def cpu_baseline(cfg, batch=2):
 def main():
     a = parse()
     cfg = CONFIGS[a.config]
+    if a.cpu_baseline_child:
+        print(json.dumps(cpu_baseline(cfg)))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -170,10 +191,7 @@ def main():
         if roof:
             out["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(cfg)
-            except Exception as e:                           # never lose the GPU number to a host-side problem
-                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+            out["cpu_baseline"] = cpu_baseline_subprocess(a.config, a.cpu_baseline_timeout)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

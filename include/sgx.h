@@ -50,19 +50,35 @@ int sgx_conv4x4s2_down(const void* x, const void* w, const float* bias, void* y,
  *   y[b,iy,ix,n] = sum over (oy,ky),(ox,kx) with 2oy+ky-1=iy, 2ox+kx-1=ix of x[b,oy,ox,k] * w[ky*4+kx][n][k]      */
 int sgx_conv4x4s2_up(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int dtype,
                      void* stream);
-/* weight gradients (fp32 out, same [tap][n][k] pack as the forward weight):
- *   sgx_wgrad3x3:   dw[t][n][k]        = sum_{b,h,w} dy[b,h,w,n] * x[b,h+ty-1,w+tx-1,k]
- *   sgx_wgrad4x4s2: dw[ky*4+kx][n][k]  = sum_{b,oy,ox} coarse[b,oy,ox,n] * fine[b,2oy+ky-1,2ox+kx-1,k]   (H,W = fine size)
- * (autograd of F.conv2d / F.conv_transpose2d w.r.t. weight in the reference)                                      */
+/* sgx_pack_weight: runtime weight scaling + operand packing (`self.weight * self.w_mul` and the 3x3 -> 4x4 kernel
+ * synthesis of models/CustomLayers.py:146-150,159-162) in one launch.  w: parameter [O][I][3][3] fp32.
+ * Writes BOTH operand packs of the layer in the activation dtype: fwd[taps][O][Ipad] (the layer's convolution) and
+ * adj[taps][Ipad][O] (its data gradient; 3x3 taps reversed).  Ipad >= I zero-pads the input-channel axis.
+ *   S : scale*w                      -> sgx_conv3x3 / adj: sgx_conv3x3
+ *   D : 0.25*scale*sum4shifts(w)     -> sgx_conv4x4s2_down / adj: sgx_conv4x4s2_up
+ *   U : scale*sum4shifts(w)          -> sgx_conv4x4s2_up / adj: sgx_conv4x4s2_down    (fused upscale, input >= 64)
+ *   UF: as U on the spatially flipped kernel (== nearest-up -> conv3x3 of the non-fused branch)       */
+enum { SGX_PACK_S = 0, SGX_PACK_D = 1, SGX_PACK_U = 2, SGX_PACK_UF = 3 };
+int sgx_pack_weight(const float* w, void* fwd, void* adj, int O, int I, int Ipad, int mode, float scale, int dtype,
+                    void* stream);
+/* weight gradients in the PARAMETER layout dW[O][I][3][3] (fp32): MFMA pixel-reduction into split partials (ws), then
+ * one finishing kernel that sums the splits and applies the adjoint of sgx_pack_weight (autograd of F.conv2d /
+ * F.conv_transpose2d w.r.t. weight composed with the reference's weight arithmetic).
+ *   sgx_wgrad3x3_param : y = conv3x3(x, pack_S(w)):  x has Cx channels, dy has Cdy.  adjoint=1: the launch was the
+ *                        layer's DATA-GRADIENT convolution (x: O channels, dy: Ipad channels) -- second-order path (R1).
+ *   sgx_wgrad4x4s2_param: fine/coarse = the stride-2 pair's high/low resolution tensors (H,W = fine size);
+ *                        mode D: coarse has O channels, fine has I;  mode U/UF: coarse has I, fine has O.             */
 size_t sgx_wgrad_ws_bytes(int taps, int B, int H, int W, int Ck, int Cn);
-int sgx_wgrad3x3(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, int B, int H, int W, int Cin,
-                 int Cout, int dtype, void* stream);
-int sgx_wgrad4x4s2(const void* fine, const void* coarse, float* dw, void* ws, size_t ws_bytes, int B, int H, int W,
-                   int Cfine, int Ccoarse, int dtype, void* stream);
+int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, void* ws, size_t ws_bytes, int B, int H, int W, int Cx,
+                       int Cdy, int adjoint, float scale, int O, int I, int dtype, void* stream);
+int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float* dW, void* ws, size_t ws_bytes, int B, int H, int W,
+                         int Cfine, int Ccoarse, int mode, float scale, int O, int I, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- memory-bound layer pieces
- * y = act(x + bias[c])                      bias after blur / avgpool: models/CustomLayers.py:178-179; Blocks.py:142,146 */
-int sgx_bias_act(const void* x, const float* bias, void* y, size_t npix, int C, int act, int dtype, void* stream);
+ * y = act(x + bscale*bias[c])               bias after blur / avgpool: models/CustomLayers.py:178-179; Blocks.py:142,146
+ *   bscale = the layer's b_mul (lrmul; 0.01 in the mapping network, models/CustomLayers.py:94-95,101-102)           */
+int sgx_bias_act(const void* x, const float* bias, float bscale, void* y, size_t npix, int C, int act, int dtype,
+                 void* stream);
 /* dx = dy * (y > 0 ? 1 : 0.2)               autograd of nn.LeakyReLU(0.2); y is the activation OUTPUT               */
 int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, int dtype, void* stream);
 /* out = alpha*a + beta*b (b may be NULL)    fade-in lerp: models/GAN.py:202,427,586                                 */
@@ -73,19 +89,24 @@ int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, v
 int sgx_pool2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream);
 /* y = scale * nearest_up2(x)    Upscale2d CustomLayers.py:27-36; F.interpolate(scale_factor=2) models/GAN.py:173     */
 int sgx_up2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream);
-/* out[c] = sum_p x[p][c]  (fp32 out)        bias gradient                                                            */
+/* out[c] = scale * sum_p x[p][c]  (fp32 out)        bias gradient                                                    */
 size_t sgx_colsum_ws_bytes(size_t npix, int C);
-int sgx_colsum(const void* x, float* out, void* ws, size_t ws_bytes, size_t npix, int C, int dtype, void* stream);
+int sgx_colsum(const void* x, float* out, float scale, void* ws, size_t ws_bytes, size_t npix, int C, int dtype,
+               void* stream);
 
-/* 1x1 RGB convolutions; images are fp32 [p][3]; w is fp32 [3][C] (already multiplied by w_mul)
- *   sgx_rgb_in : y[p][c] = bias[c] + sum_j img[p][j]*w[j][c]      from_rgb: models/GAN.py:358-359,377-378,425-426
- *   sgx_rgb_out: img[p][j] = bias[j] + sum_c x[p][c]*w[j][c]      to_rgb:   models/GAN.py:157,167,199-200
- *   sgx_rgb_wgrad: dw[j][c] = sum_p img[p][j]*f[p][c]                                                               */
-int sgx_rgb_in(const float* img, const float* w, const float* bias, void* y, size_t npix, int C, int dtype, void* stream);
-int sgx_rgb_out(const void* x, const float* w, const float* bias, float* img, size_t npix, int C, int dtype, void* stream);
+/* 1x1 RGB convolutions; images are fp32 [p][3].  The weight is read IN PLACE from the parameter: element (j = rgb
+ * channel, c = feature channel) is w[j*sj + c*sc] * wscale (wscale = w_mul); from_rgb parameters are [C][3][1][1]
+ * (sj=1, sc=3), to_rgb parameters are [3][C][1][1] (sj=C, sc=1).
+ *   sgx_rgb_in : y[p][c] = bias[c] + sum_j img[p][j]*W(j,c)      from_rgb: models/GAN.py:358-359,377-378,425-426
+ *   sgx_rgb_out: img[p][j] = bias[j] + sum_c x[p][c]*W(j,c)      to_rgb:   models/GAN.py:157,167,199-200
+ *   sgx_rgb_wgrad: dw[j*sj + c*sc] = wscale * sum_p img[p][j]*f[p][c]   (gradient in the parameter layout)          */
+int sgx_rgb_in(const float* img, const float* w, int sj, int sc, float wscale, const float* bias, void* y, size_t npix,
+               int C, int dtype, void* stream);
+int sgx_rgb_out(const void* x, const float* w, int sj, int sc, float wscale, const float* bias, float* img, size_t npix,
+                int C, int dtype, void* stream);
 size_t sgx_rgb_wgrad_ws_bytes(size_t npix, int C);
-int sgx_rgb_wgrad(const float* img, const void* f, float* dw, void* ws, size_t ws_bytes, size_t npix, int C, int dtype,
-                  void* stream);
+int sgx_rgb_wgrad(const float* img, const void* f, float* dw, int sj, int sc, float wscale, void* ws, size_t ws_bytes,
+                  size_t npix, int C, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- generator layer epilogue
  * LayerEpilogue (models/CustomLayers.py:219-248) = NoiseLayer (:191-200) -> LeakyReLU -> nn.InstanceNorm2d (:233,

@@ -104,11 +104,9 @@ class DiscriminatorTop(nn.Module):
         if self.stddev_layer is not None:
             x = self.stddev_layer.forward_nhwc(x)
         x = self.conv.forward_nhwc(x, act=ACT_LRELU)                      # [B,4,4,C]
-        b, h, w, c = x.shape
-        flat = x.reshape(b, h * w * c).float()
-        # the reference flattens NCHW (View(-1), index c*16+h*4+w); permute dense0's K axis to the NHWC order instead
-        w0 = self.dense0.weight.view(-1, c, h * w).transpose(1, 2).reshape(-1, h * w * c)
-        y = self.dense0(flat, act=ACT_LRELU, weight=w0)
+        b = x.shape[0]
+        flat = x.permute(0, 3, 1, 2).reshape(b, -1).float()               # View(-1) flattens NCHW (index c*16+h*4+w)
+        y = self.dense0(flat, act=ACT_LRELU)
         return self.dense1(y)
 
     def forward(self, x):

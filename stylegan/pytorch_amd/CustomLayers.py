@@ -9,7 +9,6 @@ import math
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as TF
 
 from . import functional as F
 from .native import ACT_LRELU, ACT_NONE
@@ -170,66 +169,43 @@ class EqualizedConv2d(nn.Module):
         self.intermediate = intermediate
         assert stride == 1
 
-    # ---- packed weights [taps][n][k], fp32, differentiable w.r.t. self.weight (tiny tensors: torch ops)
     def scaled_bias(self):
+        """The bias as the kernels consume it (b_mul is 1 for every convolution of the networks)."""
         if self.bias is None:
             return None
         return self.bias * self.b_mul if self.b_mul != 1 else self.bias
 
-    def pack_plain(self, pad_in_to=None):
-        w = self.weight * self.w_mul                                     # [O, I, 3, 3]
-        if pad_in_to is not None and pad_in_to > w.shape[1]:
-            w = TF.pad(w, [0, 0, 0, 0, 0, pad_in_to - w.shape[1]])
-        return w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).contiguous()
-
-    def pack_down(self):
-        w = TF.pad(self.weight * self.w_mul, [1, 1, 1, 1])                # reference :159-162
-        w = (w[:, :, 1:, 1:] + w[:, :, :-1, 1:] + w[:, :, 1:, :-1] + w[:, :, :-1, :-1]) * 0.25
-        return w.permute(2, 3, 0, 1).reshape(16, w.shape[0], w.shape[1]).contiguous()
-
-    def pack_up(self, fused_semantics):
-        w = self.weight * self.w_mul
-        if not fused_semantics:
-            w = w.flip(2, 3)                                             # nearest-up -> conv3x3 == fused form of the flipped kernel
-        w = TF.pad(w.permute(1, 0, 2, 3), [1, 1, 1, 1])                   # reference :146-150  -> [I, O, 4, 4]
-        w = w[:, :, 1:, 1:] + w[:, :, :-1, 1:] + w[:, :, 1:, :-1] + w[:, :, :-1, :-1]
-        return w.permute(2, 3, 1, 0).reshape(16, w.shape[1], w.shape[0]).contiguous()
-
-    def rgb_weight(self):
-        """[3][C] fp32 for the 1x1 RGB convolutions."""
-        w = (self.weight * self.w_mul)[:, :, 0, 0]
-        return w.t().contiguous() if w.shape[1] == 3 else w.contiguous()
-
     def forward_nhwc(self, x, act=ACT_NONE, skip_bias=False, out_dtype=None):
-        """x: NHWC.  ``skip_bias``: the caller folds the bias into the next kernel (generator epilogue)."""
+        """x: NHWC.  ``skip_bias``: the caller folds the bias into the next kernel (generator epilogue).
+        The parameter is consumed in place: w_mul, the 3x3 -> 4x4 kernel synthesis and the MFMA operand packing run in
+        sgx_pack_weight (cached per parameter version), their adjoints in the weight-gradient finishing kernel."""
         bias = None if skip_bias else self.scaled_bias()
         cin, cout = self.weight.shape[1], self.weight.shape[0]
         if self.kernel_size == 1:
             assert self.upscale is None and self.downscale is None and self.intermediate is None
-            if cin == 3 and x.dtype == torch.float32 and x.shape[3] == 3:
-                y = F.RgbInFn.apply(x, self.rgb_weight(), bias, out_dtype or torch.float32)
+            if cin == 3 and x.shape[3] == 3:
+                y = F.RgbInFn.apply(x.float(), self.weight, bias, self.w_mul, out_dtype or torch.float32)
             elif cout == 3:
-                y = F.RgbOutFn.apply(x, self.rgb_weight(), bias)
+                y = F.RgbOutFn.apply(x, self.weight, bias, self.w_mul)
             else:
                 raise NotImplementedError("1x1 EqualizedConv2d is built for the to_rgb / from_rgb layers (3 channels on one side)")
-            return F.BiasActFn.apply(y, None, act) if act else y
+            return F.BiasActFn.apply(y, None, 1.0, act) if act else y
         assert self.kernel_size == 3
         if self.upscale is not None:
             fused = min(x.shape[1], x.shape[2]) * 2 >= 128                # reference :143
-            y = F.conv(x, self.pack_up(fused), None, "U")
+            y = F.conv(x, self.weight, None, "U" if fused else "UF", self.w_mul)
             if self.intermediate is not None:
                 y = self.intermediate.forward_nhwc(y)
             if bias is not None or act:
-                y = F.BiasActFn.apply(y, bias, act)                       # bias after the blur (:178-179)
+                y = F.BiasActFn.apply(y, bias, 1.0, act)                  # bias after the blur (:178-179)
             return y
         if self.downscale is not None:
             assert self.intermediate is None                              # reference :167
-            return F.conv(x, self.pack_down(), bias, "D", act)            # bias after the 2x2 mean == bias in the fused store
+            return F.conv(x, self.weight, bias, "D", self.w_mul, act)     # bias after the 2x2 mean == bias in the fused store
         if self.intermediate is None:
-            pad = x.shape[3] if x.shape[3] != cin else None
-            return F.conv(x, self.pack_plain(pad), bias, "S", act)
-        y = self.intermediate.forward_nhwc(F.conv(x, self.pack_plain(), None, "S"))
-        return F.BiasActFn.apply(y, bias, act) if (bias is not None or act) else y
+            return F.conv(x, self.weight, bias, "S", self.w_mul, act, ipad=x.shape[3])
+        y = self.intermediate.forward_nhwc(F.conv(x, self.weight, None, "S", self.w_mul))
+        return F.BiasActFn.apply(y, bias, 1.0, act) if (bias is not None or act) else y
 
     def forward(self, x):
         if self.kernel_size == 1 and self.weight.shape[0] == 3:

@@ -404,23 +404,71 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
 }
 
-__global__ void reduce_splits_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t total, int nsplit) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * total + i];
-    out[i] = s;
+// ---- finishing pass: sum the split partials AND map the packed gradient back to the parameter layout
+// dW[O][I][3][3] (adjoint of sgx_pack_weight), in one kernel.  Partial element (t, o, i) lives at
+//   ws[s*total + ((tt*A + a)*Bd + b)],  tt = flip_t ? 8-t : t,  (a,b,A,Bd) = transposed ? (i,o,Ip,O) : (o,i,O,Ip)
+// mode S: dW[o][i][y][x] = scale * P[y*3+x];  4x4 modes: dW[o][i][y][x] = scale * sum_{a,b in {0,1}} P[(y+a)*4 + (x+b)]
+// (x0.25 for the down kernel; spatial flip of (y,x) for the non-fused-up semantics) -- the transposes of
+// reference models/CustomLayers.py:146-150 and :159-162.
+struct FinishArgs { const float* ws; float* dw; int nsplit, O, I, Ip, mode, transposed, flip_t; float scale; };
+
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(FinishArgs f) {
+    __shared__ float red[16][16][9];
+    const int pl = threadIdx.x & 15, sl = threadIdx.x >> 4;          // pair lane (consecutive i), split lane
+    const int pair = blockIdx.x * 16 + pl;
+    const int npairs = f.O * f.I;
+    const int o = pair / f.I, i = pair % f.I;
+    const int taps = f.mode == SGX_PACK_S ? 9 : 16;
+    const size_t total = (size_t)taps * f.O * f.Ip;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    if (pair < npairs) {
+        const size_t tstride = (size_t)f.O * f.Ip;
+        const size_t eoff = f.transposed ? (size_t)i * f.O + o : (size_t)o * f.Ip + i;
+        for (int s = sl; s < f.nsplit; s += 16) {
+            const float* p = f.ws + (size_t)s * total + eoff;
+            if (f.mode == SGX_PACK_S) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] += p[(size_t)(f.flip_t ? 8 - t : t) * tstride];
+            } else {
+                float v[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[t] = p[(size_t)t * tstride];
+#pragma unroll
+                for (int y = 0; y < 3; ++y)
+#pragma unroll
+                    for (int x = 0; x < 3; ++x)
+                        acc[y * 3 + x] += (v[y * 4 + x] + v[y * 4 + x + 1]) + (v[(y + 1) * 4 + x] + v[(y + 1) * 4 + x + 1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[sl][pl][k] = acc[k];
+    __syncthreads();
+    if (sl == 0 && pair < npairs) {
+        const float c = f.scale * (f.mode == SGX_PACK_D ? 0.25f : 1.f);
+        float* d = f.dw + (size_t)pair * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float sum = 0.f;
+#pragma unroll
+            for (int l = 0; l < 16; ++l) sum += red[l][pl][k];
+            d[f.mode == SGX_PACK_UF ? 8 - k : k] = c * sum;
+        }
+    }
 }
 
 static int wgrad_nsplit(int pairs, int ntiles) {
-    int want = (2048 + pairs - 1) / pairs;
+    int want = (1024 + pairs - 1) / pairs;
+    if (want > 512) want = 512;
     if (want > ntiles) want = ntiles;
     if (want < 1) want = 1;
     return want;
 }
 
 template <typename T, int GEO, int TH, int TW, int BP, int NSUB, int KSUB>
-static int launch_wgrad(WgradArgs& a, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+static int launch_wgrad(WgradArgs& a, void* ws, size_t ws_bytes, int* nsplit_out, hipStream_t st) {
     using F = WFrag<T>;
     constexpr int IS = Geo<GEO>::IS, TK = Geo<GEO>::TK, NT = TK * TK;
     constexpr int PH = (TH - 1) * IS + TK, PW = (TW - 1) * IS + TK, NI = BP / (TH * TW);
@@ -431,71 +479,137 @@ static int launch_wgrad(WgradArgs& a, float* dw, void* ws, size_t ws_bytes, hipS
     const int pairs = (a.Cn / (NSUB * 16)) * (a.Ck / (KSUB * 16));
     int nsplit = wgrad_nsplit(pairs, a.ntiles);
     const size_t total = (size_t)NT * a.Cn * a.Ck;
-    if (nsplit > 1) {
-        size_t fit = ws_bytes / (total * sizeof(float));
-        if ((size_t)nsplit > fit) nsplit = (int)fit;
-        SGX_REQUIRE(nsplit >= 1, SGX_EWORKSPACE, "wgrad: workspace too small (%zu bytes)", ws_bytes);
-    }
-    a.out = (nsplit > 1) ? static_cast<float*>(ws) : dw;
+    size_t fit = ws_bytes / (total * sizeof(float));
+    if ((size_t)nsplit > fit) nsplit = (int)fit;
+    SGX_REQUIRE(nsplit >= 1, SGX_EWORKSPACE, "wgrad: workspace too small (%zu bytes, need >= %zu)", ws_bytes, total * sizeof(float));
+    a.out = static_cast<float*>(ws);
     auto kern = wgrad_kernel<T, GEO, TH, TW, BP, NSUB, KSUB>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)attr;
     hipLaunchKernelGGL(kern, dim3(pairs, nsplit), dim3(256), LDS, st, a);
     SGX_LAUNCH_CHECK("wgrad_kernel");
-    if (nsplit > 1) {
-        hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                           static_cast<const float*>(ws), dw, total, nsplit);
-        SGX_LAUNCH_CHECK("reduce_splits_kernel");
-    }
+    *nsplit_out = nsplit;
     return 0;
 }
 
 template <typename T, int GEO, int BP, int NSUB, int KSUB>
-static int wgrad_tile(WgradArgs& a, float* dw, void* ws, size_t wsb, hipStream_t st) {
-    if (a.Hn >= 16 && a.Wn >= 16) return launch_wgrad<T, GEO, BP / 16, 16, BP, NSUB, KSUB>(a, dw, ws, wsb, st);
-    if (a.Hn >= 8 && a.Wn >= 8) return launch_wgrad<T, GEO, (BP >= 64 ? 8 : BP / 8), 8, BP, NSUB, KSUB>(a, dw, ws, wsb, st);
-    return launch_wgrad<T, GEO, (BP >= 16 ? 4 : BP / 4), 4, BP, NSUB, KSUB>(a, dw, ws, wsb, st);
+static int wgrad_tile(WgradArgs& a, void* ws, size_t wsb, int* ns, hipStream_t st) {
+    if (a.Hn >= 16 && a.Wn >= 16) return launch_wgrad<T, GEO, BP / 16, 16, BP, NSUB, KSUB>(a, ws, wsb, ns, st);
+    if (a.Hn >= 8 && a.Wn >= 8) return launch_wgrad<T, GEO, (BP >= 64 ? 8 : BP / 8), 8, BP, NSUB, KSUB>(a, ws, wsb, ns, st);
+    return launch_wgrad<T, GEO, (BP >= 16 ? 4 : BP / 4), 4, BP, NSUB, KSUB>(a, ws, wsb, ns, st);
 }
 
 template <typename T, int GEO, int BP>
-static int wgrad_ch(WgradArgs& a, float* dw, void* ws, size_t wsb, hipStream_t st) {
+static int wgrad_ch(WgradArgs& a, void* ws, size_t wsb, int* ns, hipStream_t st) {
     SGX_REQUIRE(a.Cn % 16 == 0 && a.Ck % 16 == 0, SGX_EUNSUPPORTED, "wgrad: channels must be multiples of 16");
     const bool n32 = a.Cn % 32 == 0, k32 = a.Ck % 32 == 0;
     if (GEO == GDOWN) {                                       // fine patch is 4x larger: keep the k side at 16 channels
-        if (n32) return wgrad_tile<T, GEO, BP, 2, 1>(a, dw, ws, wsb, st);
-        return wgrad_tile<T, GEO, BP, 1, 1>(a, dw, ws, wsb, st);
+        if (n32) return wgrad_tile<T, GEO, BP, 2, 1>(a, ws, wsb, ns, st);
+        return wgrad_tile<T, GEO, BP, 1, 1>(a, ws, wsb, ns, st);
     }
-    if (n32 && k32) return wgrad_tile<T, GEO, BP, 2, 2>(a, dw, ws, wsb, st);
-    if (n32) return wgrad_tile<T, GEO, BP, 2, 1>(a, dw, ws, wsb, st);
-    if (k32) return wgrad_tile<T, GEO, BP, 1, 2>(a, dw, ws, wsb, st);
-    return wgrad_tile<T, GEO, BP, 1, 1>(a, dw, ws, wsb, st);
+    if (n32 && k32) return wgrad_tile<T, GEO, BP, 2, 2>(a, ws, wsb, ns, st);
+    if (n32) return wgrad_tile<T, GEO, BP, 2, 1>(a, ws, wsb, ns, st);
+    if (k32) return wgrad_tile<T, GEO, BP, 1, 2>(a, ws, wsb, ns, st);
+    return wgrad_tile<T, GEO, BP, 1, 1>(a, ws, wsb, ns, st);
+}
+
+static int wgrad_finish(const void* ws, float* dw, int nsplit, int O, int I, int Ip, int mode, int transposed, int flip_t,
+                        float scale, hipStream_t st) {
+    FinishArgs f{static_cast<const float*>(ws), dw, nsplit, O, I, Ip, mode, transposed, flip_t, scale};
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((O * I + 15) / 16)), dim3(256), 0, st, f);
+    SGX_LAUNCH_CHECK("wgrad_finish_kernel");
+    return 0;
 }
 
 extern "C" size_t sgx_wgrad_ws_bytes(int taps, int B, int H, int W, int Ck, int Cn) {
-    // worst case: one 16x16 channel pair per block, 2048 blocks
     size_t total = (size_t)taps * Ck * Cn * sizeof(float);
     int pairs = (Ck / 32 > 0 ? Ck / 32 : 1) * (Cn / 32 > 0 ? Cn / 32 : 1);
     size_t ntiles = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
-    size_t ns = (2048 + pairs - 1) / pairs;
-    if (ns > ntiles) ns = ntiles;
-    if (ns < 1) ns = 1;
+    size_t ns = (size_t)wgrad_nsplit(pairs, ntiles > (1u << 30) ? (1 << 30) : (int)ntiles);
     return total * ns;
 }
 
-extern "C" int sgx_wgrad3x3(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, int B, int H, int W,
-                            int Cin, int Cout, int dtype, void* stream) {
-    WgradArgs a{x, dy, nullptr, B, H, W, H, W, Cin, Cout, 0, 0, 0};
-    if (dtype == SGX_F32) return wgrad_ch<float, G3X3, 128>(a, dw, ws, ws_bytes, (hipStream_t)stream);
-    if (dtype == SGX_BF16) return wgrad_ch<bf16_t, G3X3, 128>(a, dw, ws, ws_bytes, (hipStream_t)stream);
-    SGX_REQUIRE(false, SGX_EINVAL, "wgrad3x3: bad dtype");
+extern "C" int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, void* ws, size_t ws_bytes, int B, int H, int W,
+                                  int Cx, int Cdy, int adjoint, float scale, int O, int I, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int Ip = adjoint ? Cdy : Cx;
+    SGX_REQUIRE((adjoint ? Cx : Cdy) == O && Ip >= I, SGX_EINVAL, "wgrad3x3_param: channel mismatch (Cx=%d Cdy=%d O=%d I=%d adj=%d)", Cx, Cdy, O, I, adjoint);
+    WgradArgs a{x, dy, nullptr, B, H, W, H, W, Cx, Cdy, 0, 0, 0};
+    int ns = 0, rc;
+    if (dtype == SGX_F32) rc = wgrad_ch<float, G3X3, 128>(a, ws, ws_bytes, &ns, st);
+    else if (dtype == SGX_BF16) rc = wgrad_ch<bf16_t, G3X3, 128>(a, ws, ws_bytes, &ns, st);
+    else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad3x3_param: bad dtype"); }
+    if (rc) return rc;
+    return wgrad_finish(ws, dW, ns, O, I, Ip, SGX_PACK_S, adjoint, adjoint, scale, st);
 }
 
-extern "C" int sgx_wgrad4x4s2(const void* fine, const void* coarse, float* dw, void* ws, size_t ws_bytes, int B, int H,
-                              int W, int Cfine, int Ccoarse, int dtype, void* stream) {
-    SGX_REQUIRE(H % 2 == 0 && W % 2 == 0, SGX_EINVAL, "wgrad4x4s2: odd fine size");
+extern "C" int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float* dW, void* ws, size_t ws_bytes, int B, int H,
+                                    int W, int Cfine, int Ccoarse, int mode, float scale, int O, int I, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SGX_REQUIRE(H % 2 == 0 && W % 2 == 0, SGX_EINVAL, "wgrad4x4s2_param: odd fine size");
+    SGX_REQUIRE(mode == SGX_PACK_D || mode == SGX_PACK_U || mode == SGX_PACK_UF, SGX_EINVAL, "wgrad4x4s2_param: bad mode %d", mode);
+    const int transposed = mode != SGX_PACK_D;                 // kernel output is [t][coarse ch][fine ch]
+    SGX_REQUIRE(transposed ? (Ccoarse == I && Cfine == O) : (Ccoarse == O && Cfine == I), SGX_EINVAL,
+                "wgrad4x4s2_param: channel mismatch (fine %d coarse %d O %d I %d mode %d)", Cfine, Ccoarse, O, I, mode);
     WgradArgs a{fine, coarse, nullptr, B, H, W, H / 2, W / 2, Cfine, Ccoarse, 0, 0, 0};
-    if (dtype == SGX_F32) return wgrad_ch<float, GDOWN, 64>(a, dw, ws, ws_bytes, (hipStream_t)stream);
-    if (dtype == SGX_BF16) return wgrad_ch<bf16_t, GDOWN, 64>(a, dw, ws, ws_bytes, (hipStream_t)stream);
-    SGX_REQUIRE(false, SGX_EINVAL, "wgrad4x4s2: bad dtype");
+    int ns = 0, rc;
+    if (dtype == SGX_F32) rc = wgrad_ch<float, GDOWN, 64>(a, ws, ws_bytes, &ns, st);
+    else if (dtype == SGX_BF16) rc = wgrad_ch<bf16_t, GDOWN, 64>(a, ws, ws_bytes, &ns, st);
+    else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad4x4s2_param: bad dtype"); }
+    if (rc) return rc;
+    return wgrad_finish(ws, dW, ns, O, I, I, mode, transposed, 0, scale, st);
+}
+
+// =====================================================================================================
+// Weight packing: parameter [O][I][3][3] fp32 -> the two MFMA operand packs of a layer, in the activation
+// dtype, in one launch: fwd[t][O][Ip] for the layer's own convolution and adj[t'][Ip][O] for its data gradient
+// (t' = 8-t for the 3x3 kernel, whose adjoint is spatially flipped; t' = t for the 4x4 stride-2 pair).
+//   S : v = scale * w[o][i][ty][tx]                                         (models/CustomLayers.py:170-171)
+//   D : v = 0.25*scale * sum_{a,b} w[o][i][ky-a][kx-b]                      (:159-162)
+//   U : v = scale * sum_{a,b} w[o][i][ky-a][kx-b];  UF: same on the flipped 3x3 kernel   (:146-150)
+// =====================================================================================================
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ adj, int O, int I, int Ip,
+                                   int mode, float scale) {
+    const int taps = mode == SGX_PACK_S ? 9 : 16;
+    const size_t n = (size_t)taps * O * Ip;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e % Ip);
+        const int o = (int)((e / Ip) % O);
+        const int t = (int)(e / ((size_t)Ip * O));
+        float v = 0.f;
+        if (i < I) {
+            const float* wp = w + ((size_t)o * I + i) * 9;
+            if (mode == SGX_PACK_S) {
+                v = scale * wp[t];
+            } else {
+                const int ky = t >> 2, kx = t & 3;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int y = ky - a, x = kx - b;
+                        if (y >= 0 && y < 3 && x >= 0 && x < 3) v += wp[mode == SGX_PACK_UF ? (2 - y) * 3 + (2 - x) : y * 3 + x];
+                    }
+                v *= scale * (mode == SGX_PACK_D ? 0.25f : 1.f);
+            }
+        }
+        fwd[e] = from_f<T>(v);
+        const int ta = mode == SGX_PACK_S ? 8 - t : t;
+        adj[((size_t)ta * Ip + i) * O + o] = from_f<T>(v);
+    }
+}
+
+extern "C" int sgx_pack_weight(const float* w, void* fwd, void* adj, int O, int I, int Ipad, int mode, float scale, int dtype,
+                               void* stream) {
+    SGX_REQUIRE(mode >= SGX_PACK_S && mode <= SGX_PACK_UF && Ipad >= I && O > 0 && I > 0, SGX_EINVAL, "pack_weight: bad args");
+    const size_t n = (size_t)(mode == SGX_PACK_S ? 9 : 16) * O * Ipad;
+    size_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (dtype == SGX_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, (float*)fwd, (float*)adj, O, I, Ipad, mode, scale);
+    else if (dtype == SGX_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)fwd, (bf16_t*)adj, O, I, Ipad, mode, scale);
+    else { SGX_REQUIRE(false, SGX_EINVAL, "pack_weight: bad dtype"); }
+    SGX_LAUNCH_CHECK("pack_weight_kernel");
+    return 0;
 }

@@ -75,7 +75,7 @@ extern "C" int sgx_adam_multi(float* const* params, const float* const* grads, f
                               const int64_t* sizes, int n, float beta1, float beta2, float eps, const float* step_sizes,
                               const float* bc2_sqrts, const float* grad_scale, void* stream) {
     SGX_REQUIRE(n > 0, SGX_EINVAL, "adam: n=%d", n);
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(MT_BLOCKS_X, n), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(256, n), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
                        sizes, beta1, beta2, eps, step_sizes, bc2_sqrts, grad_scale);
     SGX_LAUNCH_CHECK("adam_multi");
     return 0;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void ema_multi_kernel(float* const* __restrict
 }
 extern "C" int sgx_ema_multi(float* const* tgt, const float* const* src, const int64_t* sizes, int n, float beta, void* stream) {
     SGX_REQUIRE(n > 0, SGX_EINVAL, "ema: n");
-    hipLaunchKernelGGL(ema_multi_kernel, dim3(MT_BLOCKS_X, n), dim3(256), 0, (hipStream_t)stream, tgt, src, sizes, beta);
+    hipLaunchKernelGGL(ema_multi_kernel, dim3(256, n), dim3(256), 0, (hipStream_t)stream, tgt, src, sizes, beta);
     SGX_LAUNCH_CHECK("ema_multi");
     return 0;
 }

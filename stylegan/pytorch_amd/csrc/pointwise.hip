@@ -12,8 +12,8 @@ static inline unsigned grid_for(size_t nvec, int block = 256) {
 
 // ---------------------------------------------------------------- y = act(x + bias[c])
 template <typename T>
-__global__ void bias_act_kernel(const T* __restrict__ x, const float* __restrict__ bias, T* __restrict__ y, size_t nvec,
-                                int C, int act) {
+__global__ void bias_act_kernel(const T* __restrict__ x, const float* __restrict__ bias, float bscale, T* __restrict__ y,
+                                size_t nvec, int C, int act) {
     constexpr int VE = VecTraits<T>::VE;
     const int cv = C / VE;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
@@ -22,22 +22,34 @@ __global__ void bias_act_kernel(const T* __restrict__ x, const float* __restrict
         const int c0 = (int)(i % cv) * VE;
 #pragma unroll
         for (int j = 0; j < VE; ++j) {
-            float t = v[j] + (bias ? bias[c0 + j] : 0.f);
+            float t = v[j] + (bias ? bscale * bias[c0 + j] : 0.f);
             v[j] = act == SGX_ACT_LRELU ? lrelu(t) : t;
         }
         VecTraits<T>::store(y + i * VE, v);
     }
 }
-extern "C" int sgx_bias_act(const void* x, const float* bias, void* y, size_t npix, int C, int act, int dtype, void* stream) {
+__global__ void bias_act_scalar_kernel(const float* __restrict__ x, const float* __restrict__ bias, float bscale, float* __restrict__ y,
+                                       size_t n, int C, int act) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float t = x[i] + (bias ? bscale * bias[i % C] : 0.f);
+        y[i] = act == SGX_ACT_LRELU ? lrelu(t) : t;
+    }
+}
+extern "C" int sgx_bias_act(const void* x, const float* bias, float bscale, void* y, size_t npix, int C, int act, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == SGX_F32 && C % 4 != 0) {                    // e.g. the [B,1] discriminator output
+        hipLaunchKernelGGL(bias_act_scalar_kernel, dim3(grid_for(npix * C)), dim3(256), 0, st, (const float*)x, bias, bscale, (float*)y, npix * C, C, act);
+        SGX_LAUNCH_CHECK("bias_act_scalar");
+        return 0;
+    }
     if (dtype == SGX_F32) {
         SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "bias_act: C %% 4");
         size_t nvec = npix * C / 4;
-        hipLaunchKernelGGL(bias_act_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, st, (const float*)x, bias, (float*)y, nvec, C, act);
+        hipLaunchKernelGGL(bias_act_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, st, (const float*)x, bias, bscale, (float*)y, nvec, C, act);
     } else {
         SGX_REQUIRE(C % 8 == 0, SGX_EUNSUPPORTED, "bias_act: C %% 8");
         size_t nvec = npix * C / 8;
-        hipLaunchKernelGGL(bias_act_kernel<bf16_t>, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)x, bias, (bf16_t*)y, nvec, C, act);
+        hipLaunchKernelGGL(bias_act_kernel<bf16_t>, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)x, bias, bscale, (bf16_t*)y, nvec, C, act);
     }
     SGX_LAUNCH_CHECK("bias_act");
     return 0;
@@ -270,15 +282,25 @@ __global__ void colsum_stage1(const T* __restrict__ x, double* __restrict__ ws, 
         __syncthreads();
     }
 }
-__global__ void colsum_stage2(const double* __restrict__ ws, float* __restrict__ out, int nblk, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// 32 outputs x 8 partial lanes per block: the chain over partial blocks is nblk/8 long, not nblk
+__global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ ws, float* __restrict__ out, int nblk, int C, float scale) {
+    __shared__ double sh[8][33];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * C + c];
-    out[c] = (float)s;
+    if (c < C)
+        for (int b = pl; b < nblk; b += 8) s += ws[(size_t)b * C + c];
+    sh[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sh[k][cl];
+        out[c] = (float)(t * (double)scale);
+    }
 }
 extern "C" size_t sgx_colsum_ws_bytes(size_t npix, int C) { (void)npix; return (size_t)COLSUM_BLOCKS * C * sizeof(double); }
-extern "C" int sgx_colsum(const void* x, float* out, void* ws, size_t ws_bytes, size_t npix, int C, int dtype, void* stream) {
+extern "C" int sgx_colsum(const void* x, float* out, float scale, void* ws, size_t ws_bytes, size_t npix, int C, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SGX_REQUIRE(ws_bytes >= sgx_colsum_ws_bytes(npix, C), SGX_EWORKSPACE, "colsum: workspace");
     SGX_REQUIRE(C <= 256 ? (256 % C == 0) : true, SGX_EUNSUPPORTED, "colsum: C=%d", C);
@@ -288,15 +310,15 @@ extern "C" int sgx_colsum(const void* x, float* out, void* ws, size_t ws_bytes, 
     if (dtype == SGX_F32) hipLaunchKernelGGL(colsum_stage1<float>, dim3(nblk), dim3(256), 256 * sizeof(double), st, (const float*)x, (double*)ws, npix, C);
     else hipLaunchKernelGGL(colsum_stage1<bf16_t>, dim3(nblk), dim3(256), 256 * sizeof(double), st, (const bf16_t*)x, (double*)ws, npix, C);
     SGX_LAUNCH_CHECK("colsum_stage1");
-    hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, out, nblk, C);
+    hipLaunchKernelGGL(colsum_stage2, dim3((C + 31) / 32), dim3(256), 0, st, (const double*)ws, out, nblk, C, scale);
     SGX_LAUNCH_CHECK("colsum_stage2");
     return 0;
 }
 
 // ---------------------------------------------------------------- 1x1 RGB convolutions (3 <-> C), images fp32 [p][3]
 template <typename T>
-__global__ void rgb_in_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
-                              T* __restrict__ y, size_t npix, int C) {
+__global__ void rgb_in_kernel(const float* __restrict__ img, const float* __restrict__ w, int sj, int sc, float wscale,
+                              const float* __restrict__ bias, T* __restrict__ y, size_t npix, int C) {
     constexpr int VE = VecTraits<T>::VE;
     const int cv = C / VE;
     const size_t nvec = npix * cv;
@@ -307,18 +329,18 @@ __global__ void rgb_in_kernel(const float* __restrict__ img, const float* __rest
         float v[VE];
 #pragma unroll
         for (int j = 0; j < VE; ++j)
-            v[j] = (bias ? bias[c0 + j] : 0.f) + r * w[c0 + j] + g * w[C + c0 + j] + b * w[2 * C + c0 + j];
+            v[j] = (bias ? bias[c0 + j] : 0.f) + wscale * (r * w[(c0 + j) * sc] + g * w[sj + (c0 + j) * sc] + b * w[2 * sj + (c0 + j) * sc]);
         VecTraits<T>::store(y + i * VE, v);
     }
 }
-extern "C" int sgx_rgb_in(const float* img, const float* w, const float* bias, void* y, size_t npix, int C, int dtype, void* stream) {
+extern "C" int sgx_rgb_in(const float* img, const float* w, int sj, int sc, float wscale, const float* bias, void* y, size_t npix, int C, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SGX_F32) {
         SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "rgb_in: C %% 4");
-        hipLaunchKernelGGL(rgb_in_kernel<float>, dim3(grid_for(npix * C / 4)), dim3(256), 0, st, img, w, bias, (float*)y, npix, C);
+        hipLaunchKernelGGL(rgb_in_kernel<float>, dim3(grid_for(npix * C / 4)), dim3(256), 0, st, img, w, sj, sc, wscale, bias, (float*)y, npix, C);
     } else {
         SGX_REQUIRE(C % 8 == 0, SGX_EUNSUPPORTED, "rgb_in: C %% 8");
-        hipLaunchKernelGGL(rgb_in_kernel<bf16_t>, dim3(grid_for(npix * C / 8)), dim3(256), 0, st, img, w, bias, (bf16_t*)y, npix, C);
+        hipLaunchKernelGGL(rgb_in_kernel<bf16_t>, dim3(grid_for(npix * C / 8)), dim3(256), 0, st, img, w, sj, sc, wscale, bias, (bf16_t*)y, npix, C);
     }
     SGX_LAUNCH_CHECK("rgb_in");
     return 0;
@@ -326,8 +348,8 @@ extern "C" int sgx_rgb_in(const float* img, const float* w, const float* bias, v
 
 // one pixel per group of LPP lanes (LPP = C/VE capped at 16); partial dot products reduced with shuffles
 template <typename T>
-__global__ void rgb_out_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                               float* __restrict__ img, size_t npix, int C, int lpp) {
+__global__ void rgb_out_kernel(const T* __restrict__ x, const float* __restrict__ w, int sj, int sc, float wscale,
+                               const float* __restrict__ bias, float* __restrict__ img, size_t npix, int C, int lpp) {
     constexpr int VE = VecTraits<T>::VE;
     const int cv = C / VE;
     const int sub = threadIdx.x % lpp;
@@ -344,7 +366,7 @@ __global__ void rgb_out_kernel(const T* __restrict__ x, const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < VE; ++j) {
                     const int c = v * VE + j;
-                    s0 += t[j] * w[c]; s1 += t[j] * w[C + c]; s2 += t[j] * w[2 * C + c];
+                    s0 += t[j] * w[c * sc]; s1 += t[j] * w[sj + c * sc]; s2 += t[j] * w[2 * sj + c * sc];
                 }
             }
         }
@@ -352,13 +374,13 @@ __global__ void rgb_out_kernel(const T* __restrict__ x, const float* __restrict_
             s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64);
         }
         if (p < npix && sub == 0) {
-            img[p * 3] = s0 + (bias ? bias[0] : 0.f);
-            img[p * 3 + 1] = s1 + (bias ? bias[1] : 0.f);
-            img[p * 3 + 2] = s2 + (bias ? bias[2] : 0.f);
+            img[p * 3] = wscale * s0 + (bias ? bias[0] : 0.f);
+            img[p * 3 + 1] = wscale * s1 + (bias ? bias[1] : 0.f);
+            img[p * 3 + 2] = wscale * s2 + (bias ? bias[2] : 0.f);
         }
     }
 }
-extern "C" int sgx_rgb_out(const void* x, const float* w, const float* bias, float* img, size_t npix, int C, int dtype, void* stream) {
+extern "C" int sgx_rgb_out(const void* x, const float* w, int sj, int sc, float wscale, const float* bias, float* img, size_t npix, int C, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int ve = dtype == SGX_F32 ? 4 : 8;
     SGX_REQUIRE(C % ve == 0, SGX_EUNSUPPORTED, "rgb_out: C=%d", C);
@@ -366,8 +388,8 @@ extern "C" int sgx_rgb_out(const void* x, const float* w, const float* bias, flo
     if (lpp > 16) lpp = 16;
     SGX_REQUIRE((lpp & (lpp - 1)) == 0, SGX_EUNSUPPORTED, "rgb_out: C=%d", C);
     const unsigned g = grid_for(npix * lpp);
-    if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_out_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, w, bias, img, npix, C, lpp);
-    else hipLaunchKernelGGL(rgb_out_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, w, bias, img, npix, C, lpp);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_out_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, w, sj, sc, wscale, bias, img, npix, C, lpp);
+    else hipLaunchKernelGGL(rgb_out_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, w, sj, sc, wscale, bias, img, npix, C, lpp);
     SGX_LAUNCH_CHECK("rgb_out");
     return 0;
 }
@@ -404,7 +426,25 @@ __global__ void rgb_wgrad_stage1(const float* __restrict__ img, const T* __restr
     }
 }
 extern "C" size_t sgx_rgb_wgrad_ws_bytes(size_t npix, int C) { (void)npix; return (size_t)COLSUM_BLOCKS * 3 * C * sizeof(double); }
-extern "C" int sgx_rgb_wgrad(const float* img, const void* f, float* dw, void* ws, size_t ws_bytes, size_t npix, int C, int dtype, void* stream) {
+// sums the per-block partials [blk][3][C] and scatters into the parameter layout dw[j*sj + c*sc]
+__global__ __launch_bounds__(256) void rgb_wgrad_stage2(const double* __restrict__ ws, float* __restrict__ dw, int nblk, int C, int sj, int sc,
+                                                        float wscale) {
+    __shared__ double sh[8][33];
+    const int el = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;                      // e = j*C + c
+    double s = 0.0;
+    if (e < 3 * C)
+        for (int b = pl; b < nblk; b += 8) s += ws[(size_t)b * 3 * C + e];
+    sh[pl][el] = s;
+    __syncthreads();
+    if (pl == 0 && e < 3 * C) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sh[k][el];
+        dw[(e / C) * sj + (e % C) * sc] = (float)(t * (double)wscale);
+    }
+}
+extern "C" int sgx_rgb_wgrad(const float* img, const void* f, float* dw, int sj, int sc, float wscale, void* ws, size_t ws_bytes, size_t npix, int C, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SGX_REQUIRE(ws_bytes >= sgx_rgb_wgrad_ws_bytes(npix, C), SGX_EWORKSPACE, "rgb_wgrad: workspace");
     SGX_REQUIRE(C <= 256 ? (256 % C == 0) : true, SGX_EUNSUPPORTED, "rgb_wgrad: C=%d", C);
@@ -414,7 +454,7 @@ extern "C" int sgx_rgb_wgrad(const float* img, const void* f, float* dw, void* w
     if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_wgrad_stage1<float>, dim3(nblk), dim3(256), 768 * sizeof(double), st, img, (const float*)f, (double*)ws, npix, C);
     else hipLaunchKernelGGL(rgb_wgrad_stage1<bf16_t>, dim3(nblk), dim3(256), 768 * sizeof(double), st, img, (const bf16_t*)f, (double*)ws, npix, C);
     SGX_LAUNCH_CHECK("rgb_wgrad_stage1");
-    hipLaunchKernelGGL(colsum_stage2, dim3((3 * C + 255) / 256), dim3(256), 0, st, (const double*)ws, dw, nblk, 3 * C);
+    hipLaunchKernelGGL(rgb_wgrad_stage2, dim3((3 * C + 31) / 32), dim3(256), 0, st, (const double*)ws, dw, nblk, C, sj, sc, wscale);
     SGX_LAUNCH_CHECK("rgb_wgrad_stage2");
     return 0;
 }

@@ -2,14 +2,17 @@
 
 Activations inside this module are contiguous NHWC tensors ``[B, H, W, C]`` (fp32 or bf16); the nn.Modules in
 CustomLayers.py / Blocks.py / GAN.py convert at their boundary (a logical-NCHW view with channels_last strides
-is the same memory).  Parameters, statistics, RGB images and parameter gradients are fp32.
+is the same memory).  Parameters, statistics, RGB images and parameter gradients are fp32 and stay in the
+reference's layouts: the kernels read/write them in place (weight scale, 3x3->4x4 synthesis, operand packing and
+their adjoints all run in HIP -- no torch arithmetic on parameters).
 
 Differentiation structure: every discriminator op is closed under differentiation -- the
 backward of each Function is built from other Functions of this file -- so ``create_graph=True`` (the R1 penalty,
 reference models/Losses.py:197-211) works through autograd composition.  Generator-only ops (the fused layer
-epilogue, PixelNorm) are first order.
+epilogue, PixelNorm) and parameter gradients are first order.
 """
 import contextlib
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -36,19 +39,6 @@ def data_grad_only():
 
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
-
-
-# ---------------------------------------------------------------------------------------------------
-# convolutions.  geo: 'S' 3x3 stride 1, 'D' 4x4 stride-2 down, 'U' 4x4 stride-2 transposed (up).
-# wp: packed fp32 weight [taps][n][k] (n = output channels, k = input channels).
-ADJOINT = {"S": "S", "D": "U", "U": "D"}
-
-
-def transpose_pack(wp, geo):
-    """Pack of the adjoint (data-gradient) convolution: swap n/k; the 3x3 kernel is also spatially flipped."""
-    if geo == "S":
-        return wp.flip(0).transpose(1, 2).contiguous()
-    return wp.transpose(1, 2).contiguous()
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -107,107 +97,150 @@ class _Timed:
             KERNEL_TIMES.setdefault(self.name, []).append((self.e0, e1, self.flops))
 
 
-def _conv_raw(geo, x, wq, bias, act):
+# ---------------------------------------------------------------------------------------------------
+# packed-weight cache.  mode: 'S' plain 3x3 | 'D' fused down | 'U' fused up | 'UF' non-fused-up semantics.
+# One sgx_pack_weight launch per (parameter, version) produces both MFMA operand packs in the activation dtype;
+# every forward / data-gradient / R1 pass of the step reuses them.  Parameters updated by the HIP optimizer do not
+# bump torch's version counter, so a process-wide generation number is bumped instead (optim.py).
+MODES = {"S": N.PACK_S, "D": N.PACK_D, "U": N.PACK_U, "UF": N.PACK_UF}
+FWD_GEO = {"S": "S", "D": "D", "U": "U", "UF": "U"}
+ADJ_GEO = {"S": "S", "D": "U", "U": "D", "UF": "D"}
+_PACKS = {}
+_WEIGHT_GEN = 0
+
+
+def bump_weight_generation():
+    global _WEIGHT_GEN
+    _WEIGHT_GEN += 1
+
+
+def packs(weight, mode, scale, ipad, dtype):
+    """(fwd, adj) operand packs of a [O][I][3][3] fp32 parameter; cached per (version, generation)."""
+    key = id(weight)
+    ent = _PACKS.get(key)
+    tag = (weight._version, _WEIGHT_GEN, weight.data_ptr())
+    if ent is None or ent[0]() is not weight or ent[1] != tag:
+        ent = [weakref.ref(weight, lambda _r, k=key: _PACKS.pop(k, None)), tag, {}]
+        _PACKS[key] = ent
+    sub = (mode, float(scale), int(ipad), dtype)
+    got = ent[2].get(sub)
+    if got is None:
+        w = _c(weight.detach())
+        if w.dtype != torch.float32:
+            raise N.SgxError("parameters must be fp32")
+        O, I = w.shape[0], w.shape[1]
+        taps = 9 if mode == "S" else 16
+        fwd = torch.empty((taps, O, ipad), dtype=dtype, device=w.device)
+        adj = torch.empty((taps, ipad, O), dtype=dtype, device=w.device)
+        N.check(N.lib().sgx_pack_weight(N.ptr(w), N.ptr(fwd), N.ptr(adj), O, I, ipad, MODES[mode], float(scale),
+                                        N.F32 if dtype == torch.float32 else N.BF16, N.stream()), "sgx_pack_weight")
+        got = (fwd, adj)
+        ent[2][sub] = got
+    return got
+
+
+def clear_pack_cache():
+    _PACKS.clear()
+
+
+# ---------------------------------------------------------------------------------------------------
+def _conv_launch(geo, x, wq, bias, act):
     B, H, W, Cin = x.shape
     taps, Cout, K = wq.shape
     if K != Cin:
-        raise N.SgxError(f"conv: weight expects {K} input channels, activation has {Cin}")
+        raise N.SgxError(f"conv: weight pack expects {K} input channels, activation has {Cin}")
     L = N.lib()
-    if KERNEL_TIMES is not None:
-        npix = B * H * W * (1 if geo == "S" else (0.25 if geo == "D" else 1.0))   # class-grid pixels x taps below
-        with _Timed(conv_kernel_name(geo, H, W, Cin, Cout, x.dtype), 2.0 * taps * Cin * Cout * npix):
-            return _conv_launch(L, geo, x, wq, bias, act, B, H, W, Cin, Cout)
-    return _conv_launch(L, geo, x, wq, bias, act, B, H, W, Cin, Cout)
-
-
-def _conv_launch(L, geo, x, wq, bias, act, B, H, W, Cin, Cout):
-    if geo == "S":
-        y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
-        N.check(L.sgx_conv3x3(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv3x3")
-    elif geo == "D":
-        y = torch.empty((B, H // 2, W // 2, Cout), dtype=x.dtype, device=x.device)
-        N.check(L.sgx_conv4x4s2_down(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv4x4s2_down")
-    elif geo == "U":
-        assert bias is None and act == 0
-        y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
-        N.check(L.sgx_conv4x4s2_up(N.ptr(x), N.ptr(wq), N.ptr(y), B, H, W, Cin, Cout, N.dt(x), N.stream()), "sgx_conv4x4s2_up")
-    else:
-        raise ValueError(geo)
+    npix = B * H * W * (0.25 if geo == "D" else 1.0)
+    with _Timed(conv_kernel_name(geo, H, W, Cin, Cout, x.dtype) if KERNEL_TIMES is not None else None, 2.0 * taps * Cin * Cout * npix):
+        if geo == "S":
+            y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
+            N.check(L.sgx_conv3x3(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv3x3")
+        elif geo == "D":
+            y = torch.empty((B, H // 2, W // 2, Cout), dtype=x.dtype, device=x.device)
+            N.check(L.sgx_conv4x4s2_down(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv4x4s2_down")
+        else:
+            assert bias is None and act == 0
+            y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
+            N.check(L.sgx_conv4x4s2_up(N.ptr(x), N.ptr(wq), N.ptr(y), B, H, W, Cin, Cout, N.dt(x), N.stream()), "sgx_conv4x4s2_up")
     return y
 
 
-def _wgrad_raw(geo, x, gy):
-    """dwp [taps][n][k] fp32 for y = conv_geo(x, wp)."""
+def _wgrad_param(mode, adjoint, x, gy, weight, scale):
+    """Gradient w.r.t. the [O][I][3][3] parameter of y = conv(x) (or of the layer's data-gradient conv if adjoint)."""
     L = N.lib()
+    O, I = weight.shape[0], weight.shape[1]
+    dW = torch.empty((O, I, 3, 3), dtype=torch.float32, device=x.device)
     B = x.shape[0]
-    if geo == "S":
-        _, H, W, Ck = x.shape
-        Cn = gy.shape[3]
-        dw = torch.empty((9, Cn, Ck), dtype=torch.float32, device=x.device)
-        ws = N.workspace(L.sgx_wgrad_ws_bytes(9, B, H, W, Ck, Cn), x.device)
-        with _Timed(wgrad_kernel_name("S", H, W, Ck, Cn, x.dtype), 2.0 * 9 * Ck * Cn * B * H * W):
-            N.check(L.sgx_wgrad3x3(N.ptr(x), N.ptr(gy), N.ptr(dw), N.ptr(ws), ws.numel(), B, H, W, Ck, Cn, N.dt(x), N.stream()), "sgx_wgrad3x3")
-        return dw
-    fine, coarse = (x, gy) if geo == "D" else (gy, x)
+    if mode == "S":
+        _, H, W, Cx = x.shape
+        Cdy = gy.shape[3]
+        ws = N.workspace(L.sgx_wgrad_ws_bytes(9, B, H, W, Cx, Cdy), x.device)
+        with _Timed(wgrad_kernel_name("S", H, W, Cx, Cdy, x.dtype) if KERNEL_TIMES is not None else None, 2.0 * 9 * Cx * Cdy * B * H * W):
+            N.check(L.sgx_wgrad3x3_param(N.ptr(x), N.ptr(gy), N.ptr(dW), N.ptr(ws), ws.numel(), B, H, W, Cx, Cdy, int(adjoint),
+                                         float(scale), O, I, N.dt(x), N.stream()), "sgx_wgrad3x3_param")
+        return dW
+    launched = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]          # geometry of the convolution that ran
+    fine, coarse = (x, gy) if launched == "D" else (gy, x)
     _, H, W, Cf = fine.shape
     Cc = coarse.shape[3]
-    dw = torch.empty((16, Cc, Cf), dtype=torch.float32, device=x.device)
     ws = N.workspace(L.sgx_wgrad_ws_bytes(16, B, H, W, Cf, Cc), x.device)
-    with _Timed(wgrad_kernel_name("D", H // 2, W // 2, Cf, Cc, x.dtype), 2.0 * 16 * Cf * Cc * B * (H // 2) * (W // 2)):
-        N.check(L.sgx_wgrad4x4s2(N.ptr(fine), N.ptr(coarse), N.ptr(dw), N.ptr(ws), ws.numel(), B, H, W, Cf, Cc, N.dt(x), N.stream()), "sgx_wgrad4x4s2")
-    if geo == "U":                       # kernel returns [t][coarse=k][fine=n]
-        dw = dw.transpose(1, 2).contiguous()
-    return dw
+    with _Timed(wgrad_kernel_name("D", H // 2, W // 2, Cf, Cc, x.dtype) if KERNEL_TIMES is not None else None,
+                2.0 * 16 * Cf * Cc * B * (H // 2) * (W // 2)):
+        N.check(L.sgx_wgrad4x4s2_param(N.ptr(fine), N.ptr(coarse), N.ptr(dW), N.ptr(ws), ws.numel(), B, H, W, Cf, Cc, MODES[mode],
+                                       float(scale), O, I, N.dt(x), N.stream()), "sgx_wgrad4x4s2_param")
+    return dW
 
 
 class ConvFn(Function):
-    """y = act(conv_geo(x, wp) + bias).  Twice differentiable."""
+    """y = act(conv(x, pack(weight)) + bias) for one EqualizedConv2d parameter.
+
+    ``adjoint=False``: the layer's own convolution (geometry by ``mode``).  ``adjoint=True``: its data-gradient
+    convolution (transposed/flipped pack).  The backward of either is the other, so the op is closed under
+    differentiation; the parameter gradient comes back in the parameter's own layout."""
 
     @staticmethod
-    def forward(ctx, x, wp, bias, geo, act):
+    def forward(ctx, x, weight, bias, mode, scale, ipad, adjoint, act):
         x = _c(x)
-        wq = _c(wp.detach().to(x.dtype))
-        y = _conv_raw(geo, x, wq, None if bias is None else _c(bias.detach()), act)
-        ctx.geo, ctx.act, ctx.has_bias = geo, act, bias is not None
-        ctx.save_for_backward(x, wp, y if act else None)
+        fwd, adj = packs(weight, mode, scale, ipad, x.dtype)
+        geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
+        y = _conv_launch(geo, x, adj if adjoint else fwd, None if bias is None else _c(bias.detach()), act)
+        ctx.cfg = (mode, scale, ipad, adjoint, act, bias is not None)
+        ctx.save_for_backward(x, weight, y if act else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, wp, y = ctx.saved_tensors
+        x, weight, y = ctx.saved_tensors
+        mode, scale, ipad, adjoint, act, has_bias = ctx.cfg
         gy = _c(gy)
-        if ctx.act:
+        if act:
             gy = LReluBwdFn.apply(gy, y)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = ConvFn.apply(gy, transpose_pack(wp, ctx.geo), None, ADJOINT[ctx.geo], 0)
+            gx = ConvFn.apply(gy, weight, None, mode, scale, ipad, not adjoint, 0)
         if not _DATA_GRAD_ONLY:
             if ctx.needs_input_grad[1]:
-                gw = WgradFn.apply(x, gy, ctx.geo)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = ColSumFn.apply(gy)
-        return gx, gw, gb, None, None
+                gw = WgradFn.apply(x, gy, weight, mode, scale, adjoint)
+            if has_bias and ctx.needs_input_grad[2]:
+                gb = ColSumFn.apply(gy, 1.0)
+        return gx, gw, gb, None, None, None, None, None
 
 
 class WgradFn(Function):
-    """dwp = d<gy, conv_geo(x, wp)>/dwp.  Bilinear in (x, gy): its backward is two convolutions."""
+    """Parameter gradient of ConvFn (first order only: nothing in the training step differentiates through it)."""
 
     @staticmethod
-    def forward(ctx, x, gy, geo):
-        x, gy = _c(x), _c(gy)
-        ctx.geo = geo
-        ctx.save_for_backward(x, gy)
-        return _wgrad_raw(geo, x, gy)
+    def forward(ctx, x, gy, weight, mode, scale, adjoint):
+        return _wgrad_param(mode, adjoint, _c(x), _c(gy), weight, scale)
 
     @staticmethod
-    def backward(ctx, ggw):
-        x, gy = ctx.saved_tensors
-        gx = ggy = None
-        if ctx.needs_input_grad[0]:
-            gx = ConvFn.apply(gy, transpose_pack(ggw, ctx.geo), None, ADJOINT[ctx.geo], 0)
-        if ctx.needs_input_grad[1]:
-            ggy = ConvFn.apply(x, ggw, None, ctx.geo, 0)
-        return gx, ggy, None
+    @once_differentiable
+    def backward(ctx, g):
+        raise NotImplementedError("second derivative through a weight gradient is not part of the training path")
+
+
+def conv(x, weight, bias, mode, scale, act=N.ACT_NONE, ipad=None):
+    return ConvFn.apply(x, weight, bias, mode, float(scale), int(ipad if ipad is not None else weight.shape[1]), False, act)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -229,36 +262,36 @@ class LReluBwdFn(Function):
 
 
 class ColSumFn(Function):
-    """[..., C] -> fp32 [C] (bias gradient)."""
+    """[..., C] -> fp32 [C], times ``scale`` (bias gradient)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, scale):
         x = _c(x)
         C = x.shape[-1]
         npix = x.numel() // C
         out = torch.empty((C,), dtype=torch.float32, device=x.device)
         L = N.lib()
         ws = N.workspace(L.sgx_colsum_ws_bytes(npix, C), x.device)
-        N.check(L.sgx_colsum(N.ptr(x), N.ptr(out), N.ptr(ws), ws.numel(), npix, C, N.dt(x), N.stream()), "sgx_colsum")
-        ctx.shape, ctx.dtype = x.shape, x.dtype
+        N.check(L.sgx_colsum(N.ptr(x), N.ptr(out), float(scale), N.ptr(ws), ws.numel(), npix, C, N.dt(x), N.stream()), "sgx_colsum")
+        ctx.shape, ctx.dtype, ctx.scale = x.shape, x.dtype, float(scale)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(ctx.dtype).expand(ctx.shape)
+        return (g * ctx.scale).to(ctx.dtype).expand(ctx.shape), None
 
 
 class BiasActFn(Function):
-    """y = act(x + bias[c]) on [..., C]."""
+    """y = act(x + bscale*bias[c]) on [..., C]."""
 
     @staticmethod
-    def forward(ctx, x, bias, act):
+    def forward(ctx, x, bias, bscale, act):
         x = _c(x)
         C = x.shape[-1]
         y = torch.empty_like(x)
-        N.check(N.lib().sgx_bias_act(N.ptr(x), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(y), x.numel() // C, C, act,
-                                     N.dt(x), N.stream()), "sgx_bias_act")
-        ctx.act, ctx.has_bias = act, bias is not None
+        N.check(N.lib().sgx_bias_act(N.ptr(x), N.ptr(None if bias is None else _c(bias.detach())), float(bscale), N.ptr(y),
+                                     x.numel() // C, C, act, N.dt(x), N.stream()), "sgx_bias_act")
+        ctx.act, ctx.has_bias, ctx.bscale = act, bias is not None, float(bscale)
         ctx.save_for_backward(y if act else None)
         return y
 
@@ -270,8 +303,8 @@ class BiasActFn(Function):
             g = LReluBwdFn.apply(g, y)
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[1] and not _DATA_GRAD_ONLY:
-            gb = ColSumFn.apply(g)
-        return g, gb, None
+            gb = ColSumFn.apply(g, ctx.bscale)
+        return g, gb, None, None
 
 
 class ScaleFn(Function):
@@ -358,91 +391,101 @@ class Up2Fn(Function):
 
 
 # ---------------------------------------------------------------------------------------------------
-# 1x1 RGB convolutions.  Images are fp32 [B,H,W,3]; w3c is fp32 [3][C] (w_mul already applied).
+# 1x1 RGB convolutions.  Images are fp32 [B,H,W,3]; the weight is the raw parameter ([C,3,1,1] from_rgb or
+# [3,C,1,1] to_rgb), read in place: element (j, c) at w[j*sj + c*sc], times wscale (= w_mul).
 def _dtype_code(dtype):
     return N.F32 if dtype == torch.float32 else N.BF16
 
 
+def rgb_layout(weight):
+    """(sj, sc, C) for a from_rgb [C,3,1,1] or to_rgb [3,C,1,1] parameter."""
+    if weight.shape[1] == 3 and weight.shape[0] != 3:
+        return 1, 3, weight.shape[0]
+    if weight.shape[0] == 3:
+        return weight.shape[1], 1, weight.shape[1]
+    raise N.SgxError("1x1 convolution is built for the RGB layers (3 channels on one side)")
+
+
 class RgbInFn(Function):
-    """from_rgb: f[p][c] = bias[c] + sum_j img[p][j] * w3c[j][c]."""
+    """f[p][c] = bias[c] + wscale * sum_j img[p][j] * W(j,c)."""
 
     @staticmethod
-    def forward(ctx, img, w3c, bias, out_dtype):
-        img, w = _c(img), _c(w3c.detach())
+    def forward(ctx, img, weight, bias, wscale, out_dtype):
+        img, w = _c(img), _c(weight.detach())
+        sj, sc, C = rgb_layout(w)
         B, H, W, _ = img.shape
-        C = w.shape[1]
         y = torch.empty((B, H, W, C), dtype=out_dtype, device=img.device)
-        N.check(N.lib().sgx_rgb_in(N.ptr(img), N.ptr(w), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(y), B * H * W, C,
-                                   _dtype_code(out_dtype), N.stream()), "sgx_rgb_in")
-        ctx.has_bias = bias is not None
-        ctx.save_for_backward(img, w3c)
+        N.check(N.lib().sgx_rgb_in(N.ptr(img), N.ptr(w), sj, sc, float(wscale), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(y),
+                                   B * H * W, C, _dtype_code(out_dtype), N.stream()), "sgx_rgb_in")
+        ctx.has_bias, ctx.wscale = bias is not None, float(wscale)
+        ctx.save_for_backward(img, weight)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        img, w3c = ctx.saved_tensors
+        img, weight = ctx.saved_tensors
         g = _c(g)
         gi = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gi = RgbOutFn.apply(g, w3c, None)
+            gi = RgbOutFn.apply(g, weight, None, ctx.wscale)
         if not _DATA_GRAD_ONLY:
             if ctx.needs_input_grad[1]:
-                gw = RgbWgradFn.apply(img, g)
+                gw = RgbWgradFn.apply(img, g, weight, ctx.wscale)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = ColSumFn.apply(g)
-        return gi, gw, gb, None
+                gb = ColSumFn.apply(g, 1.0)
+        return gi, gw, gb, None, None
 
 
 class RgbOutFn(Function):
-    """to_rgb: img[p][j] = bias[j] + sum_c x[p][c] * w3c[j][c]."""
+    """img[p][j] = bias[j] + wscale * sum_c x[p][c] * W(j,c)."""
 
     @staticmethod
-    def forward(ctx, x, w3c, bias):
-        x, w = _c(x), _c(w3c.detach())
-        B, H, W, C = x.shape
+    def forward(ctx, x, weight, bias, wscale):
+        x, w = _c(x), _c(weight.detach())
+        sj, sc, C = rgb_layout(w)
+        B, H, W, Cx = x.shape
+        assert Cx == C
         img = torch.empty((B, H, W, 3), dtype=torch.float32, device=x.device)
-        N.check(N.lib().sgx_rgb_out(N.ptr(x), N.ptr(w), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(img), B * H * W, C,
-                                    N.dt(x), N.stream()), "sgx_rgb_out")
-        ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, w3c)
+        N.check(N.lib().sgx_rgb_out(N.ptr(x), N.ptr(w), sj, sc, float(wscale), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(img),
+                                    B * H * W, C, N.dt(x), N.stream()), "sgx_rgb_out")
+        ctx.has_bias, ctx.wscale = bias is not None, float(wscale)
+        ctx.save_for_backward(x, weight)
         return img
 
     @staticmethod
     def backward(ctx, g):
-        x, w3c = ctx.saved_tensors
+        x, weight = ctx.saved_tensors
         g = _c(g)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = RgbInFn.apply(g, w3c, None, x.dtype)
+            gx = RgbInFn.apply(g, weight, None, ctx.wscale, x.dtype)
         if not _DATA_GRAD_ONLY:
             if ctx.needs_input_grad[1]:
-                gw = RgbWgradFn.apply(g, x)
+                gw = RgbWgradFn.apply(g, x, weight, ctx.wscale)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 gb = g.sum(dim=(0, 1, 2))                     # 3 numbers
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 class RgbWgradFn(Function):
-    """dw3c[j][c] = sum_p img[p][j] * f[p][c]."""
+    """dW(j,c) = wscale * sum_p img[p][j] * f[p][c], written in the parameter's layout.  First order."""
 
     @staticmethod
-    def forward(ctx, img, f):
+    def forward(ctx, img, f, weight, wscale):
         img, f = _c(img), _c(f)
-        C = f.shape[-1]
+        sj, sc, C = rgb_layout(weight)
         npix = img.numel() // 3
-        dw = torch.empty((3, C), dtype=torch.float32, device=f.device)
+        dw = torch.empty_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
         L = N.lib()
         ws = N.workspace(L.sgx_rgb_wgrad_ws_bytes(npix, C), f.device)
-        N.check(L.sgx_rgb_wgrad(N.ptr(img), N.ptr(f), N.ptr(dw), N.ptr(ws), ws.numel(), npix, C, N.dt(f), N.stream()), "sgx_rgb_wgrad")
-        ctx.save_for_backward(img, f)
+        N.check(L.sgx_rgb_wgrad(N.ptr(img), N.ptr(f), N.ptr(dw), sj, sc, float(wscale), N.ptr(ws), ws.numel(), npix, C, N.dt(f),
+                                N.stream()), "sgx_rgb_wgrad")
         return dw
 
     @staticmethod
-    def backward(ctx, ggw):
-        img, f = ctx.saved_tensors
-        gi = RgbOutFn.apply(f, ggw, None) if ctx.needs_input_grad[0] else None
-        gf = RgbInFn.apply(img, ggw, None, f.dtype) if ctx.needs_input_grad[1] else None
-        return gi, gf
+    @once_differentiable
+    def backward(ctx, g):
+        raise NotImplementedError("second derivative through a weight gradient is not part of the training path")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -453,9 +496,11 @@ class GEpilogueFn(Function):
     def forward(ctx, x, bias, noise, nw, style):
         x = _c(x)
         B, H, W, C = x.shape
-        noise = _c(noise.detach().reshape(B, H * W).float())
-        nw_c, style_c = _c(nw.detach().float()), _c(style.detach().float())
-        bias_c = None if bias is None else _c(bias.detach().float())
+        noise = _c(noise.detach().reshape(B, H * W))
+        if noise.dtype != torch.float32:
+            noise = noise.float()
+        nw_c, style_c = _c(nw.detach()), _c(style.detach())
+        bias_c = None if bias is None else _c(bias.detach())
         y = torch.empty_like(x)
         mean = torch.empty((B, C), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
@@ -574,21 +619,12 @@ class MatMulFn(Function):
 
 
 # ---------------------------------------------------------------------------------------------------
-# functional conveniences used by the modules
-def conv(x, wp, bias=None, geo="S", act=N.ACT_NONE):
-    return ConvFn.apply(x, wp, bias, geo, act)
-
-
 def linear(x, weight, bias, w_mul, b_mul, act=N.ACT_NONE):
-    """EqualizedLinear: F.linear(x, W*w_mul, b*b_mul) (+ LeakyReLU).  x fp32 [B, in]."""
+    """EqualizedLinear: F.linear(x, W*w_mul, b*b_mul) (+ LeakyReLU).  x fp32 [B, in]; parameters read in place."""
     y = MatMulFn.apply(x, weight, 0, 1, w_mul)
     if bias is None and act == N.ACT_NONE:
         return y
-    b = None if bias is None else (bias * b_mul if b_mul != 1 else bias)
-    if y.shape[1] % 4 != 0:                                   # [B,1] discriminator output: one bias value, no activation
-        assert act == N.ACT_NONE
-        return y + b
-    return BiasActFn.apply(y, b, act)
+    return BiasActFn.apply(y, bias, b_mul, act)
 
 
 def nhwc(x_nchw, dtype=None):

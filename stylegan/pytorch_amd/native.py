@@ -19,6 +19,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU = 0, 1
+PACK_S, PACK_D, PACK_U, PACK_UF = 0, 1, 2, 3
 
 _lib = None
 _lock = threading.Lock()
@@ -34,20 +35,21 @@ SIGNATURES = {
     "sgx_conv4x4s2_down": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_up": (I, [P, P, P, I, I, I, I, I, I, P]),
     "sgx_wgrad_ws_bytes": (Z, [I, I, I, I, I, I]),
-    "sgx_wgrad3x3": (I, [P, P, P, P, Z, I, I, I, I, I, I, P]),
-    "sgx_wgrad4x4s2": (I, [P, P, P, P, Z, I, I, I, I, I, I, P]),
-    "sgx_bias_act": (I, [P, P, P, Z, I, I, I, P]),
+    "sgx_pack_weight": (I, [P, P, P, I, I, I, I, F, I, P]),
+    "sgx_wgrad3x3_param": (I, [P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, P]),
+    "sgx_wgrad4x4s2_param": (I, [P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, P]),
+    "sgx_bias_act": (I, [P, P, F, P, Z, I, I, I, P]),
     "sgx_lrelu_bwd": (I, [P, P, P, Z, I, P]),
     "sgx_axpby": (I, [P, P, P, F, F, Z, I, P]),
     "sgx_blur3x3": (I, [P, P, I, I, I, I, I, P]),
     "sgx_pool2": (I, [P, P, I, I, I, I, F, I, P]),
     "sgx_up2": (I, [P, P, I, I, I, I, F, I, P]),
     "sgx_colsum_ws_bytes": (Z, [Z, I]),
-    "sgx_colsum": (I, [P, P, P, Z, Z, I, I, P]),
-    "sgx_rgb_in": (I, [P, P, P, P, Z, I, I, P]),
-    "sgx_rgb_out": (I, [P, P, P, P, Z, I, I, P]),
+    "sgx_colsum": (I, [P, P, F, P, Z, Z, I, I, P]),
+    "sgx_rgb_in": (I, [P, P, I, I, F, P, P, Z, I, I, P]),
+    "sgx_rgb_out": (I, [P, P, I, I, F, P, P, Z, I, I, P]),
     "sgx_rgb_wgrad_ws_bytes": (Z, [Z, I]),
-    "sgx_rgb_wgrad": (I, [P, P, P, P, Z, Z, I, I, P]),
+    "sgx_rgb_wgrad": (I, [P, P, P, I, I, F, P, Z, Z, I, I, P]),
     "sgx_gepi_ws_bytes": (Z, [I, I, I]),
     "sgx_gepi_fwd": (I, [P, P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),
     "sgx_gepi_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),

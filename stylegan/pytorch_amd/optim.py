@@ -9,6 +9,7 @@ import math
 import torch
 
 from . import native as N
+from .functional import bump_weight_generation
 
 
 def _dev_i64(vals, device):
@@ -72,6 +73,7 @@ class FusedAdam(torch.optim.Optimizer):
                                      sb, sb + 4 * n, None if grad_scale is None else N.ptr(grad_scale), N.stream()),
                     "sgx_adam_multi")
             table.record_stream(torch.cuda.current_stream()); scal.record_stream(torch.cuda.current_stream())
+        bump_weight_generation()                     # parameters changed behind torch's version counters
         return None
 
 
@@ -110,3 +112,4 @@ def ema_update(model_tgt, model_src, beta):
     table = _dev_i64(tg + sr + sizes, dev)
     base = table.data_ptr()
     N.check(N.lib().sgx_ema_multi(base, base + 8 * n, base + 16 * n, n, float(beta), N.stream()), "sgx_ema_multi")
+    bump_weight_generation()

@@ -181,8 +181,8 @@ def test_pointwise_ops():
     assert_close(F.nchw_view(F.Pool2Fn.apply(img, 0.25)), TF.avg_pool2d(img.cpu().permute(0, 3, 1, 2), 2), 1e-6, "avgpool rgb")
     assert_close(F.nchw_view(F.Up2Fn.apply(img, 1.0)), O.upscale2d(img.cpu().permute(0, 3, 1, 2)), 0, "up2 rgb")
     b = 0.1 * gu.seeded((32,), 23)
-    assert_close(F.BiasActFn.apply(xd, b.to(DEV), 1), TF.leaky_relu(x + b, 0.2), 1e-6, "bias+lrelu")
-    assert_close(F.ColSumFn.apply(xd), x.double().sum(dim=(0, 1, 2)), 1e-6, "colsum")
+    assert_close(F.BiasActFn.apply(xd, b.to(DEV), 1.0, 1), TF.leaky_relu(x + b, 0.2), 1e-6, "bias+lrelu")
+    assert_close(F.ColSumFn.apply(xd, 1.0), x.double().sum(dim=(0, 1, 2)), 1e-6, "colsum")
     odd = gu.seeded((1037,), 24)                                       # ragged length: vector tail
     assert_close(F.ScaleFn.apply(odd.to(DEV), -2.0), -2.0 * odd, 1e-7, "scale tail")
 
