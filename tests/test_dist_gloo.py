@@ -1,0 +1,120 @@
+"""CPU, world_size 2, gloo: the data-parallel layer of the G+D step (stylegan/pytorch_amd/dist.py).
+
+The kernels need the GPU, so the per-rank arithmetic here is the CPU oracle; what is under test is the N>1 logic
+itself: the stddev-preserving shard, the SUM all-reduce with bucketing, the mean-vs-sum loss scaling
+(softplus terms are batch means, R1 is a batch sum -- reference models/Losses.py:210,218), and the W-average
+broadcast.  Target: N-rank gradients == single-process gradients at the GLOBAL batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as TF
+
+import golden_util as gu
+from oracle import stylegan_oracle as O
+from stylegan.pytorch_amd.dist import DataParallelGroup, bucketize, stddev_preserving_shard
+
+WORLD = 2
+RES, DEPTH_TOTAL, DEPTH, ALPHA, B = 16, 3, 2, 0.5, 16      # tiny D: 16x16, 8 channels
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def tiny_d_params():
+    dp = O.make_discriminator_params(RES, fmap_base=32, fmap_max=8, dtype=torch.float64)
+    for k in list(dp):
+        dp[k] = gu.fill_value(k, dp[k].shape, torch.float64).requires_grad_(True)
+    return dp
+
+
+def local_d_loss(dp, real, fake, mean_scale):
+    r = O.discriminator(dp, real, DEPTH, ALPHA, DEPTH_TOTAL)
+    f = O.discriminator(dp, fake, DEPTH, ALPHA, DEPTH_TOTAL)
+    loss = (TF.softplus(f).mean() + TF.softplus(-r).mean()) * mean_scale
+    return loss + O.r1_penalty(dp, real, DEPTH, ALPHA, DEPTH_TOTAL) * 5.0
+
+
+def test_shard_keeps_stddev_groups_whole():
+    for bsz, world in [(8, 2), (32, 8), (16, 4), (16, 1)]:
+        x = gu.seeded((bsz, 6, 4, 4), 3, torch.float64)
+        full = O.minibatch_stddev(x)[:, -1]
+        seen = []
+        for rank in range(world):
+            idx = stddev_preserving_shard(bsz, world, rank)
+            seen += idx
+            local = O.minibatch_stddev(x[idx])[:, -1]
+            assert torch.allclose(local, full[idx], atol=1e-14), (bsz, world, rank)
+        assert sorted(seen) == list(range(bsz))
+    with pytest.raises(AssertionError):
+        stddev_preserving_shard(12, 2, 0)                 # 12/4 = 3 groups-slots cannot be split over 2 ranks
+
+
+def test_bucketize():
+    assert bucketize([5, 5, 5, 20, 1], 10) == [[0, 1], [2], [3], [4]]
+    assert bucketize([], 10) == []
+    assert bucketize([100], 10) == [[0]]
+
+
+def _worker(rank, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    torch.set_num_threads(2)
+    try:
+        group = DataParallelGroup(bucket_mb=0.001)          # tiny buckets: exercise the multi-bucket path
+        dp = tiny_d_params()
+        real = gu.seeded((B, 3, RES, RES), 1, torch.float64); fake = gu.seeded((B, 3, RES, RES), 2, torch.float64)
+        idx = stddev_preserving_shard(B, WORLD, rank)
+        loss = local_d_loss(dp, real[idx], fake[idx], mean_scale=1.0 / WORLD)
+        names = sorted(dp)
+        grads = torch.autograd.grad(loss, [dp[k] for k in names], allow_unused=True)   # unused from_rgb: grad None
+        params = []
+        for k, g in zip(names, grads):
+            p = torch.nn.Parameter(dp[k].detach().clone()); p.grad = None if g is None else g.clone(); params.append(p)
+        extra = torch.nn.Parameter(torch.zeros(3))           # inactive resolution: grad None on every rank, skipped
+        group.all_reduce_grads(params + [extra])
+        assert extra.grad is None
+        avg = torch.full((4,), float(rank + 1))
+        group.broadcast(avg, src=0)
+        # numpy payloads are pickled by value (torch tensors would travel as shared-memory handles of a dying process)
+        if rank == 0:
+            out_q.put(({k: (None if p.grad is None else p.grad.numpy()) for k, p in zip(names, params)}, avg.numpy()))
+        else:
+            out_q.put(avg.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_global_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(WORLD)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    grads = next(g for g in got if isinstance(g, tuple))[0]
+    for g in got:
+        avg = g[1] if isinstance(g, tuple) else g
+        assert (torch.as_tensor(avg) == 1.0).all()           # rank 0's buffer everywhere
+    # single process, global batch, un-scaled loss
+    dp = tiny_d_params()
+    real = gu.seeded((B, 3, RES, RES), 1, torch.float64); fake = gu.seeded((B, 3, RES, RES), 2, torch.float64)
+    loss = local_d_loss(dp, real, fake, mean_scale=1.0)
+    names = sorted(dp)
+    ref = dict(zip(names, torch.autograd.grad(loss, [dp[k] for k in names], allow_unused=True)))
+    assert any(v is None for v in ref.values())
+    for k in names:
+        if ref[k] is None:
+            assert grads[k] is None
+            continue
+        err = (torch.as_tensor(grads[k]) - ref[k]).abs().max().item()
+        assert err <= 1e-10 * (ref[k].abs().max().item() + 1e-30) + 1e-14, (k, err)
