@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--cpu-baseline-timeout", type=float, default=150.0)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--layer-table", default=None, help="write a per-layer conv/wgrad timing table (TSV) to this path")
     return ap.parse_args()
 
 
@@ -163,11 +164,22 @@ def main():
 
     roof = None
     if F.KERNEL_TIMES:
-        agg = {}
+        agg, layers = {}, {}
         for name, evs in F.KERNEL_TIMES.items():
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
-            agg[name] = (ms, len(evs), sum(f for _, _, f in evs))
+            ms = 0.0
+            for e0, e1, fl, desc, nb in evs:
+                t = e0.elapsed_time(e1)
+                ms += t
+                L = layers.setdefault((desc, name), [0, 0.0, fl, nb])
+                L[0] += 1; L[1] += t
+            agg[name] = (ms, len(evs), sum(e[2] for e in evs))
         F.KERNEL_TIMES = None
+        if a.layer_table and rank == 0:
+            with open(a.layer_table, "w") as fh:
+                fh.write("layer\tkernel\tcalls_per_step\tavg_us\tTFLOP/s\tGB/s(algorithmic)\tms_per_step\n")
+                for (desc, name), (n, t, fl, nb) in sorted(layers.items(), key=lambda kv: -kv[1][1]):
+                    us = t * 1e3 / n
+                    fh.write(f"{desc}\t{name}\t{n / a.steps:.1f}\t{us:.1f}\t{fl / us / 1e6:.1f}\t{nb / us / 1e3:.0f}\t{t / a.steps:.3f}\n")
         name, (ms, n, flops) = max(agg.items(), key=lambda kv: kv[1][0])
         achieved = flops / (ms * 1e-3) / 1e12
         peak = PEAK[a.dtype] / 1e12

@@ -29,6 +29,9 @@ enum { SGX_EINVAL = -1, SGX_EUNSUPPORTED = -2, SGX_EWORKSPACE = -3 };
 
 int sgx_version(void);
 const char* sgx_last_error(void);
+/* Hardware self-test of ds_read_b64_tr_b16 (the transpose read of the bf16 weight-gradient kernel): with lds[e] = e and
+ * lane l addressing elements [4l,4l+4), writes the 4 int16 values each of the 64 lanes received to out256.          */
+int sgx_selftest_tr16(void* out256, void* stream);
 
 /* ---------------------------------------------------------------- convolutions (MFMA implicit GEMM)
  * Packed weight layout for all three: w[tap][n][k], n = output channel of THIS launch, k = reduction
@@ -50,6 +53,10 @@ int sgx_conv4x4s2_down(const void* x, const void* w, const float* bias, void* y,
  *   y[b,iy,ix,n] = sum over (oy,ky),(ox,kx) with 2oy+ky-1=iy, 2ox+kx-1=ix of x[b,oy,ox,k] * w[ky*4+kx][n][k]      */
 int sgx_conv4x4s2_up(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int dtype,
                      void* stream);
+/* Host-only query: the launch configuration a convolution of this shape resolves to (geo 0: 3x3, 1: 4x4s2 down,
+ * 2: 4x4s2 up; H,W = input size).  cfg5 = {KC, TH, TW, pixels per block, output-channel sub-tiles}: the template
+ * arguments of conv_kernel<T, KC, geo, TH, TW, BP, CT> as rocprofv3 prints them.                                    */
+int sgx_conv_config(int geo, int B, int H, int W, int Cin, int Cout, int dtype, int* cfg5);
 /* sgx_pack_weight: runtime weight scaling + operand packing (`self.weight * self.w_mul` and the 3x3 -> 4x4 kernel
  * synthesis of models/CustomLayers.py:146-150,159-162) in one launch.  w: parameter [O][I][3][3] fp32.
  * Writes BOTH operand packs of the layer in the activation dtype: fwd[taps][O][Ipad] (the layer's convolution) and
@@ -134,6 +141,11 @@ int sgx_mbstd_fwd(const void* x, void* y, int B, int HW, int C, int Cpad, int dt
 int sgx_mbstd_bwd(const void* dy, const void* x, void* dx, int B, int HW, int C, int Cpad, int dtype, void* stream);
 int sgx_mbstd_bwd2(const void* ggx, const void* dy, const void* x, void* ddy, void* gx, int B, int HW, int C, int Cpad,
                    int dtype, void* stream);
+/* R1 penalty head (models/Losses.py:210): out[0] = sum(x^2) over n fp32 values (deterministic two-stage reduce), and
+ * its backward out = alpha * s[0] * x with the upstream scalar s on the device.                                      */
+size_t sgx_sumsq_ws_bytes(void);
+int sgx_sumsq_f32(const float* x, size_t n, void* ws, size_t ws_bytes, float* out, void* stream);
+int sgx_scale_dev_f32(const float* x, const float* s, float alpha, float* out, size_t n, void* stream);
 /* C[M][N] = alpha * op(A) * op(B) (+ beta*C), row-major fp32, MFMA f32 16x16x4.  EqualizedLinear
  * (models/CustomLayers.py:99-103: F.linear(x, W*w_mul)) and its gradients.  ta/tb: 0 = as stored, 1 = transposed:
  *   ta=0: A is [M][K], ta=1: A is [K][M];  tb=0: B is [K][N], tb=1: B is [N][K].                                      */

@@ -71,7 +71,7 @@ class LogisticGAN(GANLoss):
             real_grads = torch.autograd.grad(outputs=real_logit, inputs=real_img,
                                              grad_outputs=torch.ones_like(real_logit),
                                              create_graph=True, retain_graph=True)[0]
-        return torch.sum(real_grads * real_grads)     # SUM over batch and pixels (:210)
+        return F.SumSqFn.apply(real_grads)            # SUM over batch and pixels (:210)
 
     def dis_loss(self, real_samps, fake_samps, height, alpha, r1_gamma=10.0):
         r_preds = self.dis(real_samps, height, alpha)

@@ -21,6 +21,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {                    // round to
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+// two fp32 -> packed bf16x2, round to nearest even: one VALU instruction on gfx950 (the software path above is ~6)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : SGX_LRELU * v; }
 __device__ __forceinline__ float lrelu_slope(float out_or_in) { return out_or_in > 0.f ? 1.f : SGX_LRELU; }
 
@@ -46,7 +52,7 @@ template <> struct VecTraits<bf16_t> {
     __device__ static __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
         unsigned w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };

@@ -17,60 +17,87 @@
 // fp32: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain; parity configs).  bf16: v_mfma_f32_16x16x32_bf16, or
 // 16x16x16 when the layer has only 16 input channels.  Accumulation is always fp32.
 #include "common.h"
+#include <stdlib.h>
 
 enum { G3X3 = 0, GDOWN = 1, GUP = 2 };
 
+// LDS operand tiles are arrays of rows (one pixel, or one (tap, output channel) weight row) holding KC channels.
+// rowb_*: row pitch in bytes; load(): the lane's MFMA fragment (k = kk-step, q = lane>>4); lstore(): one 16-byte chunk.
+// bf16/KC=32 rows are 64 B unpadded with the four 16-byte chunks XOR-swizzled by ((row>>1)&3): ds_read_b128 is served in
+// 16-lane groups that mix rows {0-3,12-15} of one q with rows {4-11} of the neighbouring q, and this swizzle is
+// conflict-free for any row offset (brute-forced; the 80-byte padded pitch is 2-way conflicted there, but it is the
+// conflict-free choice when consecutive lanes are 2 rows apart, i.e. the stride-2 input tile).
 template <typename T, int KC> struct Frag;
 template <> struct Frag<float, 16> {
-    static constexpr int ROWB = 68;                 // 17 dwords: conflict-free ds_read_b32 across 16 pixels
     static constexpr int NK = 4;
+    static constexpr int rowb_w() { return 68; }                 // 17 dwords: conflict-free ds_read_b32 across 16 rows
+    static constexpr int rowb_in(int) { return 68; }
+    static constexpr bool swz_w() { return false; }
+    static constexpr bool swz_in(int) { return false; }
     typedef float frag_t;
-    __device__ static __forceinline__ frag_t load(const char* row, int kk, int q) {
-        return *reinterpret_cast<const float*>(row + (kk * 4 + q) * 4);
-    }
+    static constexpr int pad_pw(int pw, int) { return pw; }
+    __device__ static __forceinline__ int rd_off(int row, int rowb, bool, int q) { return row * rowb + q * 4; }
+    __device__ static __forceinline__ frag_t ld(const char* p, int kk) { return *reinterpret_cast<const float*>(p + kk * 16); }
     __device__ static __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
-    __device__ static __forceinline__ void stage(char* dst, const float* src, bool ok) {
-        float4 v = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float* d = reinterpret_cast<float*>(dst);
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    __device__ static __forceinline__ int lds_off(int row, int rowb, bool, int v) { return row * rowb + v * 16; }
+    __device__ static __forceinline__ void lstore_at(char* p, uint4 val) {   // 68-byte rows: dword stores
+        unsigned* d = reinterpret_cast<unsigned*>(p);
+        d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
     }
 };
 template <> struct Frag<bf16_t, 32> {
-    static constexpr int ROWB = 80;                 // 64 B data + 16 B pad: conflict-free ds_read_b128
     static constexpr int NK = 1;
+    static constexpr int rowb_w() { return 64; }
+    static constexpr int rowb_in(int is) { return is == 1 ? 64 : 80; }
+    static constexpr bool swz_w() { return true; }
+    static constexpr bool swz_in(int is) { return is == 1; }
     typedef bf16x8 frag_t;
-    __device__ static __forceinline__ frag_t load(const char* row, int, int q) {
-        return *reinterpret_cast<const bf16x8*>(row + q * 16);
+    // swizzled tiles: a multiple-of-8 patch width keeps (row>>1)&3 unchanged when a tap moves one patch row down,
+    // so every fragment address is (per-lane base for the tap's x shift) + compile-time immediate
+    static constexpr int pad_pw(int pw, int is) { return is == 1 ? (pw + 7) / 8 * 8 : pw; }
+    __device__ static __forceinline__ int rd_off(int row, int rowb, bool sw, int q) {
+        return row * rowb + (sw ? (q ^ ((row >> 1) & 3)) : q) * 16;
     }
+    __device__ static __forceinline__ frag_t ld(const char* p, int) { return *reinterpret_cast<const bf16x8*>(p); }
     __device__ static __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
-    __device__ static __forceinline__ void stage(char* dst, const bf16_t* src, bool ok) {
-        uint4 v = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(dst) = v;
+    __device__ static __forceinline__ int lds_off(int row, int rowb, bool sw, int v) {
+        return row * rowb + (sw ? (v ^ ((row >> 1) & 3)) : v) * 16;
     }
+    __device__ static __forceinline__ void lstore_at(char* p, uint4 val) { *reinterpret_cast<uint4*>(p) = val; }
 };
 template <> struct Frag<bf16_t, 16> {
-    static constexpr int ROWB = 48;                 // 32 B data + 16 B pad: conflict-free ds_read_b64
+    // 16 channels = 32 B per row.  Stride-1 tiles: unpadded rows, the two 16-byte halves swapped for rows with bit 3
+    // set, so a half-wave's ds_read_b64 (16 rows x {q=0,1}) touches every bank once and the 16-byte staging stores are
+    // contiguous.  Stride-2 input tile: 48-byte pitch (conflict-free reads when lanes are two rows apart).
     static constexpr int NK = 1;
+    static constexpr int rowb_w() { return 32; }
+    static constexpr int rowb_in(int is) { return is == 1 ? 32 : 48; }
+    static constexpr bool swz_w() { return true; }
+    static constexpr bool swz_in(int is) { return is == 1; }
     typedef s16x4 frag_t;
-    __device__ static __forceinline__ frag_t load(const char* row, int, int q) {
-        return *reinterpret_cast<const s16x4*>(row + q * 8);
+    static constexpr int pad_pw(int pw, int is) { return is == 1 ? (pw + 15) / 16 * 16 : pw; }
+    __device__ static __forceinline__ int rd_off(int row, int rowb, bool sw, int q) {
+        const int half = sw ? ((q >> 1) ^ ((row >> 3) & 1)) : (q >> 1);
+        return row * rowb + half * 16 + (q & 1) * 8;
     }
+    __device__ static __forceinline__ frag_t ld(const char* p, int) { return *reinterpret_cast<const s16x4*>(p); }
     __device__ static __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
     }
-    __device__ static __forceinline__ void stage(char* dst, const bf16_t* src, bool ok) {
-        uint4 v = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(dst) = v;
+    __device__ static __forceinline__ int lds_off(int row, int rowb, bool sw, int v) {
+        return row * rowb + (sw ? (v ^ ((row >> 3) & 1)) : v) * 16;
     }
+    __device__ static __forceinline__ void lstore_at(char* p, uint4 val) { *reinterpret_cast<uint4*>(p) = val; }
 };
 
 struct ConvArgs {
     const void* x; const void* w; const float* bias; void* y;
-    int B, H, W, OH, OW, OHc, OWc, Cin, Cout, act, tiles_x, tiles_y;
+    int B, H, W, OH, OW, OHc, OWc, Cin, Cout, act, tiles_x, tiles_y, ntiles;
+    int dbg;   // ablation switches (SGX_CONV_DBG, profiling only): 1 no MFMA, 2 no global loads, 4 no LDS stores, 8 no output stores
 };
 
 template <int GEO> struct Geo;
@@ -79,75 +106,147 @@ template <> struct Geo<GDOWN> { static constexpr int IS = 2, TK = 4, NCLS = 1; }
 template <> struct Geo<GUP> { static constexpr int IS = 1, TK = 2, NCLS = 4; };
 
 template <typename T, int KC, int GEO, int TH, int TW, int BP, int CT>
-__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
+// Register budget: two waves per SIMD (<= 256 VGPR+AGPR) except for the 64-channel x 256-pixel tile, whose prefetch
+// registers would spill at that bound -- and a spilled descriptor reload (scratch_load + s_waitcnt vmcnt) serialises
+// the whole global prefetch behind it (seen in the ISA), which is far worse than one wave per SIMD.
+__global__ __launch_bounds__(256, ((CT * BP >= 1024 || GEO == GDOWN) ? 1 : 2)) void conv_kernel(ConvArgs a) {
     using F = Frag<T, KC>;
     constexpr int IS = Geo<GEO>::IS, TK = Geo<GEO>::TK, NT = TK * TK;
-    constexpr int PH = (TH - 1) * IS + TK, PW = (TW - 1) * IS + TK;
+    constexpr int PH = (TH - 1) * IS + TK, PW = (TW - 1) * IS + TK, PWP = F::pad_pw(PW, IS);
     constexpr int NI = BP / (TH * TW), SPW = BP / 64, BCO = CT * 16;
     constexpr int VE = 16 / (int)sizeof(T), VPP = KC / VE;
-    constexpr int IN_BYTES = (NI * PH * PW * F::ROWB + 15) / 16 * 16;
+    constexpr int ROWI = F::rowb_in(IS), ROWW = F::rowb_w();
+    constexpr bool SWI = F::swz_in(IS), SWW = F::swz_w();
+    constexpr int IN_BYTES = (NI * PH * PWP * ROWI + 15) / 16 * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* in_lds = smem;
     char* w_lds = smem + IN_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l15 = lane & 15;
-    int bx = blockIdx.x;
-    const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
-    const int ty_i = bx % a.tiles_y;
-    const int img0 = (bx / a.tiles_y) * NI;
-    const int ty0 = ty_i * TH, tx0 = tx_i * TW;
+    // Persistent over pixel tiles: block x walks tiles x, x+gridDim.x, ... of its (output-channel block, parity class);
+    // the first K-chunk of the NEXT tile is prefetched into registers while the current tile's MFMAs run.
     const int co0 = blockIdx.y * BCO;
     int py = 0, px = 0;
     if (GEO == GUP) { py = blockIdx.z >> 1; px = blockIdx.z & 1; }
-    const int iy0 = ty0 * IS + (GEO == GUP ? py - 1 : -1);
-    const int ix0 = tx0 * IS + (GEO == GUP ? px - 1 : -1);
+    // Per-thread staging descriptors, computed ONCE: the index arithmetic of the global->LDS copy (which element of
+    // the halo patch / weight tile this thread moves) does not depend on the tile or the K-chunk.  (Measured: doing
+    // it per chunk cost 3-8 VALU instructions per MFMA and made the kernel issue-bound.)
+    constexpr int NIN = (NI * PH * PW * VPP + 255) / 256, NWT = (NT * BCO * VPP + 255) / 256;
+    int in_rel[NIN], in_pos[NIN], in_dst[NIN], w_rel[NWT];
+    const int w_dst0 = F::lds_off(tid / VPP, ROWW, SWW, tid % VPP);   // descriptor j sits 256/VPP rows further (swizzle-neutral)
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {
+        const int idx = tid + j * 256;
+        const int v = idx % VPP, pixel = idx / VPP;
+        const int il = pixel / (PH * PW), rem = pixel % (PH * PW);
+        const int pr = rem / PW, pc = rem % PW;
+        const bool in_range = idx < NI * PH * PW * VPP;
+        in_rel[j] = ((il * a.H + pr) * a.W + pc) * a.Cin + v * VE;
+        in_pos[j] = in_range ? ((il << 20) | (pr << 10) | pc) : -1;
+        in_dst[j] = F::lds_off((il * PH + pr) * PWP + pc, ROWI, SWI, v);
+    }
+#pragma unroll
+    for (int j = 0; j < NWT; ++j) {
+        const int idx = tid + j * 256;
+        const int v = idx % VPP, row = idx / VPP;
+        const int n = row % BCO, t = row / BCO;
+        int tg = t;
+        if (GEO == GUP) tg = (3 - py - 2 * (t >> 1)) * 4 + (3 - px - 2 * (t & 1));
+        w_rel[j] = (idx < NT * BCO * VPP) ? ((tg * a.Cout + co0 + n) * a.Cin + v * VE) : -1;
+    }
+    int img0, ty0, tx0;                                // coordinates of the tile being PREFETCHED (gload) ...
+    long in_base = 0;                                  // element offset of its patch origin (may be negative: halo)
+    unsigned in_ok = 0;                                // per-descriptor validity (inside image and batch)
+    auto set_tile = [&](int tile) {
+        const int tx_i = tile % a.tiles_x; tile /= a.tiles_x;
+        const int ty_i = tile % a.tiles_y;
+        img0 = (tile / a.tiles_y) * NI;
+        ty0 = ty_i * TH; tx0 = tx_i * TW;
+        const int iy0 = ty0 * IS + (GEO == GUP ? py - 1 : -1);
+        const int ix0 = tx0 * IS + (GEO == GUP ? px - 1 : -1);
+        in_base = (((long)img0 * a.H + iy0) * a.W + ix0) * a.Cin;
+        in_ok = 0;
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            const int pp = in_pos[j];
+            const int b = img0 + (pp >> 20), gy = iy0 + ((pp >> 10) & 1023), gx = ix0 + (pp & 1023);
+            const bool ok = (pp >= 0) && (b < a.B) && ((unsigned)gy < (unsigned)a.H) && ((unsigned)gx < (unsigned)a.W);
+            in_ok |= (ok ? 1u : 0u) << j;
+        }
+    };
     const T* __restrict__ xg = static_cast<const T*>(a.x);
     const T* __restrict__ wg = static_cast<const T*>(a.w);
 
-    int pixoff[SPW];
+    // LDS byte offsets of the lane's fragments, computed once: per pixel sub-tile and tap column for the input tile,
+    // one for the weight tile; taps rows / weight rows add compile-time immediates in the MFMA loop.
+    int inoff[SPW][TK];
 #pragma unroll
     for (int s = 0; s < SPW; ++s) {
         const int m = (wave * SPW + s) * 16 + l15;
         const int il = m / (TH * TW), r = (m / TW) % TH, c = m % TW;
-        pixoff[s] = ((il * PH + r * IS) * PW + c * IS) * F::ROWB;
+#pragma unroll
+        for (int tx = 0; tx < TK; ++tx) inoff[s][tx] = F::rd_off((il * PH + r * IS) * PWP + c * IS + tx, ROWI, SWI, q);
     }
+    const int woff = F::rd_off(l15, ROWW, SWW, q);
     f32x4 acc[CT][SPW];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int s = 0; s < SPW; ++s) acc[ct][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Staging is software pipelined through registers: the global loads of K-chunk c+1 (or of the next tile's first
+    // chunk) are issued before the MFMAs of chunk c and written to LDS after them, so HBM/L2 latency hides under them.
+    uint4 rin[NIN], rwt[NWT];
+    const bool w_static = (a.Cin == KC);              // one K-chunk: the weight tile is the same for every pixel tile
+    auto gload = [&](int k0, bool with_w) {
+        const T* src0 = xg + in_base + k0;
+#pragma unroll
+        for (int j = 0; j < NIN; ++j)
+            rin[j] = ((in_ok >> j) & 1u) ? *reinterpret_cast<const uint4*>(src0 + in_rel[j]) : make_uint4(0, 0, 0, 0);
+        if (with_w) {
+            const T* w0 = wg + k0;
+#pragma unroll
+            for (int j = 0; j < NWT; ++j)
+                rwt[j] = (w_rel[j] >= 0) ? *reinterpret_cast<const uint4*>(w0 + w_rel[j]) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](bool with_w) {
+#pragma unroll
+        for (int j = 0; j < NIN; ++j)
+            if (in_pos[j] >= 0) F::lstore_at(in_lds + in_dst[j], rin[j]);
+        if (with_w) {
+#pragma unroll
+            for (int j = 0; j < NWT; ++j)
+                if (w_rel[j] >= 0) F::lstore_at(w_lds + w_dst0 + j * (256 / VPP) * ROWW, rwt[j]);
+        }
+    };
+    T* __restrict__ yg = static_cast<T*>(a.y);
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    set_tile(tile);
+    gload(0, true);
+    bool first = true;
+    for (;;) {
+    const int c_img0 = img0, c_ty0 = ty0, c_tx0 = tx0;   // ... and of the tile being COMPUTED
     for (int k0 = 0; k0 < a.Cin; k0 += KC) {
-        if (k0) __syncthreads();
-        // ---- stage the input patch (zero filled outside the image / batch)
-        for (int idx = tid; idx < NI * PH * PW * VPP; idx += 256) {
-            const int v = idx % VPP, pixel = idx / VPP;
-            const int il = pixel / (PH * PW), rem = pixel % (PH * PW);
-            const int gy = iy0 + rem / PW, gx = ix0 + rem % PW, b = img0 + il;
-            const bool ok = (b < a.B) && ((unsigned)gy < (unsigned)a.H) && ((unsigned)gx < (unsigned)a.W);
-            const T* src = xg + (((size_t)b * a.H + gy) * a.W + gx) * a.Cin + k0 + v * VE;
-            F::stage(in_lds + pixel * F::ROWB + v * 16, src, ok);
-        }
-        // ---- stage the weights of every tap for this channel chunk
-        for (int idx = tid; idx < NT * BCO * VPP; idx += 256) {
-            const int v = idx % VPP, row = idx / VPP;
-            const int n = row % BCO, t = row / BCO;
-            int tg = t;
-            if (GEO == GUP) tg = (3 - py - 2 * (t >> 1)) * 4 + (3 - px - 2 * (t & 1));
-            const T* src = wg + ((size_t)tg * a.Cout + co0 + n) * a.Cin + k0 + v * VE;
-            F::stage(w_lds + row * F::ROWB + v * 16, src, true);
-        }
+        if (!first) __syncthreads();                  // every wave is done reading the previous stage
+        const bool ww = first || !w_static;
+        if (!(a.dbg & 4) || first) lstore(ww);
+        first = false;
         __syncthreads();
+        if (a.dbg & 2) { if (k0 + KC >= a.Cin && tile + (int)gridDim.x < a.ntiles) set_tile(tile + gridDim.x); }
+        else if (k0 + KC < a.Cin) gload(k0 + KC, true);    // in flight during the MFMAs below
+        else if (tile + (int)gridDim.x < a.ntiles) { set_tile(tile + gridDim.x); gload(0, !w_static); }
+        if (!(a.dbg & 1))
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int toff = ((t / TK) * PW + (t % TK)) * F::ROWB;
 #pragma unroll
             for (int kk = 0; kk < F::NK; ++kk) {
                 typename F::frag_t fa[CT], fb[SPW];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) fa[ct] = F::load(w_lds + (t * BCO + ct * 16 + l15) * F::ROWB, kk, q);
+                for (int ct = 0; ct < CT; ++ct) fa[ct] = F::ld(w_lds + woff + (t * BCO + ct * 16) * ROWW, kk);
 #pragma unroll
-                for (int s = 0; s < SPW; ++s) fb[s] = F::load(in_lds + pixoff[s] + toff, kk, q);
+                for (int s = 0; s < SPW; ++s) fb[s] = F::ld(in_lds + inoff[s][t % TK] + (t / TK) * PWP * ROWI, kk);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -155,14 +254,51 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
             }
         }
     }
-    // ---- epilogue: bias, activation, NHWC vector store (4 consecutive channels per lane)
-    T* __restrict__ yg = static_cast<T*>(a.y);
+    // ---- epilogue: bias, activation, NHWC store.
+    // bf16 with >= 32 output channels per block: a lane's natural store is 8 bytes and a wave instruction writes 32-byte
+    // pieces (measured: 14 of 43 us on the 256^2 64->64 layer).  Transpose the tile through LDS instead and write whole
+    // BCO*2-byte channel rows with 16 bytes per lane.
+    if constexpr (sizeof(T) == 2 && CT >= 2) {
+        constexpr int OROW = BCO * 2 + 16, VPR = BCO * 2 / 16;
+        __syncthreads();                                  // every wave is done reading this tile's operands
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            const int m = (wave * SPW + s) * 16 + l15;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                float v[4] = {acc[ct][s][0], acc[ct][s][1], acc[ct][s][2], acc[ct][s][3]};
+                if (a.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + co0 + ct * 16 + q * 4);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if (a.act == SGX_ACT_LRELU) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i]);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(smem + m * OROW + (ct * 16 + q * 4) * 2) = o;
+            }
+        }
+        __syncthreads();
+        if (!(a.dbg & 8))
+        for (int idx = tid; idx < BP * VPR; idx += 256) {
+            const int m = idx / VPR, v = idx % VPR;
+            const int il = m / (TH * TW), r = (m / TW) % TH, c = m % TW;
+            const int b = c_img0 + il, oyc = c_ty0 + r, oxc = c_tx0 + c;
+            if (b >= a.B || oyc >= a.OHc || oxc >= a.OWc) continue;
+            const int oy = (GEO == GUP) ? 2 * oyc + py : oyc, ox = (GEO == GUP) ? 2 * oxc + px : oxc;
+            T* dst = yg + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(smem + m * OROW + v * 16);
+        }
+    } else
 #pragma unroll
     for (int s = 0; s < SPW; ++s) {
         const int m = (wave * SPW + s) * 16 + l15;
         const int il = m / (TH * TW), r = (m / TW) % TH, c = m % TW;
-        const int b = img0 + il, oyc = ty0 + r, oxc = tx0 + c;
-        if (b >= a.B || oyc >= a.OHc || oxc >= a.OWc) continue;
+        const int b = c_img0 + il, oyc = c_ty0 + r, oxc = c_tx0 + c;
+        if (b >= a.B || oyc >= a.OHc || oxc >= a.OWc || (a.dbg & 8)) continue;
         const int oy = (GEO == GUP) ? 2 * oyc + py : oyc, ox = (GEO == GUP) ? 2 * oxc + px : oxc;
         T* dst = yg + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + q * 4;
 #pragma unroll
@@ -180,86 +316,147 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
                 *reinterpret_cast<float4*>(dst + ct * 16) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 uint2 o;
-                o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(dst + ct * 16) = o;
             }
         }
     }
+    tile += gridDim.x;
+    if (tile >= a.ntiles) break;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) acc[ct][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 }
 
 template <typename T, int KC, int GEO, int TH, int TW, int BP, int CT>
-static int launch_conv(const ConvArgs& a, int ngroups, hipStream_t st) {
+static int launch_conv(ConvArgs& a, int ngroups, hipStream_t st) {
     using F = Frag<T, KC>;
     constexpr int IS = Geo<GEO>::IS, TK = Geo<GEO>::TK;
     constexpr int PH = (TH - 1) * IS + TK, PW = (TW - 1) * IS + TK, NI = BP / (TH * TW);
-    constexpr int IN_BYTES = (NI * PH * PW * F::ROWB + 15) / 16 * 16;
-    constexpr int LDS = IN_BYTES + TK * TK * CT * 16 * F::ROWB;
+    constexpr int IN_BYTES = (NI * PH * F::pad_pw(PW, IS) * F::rowb_in(IS) + 15) / 16 * 16;
+    constexpr int OPER = IN_BYTES + TK * TK * CT * 16 * F::rowb_w();
+    constexpr int OUTB = (sizeof(T) == 2 && CT >= 2) ? BP * (CT * 32 + 16) : 0;     // LDS-transposed bf16 epilogue tile
+    constexpr int LDS = OPER > OUTB ? OPER : OUTB;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kern = conv_kernel<T, KC, GEO, TH, TW, BP, CT>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)attr;
-    dim3 grid((unsigned)(ngroups * a.tiles_y * a.tiles_x), (unsigned)(a.Cout / (CT * 16)), Geo<GEO>::NCLS);
+    a.ntiles = ngroups * a.tiles_y * a.tiles_x;
+    static const int dbg = [] { const char* e = getenv("SGX_CONV_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
+    // persistent grid: about as many blocks as can be resident (LDS- and register-limited), never more than tiles
+    int per_cu = (160 * 1024) / LDS;
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    const int yz = (a.Cout / (CT * 16)) * Geo<GEO>::NCLS;
+    int gx = (256 * per_cu + yz - 1) / yz;
+    if (gx > a.ntiles) gx = a.ntiles;
+    if (gx < 1) gx = 1;
+    dim3 grid((unsigned)gx, (unsigned)(a.Cout / (CT * 16)), Geo<GEO>::NCLS);
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, a);
     SGX_LAUNCH_CHECK("conv_kernel");
     return 0;
 }
 
-template <typename T, int KC, int GEO, int BP, int CT>
-static int dispatch_tile(ConvArgs& a, hipStream_t st) {
-    // tile shape by class-grid size; NI images per block fill the pixel tile at low resolution
-    if (a.OHc >= 16 && a.OWc >= 16) {
-        constexpr int TH = BP / 16, TW = 16;
-        a.tiles_y = (a.OHc + TH - 1) / TH; a.tiles_x = (a.OWc + TW - 1) / TW;
-        return launch_conv<T, KC, GEO, TH, TW, BP, CT>(a, a.B, st);
-    } else if (a.OHc >= 8 && a.OWc >= 8) {
-        constexpr int NI = BP / 64;
-        a.tiles_y = (a.OHc + 7) / 8; a.tiles_x = (a.OWc + 7) / 8;
-        return launch_conv<T, KC, GEO, 8, 8, BP, CT>(a, (a.B + NI - 1) / NI, st);
-    } else {
-        constexpr int NI = BP / 16;
-        a.tiles_y = (a.OHc + 3) / 4; a.tiles_x = (a.OWc + 3) / 4;
-        return launch_conv<T, KC, GEO, 4, 4, BP, CT>(a, (a.B + NI - 1) / NI, st);
+// ---- launch configuration: (pixels per block, output-channel sub-tiles per block, tile shape).  Big tiles maximise
+// operand reuse; when the problem is small (low resolution x batch 4) smaller tiles are chosen until the grid has at
+// least two blocks per CU.  Exposed through sgx_conv_config so callers can name the instantiation a launch uses.
+struct ConvCfg { int bp, ct, th, tw, ni; };
+static void tile_shape(int bp, int ohc, int owc, ConvCfg& c) {
+    if (ohc >= 16 && owc >= 16) { c.th = bp / 16; c.tw = 16; }
+    else if (ohc >= 8 && owc >= 8) { c.th = 8; c.tw = 8; }
+    else { c.th = 4; c.tw = 4; }
+    c.ni = bp / (c.th * c.tw);
+}
+static ConvCfg pick_cfg(int geo, int B, int ohc, int owc, int Cout) {
+    static const int cand_su[][2] = {{256, 4}, {256, 2}, {128, 4}, {256, 1}, {128, 2}, {128, 1}, {64, 2}, {64, 1}};
+    static const int cand_d[][2] = {{128, 2}, {128, 1}, {64, 2}, {64, 1}};
+    const int (*cand)[2] = geo == GDOWN ? cand_d : cand_su;
+    const int n = geo == GDOWN ? 4 : 8;
+    ConvCfg best{0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        static const int max_ct = [] { const char* e = getenv("SGX_CONV_MAXCT"); return e ? atoi(e) : 4; }();   // tuning knob
+        static const int max_bp = [] { const char* e = getenv("SGX_CONV_MAXBP"); return e ? atoi(e) : 256; }();
+        if (cand[i][1] > max_ct || cand[i][0] > max_bp) continue;
+        if (Cout % (16 * cand[i][1]) != 0) continue;
+        ConvCfg c{cand[i][0], cand[i][1], 0, 0, 0};
+        tile_shape(c.bp, ohc, owc, c);
+        if (c.ni < 1) continue;
+        best = c;
+        const long blocks = (long)((B + c.ni - 1) / c.ni) * ((ohc + c.th - 1) / c.th) * ((owc + c.tw - 1) / c.tw) *
+                            (Cout / (16 * c.ct)) * (geo == GUP ? 4 : 1);
+        if (blocks >= 512) break;
     }
+    return best;
 }
 
-template <typename T, int KC, int GEO, int BP>
-static int dispatch_ct(ConvArgs& a, int max_ct, hipStream_t st) {
-    if (max_ct >= 4 && a.Cout % 64 == 0) return dispatch_tile<T, KC, GEO, BP, 4>(a, st);
-    if (max_ct >= 2 && a.Cout % 32 == 0) return dispatch_tile<T, KC, GEO, BP, 2>(a, st);
-    return dispatch_tile<T, KC, GEO, BP, 1>(a, st);
+template <typename T, int KC, int GEO, int BP, int CT>
+static int dispatch_tile(ConvArgs& a, const ConvCfg& c, hipStream_t st) {
+    a.tiles_y = (a.OHc + c.th - 1) / c.th; a.tiles_x = (a.OWc + c.tw - 1) / c.tw;
+    const int ngroups = (a.B + c.ni - 1) / c.ni;
+    if (c.tw == 16) return launch_conv<T, KC, GEO, BP / 16, 16, BP, CT>(a, ngroups, st);
+    if (c.tw == 8) return launch_conv<T, KC, GEO, 8, 8, BP, CT>(a, ngroups, st);
+    return launch_conv<T, KC, GEO, 4, 4, BP, CT>(a, ngroups, st);
 }
 
-template <int GEO, int BP>
-static int dispatch_conv(ConvArgs& a, int dtype, int max_ct, hipStream_t st) {
+template <typename T, int KC, int GEO>
+static int dispatch_cfg(ConvArgs& a, hipStream_t st) {
+    const ConvCfg c = pick_cfg(GEO, a.B, a.OHc, a.OWc, a.Cout);
+    SGX_REQUIRE(c.bp != 0, SGX_EUNSUPPORTED, "conv: no launch configuration for Cout=%d", a.Cout);
+    if constexpr (GEO != GDOWN) {
+        if (c.bp == 256 && c.ct == 4) return dispatch_tile<T, KC, GEO, 256, 4>(a, c, st);
+        if (c.bp == 256 && c.ct == 2) return dispatch_tile<T, KC, GEO, 256, 2>(a, c, st);
+        if (c.bp == 256 && c.ct == 1) return dispatch_tile<T, KC, GEO, 256, 1>(a, c, st);
+        if (c.bp == 128 && c.ct == 4) return dispatch_tile<T, KC, GEO, 128, 4>(a, c, st);
+    }
+    if (c.bp == 128 && c.ct == 2) return dispatch_tile<T, KC, GEO, 128, 2>(a, c, st);
+    if (c.bp == 128 && c.ct == 1) return dispatch_tile<T, KC, GEO, 128, 1>(a, c, st);
+    if (c.bp == 64 && c.ct == 2) return dispatch_tile<T, KC, GEO, 64, 2>(a, c, st);
+    return dispatch_tile<T, KC, GEO, 64, 1>(a, c, st);
+}
+
+template <int GEO>
+static int dispatch_conv(ConvArgs& a, int dtype, hipStream_t st) {
     SGX_REQUIRE(a.Cout % 16 == 0 && a.Cin % 16 == 0, SGX_EUNSUPPORTED, "conv: channels must be multiples of 16 (Cin=%d Cout=%d)", a.Cin, a.Cout);
     SGX_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0, SGX_EINVAL, "conv: bad shape");
-    if (dtype == SGX_F32) return dispatch_ct<float, 16, GEO, BP>(a, max_ct, st);
+    if (dtype == SGX_F32) return dispatch_cfg<float, 16, GEO>(a, st);
     if (dtype == SGX_BF16) {
-        if (a.Cin % 32 == 0) return dispatch_ct<bf16_t, 32, GEO, BP>(a, max_ct, st);
-        return dispatch_ct<bf16_t, 16, GEO, BP>(a, max_ct, st);
+        if (a.Cin % 32 == 0) return dispatch_cfg<bf16_t, 32, GEO>(a, st);
+        return dispatch_cfg<bf16_t, 16, GEO>(a, st);
     }
     SGX_REQUIRE(false, SGX_EINVAL, "conv: bad dtype %d", dtype);
+}
+
+extern "C" int sgx_conv_config(int geo, int B, int H, int W, int Cin, int Cout, int dtype, int* cfg5) {
+    SGX_REQUIRE(geo >= 0 && geo <= 2 && cfg5, SGX_EINVAL, "conv_config: bad args");
+    const int ohc = geo == GDOWN ? H / 2 : H, owc = geo == GDOWN ? W / 2 : W;
+    const ConvCfg c = pick_cfg(geo, B, ohc, owc, Cout);
+    cfg5[0] = dtype == SGX_F32 ? 16 : (Cin % 32 == 0 ? 32 : 16);
+    cfg5[1] = c.th; cfg5[2] = c.tw; cfg5[3] = c.bp; cfg5[4] = c.ct;
+    return 0;
 }
 
 extern "C" int sgx_conv3x3(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin,
                            int Cout, int act, int dtype, void* stream) {
     ConvArgs a{x, w, bias, y, B, H, W, H, W, H, W, Cin, Cout, act, 0, 0};
-    return dispatch_conv<G3X3, 256>(a, dtype, 4, (hipStream_t)stream);
+    return dispatch_conv<G3X3>(a, dtype, (hipStream_t)stream);
 }
 
 extern "C" int sgx_conv4x4s2_down(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,
                                   int Cin, int Cout, int act, int dtype, void* stream) {
     SGX_REQUIRE(H % 2 == 0 && W % 2 == 0, SGX_EINVAL, "conv4x4s2_down: odd input size");
     ConvArgs a{x, w, bias, y, B, H, W, H / 2, W / 2, H / 2, W / 2, Cin, Cout, act, 0, 0};
-    return dispatch_conv<GDOWN, 128>(a, dtype, 2, (hipStream_t)stream);
+    return dispatch_conv<GDOWN>(a, dtype, (hipStream_t)stream);
 }
 
 extern "C" int sgx_conv4x4s2_up(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout,
                                 int dtype, void* stream) {
     ConvArgs a{x, w, nullptr, y, B, H, W, 2 * H, 2 * W, H, W, Cin, Cout, SGX_ACT_NONE, 0, 0};
-    return dispatch_conv<GUP, 256>(a, dtype, 4, (hipStream_t)stream);
+    return dispatch_conv<GUP>(a, dtype, (hipStream_t)stream);
 }
 
 // =====================================================================================================
@@ -302,7 +499,19 @@ template <> struct WFrag<bf16_t> {
     }
 };
 
-template <typename T, int GEO, int TH, int TW, int BP, int NSUB, int KSUB>
+// LDS transpose read (gfx950 ds_read_b64_tr_b16): within a 16-lane group, lane i supplies the 8-byte address of row i/4,
+// column block i%4 of a [4 rows][16 columns] bf16 tile and receives column i of it (4 rows) -- exactly the K-major MFMA
+// operand that a pixel-major (NHWC) tile cannot provide with plain reads.
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+}
+__device__ __forceinline__ bf16x8 cat8(s16x4 lo, s16x4 hi) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <typename T, int GEO, int TH, int TW, int BP, int NSUB, int KSUB, bool TR>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     using F = WFrag<T>;
     constexpr int IS = Geo<GEO>::IS, TK = Geo<GEO>::TK, NT = TK * TK;
@@ -360,6 +569,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             *reinterpret_cast<uint4*>(k_lds + pixel * KROW + v * 16) = val;
         }
         __syncthreads();
+        if constexpr (TR) {
+            // bf16, 32 pixels per MFMA (v_mfma_f32_16x16x32_bf16): two transpose reads per operand
+            for (int ks = 0; ks < BP / 32; ++ks) {
+                int noff2[2], koff2[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int m = ks * 32 + h * 16 + q * 4 + (l15 >> 2);
+                    const int il = m / (TH * TW), r = (m / TW) % TH, c = m % TW;
+                    noff2[h] = m * NROW + (l15 & 3) * 8;
+                    koff2[h] = ((il * PH + r * IS) * PW + c * IS) * KROW + (l15 & 3) * 8;
+                }
+                bf16x8 fa8[NSUB];
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns)
+                    fa8[ns] = cat8(lds_tr16(n_lds + noff2[0] + ns * 32), lds_tr16(n_lds + noff2[1] + ns * 32));
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const int t = wave + 4 * i;
+                    if (t < NT) {
+                        const int toff = ((t / TK) * PW + (t % TK)) * KROW;
+#pragma unroll
+                        for (int kk = 0; kk < KSUB; ++kk) {
+                            const bf16x8 fb8 = cat8(lds_tr16(k_lds + toff + koff2[0] + kk * 32), lds_tr16(k_lds + toff + koff2[1] + kk * 32));
+#pragma unroll
+                            for (int ns = 0; ns < NSUB; ++ns)
+                                acc[i][ns][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa8[ns], fb8, acc[i][ns][kk], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else
         for (int ks = 0; ks < BP / F::KPS; ++ks) {
             int noff[4], koff[4];
 #pragma unroll
@@ -460,14 +700,14 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(FinishArgs f) {
 }
 
 static int wgrad_nsplit(int pairs, int ntiles) {
-    int want = (1024 + pairs - 1) / pairs;
+    int want = (1024 + pairs - 1) / pairs;           // measured: 2048 blocks is slower (partials + finish grow faster)
     if (want > 512) want = 512;
     if (want > ntiles) want = ntiles;
     if (want < 1) want = 1;
     return want;
 }
 
-template <typename T, int GEO, int TH, int TW, int BP, int NSUB, int KSUB>
+template <typename T, int GEO, int TH, int TW, int BP, int NSUB, int KSUB, bool TR>
 static int launch_wgrad(WgradArgs& a, void* ws, size_t ws_bytes, int* nsplit_out, hipStream_t st) {
     using F = WFrag<T>;
     constexpr int IS = Geo<GEO>::IS, TK = Geo<GEO>::TK, NT = TK * TK;
@@ -483,7 +723,7 @@ static int launch_wgrad(WgradArgs& a, void* ws, size_t ws_bytes, int* nsplit_out
     if ((size_t)nsplit > fit) nsplit = (int)fit;
     SGX_REQUIRE(nsplit >= 1, SGX_EWORKSPACE, "wgrad: workspace too small (%zu bytes, need >= %zu)", ws_bytes, total * sizeof(float));
     a.out = static_cast<float*>(ws);
-    auto kern = wgrad_kernel<T, GEO, TH, TW, BP, NSUB, KSUB>;
+    auto kern = wgrad_kernel<T, GEO, TH, TW, BP, NSUB, KSUB, TR>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)attr;
@@ -493,25 +733,31 @@ static int launch_wgrad(WgradArgs& a, void* ws, size_t ws_bytes, int* nsplit_out
     return 0;
 }
 
-template <typename T, int GEO, int BP, int NSUB, int KSUB>
+template <typename T, int GEO, int BP, int NSUB, int KSUB, bool TR>
 static int wgrad_tile(WgradArgs& a, void* ws, size_t wsb, int* ns, hipStream_t st) {
-    if (a.Hn >= 16 && a.Wn >= 16) return launch_wgrad<T, GEO, BP / 16, 16, BP, NSUB, KSUB>(a, ws, wsb, ns, st);
-    if (a.Hn >= 8 && a.Wn >= 8) return launch_wgrad<T, GEO, (BP >= 64 ? 8 : BP / 8), 8, BP, NSUB, KSUB>(a, ws, wsb, ns, st);
-    return launch_wgrad<T, GEO, (BP >= 16 ? 4 : BP / 4), 4, BP, NSUB, KSUB>(a, ws, wsb, ns, st);
+    if (a.Hn >= 16 && a.Wn >= 16) return launch_wgrad<T, GEO, BP / 16, 16, BP, NSUB, KSUB, TR>(a, ws, wsb, ns, st);
+    if (a.Hn >= 8 && a.Wn >= 8) return launch_wgrad<T, GEO, (BP >= 64 ? 8 : BP / 8), 8, BP, NSUB, KSUB, TR>(a, ws, wsb, ns, st);
+    return launch_wgrad<T, GEO, (BP >= 16 ? 4 : BP / 4), 4, BP, NSUB, KSUB, TR>(a, ws, wsb, ns, st);
 }
 
-template <typename T, int GEO, int BP>
+// SGX_WGRAD_TR=0/1 selects the plain / transpose-read bf16 operand path (A/B switch for parity tests and profiling)
+static bool wgrad_use_tr() {
+    static const int v = [] { const char* e = getenv("SGX_WGRAD_TR"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+
+template <typename T, int GEO, int BP, bool TR = false>
 static int wgrad_ch(WgradArgs& a, void* ws, size_t wsb, int* ns, hipStream_t st) {
     SGX_REQUIRE(a.Cn % 16 == 0 && a.Ck % 16 == 0, SGX_EUNSUPPORTED, "wgrad: channels must be multiples of 16");
     const bool n32 = a.Cn % 32 == 0, k32 = a.Ck % 32 == 0;
     if (GEO == GDOWN) {                                       // fine patch is 4x larger: keep the k side at 16 channels
-        if (n32) return wgrad_tile<T, GEO, BP, 2, 1>(a, ws, wsb, ns, st);
-        return wgrad_tile<T, GEO, BP, 1, 1>(a, ws, wsb, ns, st);
+        if (n32) return wgrad_tile<T, GEO, BP, 2, 1, TR>(a, ws, wsb, ns, st);
+        return wgrad_tile<T, GEO, BP, 1, 1, TR>(a, ws, wsb, ns, st);
     }
-    if (n32 && k32) return wgrad_tile<T, GEO, BP, 2, 2>(a, ws, wsb, ns, st);
-    if (n32) return wgrad_tile<T, GEO, BP, 2, 1>(a, ws, wsb, ns, st);
-    if (k32) return wgrad_tile<T, GEO, BP, 1, 2>(a, ws, wsb, ns, st);
-    return wgrad_tile<T, GEO, BP, 1, 1>(a, ws, wsb, ns, st);
+    if (n32 && k32) return wgrad_tile<T, GEO, BP, 2, 2, TR>(a, ws, wsb, ns, st);
+    if (n32) return wgrad_tile<T, GEO, BP, 2, 1, TR>(a, ws, wsb, ns, st);
+    if (k32) return wgrad_tile<T, GEO, BP, 1, 2, TR>(a, ws, wsb, ns, st);
+    return wgrad_tile<T, GEO, BP, 1, 1, TR>(a, ws, wsb, ns, st);
 }
 
 static int wgrad_finish(const void* ws, float* dw, int nsplit, int O, int I, int Ip, int mode, int transposed, int flip_t,
@@ -538,7 +784,7 @@ extern "C" int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, void
     WgradArgs a{x, dy, nullptr, B, H, W, H, W, Cx, Cdy, 0, 0, 0};
     int ns = 0, rc;
     if (dtype == SGX_F32) rc = wgrad_ch<float, G3X3, 128>(a, ws, ws_bytes, &ns, st);
-    else if (dtype == SGX_BF16) rc = wgrad_ch<bf16_t, G3X3, 128>(a, ws, ws_bytes, &ns, st);
+    else if (dtype == SGX_BF16) rc = wgrad_use_tr() ? wgrad_ch<bf16_t, G3X3, 128, true>(a, ws, ws_bytes, &ns, st) : wgrad_ch<bf16_t, G3X3, 128>(a, ws, ws_bytes, &ns, st);
     else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad3x3_param: bad dtype"); }
     if (rc) return rc;
     return wgrad_finish(ws, dW, ns, O, I, Ip, SGX_PACK_S, adjoint, adjoint, scale, st);
@@ -555,7 +801,7 @@ extern "C" int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float*
     WgradArgs a{fine, coarse, nullptr, B, H, W, H / 2, W / 2, Cfine, Ccoarse, 0, 0, 0};
     int ns = 0, rc;
     if (dtype == SGX_F32) rc = wgrad_ch<float, GDOWN, 64>(a, ws, ws_bytes, &ns, st);
-    else if (dtype == SGX_BF16) rc = wgrad_ch<bf16_t, GDOWN, 64>(a, ws, ws_bytes, &ns, st);
+    else if (dtype == SGX_BF16) rc = wgrad_use_tr() ? wgrad_ch<bf16_t, GDOWN, 64, true>(a, ws, ws_bytes, &ns, st) : wgrad_ch<bf16_t, GDOWN, 64>(a, ws, ws_bytes, &ns, st);
     else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad4x4s2_param: bad dtype"); }
     if (rc) return rc;
     return wgrad_finish(ws, dW, ns, O, I, I, mode, transposed, 0, scale, st);

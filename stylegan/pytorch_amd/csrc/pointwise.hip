@@ -299,15 +299,67 @@ __global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ 
         out[c] = (float)(t * (double)scale);
     }
 }
+// Vector variant (C % VE == 0, C/VE <= 256, power of two): one 16-byte load per lane per row; per-lane fp32 partials over
+// <= 64 rows, then fp64.  NJ = 1: plain column sums.  NJ = 3: column sums weighted by the three RGB values of the pixel
+// (the 1x1 RGB weight gradient), output ws[blk][j][C].
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void colsum_vec_stage1(const T* __restrict__ x, const float* __restrict__ img, double* __restrict__ ws,
+                                                         size_t npix, int C) {
+    constexpr int VE = VecTraits<T>::VE;
+    extern __shared__ double sh[];                                   // [256][NJ*VE]
+    const int cv = C / VE, rows = 256 / cv;
+    const int tc = threadIdx.x % cv, tr = threadIdx.x / cv;
+    const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const size_t p0 = (size_t)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
+    double acc[NJ * VE];
+    float part[NJ * VE];
+#pragma unroll
+    for (int k = 0; k < NJ * VE; ++k) { acc[k] = 0.0; part[k] = 0.f; }
+    int cnt = 0;
+    for (size_t p = p0 + tr; p < p1; p += rows) {
+        float v[VE];
+        VecTraits<T>::load(x + (p * cv + tc) * VE, v);
+        if (NJ == 1) {
+#pragma unroll
+            for (int k = 0; k < VE; ++k) part[k] += v[k];
+        } else {
+            const float r = img[p * 3], g = img[p * 3 + 1], b = img[p * 3 + 2];
+#pragma unroll
+            for (int k = 0; k < VE; ++k) { part[k] += v[k] * r; part[VE + k] += v[k] * g; part[2 * VE + k] += v[k] * b; }
+        }
+        if (++cnt == 64) {
+#pragma unroll
+            for (int k = 0; k < NJ * VE; ++k) { acc[k] += (double)part[k]; part[k] = 0.f; }
+            cnt = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NJ * VE; ++k) sh[threadIdx.x * NJ * VE + k] = acc[k] + (double)part[k];
+    __syncthreads();
+    if (tr == 0) {
+#pragma unroll
+        for (int k = 0; k < NJ * VE; ++k) {
+            double s = 0.0;
+            for (int r = 0; r < rows; ++r) s += sh[(r * cv + tc) * NJ * VE + k];
+            ws[((size_t)blockIdx.x * NJ + k / VE) * C + tc * VE + (k % VE)] = s;
+        }
+    }
+}
+static bool colsum_vec_ok(int C, int ve) { const int cv = C / ve; return C % ve == 0 && cv >= 1 && cv <= 256 && (cv & (cv - 1)) == 0; }
+
 extern "C" size_t sgx_colsum_ws_bytes(size_t npix, int C) { (void)npix; return (size_t)COLSUM_BLOCKS * C * sizeof(double); }
 extern "C" int sgx_colsum(const void* x, float* out, float scale, void* ws, size_t ws_bytes, size_t npix, int C, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SGX_REQUIRE(ws_bytes >= sgx_colsum_ws_bytes(npix, C), SGX_EWORKSPACE, "colsum: workspace");
-    SGX_REQUIRE(C <= 256 ? (256 % C == 0) : true, SGX_EUNSUPPORTED, "colsum: C=%d", C);
+    SGX_REQUIRE(C >= 1, SGX_EINVAL, "colsum: C=%d", C);     // scalar kernel: any C (C=3 for the RGB bias gradient)
     int nblk = (int)((npix + 63) / 64);
     if (nblk > COLSUM_BLOCKS) nblk = COLSUM_BLOCKS;
     if (nblk < 1) nblk = 1;
-    if (dtype == SGX_F32) hipLaunchKernelGGL(colsum_stage1<float>, dim3(nblk), dim3(256), 256 * sizeof(double), st, (const float*)x, (double*)ws, npix, C);
+    if (dtype == SGX_F32 && colsum_vec_ok(C, 4))
+        hipLaunchKernelGGL((colsum_vec_stage1<float, 1>), dim3(nblk), dim3(256), 256 * 4 * sizeof(double), st, (const float*)x, (const float*)nullptr, (double*)ws, npix, C);
+    else if (dtype == SGX_BF16 && colsum_vec_ok(C, 8))
+        hipLaunchKernelGGL((colsum_vec_stage1<bf16_t, 1>), dim3(nblk), dim3(256), 256 * 8 * sizeof(double), st, (const bf16_t*)x, (const float*)nullptr, (double*)ws, npix, C);
+    else if (dtype == SGX_F32) hipLaunchKernelGGL(colsum_stage1<float>, dim3(nblk), dim3(256), 256 * sizeof(double), st, (const float*)x, (double*)ws, npix, C);
     else hipLaunchKernelGGL(colsum_stage1<bf16_t>, dim3(nblk), dim3(256), 256 * sizeof(double), st, (const bf16_t*)x, (double*)ws, npix, C);
     SGX_LAUNCH_CHECK("colsum_stage1");
     hipLaunchKernelGGL(colsum_stage2, dim3((C + 31) / 32), dim3(256), 0, st, (const double*)ws, out, nblk, C, scale);
@@ -451,7 +503,11 @@ extern "C" int sgx_rgb_wgrad(const float* img, const void* f, float* dw, int sj,
     int nblk = (int)((npix + 63) / 64);
     if (nblk > COLSUM_BLOCKS) nblk = COLSUM_BLOCKS;
     if (nblk < 1) nblk = 1;
-    if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_wgrad_stage1<float>, dim3(nblk), dim3(256), 768 * sizeof(double), st, img, (const float*)f, (double*)ws, npix, C);
+    if (dtype == SGX_F32 && colsum_vec_ok(C, 4))
+        hipLaunchKernelGGL((colsum_vec_stage1<float, 3>), dim3(nblk), dim3(256), 256 * 12 * sizeof(double), st, (const float*)f, img, (double*)ws, npix, C);
+    else if (dtype == SGX_BF16 && colsum_vec_ok(C, 8))
+        hipLaunchKernelGGL((colsum_vec_stage1<bf16_t, 3>), dim3(nblk), dim3(256), 256 * 24 * sizeof(double), st, (const bf16_t*)f, img, (double*)ws, npix, C);
+    else if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_wgrad_stage1<float>, dim3(nblk), dim3(256), 768 * sizeof(double), st, img, (const float*)f, (double*)ws, npix, C);
     else hipLaunchKernelGGL(rgb_wgrad_stage1<bf16_t>, dim3(nblk), dim3(256), 768 * sizeof(double), st, img, (const bf16_t*)f, (double*)ws, npix, C);
     SGX_LAUNCH_CHECK("rgb_wgrad_stage1");
     hipLaunchKernelGGL(rgb_wgrad_stage2, dim3((3 * C + 31) / 32), dim3(256), 0, st, (const double*)ws, dw, nblk, C, sj, sc, wscale);

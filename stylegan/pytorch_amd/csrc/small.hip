@@ -192,16 +192,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, l15 = lane & 15;
     const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
     const int i = i0 + l15, j = j0 + l15;
-    const int kper = ((K + 3) / 4 + 3) / 4 * 4;                    // K slice per wave, multiple of 4
+    const int kper = ((K + 3) / 4 + 15) / 16 * 16;                 // K slice per wave, multiple of 16
     const int kb = wave * kper, ke = (kb + kper < K) ? kb + kper : K;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const size_t sa_i = ta ? 1 : (size_t)K, sa_k = ta ? (size_t)M : 1;
     const size_t sb_k = tb ? 1 : (size_t)N, sb_j = tb ? (size_t)K : 1;
-    for (int k = kb; k < ke; k += 4) {
-        const int kk = k + q;
-        const float a = (i < M && kk < ke) ? A[i * sa_i + kk * sa_k] : 0.f;
-        const float b = (j < N && kk < ke) ? Bm[kk * sb_k + j * sb_j] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    // 16 k per iteration: lane group q owns k = k0+4q..+3 (any k order is valid as long as A and B agree), so an
+    // operand whose k axis is contiguous is fetched with one 16-byte load per lane instead of four 4-byte ones.
+    const bool va = !ta && (K % 4 == 0), vb = tb && (K % 4 == 0);
+#pragma unroll 2
+    for (int k = kb; k < ke; k += 16) {
+        const int kk = k + 4 * q;
+        float a4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (i < M) {
+            if (va && kk + 3 < ke) {
+                const float4 t = *reinterpret_cast<const float4*>(A + i * sa_i + kk);
+                a4[0] = t.x; a4[1] = t.y; a4[2] = t.z; a4[3] = t.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) if (kk + s < ke) a4[s] = A[i * sa_i + (kk + s) * sa_k];
+            }
+        }
+        if (j < N) {
+            if (vb && kk + 3 < ke) {
+                const float4 t = *reinterpret_cast<const float4*>(Bm + j * sb_j + kk);
+                b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) if (kk + s < ke) b4[s] = Bm[(kk + s) * sb_k + j * sb_j];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], b4[s], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][q * 4 + r][l15] = acc[r];
@@ -219,5 +241,63 @@ extern "C" int sgx_gemm_f32(const float* A, const float* Bm, float* C, int M, in
     SGX_REQUIRE(M > 0 && N > 0 && K > 0, SGX_EINVAL, "gemm: bad shape %d %d %d", M, N, K);
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, A, Bm, C, M, N, K, ta, tb, alpha);
     SGX_LAUNCH_CHECK("gemm_f32");
+    return 0;
+}
+
+// ---------------------------------------------------------------- R1 penalty head: out[0] = sum(x^2)   (models/Losses.py:210)
+// and its backward  out = alpha * s[0] * x  with the upstream scalar s kept on the device.
+#define SUMSQ_BLOCKS 1024
+__global__ __launch_bounds__(256) void sumsq_f32_stage1(const float* __restrict__ x, size_t n, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    const size_t nvec = n / 4;
+    double acc = 0.0;
+    float part = 0.f; int cnt = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        part += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        if (++cnt == 16) { acc += (double)part; part = 0.f; cnt = 0; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = nvec * 4; i < n; ++i) part += x[i] * x[i];
+    acc += (double)part;
+    const double s = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_f32_stage2(const double* __restrict__ partial, int nblk, float* __restrict__ out) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) acc += partial[i];
+    const double s = block_sum_d(acc, sh);
+    if (threadIdx.x == 0) out[0] = (float)s;
+}
+extern "C" size_t sgx_sumsq_ws_bytes(void) { return SUMSQ_BLOCKS * sizeof(double); }
+extern "C" int sgx_sumsq_f32(const float* x, size_t n, void* ws, size_t ws_bytes, float* out, void* stream) {
+    SGX_REQUIRE(ws_bytes >= SUMSQ_BLOCKS * sizeof(double), SGX_EWORKSPACE, "sumsq: workspace");
+    int nblk = (int)((n / 4 + 255) / 256);
+    if (nblk > SUMSQ_BLOCKS) nblk = SUMSQ_BLOCKS;
+    if (nblk < 1) nblk = 1;
+    hipLaunchKernelGGL(sumsq_f32_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, n, (double*)ws);
+    SGX_LAUNCH_CHECK("sumsq_stage1");
+    hipLaunchKernelGGL(sumsq_f32_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, nblk, out);
+    SGX_LAUNCH_CHECK("sumsq_stage2");
+    return 0;
+}
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ s, float alpha, float* __restrict__ out, size_t n) {
+    const float k = alpha * s[0];
+    const size_t nvec = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x *= k; v.y *= k; v.z *= k; v.w *= k;
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = nvec * 4; i < n; ++i) out[i] = k * x[i];
+}
+extern "C" int sgx_scale_dev_f32(const float* x, const float* s, float alpha, float* out, size_t n, void* stream) {
+    size_t g = (n / 4 + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(scale_dev_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, s, alpha, out, n);
+    SGX_LAUNCH_CHECK("scale_dev");
     return 0;
 }

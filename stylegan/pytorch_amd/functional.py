@@ -47,21 +47,14 @@ def _c(t):
 KERNEL_TIMES = None
 
 
-def conv_kernel_name(geo, H, W, Cin, Cout, dtype):
-    """Mirror of dispatch_conv() in csrc/conv.hip: the template instantiation a launch resolves to."""
+def conv_kernel_name(geo, B, H, W, Cin, Cout, dtype):
+    """The template instantiation a launch resolves to (sgx_conv_config), spelled as rocprofv3 prints it."""
+    import ctypes
     f32 = dtype == torch.float32
-    kc = 16 if f32 else (32 if Cin % 32 == 0 else 16)
     g = {"S": 0, "D": 1, "U": 2}[geo]
-    bp = 128 if geo == "D" else 256
-    oh, ow = (H // 2, W // 2) if geo == "D" else (H, W)
-    if oh >= 16 and ow >= 16:
-        th, tw = bp // 16, 16
-    elif oh >= 8 and ow >= 8:
-        th, tw = 8, 8
-    else:
-        th, tw = 4, 4
-    max_ct = 2 if geo == "D" else 4
-    ct = 4 if (max_ct >= 4 and Cout % 64 == 0) else (2 if (max_ct >= 2 and Cout % 32 == 0) else 1)
+    cfg = (ctypes.c_int * 5)()
+    N.check(N.lib().sgx_conv_config(g, B, H, W, Cin, Cout, N.F32 if f32 else N.BF16, ctypes.addressof(cfg)), "sgx_conv_config")
+    kc, th, tw, bp, ct = list(cfg)
     return f"void conv_kernel<{'float' if f32 else 'unsigned short'}, {kc}, {g}, {th}, {tw}, {bp}, {ct}>(ConvArgs)"
 
 
@@ -78,12 +71,14 @@ def wgrad_kernel_name(geo, Hn, Wn, Ck, Cn, dtype):
         th, tw = (4 if bp >= 16 else bp // 4), 4
     nsub = 2 if Cn % 32 == 0 else 1
     ksub = 1 if geo == "D" else (2 if Ck % 32 == 0 else 1)
-    return f"void wgrad_kernel<{'float' if f32 else 'unsigned short'}, {g}, {th}, {tw}, {bp}, {nsub}, {ksub}>(WgradArgs)"
+    import os
+    tr = "true" if (not f32 and os.environ.get("SGX_WGRAD_TR", "1") not in ("0", "")) else "false"
+    return f"void wgrad_kernel<{'float' if f32 else 'unsigned short'}, {g}, {th}, {tw}, {bp}, {nsub}, {ksub}, {tr}>(WgradArgs)"
 
 
 class _Timed:
-    def __init__(self, name, flops):
-        self.name, self.flops = name, flops
+    def __init__(self, name, flops, desc="", nbytes=0.0):
+        self.name, self.flops, self.desc, self.nbytes = name, flops, desc, nbytes
 
     def __enter__(self):
         if KERNEL_TIMES is not None:
@@ -94,7 +89,7 @@ class _Timed:
         if KERNEL_TIMES is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            KERNEL_TIMES.setdefault(self.name, []).append((self.e0, e1, self.flops))
+            KERNEL_TIMES.setdefault(self.name, []).append((self.e0, e1, self.flops, self.desc, self.nbytes))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -151,7 +146,9 @@ def _conv_launch(geo, x, wq, bias, act):
         raise N.SgxError(f"conv: weight pack expects {K} input channels, activation has {Cin}")
     L = N.lib()
     npix = B * H * W * (0.25 if geo == "D" else 1.0)
-    with _Timed(conv_kernel_name(geo, H, W, Cin, Cout, x.dtype) if KERNEL_TIMES is not None else None, 2.0 * taps * Cin * Cout * npix):
+    osz = {"S": 1.0, "D": 0.25, "U": 4.0}[geo]
+    with _Timed(conv_kernel_name(geo, B, H, W, Cin, Cout, x.dtype) if KERNEL_TIMES is not None else None, 2.0 * taps * Cin * Cout * npix,
+                f"conv{geo} B{B} {H}x{W} {Cin}->{Cout}", (Cin + Cout * osz) * B * H * W * x.element_size()):
         if geo == "S":
             y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
             N.check(L.sgx_conv3x3(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv3x3")
@@ -175,7 +172,8 @@ def _wgrad_param(mode, adjoint, x, gy, weight, scale):
         _, H, W, Cx = x.shape
         Cdy = gy.shape[3]
         ws = N.workspace(L.sgx_wgrad_ws_bytes(9, B, H, W, Cx, Cdy), x.device)
-        with _Timed(wgrad_kernel_name("S", H, W, Cx, Cdy, x.dtype) if KERNEL_TIMES is not None else None, 2.0 * 9 * Cx * Cdy * B * H * W):
+        with _Timed(wgrad_kernel_name("S", H, W, Cx, Cdy, x.dtype) if KERNEL_TIMES is not None else None, 2.0 * 9 * Cx * Cdy * B * H * W,
+                    f"wgradS B{B} {H}x{W} {Cx}x{Cdy}", (Cx + Cdy) * B * H * W * x.element_size()):
             N.check(L.sgx_wgrad3x3_param(N.ptr(x), N.ptr(gy), N.ptr(dW), N.ptr(ws), ws.numel(), B, H, W, Cx, Cdy, int(adjoint),
                                          float(scale), O, I, N.dt(x), N.stream()), "sgx_wgrad3x3_param")
         return dW
@@ -185,7 +183,8 @@ def _wgrad_param(mode, adjoint, x, gy, weight, scale):
     Cc = coarse.shape[3]
     ws = N.workspace(L.sgx_wgrad_ws_bytes(16, B, H, W, Cf, Cc), x.device)
     with _Timed(wgrad_kernel_name("D", H // 2, W // 2, Cf, Cc, x.dtype) if KERNEL_TIMES is not None else None,
-                2.0 * 16 * Cf * Cc * B * (H // 2) * (W // 2)):
+                2.0 * 16 * Cf * Cc * B * (H // 2) * (W // 2), f"wgradD B{B} fine{H}x{W} {Cf}x{Cc}",
+                (Cf + Cc * 0.25) * B * H * W * x.element_size()):
         N.check(L.sgx_wgrad4x4s2_param(N.ptr(fine), N.ptr(coarse), N.ptr(dW), N.ptr(ws), ws.numel(), B, H, W, Cf, Cc, MODES[mode],
                                        float(scale), O, I, N.dt(x), N.stream()), "sgx_wgrad4x4s2_param")
     return dW
@@ -463,7 +462,7 @@ class RgbOutFn(Function):
             if ctx.needs_input_grad[1]:
                 gw = RgbWgradFn.apply(g, x, weight, ctx.wscale)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = g.sum(dim=(0, 1, 2))                     # 3 numbers
+                gb = ColSumFn.apply(g, 1.0)                   # 3 numbers
         return gx, gw, gb, None
 
 
@@ -588,6 +587,40 @@ class MbstdBwdFn(Function):
         N.check(N.lib().sgx_mbstd_bwd2(N.ptr(ggx), N.ptr(gy), N.ptr(x), N.ptr(ddy), N.ptr(gx), B, H * W, C, gy.shape[3], N.dt(x),
                                        N.stream()), "sgx_mbstd_bwd2")
         return ddy, gx
+
+
+def _dense_view(x):
+    """A contiguous view of x's storage (NHWC-stored images arrive as permuted NCHW views), plus how to undo it."""
+    if x.is_contiguous():
+        return x, None
+    if x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous():
+        return x.permute(0, 2, 3, 1), (0, 3, 1, 2)
+    return x.contiguous(), None
+
+
+class SumSqFn(Function):
+    """sum(x*x) -> fp32 scalar tensor (the R1 penalty head).  First order."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xv, back = _dense_view(x.detach())
+        if xv.dtype != torch.float32:
+            raise N.SgxError("SumSqFn expects fp32 (image gradients)")
+        L = N.lib()
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        ws = N.workspace(L.sgx_sumsq_ws_bytes(), x.device)
+        N.check(L.sgx_sumsq_f32(N.ptr(xv), xv.numel(), N.ptr(ws), ws.numel(), N.ptr(out), N.stream()), "sgx_sumsq_f32")
+        ctx.back = back
+        ctx.save_for_backward(xv)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (xv,) = ctx.saved_tensors
+        gx = torch.empty_like(xv)
+        N.check(N.lib().sgx_scale_dev_f32(N.ptr(xv), N.ptr(_c(g.float())), 2.0, N.ptr(gx), xv.numel(), N.stream()), "sgx_scale_dev_f32")
+        return gx if ctx.back is None else gx.permute(*ctx.back)
 
 
 class MatMulFn(Function):

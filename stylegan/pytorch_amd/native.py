@@ -35,6 +35,8 @@ SIGNATURES = {
     "sgx_conv4x4s2_down": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_up": (I, [P, P, P, I, I, I, I, I, I, P]),
     "sgx_wgrad_ws_bytes": (Z, [I, I, I, I, I, I]),
+    "sgx_selftest_tr16": (I, [P, P]),
+    "sgx_conv_config": (I, [I, I, I, I, I, I, I, P]),
     "sgx_pack_weight": (I, [P, P, P, I, I, I, I, F, I, P]),
     "sgx_wgrad3x3_param": (I, [P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, P]),
     "sgx_wgrad4x4s2_param": (I, [P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, P]),
@@ -58,6 +60,9 @@ SIGNATURES = {
     "sgx_mbstd_fwd": (I, [P, P, I, I, I, I, I, P]),
     "sgx_mbstd_bwd": (I, [P, P, P, I, I, I, I, I, P]),
     "sgx_mbstd_bwd2": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "sgx_sumsq_ws_bytes": (Z, []),
+    "sgx_sumsq_f32": (I, [P, Z, P, Z, P, P]),
+    "sgx_scale_dev_f32": (I, [P, P, F, P, Z, P]),
     "sgx_gemm_ws_bytes": (Z, [I, I, I]),
     "sgx_gemm_f32": (I, [P, P, P, I, I, I, I, I, F, P, Z, P]),
     "sgx_adam_multi": (I, [P, P, P, P, P, I, F, F, F, P, P, P, P]),

@@ -62,6 +62,41 @@ def test_conv_forward_backward(mode, cin, cout, B, H):
     assert_close(m.bias.grad, b64.grad, TIGHT, "db")
 
 
+@pytest.mark.parametrize("mode,cin,cout,B,H", [("plain", 16, 16, 2, 32), ("plain", 64, 32, 3, 16), ("plain", 32, 64, 5, 8),
+                                                ("plain", 32, 32, 4, 4), ("up", 32, 16, 2, 16), ("up", 64, 64, 3, 4),
+                                                ("down", 16, 32, 2, 32), ("down", 64, 64, 5, 8), ("down", 32, 32, 2, 64)])
+def test_conv_bf16_storage(mode, cin, cout, B, H):
+    """bf16 activations / operand packs, fp32 accumulation.  Inputs are bf16-exact, so the only error sources are the
+    bf16 rounding of the packed weights (y, dx: ~4e-3) and of the stored outputs; dW sees neither (x and dy exact, fp32
+    accumulate and output) and must be tight -- that pins the bf16 weight-gradient operand path."""
+    from stylegan.pytorch_amd import functional as F
+    m = conv_module(cin, cout, upscale=(mode == "up"), downscale=(mode == "down"))
+    x = gu.seeded((B, cin, H, H), 7).bfloat16().float()
+    xg = F.nhwc(x.to(DEV)).bfloat16().requires_grad_(True)
+    y = m.forward_nhwc(xg, skip_bias=True)
+    assert y.dtype == torch.bfloat16
+    w64 = m.weight.detach().double().cpu().requires_grad_(True)
+    x64 = x.double().requires_grad_(True)
+    y64 = O.eq_conv2d(x64, w64, None, up=(mode == "up"), down=(mode == "down"))
+    assert_close(F.nchw_view(y), y64, 1e-2, "y")
+    gy = gu.seeded(y64.shape, 8).bfloat16().float()
+    y.backward(F.nhwc(gy.to(DEV)).bfloat16())
+    y64.backward(gy.double())
+    assert_close(F.nchw_view(xg.grad), x64.grad, 1e-2, "dx")
+    assert_close(m.weight.grad, w64.grad, 1e-4, "dW (bf16 operands, fp32 accumulate)")
+
+
+def test_lds_transpose_read_semantics():
+    """ds_read_b64_tr_b16: lane i of a 16-lane group supplies row i/4, column block i%4 and receives column i."""
+    from stylegan.pytorch_amd import native as N
+    out = torch.zeros(256, dtype=torch.int16, device=DEV)
+    N.check(N.lib().sgx_selftest_tr16(N.ptr(out), N.stream()), "selftest")
+    got = out.cpu().view(64, 4).tolist()
+    expect = [[(l >> 4) * 64 + j * 16 + (l & 15) for j in range(4)] for l in range(64)]
+    print("tr16 lane0..3:", got[:4], "lane16:", got[16])
+    assert got == expect, got[:20]
+
+
 def test_conv_edge_shapes():
     """Ragged sizes: non-power-of-two spatial extent and batch not filling the per-block image group."""
     for (B, H, W) in [(1, 4, 4), (3, 12, 20), (7, 8, 8), (2, 24, 40)]:
