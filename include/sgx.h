@@ -33,6 +33,15 @@ const char* sgx_last_error(void);
  * lane l addressing elements [4l,4l+4), writes the 4 int16 values each of the 64 lanes received to out256.          */
 int sgx_selftest_tr16(void* out256, void* stream);
 
+/* ---- per-launch profiler.  Every kernel the library launches can be bracketed by two HIP events recorded on the launch
+ * stream itself.  sgx_prof_start(1, 0): record every launch (clears earlier records); (2, i): record only launches of
+ * the kernel that record i belongs to; (0, 0): stop, keeping the records.  sgx_prof_get waits for record i and returns
+ * the demangled kernel name (as rocprofv3 prints it), the milliseconds between its events, and the flops, algorithmic
+ * bytes and layer description attached by the entry point that launched it (0 / "" when it attached none). */
+int sgx_prof_start(int mode, int only_of);
+int sgx_prof_count(void);
+int sgx_prof_get(int i, char* name, int name_cap, float* ms, double* flops, double* bytes, char* desc, int desc_cap);
+
 /* ---------------------------------------------------------------- convolutions (MFMA implicit GEMM)
  * Packed weight layout for all three: w[tap][n][k], n = output channel of THIS launch, k = reduction
  * channel, k contiguous; dtype = activation dtype.  bias (fp32, may be NULL) and act are fused in the store.

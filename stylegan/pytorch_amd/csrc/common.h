@@ -92,3 +92,25 @@ void sgx_set_error(const char* fmt, ...);
     } while (0)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- per-launch profiler (sgx_prof_* in include/sgx.h) --------------------------------------
+// Every kernel launch of the library goes through sgx_launch.  When profiling is on it is bracketed by two HIP events
+// recorded on the launch stream itself; records are resolved to kernel names and milliseconds by sgx_prof_get.
+extern int sgx_prof_mode;                                  // 0 off, 1 every kernel, 2 only sgx_prof_only_fn
+extern const void* sgx_prof_only_fn;
+void sgx_prof_begin(const void* fn, hipStream_t st, int* slot);
+void sgx_prof_end(int slot, hipStream_t st);
+void sgx_prof_note(double flops, double bytes, const char* fmt, ...);   // describes the NEXT launch of this thread
+template <typename K, typename... Args>
+static inline void sgx_launch(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    int slot = -1;
+    if (sgx_prof_mode) sgx_prof_begin(reinterpret_cast<const void*>(kern), st, &slot);
+    kern<<<grid, block, lds, st>>>(args...);
+    if (slot >= 0) sgx_prof_end(slot, st);
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kern, grid, block, lds, st, ...) sgx_launch(kern, grid, block, lds, st, __VA_ARGS__)
+#define SGX_NOTE(flops, bytes, ...)                                     \
+    do {                                                                \
+        if (sgx_prof_mode) sgx_prof_note((flops), (bytes), __VA_ARGS__); \
+    } while (0)

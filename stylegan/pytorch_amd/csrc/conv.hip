@@ -105,11 +105,21 @@ template <> struct Geo<G3X3> { static constexpr int IS = 1, TK = 3, NCLS = 1; };
 template <> struct Geo<GDOWN> { static constexpr int IS = 2, TK = 4, NCLS = 1; };
 template <> struct Geo<GUP> { static constexpr int IS = 1, TK = 2, NCLS = 4; };
 
+// Small tiles of the HBM-bound layers (16/32 channels at 512^2..1024^2) want MANY resident blocks: a block has one
+// tile's loads in flight, and bytes in flight per CU -- not MFMA rate -- set their speed.
+#ifndef SGX_CONV_OCC_SMALL
+#define SGX_CONV_OCC_SMALL 3
+#endif
+constexpr int conv_min_waves(int tsize, int CT, int BP, int GEO) {
+    if (CT * BP >= 1024 || GEO == GDOWN) return 1;
+    if (tsize == 2 && CT * BP <= 256) return SGX_CONV_OCC_SMALL;
+    return 2;
+}
 template <typename T, int KC, int GEO, int TH, int TW, int BP, int CT>
 // Register budget: two waves per SIMD (<= 256 VGPR+AGPR) except for the 64-channel x 256-pixel tile, whose prefetch
 // registers would spill at that bound -- and a spilled descriptor reload (scratch_load + s_waitcnt vmcnt) serialises
 // the whole global prefetch behind it (seen in the ISA), which is far worse than one wave per SIMD.
-__global__ __launch_bounds__(256, ((CT * BP >= 1024 || GEO == GDOWN) ? 1 : 2)) void conv_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO)) void conv_kernel(ConvArgs a) {
     using F = Frag<T, KC>;
     constexpr int IS = Geo<GEO>::IS, TK = Geo<GEO>::TK, NT = TK * TK;
     constexpr int PH = (TH - 1) * IS + TK, PW = (TW - 1) * IS + TK, PWP = F::pad_pw(PW, IS);
@@ -348,12 +358,23 @@ static int launch_conv(ConvArgs& a, int ngroups, hipStream_t st) {
     a.ntiles = ngroups * a.tiles_y * a.tiles_x;
     static const int dbg = [] { const char* e = getenv("SGX_CONV_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
-    // persistent grid: about as many blocks as can be resident (LDS- and register-limited), never more than tiles
-    int per_cu = (160 * 1024) / LDS;
-    if (per_cu > 4) per_cu = 4;
-    if (per_cu < 1) per_cu = 1;
+    // persistent grid: exactly as many blocks as are resident at once (register- and LDS-limited; asked of the runtime
+    // for this instantiation), never more than tiles.  More blocks than that would run as a second, under-occupied round.
+    static const int resident = [] {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(conv_kernel<T, KC, GEO, TH, TW, BP, CT>), 256, LDS) != hipSuccess || nb < 1) nb = 1;
+        const char* e = getenv("SGX_CONV_PERCU");
+        if (e && atoi(e) > 0 && atoi(e) < nb) nb = atoi(e);
+        return nb;
+    }();
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    const int per_cu = resident;
     const int yz = (a.Cout / (CT * 16)) * Geo<GEO>::NCLS;
-    int gx = (256 * per_cu + yz - 1) / yz;
+    int gx = (ncu * per_cu + yz - 1) / yz;
     if (gx > a.ntiles) gx = a.ntiles;
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)(a.Cout / (CT * 16)), Geo<GEO>::NCLS);
@@ -443,6 +464,8 @@ extern "C" int sgx_conv_config(int geo, int B, int H, int W, int Cin, int Cout, 
 extern "C" int sgx_conv3x3(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin,
                            int Cout, int act, int dtype, void* stream) {
     ConvArgs a{x, w, bias, y, B, H, W, H, W, H, W, Cin, Cout, act, 0, 0};
+    const double es = dtype == SGX_F32 ? 4 : 2;
+    SGX_NOTE(2.0 * 9 * Cin * Cout * B * H * W, es * ((double)B * H * W * (Cin + Cout) + 9.0 * Cin * Cout), "convS B%d %dx%d %d->%d", B, H, W, Cin, Cout);
     return dispatch_conv<G3X3>(a, dtype, (hipStream_t)stream);
 }
 
@@ -450,12 +473,16 @@ extern "C" int sgx_conv4x4s2_down(const void* x, const void* w, const float* bia
                                   int Cin, int Cout, int act, int dtype, void* stream) {
     SGX_REQUIRE(H % 2 == 0 && W % 2 == 0, SGX_EINVAL, "conv4x4s2_down: odd input size");
     ConvArgs a{x, w, bias, y, B, H, W, H / 2, W / 2, H / 2, W / 2, Cin, Cout, act, 0, 0};
+    const double es = dtype == SGX_F32 ? 4 : 2;
+    SGX_NOTE(2.0 * 16 * Cin * Cout * B * (H / 2) * (W / 2), es * ((double)B * H * W * (Cin + Cout / 4.0) + 16.0 * Cin * Cout), "convD B%d %dx%d %d->%d", B, H, W, Cin, Cout);
     return dispatch_conv<GDOWN>(a, dtype, (hipStream_t)stream);
 }
 
 extern "C" int sgx_conv4x4s2_up(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout,
                                 int dtype, void* stream) {
     ConvArgs a{x, w, nullptr, y, B, H, W, 2 * H, 2 * W, H, W, Cin, Cout, SGX_ACT_NONE, 0, 0};
+    const double es = dtype == SGX_F32 ? 4 : 2;
+    SGX_NOTE(2.0 * 16 * Cin * Cout * B * H * W, es * ((double)B * H * W * (Cin + 4.0 * Cout) + 16.0 * Cin * Cout), "convU B%d %dx%d %d->%d", B, H, W, Cin, Cout);
     return dispatch_conv<GUP>(a, dtype, (hipStream_t)stream);
 }
 
@@ -782,6 +809,7 @@ extern "C" int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, void
     const int Ip = adjoint ? Cdy : Cx;
     SGX_REQUIRE((adjoint ? Cx : Cdy) == O && Ip >= I, SGX_EINVAL, "wgrad3x3_param: channel mismatch (Cx=%d Cdy=%d O=%d I=%d adj=%d)", Cx, Cdy, O, I, adjoint);
     WgradArgs a{x, dy, nullptr, B, H, W, H, W, Cx, Cdy, 0, 0, 0};
+    SGX_NOTE(2.0 * 9 * Cx * Cdy * B * H * W, (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * (Cx + Cdy), "wgradS B%d %dx%d %dx%d", B, H, W, Cx, Cdy);
     int ns = 0, rc;
     if (dtype == SGX_F32) rc = wgrad_ch<float, G3X3, 128>(a, ws, ws_bytes, &ns, st);
     else if (dtype == SGX_BF16) rc = wgrad_use_tr() ? wgrad_ch<bf16_t, G3X3, 128, true>(a, ws, ws_bytes, &ns, st) : wgrad_ch<bf16_t, G3X3, 128>(a, ws, ws_bytes, &ns, st);
@@ -799,6 +827,7 @@ extern "C" int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float*
     SGX_REQUIRE(transposed ? (Ccoarse == I && Cfine == O) : (Ccoarse == O && Cfine == I), SGX_EINVAL,
                 "wgrad4x4s2_param: channel mismatch (fine %d coarse %d O %d I %d mode %d)", Cfine, Ccoarse, O, I, mode);
     WgradArgs a{fine, coarse, nullptr, B, H, W, H / 2, W / 2, Cfine, Ccoarse, 0, 0, 0};
+    SGX_NOTE(2.0 * 16 * Cfine * Ccoarse * B * (H / 2) * (W / 2), (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * (Cfine + Ccoarse / 4.0), "wgradD B%d fine%dx%d %dx%d", B, H, W, Cfine, Ccoarse);
     int ns = 0, rc;
     if (dtype == SGX_F32) rc = wgrad_ch<float, GDOWN, 64>(a, ws, ws_bytes, &ns, st);
     else if (dtype == SGX_BF16) rc = wgrad_use_tr() ? wgrad_ch<bf16_t, GDOWN, 64, true>(a, ws, ws_bytes, &ns, st) : wgrad_ch<bf16_t, GDOWN, 64>(a, ws, ws_bytes, &ns, st);

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
             if (MODE == 2) { k1[j] = coef[((size_t)b * C + c0 + j) * 2]; k2[j] = coef[((size_t)b * C + c0 + j) * 2 + 1]; }
         }
         if (tr < rows) {
+#pragma unroll 4
             for (int p = p0 + tr; p < p1; p += rows) {
                 const size_t off = (((size_t)b * HW + p) * cv + v) * VE;
                 const float nz = noise[(size_t)b * HW + p];
@@ -163,27 +164,43 @@ __global__ void gepi_fin_bwd2(const double* __restrict__ part, float* __restrict
     if (dbias) dbias[c] = (float)d;
 }
 
+// forward apply pass, same block geometry as gepi_pass: image b and channel vector are fixed per thread, so the six
+// per-(b,c) coefficients live in registers and the pixel loop is pure streaming (4 rows in flight per lane).
 template <typename T>
-__global__ void gepi_apply(const T* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ noise,
-                           const float* __restrict__ nw, const float* __restrict__ style, const float* __restrict__ mean,
-                           const float* __restrict__ rstd, T* __restrict__ y, size_t nvec, int HW, int C) {
+__global__ __launch_bounds__(256) void gepi_apply(const T* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ noise,
+                                                  const float* __restrict__ nw, const float* __restrict__ style,
+                                                  const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ y,
+                                                  int HW, int C, int cvt, int rows, int chunk) {
     constexpr int VE = VecTraits<T>::VE;
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int tc = threadIdx.x % cvt, tr = threadIdx.x / cvt;
     const int cv = C / VE;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cv) * VE;
-        const size_t p = i / cv;
-        const int b = (int)(p / HW);
-        const float nz = noise[p];
-        float v[VE];
-        VecTraits<T>::load(x + i * VE, v);
+    const int p0 = ch * chunk, p1 = (p0 + chunk < HW) ? p0 + chunk : HW;
+    if (tr >= rows) return;
+    for (int vb = 0; vb < cv; vb += cvt) {
+        const int v = vb + tc, c0 = v * VE;
+        float kb[VE], kw[VE], km[VE], kr[VE], ks[VE], k1[VE];
 #pragma unroll
         for (int j = 0; j < VE; ++j) {
-            const int c = c0 + j;
-            const float a = lrelu(v[j] + (bias ? bias[c] : 0.f) + nw[c] * nz);
-            const float xh = (a - mean[(size_t)b * C + c]) * rstd[(size_t)b * C + c];
-            v[j] = xh * (style[(size_t)b * 2 * C + c] + 1.f) + style[(size_t)b * 2 * C + C + c];
+            kb[j] = bias ? bias[c0 + j] : 0.f;
+            kw[j] = nw[c0 + j];
+            km[j] = mean[(size_t)b * C + c0 + j]; kr[j] = rstd[(size_t)b * C + c0 + j];
+            ks[j] = style[(size_t)b * 2 * C + c0 + j] + 1.f; k1[j] = style[(size_t)b * 2 * C + C + c0 + j];
         }
-        VecTraits<T>::store(y + i * VE, v);
+#pragma unroll 4
+        for (int p = p0 + tr; p < p1; p += rows) {
+            const size_t off = (((size_t)b * HW + p) * cv + v) * VE;
+            const float nz = noise[(size_t)b * HW + p];
+            float xv[VE];
+            VecTraits<T>::load(x + off, xv);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {
+                const float a = lrelu(xv[j] + kb[j] + kw[j] * nz);
+                const float xh = (a - km[j]) * kr[j];
+                xv[j] = xh * ks[j] + k1[j];
+            }
+            VecTraits<T>::store(y + off, xv);
+        }
     }
 }
 
@@ -193,17 +210,17 @@ static int gepi_fwd_t(const void* x, const float* bias, const float* noise, cons
     constexpr int VE = VecTraits<T>::VE;
     GepiGeom g = gepi_geom(HW, C, VE);
     double* part = static_cast<double*>(ws);
+    const double nb = (double)sizeof(T) * B * HW * C;
+    SGX_NOTE(0.0, nb, "gepi_stats B%d HW%d C%d", B, HW, C);
     hipLaunchKernelGGL((gepi_pass<T, 0>), dim3(g.nchunk, B), dim3(256), 256 * 2 * VE * sizeof(double), st, (const T*)x,
                        (const T*)nullptr, (T*)nullptr, bias, noise, nw, style, mean, rstd, (const float*)nullptr, part, HW, C,
                        g.cvt, g.rows, g.chunk);
     SGX_LAUNCH_CHECK("gepi_stats");
     hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 255) / 256), dim3(256), 0, st, part, mean, rstd, B, C, g.nchunk, HW);
     SGX_LAUNCH_CHECK("gepi_fin_stats");
-    const size_t nvec = (size_t)B * HW * C / VE;
-    size_t grid = (nvec + 255) / 256;
-    if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(gepi_apply<T>, dim3((unsigned)grid), dim3(256), 0, st, (const T*)x, bias, noise, nw, style, mean, rstd,
-                       (T*)y, nvec, HW, C);
+    SGX_NOTE(0.0, 2.0 * nb, "gepi_apply B%d HW%d C%d", B, HW, C);
+    hipLaunchKernelGGL(gepi_apply<T>, dim3(g.nchunk, B), dim3(256), 0, st, (const T*)x, bias, noise, nw, style, mean, rstd,
+                       (T*)y, HW, C, g.cvt, g.rows, g.chunk);
     SGX_LAUNCH_CHECK("gepi_apply");
     return 0;
 }
@@ -218,11 +235,14 @@ static int gepi_bwd_t(const void* dy, const void* x, const float* bias, const fl
     double* partB = partA + (size_t)B * g.nchunk * C * 2;
     float* coef = reinterpret_cast<float*>(partB + (size_t)B * g.nchunk * C * 2);
     const size_t shb = 256 * 2 * VE * sizeof(double);
+    const double nb = (double)sizeof(T) * B * HW * C;
+    SGX_NOTE(0.0, 2.0 * nb, "gepi_bwd1 B%d HW%d C%d", B, HW, C);
     hipLaunchKernelGGL((gepi_pass<T, 1>), dim3(g.nchunk, B), dim3(256), shb, st, (const T*)x, (const T*)dy, (T*)nullptr, bias,
                        noise, nw, style, mean, rstd, (const float*)nullptr, partA, HW, C, g.cvt, g.rows, g.chunk);
     SGX_LAUNCH_CHECK("gepi_bwd1");
     hipLaunchKernelGGL(gepi_fin_bwd1, dim3((B * C + 255) / 256), dim3(256), 0, st, partA, style, dstyle, coef, B, C, g.nchunk, HW);
     SGX_LAUNCH_CHECK("gepi_fin_bwd1");
+    SGX_NOTE(0.0, 3.0 * nb, "gepi_bwd2 B%d HW%d C%d", B, HW, C);
     hipLaunchKernelGGL((gepi_pass<T, 2>), dim3(g.nchunk, B), dim3(256), shb, st, (const T*)x, (const T*)dy, (T*)dx, bias, noise,
                        nw, style, mean, rstd, (const float*)coef, partB, HW, C, g.cvt, g.rows, g.chunk);
     SGX_LAUNCH_CHECK("gepi_bwd2");

@@ -37,6 +37,7 @@ __global__ void bias_act_scalar_kernel(const float* __restrict__ x, const float*
 }
 extern "C" int sgx_bias_act(const void* x, const float* bias, float bscale, void* y, size_t npix, int C, int act, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    SGX_NOTE(0.0, 2.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * npix * C, "bias_act %zux%d", npix, C);
     if (dtype == SGX_F32 && C % 4 != 0) {                    // e.g. the [B,1] discriminator output
         hipLaunchKernelGGL(bias_act_scalar_kernel, dim3(grid_for(npix * C)), dim3(256), 0, st, (const float*)x, bias, bscale, (float*)y, npix * C, C, act);
         SGX_LAUNCH_CHECK("bias_act_scalar");
@@ -70,6 +71,7 @@ __global__ void lrelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__
 }
 extern "C" int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    SGX_NOTE(0.0, 3.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * n, "lrelu_bwd %zu", n);
     if (dtype == SGX_F32) {
         SGX_REQUIRE(n % 4 == 0, SGX_EUNSUPPORTED, "lrelu_bwd: n %% 4");
         hipLaunchKernelGGL(lrelu_bwd_kernel<float>, dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)dx, n / 4);
@@ -109,6 +111,7 @@ __global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T
 }
 extern "C" int sgx_axpby(const void* a, const void* b, void* out, float alpha, float beta, size_t n, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    SGX_NOTE(0.0, (b ? 3.0 : 2.0) * (dtype == SGX_F32 ? 4.0 : 2.0) * n, "axpby %zu", n);
     if (n == 0) return 0;
     if (dtype == SGX_F32) {
         size_t nvec = (n + 3) / 4;
@@ -156,6 +159,7 @@ __global__ void blur3x3_kernel(const T* __restrict__ x, T* __restrict__ y, int B
 }
 extern "C" int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    SGX_NOTE(0.0, 2.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * C, "blur B%d %dx%d C%d", B, H, W, C);
     if (dtype == SGX_F32) {
         SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "blur: C %% 4");
         hipLaunchKernelGGL(blur3x3_kernel<float>, dim3(grid_for((size_t)B * H * W * C / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C);
@@ -198,6 +202,7 @@ __global__ void pool2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, 
 }
 extern "C" int sgx_pool2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    SGX_NOTE(0.0, 1.25 * (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * C, "pool2 B%d %dx%d C%d", B, H, W, C);
     SGX_REQUIRE(H % 2 == 0 && W % 2 == 0, SGX_EINVAL, "pool2: odd size");
     const size_t nout = (size_t)B * (H / 2) * (W / 2) * C;
     if (dtype == SGX_F32) {
@@ -236,6 +241,7 @@ __global__ void up2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, in
 }
 extern "C" int sgx_up2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    SGX_NOTE(0.0, 5.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * C, "up2 B%d %dx%d C%d", B, H, W, C);
     const size_t nout = (size_t)B * H * W * 4 * C;
     if (dtype == SGX_F32) {
         if (C % 4 == 0) hipLaunchKernelGGL((up2_kernel<float, true>), dim3(grid_for(nout / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
@@ -352,6 +358,7 @@ extern "C" int sgx_colsum(const void* x, float* out, float scale, void* ws, size
     hipStream_t st = (hipStream_t)stream;
     SGX_REQUIRE(ws_bytes >= sgx_colsum_ws_bytes(npix, C), SGX_EWORKSPACE, "colsum: workspace");
     SGX_REQUIRE(C >= 1, SGX_EINVAL, "colsum: C=%d", C);     // scalar kernel: any C (C=3 for the RGB bias gradient)
+    SGX_NOTE(0.0, (dtype == SGX_F32 ? 4.0 : 2.0) * npix * C, "colsum %zux%d", npix, C);
     int nblk = (int)((npix + 63) / 64);
     if (nblk > COLSUM_BLOCKS) nblk = COLSUM_BLOCKS;
     if (nblk < 1) nblk = 1;
@@ -372,37 +379,55 @@ template <typename T>
 __global__ void rgb_in_kernel(const float* __restrict__ img, const float* __restrict__ w, int sj, int sc, float wscale,
                               const float* __restrict__ bias, T* __restrict__ y, size_t npix, int C) {
     constexpr int VE = VecTraits<T>::VE;
-    const int cv = C / VE;
+    const int cv = C / VE;                                   // power of two <= 64, divides the grid stride
     const size_t nvec = npix * cv;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = (int)(i0 % cv) * VE;                      // the thread's channel group never changes: hoist its weights
+    float wr[VE], wg[VE], wb[VE], bb[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+        wr[j] = wscale * w[(c0 + j) * sc]; wg[j] = wscale * w[sj + (c0 + j) * sc]; wb[j] = wscale * w[2 * sj + (c0 + j) * sc];
+        bb[j] = bias ? bias[c0 + j] : 0.f;
+    }
+    for (size_t i = i0; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
         const size_t p = i / cv;
-        const int c0 = (int)(i % cv) * VE;
         const float r = img[p * 3], g = img[p * 3 + 1], b = img[p * 3 + 2];
         float v[VE];
 #pragma unroll
-        for (int j = 0; j < VE; ++j)
-            v[j] = (bias ? bias[c0 + j] : 0.f) + wscale * (r * w[(c0 + j) * sc] + g * w[sj + (c0 + j) * sc] + b * w[2 * sj + (c0 + j) * sc]);
+        for (int j = 0; j < VE; ++j) v[j] = bb[j] + (r * wr[j] + g * wg[j] + b * wb[j]);
         VecTraits<T>::store(y + i * VE, v);
     }
 }
+// the kernel hoists its channel group's weights, so the grid stride (256 * blocks) must be a multiple of cv
+static inline unsigned rgb_in_grid(size_t nvec, int cv) {
+    unsigned g = grid_for(nvec);
+    if (256 % cv != 0) g = (g + cv - 1) / cv * cv;
+    return g;
+}
 extern "C" int sgx_rgb_in(const float* img, const float* w, int sj, int sc, float wscale, const float* bias, void* y, size_t npix, int C, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    SGX_NOTE(6.0 * npix * C, npix * (12.0 + (dtype == SGX_F32 ? 4.0 : 2.0) * C), "rgb_in %zux%d", npix, C);
     if (dtype == SGX_F32) {
         SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "rgb_in: C %% 4");
-        hipLaunchKernelGGL(rgb_in_kernel<float>, dim3(grid_for(npix * C / 4)), dim3(256), 0, st, img, w, sj, sc, wscale, bias, (float*)y, npix, C);
+        hipLaunchKernelGGL(rgb_in_kernel<float>, dim3(rgb_in_grid(npix * C / 4, C / 4)), dim3(256), 0, st, img, w, sj, sc, wscale, bias, (float*)y, npix, C);
     } else {
         SGX_REQUIRE(C % 8 == 0, SGX_EUNSUPPORTED, "rgb_in: C %% 8");
-        hipLaunchKernelGGL(rgb_in_kernel<bf16_t>, dim3(grid_for(npix * C / 8)), dim3(256), 0, st, img, w, sj, sc, wscale, bias, (bf16_t*)y, npix, C);
+        hipLaunchKernelGGL(rgb_in_kernel<bf16_t>, dim3(rgb_in_grid(npix * C / 8, C / 8)), dim3(256), 0, st, img, w, sj, sc, wscale, bias, (bf16_t*)y, npix, C);
     }
     SGX_LAUNCH_CHECK("rgb_in");
     return 0;
 }
 
-// one pixel per group of LPP lanes (LPP = C/VE capped at 16); partial dot products reduced with shuffles
+// one pixel per group of LPP lanes (LPP = C/VE capped at 16); partial dot products reduced with shuffles.
+// The 3 x C weights are staged once per block in LDS, pre-multiplied by wscale.
 template <typename T>
 __global__ void rgb_out_kernel(const T* __restrict__ x, const float* __restrict__ w, int sj, int sc, float wscale,
                                const float* __restrict__ bias, float* __restrict__ img, size_t npix, int C, int lpp) {
     constexpr int VE = VecTraits<T>::VE;
+    extern __shared__ float sw[];                            // [3][C]
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) sw[i] = wscale * w[(i / C) * sj + (i % C) * sc];
+    __syncthreads();
+    const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f, b2 = bias ? bias[2] : 0.f;
     const int cv = C / VE;
     const int sub = threadIdx.x % lpp;
     const size_t gid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / lpp;
@@ -416,9 +441,14 @@ __global__ void rgb_out_kernel(const T* __restrict__ x, const float* __restrict_
                 float t[VE];
                 VecTraits<T>::load(x + (p * cv + v) * VE, t);
 #pragma unroll
-                for (int j = 0; j < VE; ++j) {
-                    const int c = v * VE + j;
-                    s0 += t[j] * w[c * sc]; s1 += t[j] * w[sj + c * sc]; s2 += t[j] * w[2 * sj + c * sc];
+                for (int q = 0; q < VE / 4; ++q) {
+                    const int c = v * VE + q * 4;
+                    const float4 w0 = *reinterpret_cast<const float4*>(sw + c);
+                    const float4 w1 = *reinterpret_cast<const float4*>(sw + C + c);
+                    const float4 w2 = *reinterpret_cast<const float4*>(sw + 2 * C + c);
+                    s0 += t[q * 4] * w0.x + t[q * 4 + 1] * w0.y + t[q * 4 + 2] * w0.z + t[q * 4 + 3] * w0.w;
+                    s1 += t[q * 4] * w1.x + t[q * 4 + 1] * w1.y + t[q * 4 + 2] * w1.z + t[q * 4 + 3] * w1.w;
+                    s2 += t[q * 4] * w2.x + t[q * 4 + 1] * w2.y + t[q * 4 + 2] * w2.z + t[q * 4 + 3] * w2.w;
                 }
             }
         }
@@ -426,22 +456,24 @@ __global__ void rgb_out_kernel(const T* __restrict__ x, const float* __restrict_
             s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64);
         }
         if (p < npix && sub == 0) {
-            img[p * 3] = wscale * s0 + (bias ? bias[0] : 0.f);
-            img[p * 3 + 1] = wscale * s1 + (bias ? bias[1] : 0.f);
-            img[p * 3 + 2] = wscale * s2 + (bias ? bias[2] : 0.f);
+            img[p * 3] = s0 + b0;
+            img[p * 3 + 1] = s1 + b1;
+            img[p * 3 + 2] = s2 + b2;
         }
     }
 }
 extern "C" int sgx_rgb_out(const void* x, const float* w, int sj, int sc, float wscale, const float* bias, float* img, size_t npix, int C, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    SGX_NOTE(6.0 * npix * C, npix * (12.0 + (dtype == SGX_F32 ? 4.0 : 2.0) * C), "rgb_out %zux%d", npix, C);
     const int ve = dtype == SGX_F32 ? 4 : 8;
-    SGX_REQUIRE(C % ve == 0, SGX_EUNSUPPORTED, "rgb_out: C=%d", C);
+    SGX_REQUIRE(C % ve == 0 && C <= 4096, SGX_EUNSUPPORTED, "rgb_out: C=%d", C);
     int lpp = C / ve;
     if (lpp > 16) lpp = 16;
     SGX_REQUIRE((lpp & (lpp - 1)) == 0, SGX_EUNSUPPORTED, "rgb_out: C=%d", C);
     const unsigned g = grid_for(npix * lpp);
-    if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_out_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, w, sj, sc, wscale, bias, img, npix, C, lpp);
-    else hipLaunchKernelGGL(rgb_out_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, w, sj, sc, wscale, bias, img, npix, C, lpp);
+    const size_t sh = (size_t)3 * C * sizeof(float);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_out_kernel<float>, dim3(g), dim3(256), sh, st, (const float*)x, w, sj, sc, wscale, bias, img, npix, C, lpp);
+    else hipLaunchKernelGGL(rgb_out_kernel<bf16_t>, dim3(g), dim3(256), sh, st, (const bf16_t*)x, w, sj, sc, wscale, bias, img, npix, C, lpp);
     SGX_LAUNCH_CHECK("rgb_out");
     return 0;
 }
@@ -500,6 +532,7 @@ extern "C" int sgx_rgb_wgrad(const float* img, const void* f, float* dw, int sj,
     hipStream_t st = (hipStream_t)stream;
     SGX_REQUIRE(ws_bytes >= sgx_rgb_wgrad_ws_bytes(npix, C), SGX_EWORKSPACE, "rgb_wgrad: workspace");
     SGX_REQUIRE(C <= 256 ? (256 % C == 0) : true, SGX_EUNSUPPORTED, "rgb_wgrad: C=%d", C);
+    SGX_NOTE(6.0 * npix * C, npix * (12.0 + (dtype == SGX_F32 ? 4.0 : 2.0) * C), "rgb_wgrad %zux%d", npix, C);
     int nblk = (int)((npix + 63) / 64);
     if (nblk > COLSUM_BLOCKS) nblk = COLSUM_BLOCKS;
     if (nblk < 1) nblk = 1;

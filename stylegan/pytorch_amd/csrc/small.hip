@@ -49,8 +49,8 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void mbstd_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int HW, int C, int Cpad) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int HW, int C, int Cpad) {
+    __shared__ double sh[16];
     const int G = B < 4 ? B : 4, M = B / G, m = blockIdx.x, n = HW * C;
     double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -75,9 +75,9 @@ __global__ __launch_bounds__(256) void mbstd_fwd_kernel(const T* __restrict__ x,
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, int B,
+__global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, int B,
                                                         int HW, int C, int Cpad) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     const int G = B < 4 ? B : 4, M = B / G, m = blockIdx.x, n = HW * C;
     double acc = 0.0;
     for (int i = threadIdx.x; i < G * HW; i += blockDim.x) {
@@ -101,9 +101,9 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ dy
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void mbstd_bwd2_kernel(const T* __restrict__ ggx, const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(1024) void mbstd_bwd2_kernel(const T* __restrict__ ggx, const T* __restrict__ dy, const T* __restrict__ x,
                                                          T* __restrict__ ddy, T* __restrict__ gx, int B, int HW, int C, int Cpad) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     const int G = B < 4 ? B : 4, M = B / G, m = blockIdx.x, n = HW * C;
     double a_gy = 0.0, a_dd = 0.0;
     for (int i = threadIdx.x; i < G * HW; i += blockDim.x) {
@@ -159,16 +159,16 @@ static int mbstd_check(int B, int C, int Cpad) {
 extern "C" int sgx_mbstd_fwd(const void* x, void* y, int B, int HW, int C, int Cpad, int dtype, void* stream) {
     int rc = mbstd_check(B, C, Cpad); if (rc) return rc;
     const int M = B / (B < 4 ? B : 4);
-    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_fwd_kernel<float>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, HW, C, Cpad);
-    else hipLaunchKernelGGL(mbstd_fwd_kernel<bf16_t>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, HW, C, Cpad);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_fwd_kernel<float>, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, HW, C, Cpad);
+    else hipLaunchKernelGGL(mbstd_fwd_kernel<bf16_t>, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, HW, C, Cpad);
     SGX_LAUNCH_CHECK("mbstd_fwd");
     return 0;
 }
 extern "C" int sgx_mbstd_bwd(const void* dy, const void* x, void* dx, int B, int HW, int C, int Cpad, int dtype, void* stream) {
     int rc = mbstd_check(B, C, Cpad); if (rc) return rc;
     const int M = B / (B < 4 ? B : 4);
-    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_bwd_kernel<float>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, (float*)dx, B, HW, C, Cpad);
-    else hipLaunchKernelGGL(mbstd_bwd_kernel<bf16_t>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, B, HW, C, Cpad);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_bwd_kernel<float>, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, (float*)dx, B, HW, C, Cpad);
+    else hipLaunchKernelGGL(mbstd_bwd_kernel<bf16_t>, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, B, HW, C, Cpad);
     SGX_LAUNCH_CHECK("mbstd_bwd");
     return 0;
 }
@@ -176,8 +176,8 @@ extern "C" int sgx_mbstd_bwd2(const void* ggx, const void* dy, const void* x, vo
                               int dtype, void* stream) {
     int rc = mbstd_check(B, C, Cpad); if (rc) return rc;
     const int M = B / (B < 4 ? B : 4);
-    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_bwd2_kernel<float>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)ggx, (const float*)dy, (const float*)x, (float*)ddy, (float*)gx, B, HW, C, Cpad);
-    else hipLaunchKernelGGL(mbstd_bwd2_kernel<bf16_t>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ggx, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)ddy, (bf16_t*)gx, B, HW, C, Cpad);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_bwd2_kernel<float>, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const float*)ggx, (const float*)dy, (const float*)x, (float*)ddy, (float*)gx, B, HW, C, Cpad);
+    else hipLaunchKernelGGL(mbstd_bwd2_kernel<bf16_t>, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)ggx, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)ddy, (bf16_t*)gx, B, HW, C, Cpad);
     SGX_LAUNCH_CHECK("mbstd_bwd2");
     return 0;
 }
@@ -248,7 +248,7 @@ extern "C" int sgx_gemm_f32(const float* A, const float* Bm, float* C, int M, in
 // and its backward  out = alpha * s[0] * x  with the upstream scalar s kept on the device.
 #define SUMSQ_BLOCKS 1024
 __global__ __launch_bounds__(256) void sumsq_f32_stage1(const float* __restrict__ x, size_t n, double* __restrict__ partial) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     const size_t nvec = n / 4;
     double acc = 0.0;
     float part = 0.f; int cnt = 0;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void sumsq_f32_stage1(const float* __restrict_
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 __global__ __launch_bounds__(256) void sumsq_f32_stage2(const double* __restrict__ partial, int nblk, float* __restrict__ out) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     double acc = 0.0;
     for (int i = threadIdx.x; i < nblk; i += 256) acc += partial[i];
     const double s = block_sum_d(acc, sh);

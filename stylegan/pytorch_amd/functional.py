@@ -42,57 +42,6 @@ def _c(t):
 
 
 # ---------------------------------------------------------------------------------------------------
-# optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  KERNEL_TIMES maps
-# the kernel instantiation name (as rocprofv3 prints it) to a list of (start_event, end_event, flops).
-KERNEL_TIMES = None
-
-
-def conv_kernel_name(geo, B, H, W, Cin, Cout, dtype):
-    """The template instantiation a launch resolves to (sgx_conv_config), spelled as rocprofv3 prints it."""
-    import ctypes
-    f32 = dtype == torch.float32
-    g = {"S": 0, "D": 1, "U": 2}[geo]
-    cfg = (ctypes.c_int * 5)()
-    N.check(N.lib().sgx_conv_config(g, B, H, W, Cin, Cout, N.F32 if f32 else N.BF16, ctypes.addressof(cfg)), "sgx_conv_config")
-    kc, th, tw, bp, ct = list(cfg)
-    return f"void conv_kernel<{'float' if f32 else 'unsigned short'}, {kc}, {g}, {th}, {tw}, {bp}, {ct}>(ConvArgs)"
-
-
-def wgrad_kernel_name(geo, Hn, Wn, Ck, Cn, dtype):
-    """Mirror of wgrad_ch()/wgrad_tile() in csrc/conv.hip.  geo 'S' or 'D' (4x4 stride 2, n side = coarse grid)."""
-    f32 = dtype == torch.float32
-    g = 0 if geo == "S" else 1
-    bp = 128 if geo == "S" else 64
-    if Hn >= 16 and Wn >= 16:
-        th, tw = bp // 16, 16
-    elif Hn >= 8 and Wn >= 8:
-        th, tw = (8 if bp >= 64 else bp // 8), 8
-    else:
-        th, tw = (4 if bp >= 16 else bp // 4), 4
-    nsub = 2 if Cn % 32 == 0 else 1
-    ksub = 1 if geo == "D" else (2 if Ck % 32 == 0 else 1)
-    import os
-    tr = "true" if (not f32 and os.environ.get("SGX_WGRAD_TR", "1") not in ("0", "")) else "false"
-    return f"void wgrad_kernel<{'float' if f32 else 'unsigned short'}, {g}, {th}, {tw}, {bp}, {nsub}, {ksub}, {tr}>(WgradArgs)"
-
-
-class _Timed:
-    def __init__(self, name, flops, desc="", nbytes=0.0):
-        self.name, self.flops, self.desc, self.nbytes = name, flops, desc, nbytes
-
-    def __enter__(self):
-        if KERNEL_TIMES is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
-
-    def __exit__(self, *a):
-        if KERNEL_TIMES is not None:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            KERNEL_TIMES.setdefault(self.name, []).append((self.e0, e1, self.flops, self.desc, self.nbytes))
-
-
-# ---------------------------------------------------------------------------------------------------
 # packed-weight cache.  mode: 'S' plain 3x3 | 'D' fused down | 'U' fused up | 'UF' non-fused-up semantics.
 # One sgx_pack_weight launch per (parameter, version) produces both MFMA operand packs in the activation dtype;
 # every forward / data-gradient / R1 pass of the step reuses them.  Parameters updated by the HIP optimizer do not
@@ -145,20 +94,16 @@ def _conv_launch(geo, x, wq, bias, act):
     if K != Cin:
         raise N.SgxError(f"conv: weight pack expects {K} input channels, activation has {Cin}")
     L = N.lib()
-    npix = B * H * W * (0.25 if geo == "D" else 1.0)
-    osz = {"S": 1.0, "D": 0.25, "U": 4.0}[geo]
-    with _Timed(conv_kernel_name(geo, B, H, W, Cin, Cout, x.dtype) if KERNEL_TIMES is not None else None, 2.0 * taps * Cin * Cout * npix,
-                f"conv{geo} B{B} {H}x{W} {Cin}->{Cout}", (Cin + Cout * osz) * B * H * W * x.element_size()):
-        if geo == "S":
-            y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
-            N.check(L.sgx_conv3x3(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv3x3")
-        elif geo == "D":
-            y = torch.empty((B, H // 2, W // 2, Cout), dtype=x.dtype, device=x.device)
-            N.check(L.sgx_conv4x4s2_down(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv4x4s2_down")
-        else:
-            assert bias is None and act == 0
-            y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
-            N.check(L.sgx_conv4x4s2_up(N.ptr(x), N.ptr(wq), N.ptr(y), B, H, W, Cin, Cout, N.dt(x), N.stream()), "sgx_conv4x4s2_up")
+    if geo == "S":
+        y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
+        N.check(L.sgx_conv3x3(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv3x3")
+    elif geo == "D":
+        y = torch.empty((B, H // 2, W // 2, Cout), dtype=x.dtype, device=x.device)
+        N.check(L.sgx_conv4x4s2_down(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv4x4s2_down")
+    else:
+        assert bias is None and act == 0
+        y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
+        N.check(L.sgx_conv4x4s2_up(N.ptr(x), N.ptr(wq), N.ptr(y), B, H, W, Cin, Cout, N.dt(x), N.stream()), "sgx_conv4x4s2_up")
     return y
 
 
@@ -172,21 +117,16 @@ def _wgrad_param(mode, adjoint, x, gy, weight, scale):
         _, H, W, Cx = x.shape
         Cdy = gy.shape[3]
         ws = N.workspace(L.sgx_wgrad_ws_bytes(9, B, H, W, Cx, Cdy), x.device)
-        with _Timed(wgrad_kernel_name("S", H, W, Cx, Cdy, x.dtype) if KERNEL_TIMES is not None else None, 2.0 * 9 * Cx * Cdy * B * H * W,
-                    f"wgradS B{B} {H}x{W} {Cx}x{Cdy}", (Cx + Cdy) * B * H * W * x.element_size()):
-            N.check(L.sgx_wgrad3x3_param(N.ptr(x), N.ptr(gy), N.ptr(dW), N.ptr(ws), ws.numel(), B, H, W, Cx, Cdy, int(adjoint),
-                                         float(scale), O, I, N.dt(x), N.stream()), "sgx_wgrad3x3_param")
+        N.check(L.sgx_wgrad3x3_param(N.ptr(x), N.ptr(gy), N.ptr(dW), N.ptr(ws), ws.numel(), B, H, W, Cx, Cdy, int(adjoint),
+                                     float(scale), O, I, N.dt(x), N.stream()), "sgx_wgrad3x3_param")
         return dW
     launched = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]          # geometry of the convolution that ran
     fine, coarse = (x, gy) if launched == "D" else (gy, x)
     _, H, W, Cf = fine.shape
     Cc = coarse.shape[3]
     ws = N.workspace(L.sgx_wgrad_ws_bytes(16, B, H, W, Cf, Cc), x.device)
-    with _Timed(wgrad_kernel_name("D", H // 2, W // 2, Cf, Cc, x.dtype) if KERNEL_TIMES is not None else None,
-                2.0 * 16 * Cf * Cc * B * (H // 2) * (W // 2), f"wgradD B{B} fine{H}x{W} {Cf}x{Cc}",
-                (Cf + Cc * 0.25) * B * H * W * x.element_size()):
-        N.check(L.sgx_wgrad4x4s2_param(N.ptr(fine), N.ptr(coarse), N.ptr(dW), N.ptr(ws), ws.numel(), B, H, W, Cf, Cc, MODES[mode],
-                                       float(scale), O, I, N.dt(x), N.stream()), "sgx_wgrad4x4s2_param")
+    N.check(L.sgx_wgrad4x4s2_param(N.ptr(fine), N.ptr(coarse), N.ptr(dW), N.ptr(ws), ws.numel(), B, H, W, Cf, Cc, MODES[mode],
+                                   float(scale), O, I, N.dt(x), N.stream()), "sgx_wgrad4x4s2_param")
     return dW
 
 

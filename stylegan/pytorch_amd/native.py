@@ -14,7 +14,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsgx_hip.so")
+LIB_PATH = os.environ.get("SGX_HIP_LIB") or os.path.join(_HERE, "libsgx_hip.so")   # env: kernel experiments only
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1
@@ -37,6 +37,9 @@ SIGNATURES = {
     "sgx_wgrad_ws_bytes": (Z, [I, I, I, I, I, I]),
     "sgx_selftest_tr16": (I, [P, P]),
     "sgx_conv_config": (I, [I, I, I, I, I, I, I, P]),
+    "sgx_prof_start": (I, [I, I]),
+    "sgx_prof_count": (I, []),
+    "sgx_prof_get": (I, [I, P, I, P, P, P, P, I]),
     "sgx_pack_weight": (I, [P, P, P, I, I, I, I, F, I, P]),
     "sgx_wgrad3x3_param": (I, [P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, P]),
     "sgx_wgrad4x4s2_param": (I, [P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, P]),
@@ -134,3 +137,23 @@ def ptr(t):
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------------------------------------------
+# per-launch profiler of the library (HIP events on the launch stream, recorded inside libsgx_hip.so)
+def prof_start(mode: int = 1, only_of: int = 0) -> None:
+    """mode 1: record every kernel launch; 2: only launches of the kernel record ``only_of`` belongs to; 0: stop."""
+    check(lib().sgx_prof_start(int(mode), int(only_of)), "sgx_prof_start")
+
+
+def prof_records():
+    """[(kernel name as rocprofv3 prints it, milliseconds, flops, algorithmic bytes, layer description), ...]."""
+    L = lib()
+    name, desc = ctypes.create_string_buffer(256), ctypes.create_string_buffer(64)
+    ms, fl, by = ctypes.c_float(), ctypes.c_double(), ctypes.c_double()
+    out = []
+    for i in range(L.sgx_prof_count()):
+        check(L.sgx_prof_get(i, ctypes.addressof(name), 256, ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(by),
+                             ctypes.addressof(desc), 64), "sgx_prof_get")
+        out.append((name.value.decode(), ms.value, fl.value, by.value, desc.value.decode()))
+    return out

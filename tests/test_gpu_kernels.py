@@ -309,3 +309,35 @@ def test_fused_adam_clip_ema():
     ema_update(m_t, m_s, 0.999)
     for k, v in m_t.named_parameters():
         assert_close(v, ref[k], 1e-6, "ema")
+
+
+def test_library_profiler_names_and_times_launches():
+    """sgx_prof_*: every launch is bracketed by HIP events inside the library; names are what rocprofv3 prints."""
+    from stylegan.pytorch_amd import functional as F, native
+    w = torch.nn.Parameter(torch.randn(32, 32, 3, 3, device=DEV))
+    x = torch.randn(2, 64, 64, 32, device=DEV, requires_grad=True)
+    F.conv(x, w, None, "S", 0.1)                                       # weight pack happens outside the profiled region
+    native.prof_start(1)
+    y = F.conv(x, w, None, "S", 0.1)
+    y.backward(torch.ones_like(y))
+    torch.cuda.synchronize()
+    native.prof_start(0)
+    recs = native.prof_records()
+    names = [r[0] for r in recs]
+    assert any(n.startswith("void conv_kernel<float, 16, 0,") for n in names), names
+    assert any(n.startswith("void wgrad_kernel<float, 0,") for n in names), names
+    assert any(n.startswith("wgrad_finish_kernel") for n in names), names
+    conv = [r for r in recs if r[0].startswith("void conv_kernel")]
+    assert len(conv) == 2                                              # forward + data gradient
+    for name, ms, flops, nbytes, desc in conv:
+        assert 0.0 < ms < 50.0 and flops == 2.0 * 9 * 32 * 32 * 2 * 64 * 64 and desc == "convS B2 64x64 32->32"
+    # mode 2: only the kernel of a chosen record
+    native.prof_start(2, names.index(conv[0][0]))
+    y = F.conv(x, w, None, "S", 0.1)
+    y.backward(torch.ones_like(y))
+    torch.cuda.synchronize()
+    native.prof_start(0)
+    only = native.prof_records()
+    assert len(only) == 2 and all(r[0] == conv[0][0] for r in only)
+    native.prof_start(1); native.prof_start(0)
+    assert native.prof_records() == []

@@ -47,7 +47,10 @@ def main():
         taps = 9 if mode == "S" else 16
         npix = a.batch * H * H * (0.25 if mode == "D" else 1.0)
         fl = 2.0 * taps * ci * co * npix
-        print(f"conv{mode} B{a.batch} {H}x{H} {ci}->{co}: {us:8.1f} us  {fl / us / 1e6:8.1f} TFLOP/s", flush=True)
+        es = 2 if a.dtype == "bf16" else 4
+        oh = H // 2 if mode == "D" else (2 * H if mode == "U" else H)
+        by = es * a.batch * (H * H * ci + oh * oh * co)
+        print(f"conv{mode} B{a.batch} {H}x{H} {ci}->{co}: {us:8.1f} us  {fl / us / 1e6:8.1f} TFLOP/s  {by / us / 1e3:7.0f} GB/s", flush=True)
 
 
 if __name__ == "__main__":
