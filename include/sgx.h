@@ -83,12 +83,15 @@ int sgx_pack_weight(const float* w, void* fwd, void* adj, int O, int I, int Ipad
  *   sgx_wgrad3x3_param : y = conv3x3(x, pack_S(w)):  x has Cx channels, dy has Cdy.  adjoint=1: the launch was the
  *                        layer's DATA-GRADIENT convolution (x: O channels, dy: Ipad channels) -- second-order path (R1).
  *   sgx_wgrad4x4s2_param: fine/coarse = the stride-2 pair's high/low resolution tensors (H,W = fine size);
- *                        mode D: coarse has O channels, fine has I;  mode U/UF: coarse has I, fine has O.             */
+ *                        mode D: coarse has O channels, fine has I;  mode U/UF: coarse has I, fine has O.
+ *   db (nullable, fp32 [O]): also the bias gradient sum_{b,h,w} dy[.,o] (EqualizedConv2d bias, CustomLayers.py:178),
+ *                        from the same pass over dy (one extra MFMA against a tile of ones) -- only where dy is the
+ *                        O-channel side: adjoint=0 / mode D; otherwise SGX_EINVAL.                                  */
 size_t sgx_wgrad_ws_bytes(int taps, int B, int H, int W, int Ck, int Cn);
-int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, void* ws, size_t ws_bytes, int B, int H, int W, int Cx,
-                       int Cdy, int adjoint, float scale, int O, int I, int dtype, void* stream);
-int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float* dW, void* ws, size_t ws_bytes, int B, int H, int W,
-                         int Cfine, int Ccoarse, int mode, float scale, int O, int I, int dtype, void* stream);
+int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, float* db, void* ws, size_t ws_bytes, int B, int H, int W,
+                       int Cx, int Cdy, int adjoint, float scale, int O, int I, int dtype, void* stream);
+int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float* dW, float* db, void* ws, size_t ws_bytes, int B, int H,
+                         int W, int Cfine, int Ccoarse, int mode, float scale, int O, int I, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- memory-bound layer pieces
  * y = act(x + bscale*bias[c])               bias after blur / avgpool: models/CustomLayers.py:178-179; Blocks.py:142,146

@@ -64,21 +64,31 @@ class LogisticGAN(GANLoss):
         super().__init__(dis)
         self.mean_scale = float(mean_scale)
 
-    def R1Penalty(self, real_img, height, alpha):
-        real_img = real_img.detach().requires_grad_(True)
-        real_logit = self.dis(real_img, height, alpha)
+    def _r1_from_logit(self, real_logit, real_img):
         with F.data_grad_only():                      # only d(logit)/d(image) is needed here, not the parameter grads
             real_grads = torch.autograd.grad(outputs=real_logit, inputs=real_img,
                                              grad_outputs=torch.ones_like(real_logit),
                                              create_graph=True, retain_graph=True)[0]
         return F.SumSqFn.apply(real_grads)            # SUM over batch and pixels (:210)
 
+    def R1Penalty(self, real_img, height, alpha):
+        real_img = real_img.detach().requires_grad_(True)
+        return self._r1_from_logit(self.dis(real_img, height, alpha), real_img)
+
     def dis_loss(self, real_samps, fake_samps, height, alpha, r1_gamma=10.0):
-        r_preds = self.dis(real_samps, height, alpha)
+        # The reference evaluates D(real) twice -- once for the logistic term (:216) and once more inside R1Penalty
+        # (:201) -- with identical results (D is deterministic).  Here ONE forward of D(real) feeds both terms, and
+        # the final backward walks that graph once with the two upstream gradients summed: same loss, same
+        # gradients, one D forward and one D backward less per iteration.
+        if r1_gamma != 0.0:
+            real = real_samps.detach().requires_grad_(True)
+            r_preds = self.dis(real, height, alpha)
+        else:
+            r_preds = self.dis(real_samps, height, alpha)
         f_preds = self.dis(fake_samps, height, alpha)
         loss = (torch.mean(TF.softplus(f_preds)) + torch.mean(TF.softplus(-r_preds))) * self.mean_scale
         if r1_gamma != 0.0:
-            loss = loss + self.R1Penalty(real_samps.detach(), height, alpha) * (r1_gamma * 0.5)
+            loss = loss + self._r1_from_logit(r_preds, real) * (r1_gamma * 0.5)
         return loss
 
     def gen_loss(self, _, fake_samps, height, alpha):

@@ -495,6 +495,7 @@ extern "C" int sgx_conv4x4s2_up(const void* x, const void* w, void* y, int B, in
 struct WgradArgs {
     const void* kside; const void* nside; float* out;     // out: [nsplit][NT][Cn][Ck] partials (or dw when nsplit==1)
     int B, Hk, Wk, Hn, Wn, Ck, Cn, tiles_x, tiles_y, ntiles;
+    int want_bias;                                        // also emit column sums of the n side (the bias gradient)
 };
 
 template <typename T> struct WFrag;
@@ -509,6 +510,7 @@ template <> struct WFrag<float> {
     __device__ static __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
+    __device__ static __forceinline__ frag_t ones() { return 1.f; }
 };
 template <> struct WFrag<bf16_t> {
     static constexpr int KPS = 16;
@@ -524,6 +526,7 @@ template <> struct WFrag<bf16_t> {
     __device__ static __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
     }
+    __device__ static __forceinline__ frag_t ones() { return (s16x4){0x3f80, 0x3f80, 0x3f80, 0x3f80}; }
 };
 
 // LDS transpose read (gfx950 ds_read_b64_tr_b16): within a 16-lane group, lane i supplies the 8-byte address of row i/4,
@@ -567,35 +570,63 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int k = 0; k < KSUB; ++k) acc[i][j][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.y; tile < a.ntiles; tile += gridDim.y) {
+    // Bias gradient = column sums of the n side: one extra MFMA per k-step against a tile of ones, on the wave with the
+    // fewest taps, in the blocks of k-block 0 only.  Comes out of the same split partials, summed by the finish kernel.
+    const bool do_bias = a.want_bias && (blockIdx.x % kblocks) == 0 && wave == 3;
+    f32x4 bacc[NSUB];
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) bacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // Global -> LDS staging is software pipelined through registers: the loads of the NEXT tile are issued before the
+    // MFMAs of the current one.
+    constexpr int NNV = (BP * (NCH / VE) + 255) / 256, NKV = (NI * PH * PW * (KCH / VE) + 255) / 256;
+    uint4 rn[NNV], rk[NKV];
+    auto gload = [&](int tile) {
         int bx = tile;
         const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
         const int ty_i = bx % a.tiles_y;
         const int img0 = (bx / a.tiles_y) * NI;
         const int ty0 = ty_i * TH, tx0 = tx_i * TW;
         const int iy0 = ty0 * IS - 1, ix0 = tx0 * IS - 1;
-        __syncthreads();
-        // n-side tile: BP pixels x NCH channels
-        for (int idx = tid; idx < BP * (NCH / VE); idx += 256) {
+#pragma unroll
+        for (int j = 0; j < NNV; ++j) {                   // n-side tile: BP pixels x NCH channels
+            const int idx = tid + j * 256;
             const int v = idx % (NCH / VE), m = idx / (NCH / VE);
             const int il = m / (TH * TW), r = (m / TW) % TH, c = m % TW;
             const int b = img0 + il, gy = ty0 + r, gx = tx0 + c;
-            const bool ok = (b < a.B) && (gy < a.Hn) && (gx < a.Wn);
+            const bool ok = (idx < BP * (NCH / VE)) && (b < a.B) && (gy < a.Hn) && (gx < a.Wn);
             const T* src = ng + (((size_t)b * a.Hn + gy) * a.Wn + gx) * a.Cn + n0 + v * VE;
-            uint4 val = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(n_lds + m * NROW + v * 16) = val;
+            rn[j] = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
         }
-        // k-side patch with halo: NI*PH*PW pixels x KCH channels
-        for (int idx = tid; idx < NI * PH * PW * (KCH / VE); idx += 256) {
+#pragma unroll
+        for (int j = 0; j < NKV; ++j) {                   // k-side patch with halo: NI*PH*PW pixels x KCH channels
+            const int idx = tid + j * 256;
             const int v = idx % (KCH / VE), pixel = idx / (KCH / VE);
             const int il = pixel / (PH * PW), rem = pixel % (PH * PW);
             const int gy = iy0 + rem / PW, gx = ix0 + rem % PW, b = img0 + il;
-            const bool ok = (b < a.B) && ((unsigned)gy < (unsigned)a.Hk) && ((unsigned)gx < (unsigned)a.Wk);
+            const bool ok = (idx < NI * PH * PW * (KCH / VE)) && (b < a.B) && ((unsigned)gy < (unsigned)a.Hk) && ((unsigned)gx < (unsigned)a.Wk);
             const T* src = kg + (((size_t)b * a.Hk + gy) * a.Wk + gx) * a.Ck + kc0 + v * VE;
-            uint4 val = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(k_lds + pixel * KROW + v * 16) = val;
+            rk[j] = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
         }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NNV; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < BP * (NCH / VE)) *reinterpret_cast<uint4*>(n_lds + (idx / (NCH / VE)) * NROW + (idx % (NCH / VE)) * 16) = rn[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NKV; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < NI * PH * PW * (KCH / VE)) *reinterpret_cast<uint4*>(k_lds + (idx / (KCH / VE)) * KROW + (idx % (KCH / VE)) * 16) = rk[j];
+        }
+    };
+    if ((int)blockIdx.y < a.ntiles) gload(blockIdx.y);
+    for (int tile = blockIdx.y; tile < a.ntiles; tile += gridDim.y) {
+        __syncthreads();                                  // every wave is done reading the previous tile
+        lstore();
         __syncthreads();
+        if (tile + (int)gridDim.y < a.ntiles) gload(tile + gridDim.y);   // in flight during the MFMAs below
         if constexpr (TR) {
             // bf16, 32 pixels per MFMA (v_mfma_f32_16x16x32_bf16): two transpose reads per operand
             for (int ks = 0; ks < BP / 32; ++ks) {
@@ -611,6 +642,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
                 for (int ns = 0; ns < NSUB; ++ns)
                     fa8[ns] = cat8(lds_tr16(n_lds + noff2[0] + ns * 32), lds_tr16(n_lds + noff2[1] + ns * 32));
+                if (do_bias) {
+                    const bf16x8 one8 = cat8(WFrag<bf16_t>::ones(), WFrag<bf16_t>::ones());
+#pragma unroll
+                    for (int ns = 0; ns < NSUB; ++ns) bacc[ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa8[ns], one8, bacc[ns], 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
                     const int t = wave + 4 * i;
@@ -639,6 +675,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             typename F::frag_t fa[NSUB];
 #pragma unroll
             for (int ns = 0; ns < NSUB; ++ns) fa[ns] = F::load(n_lds, noff, q, ns * 16 + l15);
+            if (do_bias) {
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns) bacc[ns] = F::mma(fa[ns], F::ones(), bacc[ns]);
+            }
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int t = wave + 4 * i;
@@ -655,7 +695,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
     }
     // partial store: out[split][t][n][k]; lane holds rows n = q*4+r, column k = l15
-    float* out = a.out + (size_t)blockIdx.y * NT * a.Cn * a.Ck;
+    float* out = a.out + (size_t)blockIdx.y * ((size_t)NT * a.Cn * a.Ck + a.Cn);
+    if (do_bias && l15 == 0) {                             // every column of bacc holds the same sums
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)NT * a.Cn * a.Ck + n0 + ns * 16 + q * 4 + r] = bacc[ns][r];
+    }
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int t = wave + 4 * i;
@@ -677,24 +723,40 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // mode S: dW[o][i][y][x] = scale * P[y*3+x];  4x4 modes: dW[o][i][y][x] = scale * sum_{a,b in {0,1}} P[(y+a)*4 + (x+b)]
 // (x0.25 for the down kernel; spatial flip of (y,x) for the non-fused-up semantics) -- the transposes of
 // reference models/CustomLayers.py:146-150 and :159-162.
-struct FinishArgs { const float* ws; float* dw; int nsplit, O, I, Ip, mode, transposed, flip_t; float scale; };
+struct FinishArgs { const float* ws; float* dw; float* db; int nsplit, O, I, Ip, mode, transposed, flip_t; float scale; };
 
+// EPB consecutive workspace elements per block (consecutive in the partials' fastest dimension, so every read is
+// coalesced) x 256/EPB split lanes.  Large weights with few splits use EPB=64; tiny weights with hundreds of splits
+// (the 16/32-channel layers at 512^2..1024^2) use EPB=4 so that the launch still has many blocks and 64 split lanes.
+template <int EPB>
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(FinishArgs f) {
-    __shared__ float red[16][16][9];
-    const int pl = threadIdx.x & 15, sl = threadIdx.x >> 4;          // pair lane (consecutive i), split lane
-    const int pair = blockIdx.x * 16 + pl;
-    const int npairs = f.O * f.I;
-    const int o = pair / f.I, i = pair % f.I;
+    constexpr int NSL = 256 / EPB;
+    __shared__ float red[NSL][EPB][9];
+    const int pl = threadIdx.x % EPB, sl = threadIdx.x / EPB;
+    const int A = f.transposed ? f.Ip : f.O, Bd = f.transposed ? f.O : f.Ip;
+    const int e = blockIdx.x * EPB + pl;                              // workspace element (a, b) = (e / Bd, e % Bd)
     const int taps = f.mode == SGX_PACK_S ? 9 : 16;
-    const size_t total = (size_t)taps * f.O * f.Ip;
+    const size_t tstride = (size_t)f.O * f.Ip, total = (size_t)taps * tstride + A;   // + the n side's column sums
+    if ((int)blockIdx.x >= (A * Bd + EPB - 1) / EPB) {                // trailing blocks: bias gradient db[o] (unscaled)
+        const int o = ((int)blockIdx.x - (A * Bd + EPB - 1) / EPB) * EPB + pl;
+        float b = 0.f;
+        if (o < f.O)
+            for (int s = sl; s < f.nsplit; s += NSL) b += f.ws[(size_t)s * total + (size_t)taps * tstride + o];
+        red[sl][pl][0] = b;
+        __syncthreads();
+        if (sl == 0 && o < f.O) {
+            float sum = 0.f;
+            for (int l = 0; l < NSL; ++l) sum += red[l][pl][0];
+            f.db[o] = sum;
+        }
+        return;
+    }
     float acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
-    if (pair < npairs) {
-        const size_t tstride = (size_t)f.O * f.Ip;
-        const size_t eoff = f.transposed ? (size_t)i * f.O + o : (size_t)o * f.Ip + i;
-        for (int s = sl; s < f.nsplit; s += 16) {
-            const float* p = f.ws + (size_t)s * total + eoff;
+    if (e < A * Bd) {
+        for (int s = sl; s < f.nsplit; s += NSL) {
+            const float* p = f.ws + (size_t)s * total + e;
             if (f.mode == SGX_PACK_S) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc[t] += p[(size_t)(f.flip_t ? 8 - t : t) * tstride];
@@ -713,16 +775,18 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(FinishArgs f) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) red[sl][pl][k] = acc[k];
     __syncthreads();
-    if (sl == 0 && pair < npairs) {
+    for (int t = threadIdx.x; t < EPB * 9; t += 256) {                // output (element, tap): fixed summation order
+        const int el = t / 9, k = t % 9;
+        const int ee = blockIdx.x * EPB + el;
+        if (ee >= A * Bd) continue;
+        const int a = ee / Bd, bb = ee % Bd;
+        const int o = f.transposed ? bb : a, i = f.transposed ? a : bb;
+        if (i >= f.I) continue;                                       // padded input channels carry no parameter
+        float sum = 0.f;
+#pragma unroll 8
+        for (int l = 0; l < NSL; ++l) sum += red[l][el][k];
         const float c = f.scale * (f.mode == SGX_PACK_D ? 0.25f : 1.f);
-        float* d = f.dw + (size_t)pair * 9;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            float sum = 0.f;
-#pragma unroll
-            for (int l = 0; l < 16; ++l) sum += red[l][pl][k];
-            d[f.mode == SGX_PACK_UF ? 8 - k : k] = c * sum;
-        }
+        f.dw[((size_t)o * f.I + i) * 9 + (f.mode == SGX_PACK_UF ? 8 - k : k)] = c * sum;
     }
 }
 
@@ -745,7 +809,7 @@ static int launch_wgrad(WgradArgs& a, void* ws, size_t ws_bytes, int* nsplit_out
     a.ntiles = ((a.B + NI - 1) / NI) * a.tiles_y * a.tiles_x;
     const int pairs = (a.Cn / (NSUB * 16)) * (a.Ck / (KSUB * 16));
     int nsplit = wgrad_nsplit(pairs, a.ntiles);
-    const size_t total = (size_t)NT * a.Cn * a.Ck;
+    const size_t total = (size_t)NT * a.Cn * a.Ck + a.Cn;             // per split: all taps + the n side's column sums
     size_t fit = ws_bytes / (total * sizeof(float));
     if ((size_t)nsplit > fit) nsplit = (int)fit;
     SGX_REQUIRE(nsplit >= 1, SGX_EWORKSPACE, "wgrad: workspace too small (%zu bytes, need >= %zu)", ws_bytes, total * sizeof(float));
@@ -787,53 +851,60 @@ static int wgrad_ch(WgradArgs& a, void* ws, size_t wsb, int* ns, hipStream_t st)
     return wgrad_tile<T, GEO, BP, 1, 1, TR>(a, ws, wsb, ns, st);
 }
 
-static int wgrad_finish(const void* ws, float* dw, int nsplit, int O, int I, int Ip, int mode, int transposed, int flip_t,
+static int wgrad_finish(const void* ws, float* dw, float* db, int nsplit, int O, int I, int Ip, int mode, int transposed, int flip_t,
                         float scale, hipStream_t st) {
-    FinishArgs f{static_cast<const float*>(ws), dw, nsplit, O, I, Ip, mode, transposed, flip_t, scale};
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((O * I + 15) / 16)), dim3(256), 0, st, f);
+    FinishArgs f{static_cast<const float*>(ws), dw, db, nsplit, O, I, Ip, mode, transposed, flip_t, scale};
+    SGX_NOTE(0.0, 4.0 * ((double)nsplit * (mode == SGX_PACK_S ? 9 : 16) * O * Ip + 9.0 * O * I), "finish %dx%d m%d tr%d ns%d", O, I, mode, transposed, nsplit);
+    const int ne = O * Ip, nb = db ? O : 0;                            // bias blocks trail the weight blocks
+    if (nsplit <= 4) hipLaunchKernelGGL(wgrad_finish_kernel<64>, dim3((unsigned)((ne + 63) / 64 + (nb + 63) / 64)), dim3(256), 0, st, f);
+    else if (nsplit <= 64) hipLaunchKernelGGL(wgrad_finish_kernel<16>, dim3((unsigned)((ne + 15) / 16 + (nb + 15) / 16)), dim3(256), 0, st, f);
+    else hipLaunchKernelGGL(wgrad_finish_kernel<4>, dim3((unsigned)((ne + 3) / 4 + (nb + 3) / 4)), dim3(256), 0, st, f);
     SGX_LAUNCH_CHECK("wgrad_finish_kernel");
     return 0;
 }
 
 extern "C" size_t sgx_wgrad_ws_bytes(int taps, int B, int H, int W, int Ck, int Cn) {
-    size_t total = (size_t)taps * Ck * Cn * sizeof(float);
+    size_t total = ((size_t)taps * Ck * Cn + Cn) * sizeof(float);
     int pairs = (Ck / 32 > 0 ? Ck / 32 : 1) * (Cn / 32 > 0 ? Cn / 32 : 1);
     size_t ntiles = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
     size_t ns = (size_t)wgrad_nsplit(pairs, ntiles > (1u << 30) ? (1 << 30) : (int)ntiles);
     return total * ns;
 }
 
-extern "C" int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, void* ws, size_t ws_bytes, int B, int H, int W,
-                                  int Cx, int Cdy, int adjoint, float scale, int O, int I, int dtype, void* stream) {
+extern "C" int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, float* db, void* ws, size_t ws_bytes, int B, int H,
+                                  int W, int Cx, int Cdy, int adjoint, float scale, int O, int I, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int Ip = adjoint ? Cdy : Cx;
+    SGX_REQUIRE(!db || !adjoint, SGX_EINVAL, "wgrad3x3_param: bias gradient asked of the adjoint launch");
     SGX_REQUIRE((adjoint ? Cx : Cdy) == O && Ip >= I, SGX_EINVAL, "wgrad3x3_param: channel mismatch (Cx=%d Cdy=%d O=%d I=%d adj=%d)", Cx, Cdy, O, I, adjoint);
-    WgradArgs a{x, dy, nullptr, B, H, W, H, W, Cx, Cdy, 0, 0, 0};
+    WgradArgs a{x, dy, nullptr, B, H, W, H, W, Cx, Cdy, 0, 0, 0, db ? 1 : 0};
     SGX_NOTE(2.0 * 9 * Cx * Cdy * B * H * W, (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * (Cx + Cdy), "wgradS B%d %dx%d %dx%d", B, H, W, Cx, Cdy);
     int ns = 0, rc;
     if (dtype == SGX_F32) rc = wgrad_ch<float, G3X3, 128>(a, ws, ws_bytes, &ns, st);
     else if (dtype == SGX_BF16) rc = wgrad_use_tr() ? wgrad_ch<bf16_t, G3X3, 128, true>(a, ws, ws_bytes, &ns, st) : wgrad_ch<bf16_t, G3X3, 128>(a, ws, ws_bytes, &ns, st);
     else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad3x3_param: bad dtype"); }
     if (rc) return rc;
-    return wgrad_finish(ws, dW, ns, O, I, Ip, SGX_PACK_S, adjoint, adjoint, scale, st);
+    return wgrad_finish(ws, dW, db, ns, O, I, Ip, SGX_PACK_S, adjoint, adjoint, scale, st);
 }
 
-extern "C" int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float* dW, void* ws, size_t ws_bytes, int B, int H,
-                                    int W, int Cfine, int Ccoarse, int mode, float scale, int O, int I, int dtype, void* stream) {
+extern "C" int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float* dW, float* db, void* ws, size_t ws_bytes, int B,
+                                    int H, int W, int Cfine, int Ccoarse, int mode, float scale, int O, int I, int dtype,
+                                    void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SGX_REQUIRE(H % 2 == 0 && W % 2 == 0, SGX_EINVAL, "wgrad4x4s2_param: odd fine size");
     SGX_REQUIRE(mode == SGX_PACK_D || mode == SGX_PACK_U || mode == SGX_PACK_UF, SGX_EINVAL, "wgrad4x4s2_param: bad mode %d", mode);
     const int transposed = mode != SGX_PACK_D;                 // kernel output is [t][coarse ch][fine ch]
+    SGX_REQUIRE(!db || !transposed, SGX_EINVAL, "wgrad4x4s2_param: bias gradient only for mode D (dy is the coarse side)");
     SGX_REQUIRE(transposed ? (Ccoarse == I && Cfine == O) : (Ccoarse == O && Cfine == I), SGX_EINVAL,
                 "wgrad4x4s2_param: channel mismatch (fine %d coarse %d O %d I %d mode %d)", Cfine, Ccoarse, O, I, mode);
-    WgradArgs a{fine, coarse, nullptr, B, H, W, H / 2, W / 2, Cfine, Ccoarse, 0, 0, 0};
+    WgradArgs a{fine, coarse, nullptr, B, H, W, H / 2, W / 2, Cfine, Ccoarse, 0, 0, 0, db ? 1 : 0};
     SGX_NOTE(2.0 * 16 * Cfine * Ccoarse * B * (H / 2) * (W / 2), (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * (Cfine + Ccoarse / 4.0), "wgradD B%d fine%dx%d %dx%d", B, H, W, Cfine, Ccoarse);
     int ns = 0, rc;
     if (dtype == SGX_F32) rc = wgrad_ch<float, GDOWN, 64>(a, ws, ws_bytes, &ns, st);
     else if (dtype == SGX_BF16) rc = wgrad_use_tr() ? wgrad_ch<bf16_t, GDOWN, 64, true>(a, ws, ws_bytes, &ns, st) : wgrad_ch<bf16_t, GDOWN, 64>(a, ws, ws_bytes, &ns, st);
     else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad4x4s2_param: bad dtype"); }
     if (rc) return rc;
-    return wgrad_finish(ws, dW, ns, O, I, I, mode, transposed, 0, scale, st);
+    return wgrad_finish(ws, dW, db, ns, O, I, I, mode, transposed, 0, scale, st);
 }
 
 // =====================================================================================================
@@ -882,6 +953,7 @@ extern "C" int sgx_pack_weight(const float* w, void* fwd, void* adj, int O, int 
     const size_t n = (size_t)(mode == SGX_PACK_S ? 9 : 16) * O * Ipad;
     size_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
+    SGX_NOTE(0.0, 36.0 * O * I + 2.0 * n * (dtype == SGX_F32 ? 4 : 2), "pack %dx%d m%d", O, I, mode);
     if (dtype == SGX_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, (float*)fwd, (float*)adj, O, I, Ipad, mode, scale);
     else if (dtype == SGX_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)fwd, (bf16_t*)adj, O, I, Ipad, mode, scale);
     else { SGX_REQUIRE(false, SGX_EINVAL, "pack_weight: bad dtype"); }

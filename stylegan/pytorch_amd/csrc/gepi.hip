@@ -11,20 +11,31 @@
 #define GEPI_ROWS_PER_THREAD 64
 
 struct GepiGeom { int cvt, rows, chunk, nchunk; };
-static GepiGeom gepi_geom(int HW, int C, int ve) {
+// Rows per thread: 64 for the big layers (few partials), fewer for the small ones so that a launch still has ~1024
+// blocks (a 4x4..64x64 layer with 64 rows per thread is a handful of blocks walking a long serial loop).
+static GepiGeom gepi_geom(int B, int HW, int C, int ve) {
     GepiGeom g;
     int cv = C / ve;
     g.cvt = cv < 256 ? cv : 256;
     g.rows = 256 / g.cvt;
-    g.chunk = g.rows * GEPI_ROWS_PER_THREAD;
+    int rpt = GEPI_ROWS_PER_THREAD;
+    while (rpt > 4 && (long)B * ((HW + g.rows * rpt - 1) / (g.rows * rpt)) < 1024) rpt >>= 1;
+    g.chunk = g.rows * rpt;
     g.nchunk = (HW + g.chunk - 1) / g.chunk;
     return g;
 }
 
 extern "C" size_t sgx_gepi_ws_bytes(int B, int HW, int C) {
-    GepiGeom g4 = gepi_geom(HW, C, 4), g8 = gepi_geom(HW, C, 8);
+    GepiGeom g4 = gepi_geom(B, HW, C, 4), g8 = gepi_geom(B, HW, C, 8);
     int nchunk = g4.nchunk > g8.nchunk ? g4.nchunk : g8.nchunk;
     return (size_t)2 * B * nchunk * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float) + 256;
+}
+
+// sum over 16 consecutive lanes (the finalizers give every output 16 lanes that stride over the chunk partials)
+__device__ __forceinline__ double sum16(double v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
 // mode 0: (sum a, sum a^2)                       [forward statistics]
@@ -114,17 +125,20 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
     }
 }
 
-// forward finalize: mean / rstd per (b,c)
+// forward finalize: mean / rstd per (b,c); 16 lanes per output
 __global__ void gepi_fin_stats(const double* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd, int B, int C,
                                int nchunk, int HW) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i % C;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
+    const bool ok = i < B * C;
+    const int b = ok ? i / C : 0, c = ok ? i % C : 0;
     double s = 0.0, ss = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-        const double* p = part + (((size_t)b * nchunk + k) * C + c) * 2;
-        s += p[0]; ss += p[1];
-    }
+    if (ok)
+        for (int k = l; k < nchunk; k += 16) {
+            const double* p = part + (((size_t)b * nchunk + k) * C + c) * 2;
+            s += p[0]; ss += p[1];
+        }
+    s = sum16(s); ss = sum16(ss);
+    if (!ok || l) return;
     const double m = s / HW;
     double var = ss / HW - m * m;
     if (var < 0.0) var = 0.0;
@@ -135,14 +149,17 @@ __global__ void gepi_fin_stats(const double* __restrict__ part, float* __restric
 // backward finalize 1: dstyle and the two per-(b,c) coefficients of the apply pass
 __global__ void gepi_fin_bwd1(const double* __restrict__ part, const float* __restrict__ style, float* __restrict__ dstyle,
                               float* __restrict__ coef, int B, int C, int nchunk, int HW) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i % C;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
+    const bool ok = i < B * C;
+    const int b = ok ? i / C : 0, c = ok ? i % C : 0;
     double s1 = 0.0, s0 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-        const double* p = part + (((size_t)b * nchunk + k) * C + c) * 2;
-        s1 += p[0]; s0 += p[1];
-    }
+    if (ok)
+        for (int k = l; k < nchunk; k += 16) {
+            const double* p = part + (((size_t)b * nchunk + k) * C + c) * 2;
+            s1 += p[0]; s0 += p[1];
+        }
+    s1 = sum16(s1); s0 = sum16(s0);
+    if (!ok || l) return;
     dstyle[(size_t)b * 2 * C + c] = (float)s0;              // d/d style[:,0] = sum dy*xh
     dstyle[(size_t)b * 2 * C + C + c] = (float)s1;          // d/d style[:,1] = sum dy
     const double sc = (double)style[(size_t)b * 2 * C + c] + 1.0;
@@ -150,16 +167,19 @@ __global__ void gepi_fin_bwd1(const double* __restrict__ part, const float* __re
     coef[(size_t)i * 2 + 1] = (float)(sc * s0 / HW);
 }
 
-// backward finalize 2: d noise-weight and d bias per channel (sum over images and chunks)
+// backward finalize 2: d noise-weight and d bias per channel (sum over images and chunks); 16 lanes per channel
 __global__ void gepi_fin_bwd2(const double* __restrict__ part, float* __restrict__ dnw, float* __restrict__ dbias, int B, int C,
                               int nchunk) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
+    const bool ok = c < C;
     double a = 0.0, d = 0.0;
-    for (int k = 0; k < B * nchunk; ++k) {
-        const double* p = part + ((size_t)k * C + c) * 2;
-        a += p[0]; d += p[1];
-    }
+    if (ok)
+        for (int k = l; k < B * nchunk; k += 16) {
+            const double* p = part + ((size_t)k * C + c) * 2;
+            a += p[0]; d += p[1];
+        }
+    a = sum16(a); d = sum16(d);
+    if (!ok || l) return;
     dnw[c] = (float)a;
     if (dbias) dbias[c] = (float)d;
 }
@@ -208,7 +228,7 @@ template <typename T>
 static int gepi_fwd_t(const void* x, const float* bias, const float* noise, const float* nw, const float* style, void* y,
                       float* mean, float* rstd, void* ws, int B, int HW, int C, hipStream_t st) {
     constexpr int VE = VecTraits<T>::VE;
-    GepiGeom g = gepi_geom(HW, C, VE);
+    GepiGeom g = gepi_geom(B, HW, C, VE);
     double* part = static_cast<double*>(ws);
     const double nb = (double)sizeof(T) * B * HW * C;
     SGX_NOTE(0.0, nb, "gepi_stats B%d HW%d C%d", B, HW, C);
@@ -216,7 +236,7 @@ static int gepi_fwd_t(const void* x, const float* bias, const float* noise, cons
                        (const T*)nullptr, (T*)nullptr, bias, noise, nw, style, mean, rstd, (const float*)nullptr, part, HW, C,
                        g.cvt, g.rows, g.chunk);
     SGX_LAUNCH_CHECK("gepi_stats");
-    hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 255) / 256), dim3(256), 0, st, part, mean, rstd, B, C, g.nchunk, HW);
+    hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 15) / 16), dim3(256), 0, st, part, mean, rstd, B, C, g.nchunk, HW);
     SGX_LAUNCH_CHECK("gepi_fin_stats");
     SGX_NOTE(0.0, 2.0 * nb, "gepi_apply B%d HW%d C%d", B, HW, C);
     hipLaunchKernelGGL(gepi_apply<T>, dim3(g.nchunk, B), dim3(256), 0, st, (const T*)x, bias, noise, nw, style, mean, rstd,
@@ -230,7 +250,7 @@ static int gepi_bwd_t(const void* dy, const void* x, const float* bias, const fl
                       const float* style, const float* mean, const float* rstd, void* dx, float* dstyle, float* dnw,
                       float* dbias, void* ws, int B, int HW, int C, hipStream_t st) {
     constexpr int VE = VecTraits<T>::VE;
-    GepiGeom g = gepi_geom(HW, C, VE);
+    GepiGeom g = gepi_geom(B, HW, C, VE);
     double* partA = static_cast<double*>(ws);
     double* partB = partA + (size_t)B * g.nchunk * C * 2;
     float* coef = reinterpret_cast<float*>(partB + (size_t)B * g.nchunk * C * 2);
@@ -240,13 +260,13 @@ static int gepi_bwd_t(const void* dy, const void* x, const float* bias, const fl
     hipLaunchKernelGGL((gepi_pass<T, 1>), dim3(g.nchunk, B), dim3(256), shb, st, (const T*)x, (const T*)dy, (T*)nullptr, bias,
                        noise, nw, style, mean, rstd, (const float*)nullptr, partA, HW, C, g.cvt, g.rows, g.chunk);
     SGX_LAUNCH_CHECK("gepi_bwd1");
-    hipLaunchKernelGGL(gepi_fin_bwd1, dim3((B * C + 255) / 256), dim3(256), 0, st, partA, style, dstyle, coef, B, C, g.nchunk, HW);
+    hipLaunchKernelGGL(gepi_fin_bwd1, dim3((B * C + 15) / 16), dim3(256), 0, st, partA, style, dstyle, coef, B, C, g.nchunk, HW);
     SGX_LAUNCH_CHECK("gepi_fin_bwd1");
     SGX_NOTE(0.0, 3.0 * nb, "gepi_bwd2 B%d HW%d C%d", B, HW, C);
     hipLaunchKernelGGL((gepi_pass<T, 2>), dim3(g.nchunk, B), dim3(256), shb, st, (const T*)x, (const T*)dy, (T*)dx, bias, noise,
                        nw, style, mean, rstd, (const float*)coef, partB, HW, C, g.cvt, g.rows, g.chunk);
     SGX_LAUNCH_CHECK("gepi_bwd2");
-    hipLaunchKernelGGL(gepi_fin_bwd2, dim3((C + 255) / 256), dim3(256), 0, st, partB, dnw, dbias, B, C, g.nchunk);
+    hipLaunchKernelGGL(gepi_fin_bwd2, dim3((C + 15) / 16), dim3(256), 0, st, partB, dnw, dbias, B, C, g.nchunk);
     SGX_LAUNCH_CHECK("gepi_fin_bwd2");
     return 0;
 }

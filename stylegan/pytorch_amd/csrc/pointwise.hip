@@ -125,36 +125,56 @@ extern "C" int sgx_axpby(const void* a, const void* b, void* out, float alpha, f
 }
 
 // ---------------------------------------------------------------- depthwise blur [1,2,1]x[1,2,1]/16, zero pad
+// Separable, sliding window down a strip of BLUR_ROWS output rows per thread: per input row three 16-byte loads
+// (left / centre / right pixel; the neighbours are L1 hits of the adjacent lanes' centres) give the horizontal sum,
+// three consecutive horizontal sums give one output row: 3.75 loads per output vector instead of 9.
+#define BLUR_ROWS 8
 template <typename T>
-__global__ void blur3x3_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+__global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
     constexpr int VE = VecTraits<T>::VE;
     const int cv = C / VE;
-    const size_t nvec = (size_t)B * H * W * cv;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    const int strips = (H + BLUR_ROWS - 1) / BLUR_ROWS;
+    const size_t nthr = (size_t)B * strips * W * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nthr; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % cv);
         size_t p = i / cv;
         const int w = (int)(p % W); p /= W;
-        const int h = (int)(p % H);
-        const int b = (int)(p / H);
-        float acc[VE];
+        const int sidx = (int)(p % strips);
+        const int b = (int)(p / strips);
+        const int h0 = sidx * BLUR_ROWS;
+        const bool hasl = w > 0, hasr = w + 1 < W;
+        const T* col = x + (((size_t)b * H * W + w) * cv + c) * VE;          // (b, row 0, w, c)
+        const size_t rstride = (size_t)W * cv * VE;
+        float ha[VE], hb[VE], hc[VE];                                         // horizontal sums of rows r-2, r-1, r
 #pragma unroll
-        for (int j = 0; j < VE; ++j) acc[j] = 0.f;
+        for (int j = 0; j < VE; ++j) { ha[j] = 0.f; hb[j] = 0.f; }
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int hh = h + dy;
-            if ((unsigned)hh >= (unsigned)H) continue;
+        for (int k = 0; k < BLUR_ROWS + 2; ++k) {
+            const int r = h0 - 1 + k;                                         // input row
+            if ((unsigned)r < (unsigned)H) {
+                const T* src = col + (size_t)r * rstride;
+                float l[VE], m[VE], rr[VE];
+                VecTraits<T>::load(src, m);
+                if (hasl) VecTraits<T>::load(src - cv * VE, l);
+                if (hasr) VecTraits<T>::load(src + cv * VE, rr);
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int ww = w + dx;
-                if ((unsigned)ww >= (unsigned)W) continue;
-                const float k = (dy == 0 ? 2.f : 1.f) * (dx == 0 ? 2.f : 1.f) * (1.f / 16.f);
-                float v[VE];
-                VecTraits<T>::load(x + ((((size_t)b * H + hh) * W + ww) * cv + c) * VE, v);
+                for (int j = 0; j < VE; ++j) hc[j] = (hasl ? l[j] : 0.f) + 2.f * m[j] + (hasr ? rr[j] : 0.f);
+            } else {
 #pragma unroll
-                for (int j = 0; j < VE; ++j) acc[j] += k * v[j];
+                for (int j = 0; j < VE; ++j) hc[j] = 0.f;
             }
+            if (k >= 2) {
+                const int ro = r - 1;                                         // output row
+                if (ro < H) {
+                    float o[VE];
+#pragma unroll
+                    for (int j = 0; j < VE; ++j) o[j] = (ha[j] + 2.f * hb[j] + hc[j]) * (1.f / 16.f);
+                    VecTraits<T>::store(y + (((size_t)b * H + ro) * W + w) * cv * VE + c * VE, o);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < VE; ++j) { ha[j] = hb[j]; hb[j] = hc[j]; }
         }
-        VecTraits<T>::store(y + i * VE, acc);
     }
 }
 extern "C" int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
@@ -162,10 +182,10 @@ extern "C" int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, i
     SGX_NOTE(0.0, 2.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * C, "blur B%d %dx%d C%d", B, H, W, C);
     if (dtype == SGX_F32) {
         SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "blur: C %% 4");
-        hipLaunchKernelGGL(blur3x3_kernel<float>, dim3(grid_for((size_t)B * H * W * C / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C);
+        hipLaunchKernelGGL(blur3x3_kernel<float>, dim3(grid_for((size_t)B * ((H + BLUR_ROWS - 1) / BLUR_ROWS) * W * C / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C);
     } else {
         SGX_REQUIRE(C % 8 == 0, SGX_EUNSUPPORTED, "blur: C %% 8");
-        hipLaunchKernelGGL(blur3x3_kernel<bf16_t>, dim3(grid_for((size_t)B * H * W * C / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+        hipLaunchKernelGGL(blur3x3_kernel<bf16_t>, dim3(grid_for((size_t)B * ((H + BLUR_ROWS - 1) / BLUR_ROWS) * W * C / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
     }
     SGX_LAUNCH_CHECK("blur3x3");
     return 0;

@@ -192,15 +192,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, l15 = lane & 15;
     const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
     const int i = i0 + l15, j = j0 + l15;
-    const int kper = ((K + 3) / 4 + 15) / 16 * 16;                 // K slice per wave, multiple of 16
-    const int kb = wave * kper, ke = (kb + kper < K) ? kb + kper : K;
+    // split K: blockIdx.z owns [z*kz, (z+1)*kz) (partials go to Cm + z*M*N, summed by gemm_splitk_reduce), its 4 waves
+    // split that range again
+    const int kz = ((K + (int)gridDim.z - 1) / (int)gridDim.z + 15) / 16 * 16;
+    const int kz0 = blockIdx.z * kz, kz1 = (kz0 + kz < K) ? kz0 + kz : K;
+    const int kper = (((kz1 > kz0 ? kz1 - kz0 : 0) + 3) / 4 + 15) / 16 * 16;   // K slice per wave, multiple of 16
+    const int kb = kz0 + wave * kper, ke = (kb + kper < kz1) ? kb + kper : kz1;
+    Cm += (size_t)blockIdx.z * M * N;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const size_t sa_i = ta ? 1 : (size_t)K, sa_k = ta ? (size_t)M : 1;
     const size_t sb_k = tb ? 1 : (size_t)N, sb_j = tb ? (size_t)K : 1;
     // 16 k per iteration: lane group q owns k = k0+4q..+3 (any k order is valid as long as A and B agree), so an
     // operand whose k axis is contiguous is fetched with one 16-byte load per lane instead of four 4-byte ones.
     const bool va = !ta && (K % 4 == 0), vb = tb && (K % 4 == 0);
-#pragma unroll 2
+#pragma unroll 8
     for (int k = kb; k < ke; k += 16) {
         const int kk = k + 4 * q;
         float a4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -234,13 +239,42 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         Cm[(size_t)(i0 + r) * N + j0 + c] = alpha * s;
     }
 }
-extern "C" size_t sgx_gemm_ws_bytes(int M, int N, int K) { (void)M; (void)N; (void)K; return 0; }
+__global__ void gemm_splitk_reduce(const float* __restrict__ part, float* __restrict__ Cm, int MN, int splits, float alpha) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= MN) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += part[(size_t)z * MN + i];     // fixed order: deterministic
+    Cm[i] = alpha * s;
+}
+// Skinny problems (M = batch: few 16x16 output tiles) with a long K are split over blockIdx.z so that the weight
+// matrix is streamed by many CUs instead of a handful.
+static int gemm_splits(int M, int N, int K) {
+    const int tiles = ((M + 15) / 16) * ((N + 15) / 16);
+    if (tiles >= 256 || K < 1024) return 1;
+    int s = K / 256, cap = (512 + tiles - 1) / tiles;
+    if (s > cap) s = cap;
+    return s < 1 ? 1 : s;
+}
+extern "C" size_t sgx_gemm_ws_bytes(int M, int N, int K) {
+    const int s = gemm_splits(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
 extern "C" int sgx_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, int ta, int tb, float alpha, void* ws,
                             size_t ws_bytes, void* stream) {
-    (void)ws; (void)ws_bytes;
     SGX_REQUIRE(M > 0 && N > 0 && K > 0, SGX_EINVAL, "gemm: bad shape %d %d %d", M, N, K);
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, A, Bm, C, M, N, K, ta, tb, alpha);
+    hipStream_t st = (hipStream_t)stream;
+    int splits = gemm_splits(M, N, K);
+    if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float))) splits = 1;   // no workspace: plain path
+    SGX_NOTE(2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N), "gemm %dx%dx%d t%d%d", M, N, K, ta, tb);
+    if (splits == 1) {
+        hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16, 1), dim3(256), 0, st, A, Bm, C, M, N, K, ta, tb, alpha);
+        SGX_LAUNCH_CHECK("gemm_f32");
+        return 0;
+    }
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16, splits), dim3(256), 0, st, A, Bm, (float*)ws, M, N, K, ta, tb, 1.0f);
     SGX_LAUNCH_CHECK("gemm_f32");
+    hipLaunchKernelGGL(gemm_splitk_reduce, dim3((M * N + 255) / 256), dim3(256), 0, st, (const float*)ws, C, M * N, splits, alpha);
+    SGX_LAUNCH_CHECK("gemm_splitk_reduce");
     return 0;
 }
 

@@ -107,27 +107,31 @@ def _conv_launch(geo, x, wq, bias, act):
     return y
 
 
-def _wgrad_param(mode, adjoint, x, gy, weight, scale):
-    """Gradient w.r.t. the [O][I][3][3] parameter of y = conv(x) (or of the layer's data-gradient conv if adjoint)."""
+def _wgrad_param(mode, adjoint, x, gy, weight, scale, want_bias=False):
+    """Gradient w.r.t. the [O][I][3][3] parameter of y = conv(x) (or of the layer's data-gradient conv if adjoint);
+    with ``want_bias`` also the bias gradient sum(gy) over batch and pixels, out of the same pass -> (dW, db|None)."""
     L = N.lib()
     O, I = weight.shape[0], weight.shape[1]
     dW = torch.empty((O, I, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((O,), dtype=torch.float32, device=x.device) if want_bias else None
     B = x.shape[0]
     if mode == "S":
         _, H, W, Cx = x.shape
         Cdy = gy.shape[3]
-        ws = N.workspace(L.sgx_wgrad_ws_bytes(9, B, H, W, Cx, Cdy), x.device)
-        N.check(L.sgx_wgrad3x3_param(N.ptr(x), N.ptr(gy), N.ptr(dW), N.ptr(ws), ws.numel(), B, H, W, Cx, Cdy, int(adjoint),
+        wsb = L.sgx_wgrad_ws_bytes(9, B, H, W, Cx, Cdy)
+        ws = N.workspace(wsb, x.device)
+        N.check(L.sgx_wgrad3x3_param(N.ptr(x), N.ptr(gy), N.ptr(dW), N.ptr(db), N.ptr(ws), wsb, B, H, W, Cx, Cdy, int(adjoint),
                                      float(scale), O, I, N.dt(x), N.stream()), "sgx_wgrad3x3_param")
-        return dW
+        return dW, db
     launched = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]          # geometry of the convolution that ran
     fine, coarse = (x, gy) if launched == "D" else (gy, x)
     _, H, W, Cf = fine.shape
     Cc = coarse.shape[3]
-    ws = N.workspace(L.sgx_wgrad_ws_bytes(16, B, H, W, Cf, Cc), x.device)
-    N.check(L.sgx_wgrad4x4s2_param(N.ptr(fine), N.ptr(coarse), N.ptr(dW), N.ptr(ws), ws.numel(), B, H, W, Cf, Cc, MODES[mode],
+    wsb = L.sgx_wgrad_ws_bytes(16, B, H, W, Cf, Cc)
+    ws = N.workspace(wsb, x.device)
+    N.check(L.sgx_wgrad4x4s2_param(N.ptr(fine), N.ptr(coarse), N.ptr(dW), N.ptr(db), N.ptr(ws), wsb, B, H, W, Cf, Cc, MODES[mode],
                                    float(scale), O, I, N.dt(x), N.stream()), "sgx_wgrad4x4s2_param")
-    return dW
+    return dW, db
 
 
 class ConvFn(Function):
@@ -158,23 +162,26 @@ class ConvFn(Function):
         if ctx.needs_input_grad[0]:
             gx = ConvFn.apply(gy, weight, None, mode, scale, ipad, not adjoint, 0)
         if not _DATA_GRAD_ONLY:
+            want_b = has_bias and ctx.needs_input_grad[2]
+            # the bias gradient rides along in the weight-gradient pass when gy is its O-channel side
+            fuse_b = want_b and ctx.needs_input_grad[1] and not adjoint and mode in ("S", "D")
             if ctx.needs_input_grad[1]:
-                gw = WgradFn.apply(x, gy, weight, mode, scale, adjoint)
-            if has_bias and ctx.needs_input_grad[2]:
+                gw, gb = WgradFn.apply(x, gy, weight, mode, scale, adjoint, fuse_b)
+            if want_b and not fuse_b:
                 gb = ColSumFn.apply(gy, 1.0)
         return gx, gw, gb, None, None, None, None, None
 
 
 class WgradFn(Function):
-    """Parameter gradient of ConvFn (first order only: nothing in the training step differentiates through it)."""
+    """Parameter gradient(s) of ConvFn (first order only: nothing in the training step differentiates through it)."""
 
     @staticmethod
-    def forward(ctx, x, gy, weight, mode, scale, adjoint):
-        return _wgrad_param(mode, adjoint, _c(x), _c(gy), weight, scale)
+    def forward(ctx, x, gy, weight, mode, scale, adjoint, want_bias):
+        return _wgrad_param(mode, adjoint, _c(x), _c(gy), weight, scale, want_bias)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g, gb):
         raise NotImplementedError("second derivative through a weight gradient is not part of the training path")
 
 
@@ -574,7 +581,9 @@ class MatMulFn(Function):
         K2, Nn = (Bm.shape[1], Bm.shape[0]) if tb else (Bm.shape[0], Bm.shape[1])
         assert K == K2, (A.shape, Bm.shape, ta, tb)
         C = torch.empty((M, Nn), dtype=torch.float32, device=A.device)
-        N.check(N.lib().sgx_gemm_f32(N.ptr(A), N.ptr(Bm), N.ptr(C), M, Nn, K, int(ta), int(tb), float(alpha), None, 0, N.stream()), "sgx_gemm_f32")
+        wsb = N.lib().sgx_gemm_ws_bytes(M, Nn, K)
+        ws = N.workspace(wsb, A.device) if wsb else None
+        N.check(N.lib().sgx_gemm_f32(N.ptr(A), N.ptr(Bm), N.ptr(C), M, Nn, K, int(ta), int(tb), float(alpha), N.ptr(ws), wsb, N.stream()), "sgx_gemm_f32")
         ctx.ta, ctx.tb, ctx.alpha = int(ta), int(tb), float(alpha)
         ctx.save_for_backward(A, Bm)
         return C
