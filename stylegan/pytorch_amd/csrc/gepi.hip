@@ -19,7 +19,7 @@ static GepiGeom gepi_geom(int B, int HW, int C, int ve) {
     g.cvt = cv < 256 ? cv : 256;
     g.rows = 256 / g.cvt;
     int rpt = GEPI_ROWS_PER_THREAD;
-    while (rpt > 4 && (long)B * ((HW + g.rows * rpt - 1) / (g.rows * rpt)) < 1024) rpt >>= 1;
+    while (rpt > 8 && (long)B * ((HW + g.rows * rpt - 1) / (g.rows * rpt)) < 512) rpt >>= 1;
     g.chunk = g.rows * rpt;
     g.nchunk = (HW + g.chunk - 1) / g.chunk;
     return g;
@@ -36,6 +36,16 @@ __device__ __forceinline__ double sum16(double v) {
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// VE consecutive per-channel coefficients with 16-byte loads (c0 is a multiple of VE, the arrays are 16-byte aligned)
+template <int VE>
+__device__ __forceinline__ void load_coef(const float* __restrict__ p, float (&k)[VE]) {
+#pragma unroll
+    for (int j = 0; j < VE; j += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p + j);
+        k[j] = t.x; k[j + 1] = t.y; k[j + 2] = t.z; k[j + 3] = t.w;
+    }
 }
 
 // mode 0: (sum a, sum a^2)                       [forward statistics]
@@ -58,15 +68,21 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
         const int v = vb + tc, c0 = v * VE;
         float s0[VE], s1[VE], kb[VE], kw[VE], km[VE], kr[VE], ks[VE], k1[VE], k2[VE];
 #pragma unroll
-        for (int j = 0; j < VE; ++j) {
-            s0[j] = 0.f; s1[j] = 0.f;
-            kb[j] = bias ? bias[c0 + j] : 0.f;
-            kw[j] = nw[c0 + j];
-            if (MODE >= 1) {
-                km[j] = mean[(size_t)b * C + c0 + j]; kr[j] = rstd[(size_t)b * C + c0 + j];
-                ks[j] = style[(size_t)b * 2 * C + c0 + j] + 1.f;
-            }
-            if (MODE == 2) { k1[j] = coef[((size_t)b * C + c0 + j) * 2]; k2[j] = coef[((size_t)b * C + c0 + j) * 2 + 1]; }
+        for (int j = 0; j < VE; ++j) { s0[j] = 0.f; s1[j] = 0.f; kb[j] = 0.f; }
+        if (bias) load_coef<VE>(bias + c0, kb);
+        load_coef<VE>(nw + c0, kw);
+        if (MODE >= 1) {
+            load_coef<VE>(mean + (size_t)b * C + c0, km);
+            load_coef<VE>(rstd + (size_t)b * C + c0, kr);
+            load_coef<VE>(style + (size_t)b * 2 * C + c0, ks);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) ks[j] += 1.f;
+        }
+        if (MODE == 2) {
+            float kk[2 * VE];
+            load_coef<2 * VE>(coef + ((size_t)b * C + c0) * 2, kk);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) { k1[j] = kk[2 * j]; k2[j] = kk[2 * j + 1]; }
         }
         if (tr < rows) {
 #pragma unroll 4
@@ -201,12 +217,15 @@ __global__ __launch_bounds__(256) void gepi_apply(const T* __restrict__ x, const
         const int v = vb + tc, c0 = v * VE;
         float kb[VE], kw[VE], km[VE], kr[VE], ks[VE], k1[VE];
 #pragma unroll
-        for (int j = 0; j < VE; ++j) {
-            kb[j] = bias ? bias[c0 + j] : 0.f;
-            kw[j] = nw[c0 + j];
-            km[j] = mean[(size_t)b * C + c0 + j]; kr[j] = rstd[(size_t)b * C + c0 + j];
-            ks[j] = style[(size_t)b * 2 * C + c0 + j] + 1.f; k1[j] = style[(size_t)b * 2 * C + C + c0 + j];
-        }
+        for (int j = 0; j < VE; ++j) kb[j] = 0.f;
+        if (bias) load_coef<VE>(bias + c0, kb);
+        load_coef<VE>(nw + c0, kw);
+        load_coef<VE>(mean + (size_t)b * C + c0, km);
+        load_coef<VE>(rstd + (size_t)b * C + c0, kr);
+        load_coef<VE>(style + (size_t)b * 2 * C + c0, ks);
+        load_coef<VE>(style + (size_t)b * 2 * C + C + c0, k1);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) ks[j] += 1.f;
 #pragma unroll 4
         for (int p = p0 + tr; p < p1; p += rows) {
             const size_t off = (((size_t)b * HW + p) * cv + v) * VE;

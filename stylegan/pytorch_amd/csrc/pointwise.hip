@@ -277,7 +277,7 @@ extern "C" int sgx_up2(const void* x, void* y, int B, int H, int W, int C, float
 // ---------------------------------------------------------------- out[c] = sum_p x[p][c]
 // stage 1: each block sums a pixel range into ws[block][C] (fp32 per-thread, double across the block);
 // stage 2: one block sums the partials in double.  Deterministic.
-#define COLSUM_BLOCKS 512
+#define COLSUM_BLOCKS 1024
 template <typename T>
 __global__ void colsum_stage1(const T* __restrict__ x, double* __restrict__ ws, size_t npix, int C) {
     // thread t handles channel (t % C') of pixel rows t / C' ... generic scalar layout: C <= 1024
@@ -342,9 +342,7 @@ __global__ __launch_bounds__(256) void colsum_vec_stage1(const T* __restrict__ x
 #pragma unroll
     for (int k = 0; k < NJ * VE; ++k) { acc[k] = 0.0; part[k] = 0.f; }
     int cnt = 0;
-    for (size_t p = p0 + tr; p < p1; p += rows) {
-        float v[VE];
-        VecTraits<T>::load(x + (p * cv + tc) * VE, v);
+    auto accum = [&](const float (&v)[VE], size_t p) {
         if (NJ == 1) {
 #pragma unroll
             for (int k = 0; k < VE; ++k) part[k] += v[k];
@@ -353,11 +351,25 @@ __global__ __launch_bounds__(256) void colsum_vec_stage1(const T* __restrict__ x
 #pragma unroll
             for (int k = 0; k < VE; ++k) { part[k] += v[k] * r; part[VE + k] += v[k] * g; part[2 * VE + k] += v[k] * b; }
         }
-        if (++cnt == 64) {
+    };
+    size_t p = p0 + tr;
+    for (; p + 3 * (size_t)rows < p1; p += 4 * (size_t)rows) {          // four rows in flight per lane
+        float v0[VE], v1[VE], v2[VE], v3[VE];
+        VecTraits<T>::load(x + (p * cv + tc) * VE, v0);
+        VecTraits<T>::load(x + ((p + rows) * cv + tc) * VE, v1);
+        VecTraits<T>::load(x + ((p + 2 * (size_t)rows) * cv + tc) * VE, v2);
+        VecTraits<T>::load(x + ((p + 3 * (size_t)rows) * cv + tc) * VE, v3);
+        accum(v0, p); accum(v1, p + rows); accum(v2, p + 2 * (size_t)rows); accum(v3, p + 3 * (size_t)rows);
+        if (++cnt == 16) {                                               // fp32 over <= 64 rows, then double
 #pragma unroll
             for (int k = 0; k < NJ * VE; ++k) { acc[k] += (double)part[k]; part[k] = 0.f; }
             cnt = 0;
         }
+    }
+    for (; p < p1; p += rows) {
+        float v[VE];
+        VecTraits<T>::load(x + (p * cv + tc) * VE, v);
+        accum(v, p);
     }
 #pragma unroll
     for (int k = 0; k < NJ * VE; ++k) sh[threadIdx.x * NJ * VE + k] = acc[k] + (double)part[k];

@@ -53,16 +53,22 @@ _PACKS = {}
 _WEIGHT_GEN = 0
 
 
-def bump_weight_generation():
+def bump_weight_generation(params=None):
+    """Mark parameters as changed behind torch's version counters (the HIP optimizer / EMA kernels write them in
+    place).  ``params``: the tensors that changed; None: everything."""
     global _WEIGHT_GEN
-    _WEIGHT_GEN += 1
+    if params is None:
+        _WEIGHT_GEN += 1
+        return
+    for p in params:
+        p._sgx_gen = getattr(p, "_sgx_gen", 0) + 1
 
 
 def packs(weight, mode, scale, ipad, dtype):
     """(fwd, adj) operand packs of a [O][I][3][3] fp32 parameter; cached per (version, generation)."""
     key = id(weight)
     ent = _PACKS.get(key)
-    tag = (weight._version, _WEIGHT_GEN, weight.data_ptr())
+    tag = (weight._version, _WEIGHT_GEN, getattr(weight, "_sgx_gen", 0), weight.data_ptr())
     if ent is None or ent[0]() is not weight or ent[1] != tag:
         ent = [weakref.ref(weight, lambda _r, k=key: _PACKS.pop(k, None)), tag, {}]
         _PACKS[key] = ent

@@ -46,10 +46,12 @@ class FusedAdam(torch.optim.Optimizer):
         """``grad_scale``: optional device fp32 scalar multiplied into every gradient (clip coefficient)."""
         assert closure is None
         L = N.lib()
+        changed = []
         for group in self.param_groups:
             act = self._active(group)
             if not act:
                 continue
+            changed.extend(p for p, _ in act)
             b1, b2 = group["betas"]
             lr, eps = group["lr"], group["eps"]
             dev = act[0][0].device
@@ -73,7 +75,7 @@ class FusedAdam(torch.optim.Optimizer):
                                      sb, sb + 4 * n, None if grad_scale is None else N.ptr(grad_scale), N.stream()),
                     "sgx_adam_multi")
             table.record_stream(torch.cuda.current_stream()); scal.record_stream(torch.cuda.current_stream())
-        bump_weight_generation()                     # parameters changed behind torch's version counters
+        bump_weight_generation(changed)              # parameters changed behind torch's version counters
         return None
 
 
@@ -101,7 +103,9 @@ def ema_update(model_tgt, model_src, beta):
     src = dict(model_src.named_parameters())
     tg, sr, sizes = [], [], []
     dev = None
+    changed = []
     for name, p in model_tgt.named_parameters():
+        changed.append(p)
         q = src[name]
         assert q is not p
         if not p.is_cuda:
@@ -112,4 +116,4 @@ def ema_update(model_tgt, model_src, beta):
     table = _dev_i64(tg + sr + sizes, dev)
     base = table.data_ptr()
     N.check(N.lib().sgx_ema_multi(base, base + 8 * n, base + 16 * n, n, float(beta), N.stream()), "sgx_ema_multi")
-    bump_weight_generation()
+    bump_weight_generation(changed)
