@@ -173,6 +173,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + 1 + i)
+    t_enq = time.perf_counter() - t0                        # host time to enqueue the region (launch-bound if ~= dt)
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -220,6 +221,7 @@ def main():
                "config": {"workload": f"{a.config}: StyleGAN {res}x{res}, progressive depth index {depth}, logistic+R1, "
                                       f"alpha {a.alpha}, batch {B}/GPU, global batch {B * world}",
                           "global_batch": B * world, "parallelism": f"dp{world}"},
+               "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
                "useful_tflops": value * cfg["flops_per_img"] / 1e12,
                "mfma_frac_of_step": value * cfg["flops_per_img"] / (PEAK[a.dtype] * world)}
         if roof:

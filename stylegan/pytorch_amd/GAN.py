@@ -22,6 +22,51 @@ from .native import ACT_LRELU
 from .optim import FusedAdam, clip_and_step, ema_update
 
 
+class DeferredLoss:
+    """What ``optimize_discriminator`` / ``optimize_generator`` return in place of the reference's ``loss.item()``
+    (models/GAN.py:620,:659): the value is copied to pinned host memory asynchronously and the host only waits for it when
+    somebody actually reads it (``float(x)``, ``"%f" % x``, ``f"{x:.3f}"``, arithmetic, comparison).  The training loop
+    can thus enqueue the next half-iteration while the GPU is still finishing this one."""
+
+    __slots__ = ("_host", "_event", "_scale", "_value")
+
+    def __init__(self, dev_scalar, scale=1.0):
+        t = dev_scalar.detach().reshape(1).float()
+        self._scale, self._value = float(scale), None
+        if t.is_cuda:
+            self._host = torch.empty(1, dtype=torch.float32).pin_memory()
+            self._host.copy_(t, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+        else:
+            self._host, self._event = t.clone(), None
+
+    def item(self):
+        if self._value is None:
+            if self._event is not None:
+                self._event.synchronize()
+            self._value = float(self._host[0]) * self._scale
+        return self._value
+
+    __float__ = item
+
+    def __format__(self, spec): return format(self.item(), spec)
+    def __repr__(self): return repr(self.item())
+    def __add__(self, o): return self.item() + float(o)
+    __radd__ = __add__
+    def __sub__(self, o): return self.item() - float(o)
+    def __rsub__(self, o): return float(o) - self.item()
+    def __mul__(self, o): return self.item() * float(o)
+    __rmul__ = __mul__
+    def __truediv__(self, o): return self.item() / float(o)
+    def __lt__(self, o): return self.item() < float(o)
+    def __gt__(self, o): return self.item() > float(o)
+    def __eq__(self, o): return self.item() == float(o)
+    def __abs__(self): return abs(self.item())
+    def __neg__(self): return -self.item()
+    def __hash__(self): return hash(self.item())
+
+
 def update_average(model_tgt, model_src, beta):
     """EMA of the generator weights into the shadow copy -- reference models/__init__.py:13-40."""
     ema_update(model_tgt, model_src, beta)
@@ -160,7 +205,9 @@ class Generator(nn.Module):
             if self.truncation is not None:
                 self.truncation.update(dlatents_in[0, 0].detach())                       # sample 0 only (:278)
             if self.style_mixing_prob is not None and self.style_mixing_prob > 0:
-                latents2 = torch.randn(latents_in.shape).to(latents_in.device)           # CPU RNG first (:282)
+                latents2 = torch.randn(latents_in.shape)                                 # CPU RNG first (:282)
+                if latents_in.is_cuda:
+                    latents2 = latents2.pin_memory().to(latents_in.device, non_blocking=True)   # no host wait on the queue
                 dlatents2 = self.g_mapping(latents2)
                 layer_idx = torch.arange(self.num_layers, device=latents_in.device).view(1, -1, 1)
                 cur_layers = 2 * (depth + 1)
@@ -318,7 +365,7 @@ class StyleGAN:
     def optimize_discriminator(self, noise, real_batch, depth, alpha, labels=None):
         """One discriminator update -- reference models/GAN.py:591-622."""
         real_samples = self.progressive_down_sampling(real_batch, depth, alpha)
-        loss_val = 0
+        loss_val = None
         for _ in range(self.d_repeats):
             with torch.no_grad():                     # the reference builds and drops this graph (.detach(), :607)
                 fake_samples = self.gen(noise, depth, alpha, labels)
@@ -329,8 +376,8 @@ class StyleGAN:
             if self.dp is not None:
                 self.dp.all_reduce_grads(self.dis.parameters())
             self.dis_optim.step()
-            loss_val += loss.item()
-        return loss_val / self.d_repeats
+            loss_val = loss.detach() if loss_val is None else loss_val + loss.detach()
+        return DeferredLoss(loss_val, 1.0 / self.d_repeats)
 
     def optimize_generator(self, noise, real_batch, depth, alpha, labels=None):
         """One generator update incl. gradient clipping and EMA -- reference models/GAN.py:624-659."""
@@ -356,4 +403,4 @@ class StyleGAN:
         clip_and_step(self.gen_optim, max_norm=10.)                                   # :651-652 without a host sync
         if self.use_ema:
             self.ema_updater(self.gen_shadow, self.gen, self.ema_decay)
-        return loss.item()
+        return DeferredLoss(loss)

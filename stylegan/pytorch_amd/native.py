@@ -112,7 +112,13 @@ def check(rc: int, what: str):
         raise SgxError(f"{what} failed (code {rc}): {msg}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream() -> int:
+    """hipStream_t of torch's current stream on the current device (the raw getter: this is called once per launch)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -12,12 +12,28 @@ from . import native as N
 from .functional import bump_weight_generation
 
 
+# Host -> device tables of the multi-tensor kernels.  Pinned staging + non_blocking so that the copy is stream ordered
+# and the host does not wait for the GPU queue to drain; pointer tables are cached (parameter / state / gradient
+# addresses are stable from step to step).
+_TABLES = {}
+
+
+def _to_dev(t, device):
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def _dev_i64(vals, device):
-    return torch.tensor(vals, dtype=torch.int64).to(device)
+    key = (tuple(vals), str(device))
+    got = _TABLES.get(key)
+    if got is None:
+        if len(_TABLES) > 64:
+            _TABLES.clear()
+        got = _TABLES[key] = _to_dev(torch.tensor(vals, dtype=torch.int64), device)
+    return got
 
 
 def _dev_f32(vals, device):
-    return torch.tensor(vals, dtype=torch.float32).to(device)
+    return _to_dev(torch.tensor(vals, dtype=torch.float32), device)
 
 
 class FusedAdam(torch.optim.Optimizer):

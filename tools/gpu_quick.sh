@@ -9,5 +9,5 @@ timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --layer-table
 python - <<PY
 import json
 d=json.load(open("$O/bench.json"))
-print("img/s", round(d["value"],2), "ms/step", round(d["ms_per_step"],2), "dominant", d["roofline"]["kernel"][:60], "frac", d["roofline"]["frac"], "lib ms", d["roofline"]["library_kernels_ms_per_step"], "launches", d["roofline"]["library_launches_per_step"])
+print("img/s", round(d["value"],2), "ms/step", round(d["ms_per_step"],2), "dominant", d["roofline"]["kernel"][:60], "frac", d["roofline"]["frac"], "lib ms", d["roofline"]["library_kernels_ms_per_step"], "launches", d["roofline"]["library_launches_per_step"], "host enqueue ms", round(d["host_enqueue_ms_per_step"],2))
 PY

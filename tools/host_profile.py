@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Host-side profile of the training iteration (cProfile over a few steps, GPU running asynchronously): shows where the
+Python/ctypes/autograd launch path spends its time when the step becomes launch-bound.   python tools/host_profile.py [steps]"""
+import cProfile
+import os
+import pstats
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from stylegan.pytorch_amd.GAN import StyleGAN  # noqa: E402
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0); random.seed(0)
+    opt = dict(learning_rate=0.003, beta_1=0, beta_2=0.99, eps=1e-8)
+    sg = StyleGAN("linear", 1024, 3, 512, g_args=dict(latent_size=512, mapping_layers=8, blur_filter=[1, 2, 1], truncation_psi=-1.0, truncation_cutoff=8),
+                  d_args=dict(use_wscale=True, blur_filter=[1, 2, 1]), g_opt_args=opt, d_opt_args=opt, loss="logistic", use_ema=True,
+                  device=dev, act_dtype=torch.bfloat16)
+    z = torch.randn(4, 512, device=dev)
+    x = torch.randn(4, 1024, 1024, 3, device=dev).permute(0, 3, 1, 2)
+
+    def step():
+        sg.optimize_discriminator(z, x, 8, 0.5)
+        sg.optimize_generator(z, x, 8, 0.5)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(steps):
+        step()
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(28)
+    st.sort_stats("cumulative").print_stats(22)
+
+
+if __name__ == "__main__":
+    main()
