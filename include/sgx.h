@@ -102,6 +102,10 @@ int sgx_bias_act(const void* x, const float* bias, float bscale, void* y, size_t
 int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, int dtype, void* stream);
 /* out = alpha*a + beta*b (b may be NULL)    fade-in lerp: models/GAN.py:202,427,586                                 */
 int sgx_axpby(const void* a, const void* b, void* out, float alpha, float beta, size_t n, int dtype, void* stream);
+/* same with the coefficients read from device memory (alpha_dev[0], beta_dev[0]): the fade-in alpha changes every
+ * iteration (models/GAN.py:744), so a captured hipGraph of the step must not bake it into kernel arguments */
+int sgx_axpby_dev(const void* a, const void* b, void* out, const float* alpha_dev, const float* beta_dev, size_t n, int dtype,
+                  void* stream);
 /* depthwise [1,2,1]x[1,2,1]/16 blur, zero pad   BlurLayer: models/CustomLayers.py:251-276 (self-adjoint)           */
 int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 /* y = scale * (2x2 block sum)   scale .25: AvgPool2d(2) models/GAN.py:382,423; Downscale2d CustomLayers.py:60-64   */

@@ -166,7 +166,7 @@ class GSynthesis(nn.Module):
                 residual = F.Up2Fn.apply(self.to_rgb[depth - 1].forward_nhwc(x), 1.0)
                 straight = self.to_rgb[depth].forward_nhwc(
                     self.blocks[depth - 1].forward_nhwc(x, dl[:, 2 * depth:2 * (depth + 1)]))
-                images = F.AxpbyFn.apply(straight, residual, float(alpha), float(1 - alpha))     # GAN.py:202
+                images = F.fade(straight, residual, alpha)                                        # GAN.py:202
             else:
                 images = self.to_rgb[0].forward_nhwc(x)
         else:
@@ -196,6 +196,21 @@ class Generator(nn.Module):
         else:
             self.truncation = None
 
+    _mixing_override = None          # (latents2 device tensor, cutoff int or device tensor) supplied by a step graph
+
+    def draw_mixing_host(self, shape, depth):
+        """The host-side random draws of style mixing, in the reference's order: (latents2 CPU tensor, cutoff int)."""
+        latents2 = torch.randn(shape)                                                    # CPU RNG first (:282)
+        cur_layers = 2 * (depth + 1)
+        cutoff = random.randint(1, cur_layers) if random.random() < self.style_mixing_prob else cur_layers
+        return latents2, cutoff
+
+    def draw_mixing(self, shape, depth, device):
+        latents2, cutoff = self.draw_mixing_host(shape, depth)
+        if device.type == "cuda":
+            latents2 = latents2.pin_memory().to(device, non_blocking=True)               # no host wait on the queue
+        return latents2, cutoff
+
     def forward(self, latents_in, depth, alpha, labels_in=None):
         if self.conditional:
             assert labels_in is not None, "Conditional discriminatin requires labels"
@@ -205,13 +220,11 @@ class Generator(nn.Module):
             if self.truncation is not None:
                 self.truncation.update(dlatents_in[0, 0].detach())                       # sample 0 only (:278)
             if self.style_mixing_prob is not None and self.style_mixing_prob > 0:
-                latents2 = torch.randn(latents_in.shape)                                 # CPU RNG first (:282)
-                if latents_in.is_cuda:
-                    latents2 = latents2.pin_memory().to(latents_in.device, non_blocking=True)   # no host wait on the queue
+                # host RNG (CPU randn first, then the mixing coin and cutoff: models/GAN.py:282-287) -- or the values a
+                # captured-step wrapper drew in that same order and staged in static device tensors
+                latents2, mixing_cutoff = self._mixing_override or self.draw_mixing(latents_in.shape, depth, latents_in.device)
                 dlatents2 = self.g_mapping(latents2)
                 layer_idx = torch.arange(self.num_layers, device=latents_in.device).view(1, -1, 1)
-                cur_layers = 2 * (depth + 1)
-                mixing_cutoff = random.randint(1, cur_layers) if random.random() < self.style_mixing_prob else cur_layers
                 dlatents_in = torch.where(layer_idx < mixing_cutoff, dlatents_in, dlatents2)
             if self.truncation is not None:
                 dlatents_in = self.truncation(dlatents_in)
@@ -269,7 +282,7 @@ class Discriminator(nn.Module):
                 residual = self.from_rgb[self.depth - depth].forward_nhwc(F.Pool2Fn.apply(img, 0.25), out_dtype=dt)
                 straight = self.blocks[self.depth - depth - 1].forward_nhwc(
                     self.from_rgb[self.depth - depth - 1].forward_nhwc(img, out_dtype=dt))
-                x = F.AxpbyFn.apply(straight, residual, float(alpha), float(1 - alpha))   # GAN.py:427
+                x = F.fade(straight, residual, alpha)                                      # GAN.py:427
                 for block in self.blocks[(self.depth - depth):]:
                     x = block.forward_nhwc(x)
             else:
@@ -285,7 +298,8 @@ class StyleGAN:
 
     def __init__(self, structure, resolution, num_channels, latent_size, g_args, d_args, g_opt_args, d_opt_args,
                  conditional=False, n_classes=0, loss="relativistic-hinge", drift=0.001, d_repeats=1, use_ema=False,
-                 ema_decay=0.999, device=torch.device("cpu"), act_dtype=torch.float32, data_parallel=None):
+                 ema_decay=0.999, device=torch.device("cpu"), act_dtype=torch.float32, data_parallel=None,
+                 use_graphs=False):
         assert structure in ['fixed', 'linear']
         if conditional:
             assert n_classes > 0, "Conditional GANs require n_classes > 0"
@@ -299,6 +313,10 @@ class StyleGAN:
         self.use_ema = use_ema
         self.ema_decay = ema_decay
         self.dp = data_parallel                       # parallel.DataParallelGroup or None
+        # hipGraph replay of the two half-iterations (one graph per (kind, depth, shapes)); eager when off, with
+        # data parallelism, with labels or with d_repeats != 1
+        self.use_graphs = bool(use_graphs)
+        self._step_graphs = {}
         if self.device.type != "cuda":
             raise RuntimeError("stylegan.pytorch_amd runs on MI355X only: device must be a cuda (ROCm) device; the "
                                "reference's CPU path is the oracle, not a fallback of this package")
@@ -349,9 +367,9 @@ class StyleGAN:
             x = F.Pool2Fn.apply(x, 0.25)
         if depth > 0:
             prior = F.Up2Fn.apply(F.Pool2Fn.apply(x, 0.25), 1.0)
-            x = F.AxpbyFn.apply(x, prior, float(alpha), float(1 - alpha))
+            x = F.fade(x, prior, alpha)
         else:
-            x = F.AxpbyFn.apply(x, x, float(alpha), float(1 - alpha))    # prior == current at depth 0 (:583-584)
+            x = F.fade(x, x, alpha)                                       # prior == current at depth 0 (:583-584)
         return F.nchw_view(x)
 
     # name-mangled alias so code written against the reference's private helper keeps working
@@ -362,25 +380,24 @@ class StyleGAN:
         if self.dp is not None and self.gen.truncation is not None:
             self.dp.broadcast(self.gen.truncation.avg_latent, src=0)
 
-    def optimize_discriminator(self, noise, real_batch, depth, alpha, labels=None):
-        """One discriminator update -- reference models/GAN.py:591-622."""
-        real_samples = self.progressive_down_sampling(real_batch, depth, alpha)
-        loss_val = None
-        for _ in range(self.d_repeats):
-            with torch.no_grad():                     # the reference builds and drops this graph (.detach(), :607)
-                fake_samples = self.gen(noise, depth, alpha, labels)
-            self._sync_w_avg()
-            loss = self.loss.dis_loss(real_samples, fake_samples, depth, alpha)
-            self.dis_optim.zero_grad()
-            loss.backward()
-            if self.dp is not None:
-                self.dp.all_reduce_grads(self.dis.parameters())
-            self.dis_optim.step()
-            loss_val = loss.detach() if loss_val is None else loss_val + loss.detach()
-        return DeferredLoss(loss_val, 1.0 / self.d_repeats)
+    def _graphable(self, labels):
+        return self.use_graphs and self.dp is None and labels is None and self.d_repeats == 1 and self.structure == "linear"
 
-    def optimize_generator(self, noise, real_batch, depth, alpha, labels=None):
-        """One generator update incl. gradient clipping and EMA -- reference models/GAN.py:624-659."""
+    def _d_body(self, noise, real_batch, depth, alpha, labels=None):
+        """The discriminator half-iteration up to and including the optimizer step; returns the (device) loss."""
+        real_samples = self.progressive_down_sampling(real_batch, depth, alpha)
+        with torch.no_grad():                         # the reference builds and drops this graph (.detach(), :607)
+            fake_samples = self.gen(noise, depth, alpha, labels)
+        self._sync_w_avg()
+        loss = self.loss.dis_loss(real_samples, fake_samples, depth, alpha)
+        self.dis_optim.zero_grad()
+        loss.backward()
+        if self.dp is not None:
+            self.dp.all_reduce_grads(self.dis.parameters())
+        self.dis_optim.step()
+        return loss.detach()
+
+    def _g_body(self, noise, real_batch, depth, alpha, labels=None):
         real_samples = None
         if not isinstance(self.loss, (Losses.LogisticGAN, Losses.HingeGAN)):
             real_samples = self.progressive_down_sampling(real_batch, depth, alpha)   # only the relativistic loss reads it
@@ -403,4 +420,136 @@ class StyleGAN:
         clip_and_step(self.gen_optim, max_norm=10.)                                   # :651-652 without a host sync
         if self.use_ema:
             self.ema_updater(self.gen_shadow, self.gen, self.ema_decay)
-        return DeferredLoss(loss)
+        return loss.detach()
+
+    def _graphed(self, kind, noise, real_batch, depth, alpha):
+        key = (kind, int(depth), tuple(noise.shape), tuple(real_batch.shape), tuple(real_batch.stride()), real_batch.dtype)
+        g = self._step_graphs.get(key)
+        if g is None:
+            g = self._step_graphs[key] = _StepGraph(self, kind, depth)
+        return g.run(noise, real_batch, alpha)
+
+    def optimize_discriminator(self, noise, real_batch, depth, alpha, labels=None):
+        """One discriminator update -- reference models/GAN.py:591-622."""
+        if self._graphable(labels):
+            return self._graphed("d", noise, real_batch, depth, alpha)
+        loss_val = None
+        for _ in range(self.d_repeats):
+            loss = self._d_body(noise, real_batch, depth, alpha, labels)
+            loss_val = loss if loss_val is None else loss_val + loss
+        return DeferredLoss(loss_val, 1.0 / self.d_repeats)
+
+    def optimize_generator(self, noise, real_batch, depth, alpha, labels=None):
+        """One generator update incl. gradient clipping and EMA -- reference models/GAN.py:624-659."""
+        if self._graphable(labels):
+            return self._graphed("g", noise, real_batch, depth, alpha)
+        return DeferredLoss(self._g_body(noise, real_batch, depth, alpha, labels))
+
+
+class _StepGraph:
+    """One half-iteration (kind 'd' or 'g') at one depth and one batch shape as a replayable hipGraph.
+
+    The first ``WARMUP`` calls run eagerly on the capture stream (they are real iterations); the next call captures the
+    half-iteration and every call from then on replays it.  Everything that changes from iteration to iteration lives
+    in static device tensors written before the replay: latents, images, the fade-in alpha, the style-mixing latents and
+    cutoff (drawn on the host in the reference's RNG order) and Adam's bias-correction scalars.  The noise inputs are
+    drawn inside the graph by torch's graph-safe CUDA generator."""
+
+    WARMUP = 2
+
+    def __init__(self, sg, kind, depth):
+        self.sg, self.kind, self.depth = sg, kind, int(depth)
+        self.calls = 0
+        self.graph = None
+        self.stream = torch.cuda.Stream(device=sg.device)
+        self.z = self.real = self.loss = None
+        dev = sg.device
+        self.ab = torch.zeros(2, dtype=torch.float32, device=dev)                 # [alpha, 1 - alpha]
+        self.ab_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        self.cutoff = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.cutoff_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.latents2 = self.latents2_host = None
+        self.adam_entries = []
+        self.done = torch.cuda.Event()
+
+    def _mixing(self):
+        gen = self.sg.gen
+        return gen.training and gen.style_mixing_prob is not None and gen.style_mixing_prob > 0
+
+    def _stage(self, noise, real_batch, alpha):
+        """Host RNG in the eager order, then every per-iteration input into its static tensor (stream ordered)."""
+        if self.z is None:
+            self.z = torch.empty_like(noise)
+            self.real = torch.empty_like(real_batch)                               # keeps the (NHWC) strides
+            if self._mixing():
+                self.latents2 = torch.empty_like(noise)
+                self.latents2_host = torch.empty(noise.shape, dtype=noise.dtype).pin_memory()
+        if self._mixing():
+            l2, cut = self.sg.gen.draw_mixing_host(noise.shape, self.depth)
+            self.latents2_host.copy_(l2); self.cutoff_host[0] = cut
+            self.latents2.copy_(self.latents2_host, non_blocking=True)
+            self.cutoff.copy_(self.cutoff_host, non_blocking=True)
+        self.ab_host[0] = float(alpha); self.ab_host[1] = 1.0 - float(alpha)
+        self.ab.copy_(self.ab_host, non_blocking=True)
+        self.z.copy_(noise); self.real.copy_(real_batch)
+
+    def _body(self):
+        sg = self.sg
+        sg.gen._mixing_override = (self.latents2, self.cutoff) if self._mixing() else None
+        try:
+            fn = sg._d_body if self.kind == "d" else sg._g_body
+            return fn(self.z, self.real, self.depth, self.ab)
+        finally:
+            sg.gen._mixing_override = None
+
+    def _changed_params(self):
+        sg = self.sg
+        if self.kind == "d":
+            return list(sg.dis.parameters())
+        return list(sg.gen.parameters()) + (list(sg.gen_shadow.parameters()) if sg.use_ema else [])
+
+    def run(self, noise, real_batch, alpha):
+        cur = torch.cuda.current_stream()
+        # The pinned staging buffers (mixing latents, alpha, Adam scalars) are rewritten below and re-read by this graph's
+        # copy nodes at replay time: the previous call of THIS graph must have finished.  (The other half-iteration's
+        # graph runs in between, so the host still runs one half-iteration ahead of the GPU.)
+        self.done.synchronize()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self._stage(noise, real_batch, alpha)
+            if self.graph is None and self.calls < self.WARMUP:
+                loss = self._body()                                                # eager, on the capture stream
+            else:
+                if self.graph is None:
+                    self._capture()
+                else:
+                    FusedAdam.graph_advance(self.adam_entries)
+                self.graph.replay()
+                F.bump_weight_generation(self._changed_params())                   # eager users must re-pack these
+                for p, g in self.grads:
+                    if p.grad is not g:
+                        p.grad = g
+                loss = self.loss
+            out = DeferredLoss(loss)
+            self.done.record()
+        self.calls += 1
+        cur.wait_stream(self.stream)
+        return out
+
+    def _capture(self):
+        sg = self.sg
+        opt = sg.dis_optim if self.kind == "d" else sg.gen_optim
+        opt.ensure_state()
+        F.clear_pack_cache()                                   # the graph packs every weight it uses itself
+        torch.cuda.synchronize()
+        opt._capture_log = []
+        self.graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="relaxed"):
+                self.loss = self._body()
+        finally:
+            self.adam_entries, opt._capture_log = opt._capture_log, None
+        # the gradient tensors the graph writes (static addresses): re-attached after every replay so that .grad shows
+        # this iteration's gradients even if an eager call in between replaced them
+        net = sg.dis if self.kind == "d" else sg.gen
+        self.grads = [(p, p.grad) for p in net.parameters() if p.grad is not None]

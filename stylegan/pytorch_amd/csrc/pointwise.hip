@@ -86,8 +86,10 @@ extern "C" int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, 
 // ---------------------------------------------------------------- out = alpha*a + beta*b
 template <typename T>
 __global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, float alpha, float beta,
-                             size_t nvec, size_t n) {
+                             const float* __restrict__ alpha_dev, const float* __restrict__ beta_dev, size_t nvec, size_t n) {
     constexpr int VE = VecTraits<T>::VE;
+    if (alpha_dev) alpha = alpha_dev[0];                       // coefficients kept on the device (graph replay: the
+    if (beta_dev) beta = beta_dev[0];                          // fade-in alpha changes every iteration)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
         if ((i + 1) * VE <= n) {
             float va[VE], vb[VE];
@@ -109,19 +111,28 @@ __global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T
         }
     }
 }
-extern "C" int sgx_axpby(const void* a, const void* b, void* out, float alpha, float beta, size_t n, int dtype, void* stream) {
+static int axpby_launch(const void* a, const void* b, void* out, float alpha, float beta, const float* alpha_dev, const float* beta_dev,
+                        size_t n, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SGX_NOTE(0.0, (b ? 3.0 : 2.0) * (dtype == SGX_F32 ? 4.0 : 2.0) * n, "axpby %zu", n);
     if (n == 0) return 0;
     if (dtype == SGX_F32) {
         size_t nvec = (n + 3) / 4;
-        hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, alpha, beta, nvec, n);
+        hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, alpha, beta, alpha_dev, beta_dev, nvec, n);
     } else {
         size_t nvec = (n + 7) / 8;
-        hipLaunchKernelGGL(axpby_kernel<bf16_t>, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, alpha, beta, nvec, n);
+        hipLaunchKernelGGL(axpby_kernel<bf16_t>, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, alpha, beta, alpha_dev, beta_dev, nvec, n);
     }
     SGX_LAUNCH_CHECK("axpby");
     return 0;
+}
+extern "C" int sgx_axpby(const void* a, const void* b, void* out, float alpha, float beta, size_t n, int dtype, void* stream) {
+    return axpby_launch(a, b, out, alpha, beta, nullptr, nullptr, n, dtype, stream);
+}
+extern "C" int sgx_axpby_dev(const void* a, const void* b, void* out, const float* alpha_dev, const float* beta_dev, size_t n, int dtype,
+                             void* stream) {
+    SGX_REQUIRE(alpha_dev && (beta_dev || !b), SGX_EINVAL, "axpby_dev: missing device coefficient");
+    return axpby_launch(a, b, out, 0.f, 0.f, alpha_dev, b ? beta_dev : nullptr, n, dtype, stream);
 }
 
 // ---------------------------------------------------------------- depthwise blur [1,2,1]x[1,2,1]/16, zero pad

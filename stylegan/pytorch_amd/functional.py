@@ -292,6 +292,49 @@ class AxpbyFn(Function):
         return ga, gb, None, None
 
 
+class ScaleDevFn(Function):
+    """x * s[0], s a device fp32 tensor (no gradient w.r.t. s)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        x = _c(x)
+        out = torch.empty_like(x)
+        N.check(N.lib().sgx_axpby_dev(N.ptr(x), None, N.ptr(out), s.data_ptr(), None, x.numel(), N.dt(x), N.stream()), "sgx_axpby_dev")
+        ctx.s = s
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return ScaleDevFn.apply(g, ctx.s), None
+
+
+class FadeFn(Function):
+    """ab[0]*a + ab[1]*b with the two coefficients in a device fp32 tensor (fade-in under graph replay)."""
+
+    @staticmethod
+    def forward(ctx, a, b, ab):
+        a, b = _c(a), _c(b)
+        assert a.shape == b.shape and a.dtype == b.dtype and ab.dtype == torch.float32 and ab.numel() == 2 and ab.is_contiguous()
+        out = torch.empty_like(a)
+        N.check(N.lib().sgx_axpby_dev(N.ptr(a), N.ptr(b), N.ptr(out), ab.data_ptr(), ab.data_ptr() + 4, a.numel(), N.dt(a), N.stream()),
+                "sgx_axpby_dev")
+        ctx.ab = ab
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ga = ScaleDevFn.apply(g, ctx.ab[0:1]) if ctx.needs_input_grad[0] else None
+        gb = ScaleDevFn.apply(g, ctx.ab[1:2]) if ctx.needs_input_grad[1] else None
+        return ga, gb, None
+
+
+def fade(a, b, alpha):
+    """alpha*a + (1-alpha)*b.  ``alpha``: python float, or a device fp32 tensor [alpha, 1-alpha] (graph replay)."""
+    if isinstance(alpha, torch.Tensor):
+        return FadeFn.apply(a, b, alpha)
+    return AxpbyFn.apply(a, b, float(alpha), float(1 - alpha))
+
+
 class BlurFn(Function):
     """Depthwise [1,2,1]x[1,2,1]/16 blur with zero padding; self-adjoint."""
 

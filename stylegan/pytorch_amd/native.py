@@ -46,6 +46,7 @@ SIGNATURES = {
     "sgx_bias_act": (I, [P, P, F, P, Z, I, I, I, P]),
     "sgx_lrelu_bwd": (I, [P, P, P, Z, I, P]),
     "sgx_axpby": (I, [P, P, P, F, F, Z, I, P]),
+    "sgx_axpby_dev": (I, [P, P, P, P, P, Z, I, P]),
     "sgx_blur3x3": (I, [P, P, I, I, I, I, I, P]),
     "sgx_pool2": (I, [P, P, I, I, I, I, F, I, P]),
     "sgx_up2": (I, [P, P, I, I, I, I, F, I, P]),

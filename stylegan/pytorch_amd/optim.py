@@ -16,23 +16,32 @@ from .functional import bump_weight_generation
 # and the host does not wait for the GPU queue to drain; pointer tables are cached (parameter / state / gradient
 # addresses are stable from step to step).
 _TABLES = {}
+_CAPTURE_KEEP = []            # pinned staging tensors that captured H2D copy nodes re-read at every graph replay
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
 def _to_dev(t, device):
-    return t.pin_memory().to(device, non_blocking=True)
+    pinned = t.pin_memory()
+    if _capturing():
+        _CAPTURE_KEEP.append(pinned)
+    return pinned.to(device, non_blocking=True), pinned
 
 
 def _dev_i64(vals, device):
     key = (tuple(vals), str(device))
     got = _TABLES.get(key)
     if got is None:
-        if len(_TABLES) > 64:
+        if len(_TABLES) > 256:
             _TABLES.clear()
-        got = _TABLES[key] = _to_dev(torch.tensor(vals, dtype=torch.int64), device)
+        got = _TABLES[key] = _to_dev(torch.tensor(vals, dtype=torch.int64), device)[0]
     return got
 
 
 def _dev_f32(vals, device):
+    """-> (device tensor, pinned staging tensor)."""
     return _to_dev(torch.tensor(vals, dtype=torch.float32), device)
 
 
@@ -43,6 +52,37 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=(float(betas[0]), float(betas[1])), eps=eps, weight_decay=0, amsgrad=False,
                         maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
         super().__init__(params, defaults)
+
+    _capture_log = None              # list collecting (pinned scalars, group, active params) while a step graph is captured
+
+    def ensure_state(self):
+        """Create the moment buffers of every parameter now (a graph capture must not allocate-and-zero them)."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+    @staticmethod
+    def _bias_scalars(act, lr, b1, b2):
+        steps, bc2s = [], []
+        for _, st in act:
+            t = float(st["step"])
+            steps.append(lr / (1.0 - b1 ** t))
+            bc2s.append(math.sqrt(1.0 - b2 ** t))
+        return steps + bc2s
+
+    @staticmethod
+    def graph_advance(entries):
+        """Before replaying a captured step: advance the step counts and refresh the bias-correction scalars that the
+        graph's H2D copy node reads from pinned memory."""
+        for pinned, act, group in entries:
+            for _, st in act:
+                st["step"] += 1
+            b1, b2 = group["betas"]
+            pinned.copy_(torch.tensor(FusedAdam._bias_scalars(act, group["lr"], b1, b2), dtype=torch.float32))
 
     def _active(self, group):
         out = []
@@ -71,26 +111,26 @@ class FusedAdam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             lr, eps = group["lr"], group["eps"]
             dev = act[0][0].device
-            ptrs, sizes, steps, bc2s = [[], [], [], []], [], [], []
+            ptrs, sizes = [[], [], [], []], []
             for p, st in act:
                 g = p.grad
                 if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32):
                     raise N.SgxError("FusedAdam: parameters and gradients must be contiguous fp32")
                 st["step"] += 1
-                t = float(st["step"])
                 ptrs[0].append(p.data_ptr()); ptrs[1].append(g.data_ptr())
                 ptrs[2].append(st["exp_avg"].data_ptr()); ptrs[3].append(st["exp_avg_sq"].data_ptr())
                 sizes.append(p.numel())
-                steps.append(lr / (1.0 - b1 ** t))
-                bc2s.append(math.sqrt(1.0 - b2 ** t))
             n = len(act)
             table = _dev_i64(ptrs[0] + ptrs[1] + ptrs[2] + ptrs[3] + sizes, dev)
-            scal = _dev_f32(steps + bc2s, dev)
+            scal, pinned = _dev_f32(self._bias_scalars(act, lr, b1, b2), dev)
+            if self._capture_log is not None and _capturing():
+                self._capture_log.append((pinned, act, group))
             base, sb = table.data_ptr(), scal.data_ptr()
             N.check(L.sgx_adam_multi(base, base + 8 * n, base + 16 * n, base + 24 * n, base + 32 * n, n, b1, b2, eps,
                                      sb, sb + 4 * n, None if grad_scale is None else N.ptr(grad_scale), N.stream()),
                     "sgx_adam_multi")
-            table.record_stream(torch.cuda.current_stream()); scal.record_stream(torch.cuda.current_stream())
+            if not _capturing():
+                table.record_stream(torch.cuda.current_stream()); scal.record_stream(torch.cuda.current_stream())
         bump_weight_generation(changed)              # parameters changed behind torch's version counters
         return None
 

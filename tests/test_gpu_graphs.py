@@ -1,0 +1,98 @@
+"""-m gpu: the hipGraph-replayed training iteration (StyleGAN(use_graphs=True)) against the eager one, over iterations
+that change the fade-in alpha, the latents, the images and the style-mixing draw (all of which reach the graph through
+static device tensors, not through kernel arguments), with the per-layer noise pinned.
+
+Both run the same kernels on the same data.  The comparison is to a few fp32 ulps rather than bit for bit because
+torch's autograd engine sums the three gradient contributions of a discriminator parameter (fake pass, real pass,
+R1 double-backward) in an order that depends on thread-local sequence numbers, i.e. on the history of the process: two
+EAGER runs in one process already differ by one ulp in such a gradient (measured), and Adam with beta1 = 0 then carries
+that forward."""
+import random
+
+import pytest
+import torch
+
+import golden_util as gu
+from gpu_util import DEV, MID, load_into, mid_params, pin_noise
+from test_gpu_networks import mid_noises
+
+pytestmark = pytest.mark.gpu
+
+
+def make(use_graphs, act_dtype):
+    from stylegan.pytorch_amd.GAN import StyleGAN
+    kw = dict(learning_rate=0.003, beta_1=0, beta_2=0.99, eps=1e-8)
+    sg = StyleGAN(structure="linear", resolution=128, num_channels=3, latent_size=512,
+                  g_args=dict(latent_size=512, mapping_layers=MID["mapping_layers"], blur_filter=[1, 2, 1], truncation_psi=0.7,
+                              truncation_cutoff=8, fmap_base=MID["fmap_base"], fmap_max=MID["fmap_max"]),
+                  d_args=dict(use_wscale=True, blur_filter=[1, 2, 1], fmap_base=MID["fmap_base"], fmap_max=MID["fmap_max"]),
+                  g_opt_args=kw, d_opt_args=kw, loss="logistic", d_repeats=1, use_ema=True, ema_decay=0.999,
+                  device=torch.device(DEV), act_dtype=act_dtype, use_graphs=use_graphs)
+    gp, dp = mid_params(torch.float64)
+    load_into(sg.gen, gp); load_into(sg.dis, dp); load_into(sg.gen_shadow, gp)
+    sg.gen.train(); sg.dis.train()
+    pin_noise(sg.gen, mid_noises(4))
+    return sg
+
+
+def run(use_graphs, act_dtype, iters, depth=5):
+    sg = make(use_graphs, act_dtype)
+    torch.manual_seed(5); random.seed(5)
+    losses = []
+    for i in range(iters):
+        alpha = min(1.0, 0.25 + 0.15 * i)
+        z = gu.seeded((4, 512), 100 + i).to(DEV); real = gu.seeded((4, 3, 128, 128), 200 + i).to(DEV)
+        d = sg.optimize_discriminator(z, real, depth, alpha)
+        g = sg.optimize_generator(z, real, depth, alpha)
+        losses.append((float(d), float(g)))
+    torch.cuda.synchronize()
+    state = {"gen": {k: v.detach().clone() for k, v in sg.gen.state_dict().items()},
+             "dis": {k: v.detach().clone() for k, v in sg.dis.state_dict().items()},
+             "shadow": {k: v.detach().clone() for k, v in sg.gen_shadow.state_dict().items()},
+             "dgrad": {k: p.grad.detach().clone() for k, p in sg.dis.named_parameters() if p.grad is not None},
+             "dstep": [float(st["step"]) for st in sg.dis_optim.state.values() if "step" in st]}
+    return losses, state, sg
+
+
+def close(a, b, tol):
+    a = a.double(); b = b.double()
+    return float((a - b).norm()) <= tol * float(b.norm()) + 1e-12
+
+
+@pytest.mark.parametrize("act_dtype,iters,ltol,ptol", [(torch.float32, 6, 2e-5, 2e-5), (torch.bfloat16, 4, 2e-3, 2e-3)])
+def test_graph_replay_matches_eager(act_dtype, iters, ltol, ptol):
+    le, se, _ = run(False, act_dtype, iters)                         # 2 eager warm-up calls, the capture, pure replays
+    lg, sgr, sg = run(True, act_dtype, iters)
+    assert all(g.graph is not None and g.calls == iters for g in sg._step_graphs.values()) and len(sg._step_graphs) == 2
+    for (d0, g0), (d1, g1) in zip(le, lg):
+        assert abs(d0 - d1) <= ltol * abs(d0) and abs(g0 - g1) <= ltol * abs(g0), (le, lg)
+    for part in ("gen", "dis", "shadow"):
+        for k, v in se[part].items():
+            assert close(sgr[part][k], v, ptol), (part, k)
+    assert max(se["dstep"]) == iters and sorted(set(sgr["dstep"])) in ([float(iters)], [0.0, float(iters)])   # graph_advance kept Adam's t
+    assert set(se["dgrad"]) == set(sgr["dgrad"])                     # .grad of the replayed step is visible
+
+
+def test_graph_and_eager_calls_interleave():
+    """An eager call between replays (bench.py's surveyed step, or a user generating samples) sees current weights and
+    leaves the graphs consistent."""
+    le, se, _ = run(False, torch.float32, 7)
+    sg = make(True, torch.float32)
+    torch.manual_seed(5); random.seed(5)
+    losses = []
+    for i in range(7):
+        sg.use_graphs = i != 4                                       # iteration 4 runs eagerly, after the capture
+        alpha = min(1.0, 0.25 + 0.15 * i)
+        z = gu.seeded((4, 512), 100 + i).to(DEV); real = gu.seeded((4, 3, 128, 128), 200 + i).to(DEV)
+        d = sg.optimize_discriminator(z, real, 5, alpha); g = sg.optimize_generator(z, real, 5, alpha)
+        losses.append((float(d), float(g)))
+    for (d0, g0), (d1, g1) in zip(le, losses):
+        assert abs(d0 - d1) <= 5e-5 * abs(d0) and abs(g0 - g1) <= 5e-5 * abs(g0), (le, losses)
+    for k, v in se["gen"].items():
+        assert close(sg.gen.state_dict()[k], v, 5e-5), k
+
+
+def test_deferred_loss_behaves_like_a_float():
+    from stylegan.pytorch_amd.GAN import DeferredLoss
+    x = DeferredLoss(torch.tensor(2.5, device=DEV), scale=0.5)
+    assert float(x) == 1.25 and "%.2f" % x == "1.25" and f"{x:.1f}" == "1.2" and x + 1 == 2.25 and abs(x - 1.25) == 0 and x < 2
