@@ -381,10 +381,12 @@ class StyleGAN:
             self.dp.broadcast(self.gen.truncation.avg_latent, src=0)
 
     def _graphable(self, labels):
-        return self.use_graphs and self.dp is None and labels is None and self.d_repeats == 1 and self.structure == "linear"
+        # with data parallelism the all-reduce stays eager between two graphs; the W-average broadcast cannot
+        return (self.use_graphs and labels is None and self.d_repeats == 1 and self.structure == "linear"
+                and (self.dp is None or self.gen.truncation is None))
 
-    def _d_body(self, noise, real_batch, depth, alpha, labels=None):
-        """The discriminator half-iteration up to and including the optimizer step; returns the (device) loss."""
+    def _d_grads(self, noise, real_batch, depth, alpha, labels=None):
+        """Discriminator half-iteration, part 1: losses and local gradients; returns the (device) loss."""
         real_samples = self.progressive_down_sampling(real_batch, depth, alpha)
         with torch.no_grad():                         # the reference builds and drops this graph (.detach(), :607)
             fake_samples = self.gen(noise, depth, alpha, labels)
@@ -392,12 +394,16 @@ class StyleGAN:
         loss = self.loss.dis_loss(real_samples, fake_samples, depth, alpha)
         self.dis_optim.zero_grad()
         loss.backward()
-        if self.dp is not None:
-            self.dp.all_reduce_grads(self.dis.parameters())
-        self.dis_optim.step()
         return loss.detach()
 
-    def _g_body(self, noise, real_batch, depth, alpha, labels=None):
+    def _d_reduce(self):
+        if self.dp is not None:
+            self.dp.all_reduce_grads(self.dis.parameters())
+
+    def _d_update(self):
+        self.dis_optim.step()
+
+    def _g_grads(self, noise, real_batch, depth, alpha, labels=None):
         real_samples = None
         if not isinstance(self.loss, (Losses.LogisticGAN, Losses.HingeGAN)):
             real_samples = self.progressive_down_sampling(real_batch, depth, alpha)   # only the relativistic loss reads it
@@ -415,12 +421,28 @@ class StyleGAN:
         finally:
             for p in d_params:
                 p.requires_grad_(True)
+        return loss.detach()
+
+    def _g_reduce(self):
         if self.dp is not None:
-            self.dp.all_reduce_grads(self.gen.parameters())
+            self.dp.all_reduce_grads(self.gen.parameters())                           # before the clip: global norm
+
+    def _g_update(self):
         clip_and_step(self.gen_optim, max_norm=10.)                                   # :651-652 without a host sync
         if self.use_ema:
             self.ema_updater(self.gen_shadow, self.gen, self.ema_decay)
-        return loss.detach()
+
+    def _d_body(self, noise, real_batch, depth, alpha, labels=None):
+        loss = self._d_grads(noise, real_batch, depth, alpha, labels)
+        self._d_reduce()
+        self._d_update()
+        return loss
+
+    def _g_body(self, noise, real_batch, depth, alpha, labels=None):
+        loss = self._g_grads(noise, real_batch, depth, alpha, labels)
+        self._g_reduce()
+        self._g_update()
+        return loss
 
     def _graphed(self, kind, noise, real_batch, depth, alpha):
         key = (kind, int(depth), tuple(noise.shape), tuple(real_batch.shape), tuple(real_batch.stride()), real_batch.dtype)
@@ -470,6 +492,7 @@ class _StepGraph:
         self.cutoff_host = torch.zeros(1, dtype=torch.int64).pin_memory()
         self.latents2 = self.latents2_host = None
         self.adam_entries = []
+        self.graph_update = None
         self.done = torch.cuda.Event()
 
     def _mixing(self):
@@ -493,12 +516,15 @@ class _StepGraph:
         self.ab.copy_(self.ab_host, non_blocking=True)
         self.z.copy_(noise); self.real.copy_(real_batch)
 
-    def _body(self):
+    def _body(self, part="all"):
+        """part 'all': the whole half-iteration; 'grads' / 'update': its two halves around the (eager) all-reduce."""
         sg = self.sg
+        if part == "update":
+            return (sg._d_update if self.kind == "d" else sg._g_update)()
         sg.gen._mixing_override = (self.latents2, self.cutoff) if self._mixing() else None
         try:
-            fn = sg._d_body if self.kind == "d" else sg._g_body
-            return fn(self.z, self.real, self.depth, self.ab)
+            name = {"all": "_body", "grads": "_grads"}[part]
+            return getattr(sg, "_" + self.kind + name)(self.z, self.real, self.depth, self.ab)
         finally:
             sg.gen._mixing_override = None
 
@@ -509,6 +535,7 @@ class _StepGraph:
         return list(sg.gen.parameters()) + (list(sg.gen_shadow.parameters()) if sg.use_ema else [])
 
     def run(self, noise, real_batch, alpha):
+        sg = self.sg
         cur = torch.cuda.current_stream()
         # The pinned staging buffers (mixing latents, alpha, Adam scalars) are rewritten below and re-read by this graph's
         # copy nodes at replay time: the previous call of THIS graph must have finished.  (The other half-iteration's
@@ -521,10 +548,29 @@ class _StepGraph:
                 loss = self._body()                                                # eager, on the capture stream
             else:
                 if self.graph is None:
-                    self._capture()
+                    try:
+                        self._capture()
+                    except Exception as e:                                         # noqa: BLE001 -- stay correct, go eager
+                        import sys
+                        print(f"stylegan.pytorch_amd: hipGraph capture of the {self.kind}-step failed ({type(e).__name__}: {e}); "
+                              "continuing eagerly", file=sys.stderr)
+                        self.graph = self.graph_update = None
+                        sg.use_graphs = False
+                        torch.cuda.synchronize()
+                        out = DeferredLoss(self._body())
+                        self.done.record()
+                        self.calls += 1
+                        cur.wait_stream(self.stream)
+                        return out
                 else:
                     FusedAdam.graph_advance(self.adam_entries)
                 self.graph.replay()
+                if self.graph_update is not None:                                  # data parallel: grads | all-reduce | update
+                    for p, g in self.grads:
+                        if p.grad is not g:
+                            p.grad = g
+                    (sg._d_reduce if self.kind == "d" else sg._g_reduce)()
+                    self.graph_update.replay()
                 F.bump_weight_generation(self._changed_params())                   # eager users must re-pack these
                 for p, g in self.grads:
                     if p.grad is not g:
@@ -544,12 +590,21 @@ class _StepGraph:
         torch.cuda.synchronize()
         opt._capture_log = []
         self.graph = torch.cuda.CUDAGraph()
+        split = sg.dp is not None
+        net = sg.dis if self.kind == "d" else sg.gen
         try:
             with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="relaxed"):
-                self.loss = self._body()
+                self.loss = self._body("grads" if split else "all")
+            if split:
+                # RCCL stays outside the graphs: [graph: losses + backward] -> eager bucketed all-reduce -> [graph:
+                # clip / Adam / EMA].  The second capture needs this iteration's gradient tensors to exist (they are
+                # allocated by the first graph's capture and only hold values after a replay), so nothing is replayed
+                # in between: a capture records launches, it does not run them.
+                self.graph_update = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_update, stream=self.stream, capture_error_mode="relaxed"):
+                    self._body("update")
         finally:
             self.adam_entries, opt._capture_log = opt._capture_log, None
         # the gradient tensors the graph writes (static addresses): re-attached after every replay so that .grad shows
         # this iteration's gradients even if an eager call in between replaced them
-        net = sg.dis if self.kind == "d" else sg.gen
         self.grads = [(p, p.grad) for p in net.parameters() if p.grad is not None]

@@ -6,7 +6,7 @@ Both run the same kernels on the same data.  The comparison is to a few fp32 ulp
 torch's autograd engine sums the three gradient contributions of a discriminator parameter (fake pass, real pass,
 R1 double-backward) in an order that depends on thread-local sequence numbers, i.e. on the history of the process: two
 EAGER runs in one process already differ by one ulp in such a gradient (measured), and Adam with beta1 = 0 then carries
-that forward."""
+that forward (a wrong alpha, a stale Adam scalar or a stale weight pack would show up at the 1e-2 level)."""
 import random
 
 import pytest
@@ -19,24 +19,26 @@ from test_gpu_networks import mid_noises
 pytestmark = pytest.mark.gpu
 
 
-def make(use_graphs, act_dtype):
+def make(use_graphs, act_dtype, psi=0.7, dp=None):
     from stylegan.pytorch_amd.GAN import StyleGAN
     kw = dict(learning_rate=0.003, beta_1=0, beta_2=0.99, eps=1e-8)
     sg = StyleGAN(structure="linear", resolution=128, num_channels=3, latent_size=512,
-                  g_args=dict(latent_size=512, mapping_layers=MID["mapping_layers"], blur_filter=[1, 2, 1], truncation_psi=0.7,
+                  g_args=dict(latent_size=512, mapping_layers=MID["mapping_layers"], blur_filter=[1, 2, 1], truncation_psi=psi,
                               truncation_cutoff=8, fmap_base=MID["fmap_base"], fmap_max=MID["fmap_max"]),
                   d_args=dict(use_wscale=True, blur_filter=[1, 2, 1], fmap_base=MID["fmap_base"], fmap_max=MID["fmap_max"]),
                   g_opt_args=kw, d_opt_args=kw, loss="logistic", d_repeats=1, use_ema=True, ema_decay=0.999,
-                  device=torch.device(DEV), act_dtype=act_dtype, use_graphs=use_graphs)
-    gp, dp = mid_params(torch.float64)
-    load_into(sg.gen, gp); load_into(sg.dis, dp); load_into(sg.gen_shadow, gp)
+                  device=torch.device(DEV), act_dtype=act_dtype, use_graphs=use_graphs, data_parallel=dp)
+    gp, dpar = mid_params(torch.float64)
+    if psi <= 0:
+        gp = {k: v for k, v in gp.items() if not k.startswith("truncation.")}
+    load_into(sg.gen, gp); load_into(sg.dis, dpar); load_into(sg.gen_shadow, gp)
     sg.gen.train(); sg.dis.train()
     pin_noise(sg.gen, mid_noises(4))
     return sg
 
 
-def run(use_graphs, act_dtype, iters, depth=5):
-    sg = make(use_graphs, act_dtype)
+def run(use_graphs, act_dtype, iters, depth=5, **kw):
+    sg = make(use_graphs, act_dtype, **kw)
     torch.manual_seed(5); random.seed(5)
     losses = []
     for i in range(iters):
@@ -54,12 +56,17 @@ def run(use_graphs, act_dtype, iters, depth=5):
     return losses, state, sg
 
 
+# g_synthesis.init_block.bias has an analytically ZERO gradient (it feeds an instance norm), so its computed gradient is
+# pure round-off and Adam with beta1 = 0 turns that into +-lr steps: not comparable between two runs of anything.
+SKIP = ("g_synthesis.init_block.bias",)
+
+
 def close(a, b, tol):
     a = a.double(); b = b.double()
     return float((a - b).norm()) <= tol * float(b.norm()) + 1e-12
 
 
-@pytest.mark.parametrize("act_dtype,iters,ltol,ptol", [(torch.float32, 6, 2e-5, 2e-5), (torch.bfloat16, 4, 2e-3, 2e-3)])
+@pytest.mark.parametrize("act_dtype,iters,ltol,ptol", [(torch.float32, 6, 2e-4, 5e-4), (torch.bfloat16, 4, 5e-3, 5e-3)])
 def test_graph_replay_matches_eager(act_dtype, iters, ltol, ptol):
     le, se, _ = run(False, act_dtype, iters)                         # 2 eager warm-up calls, the capture, pure replays
     lg, sgr, sg = run(True, act_dtype, iters)
@@ -68,7 +75,7 @@ def test_graph_replay_matches_eager(act_dtype, iters, ltol, ptol):
         assert abs(d0 - d1) <= ltol * abs(d0) and abs(g0 - g1) <= ltol * abs(g0), (le, lg)
     for part in ("gen", "dis", "shadow"):
         for k, v in se[part].items():
-            assert close(sgr[part][k], v, ptol), (part, k)
+            assert k in SKIP or close(sgr[part][k], v, ptol), (part, k)
     assert max(se["dstep"]) == iters and sorted(set(sgr["dstep"])) in ([float(iters)], [0.0, float(iters)])   # graph_advance kept Adam's t
     assert set(se["dgrad"]) == set(sgr["dgrad"])                     # .grad of the replayed step is visible
 
@@ -87,9 +94,30 @@ def test_graph_and_eager_calls_interleave():
         d = sg.optimize_discriminator(z, real, 5, alpha); g = sg.optimize_generator(z, real, 5, alpha)
         losses.append((float(d), float(g)))
     for (d0, g0), (d1, g1) in zip(le, losses):
-        assert abs(d0 - d1) <= 5e-5 * abs(d0) and abs(g0 - g1) <= 5e-5 * abs(g0), (le, losses)
+        assert abs(d0 - d1) <= 2e-4 * abs(d0) and abs(g0 - g1) <= 2e-4 * abs(g0), (le, losses)
     for k, v in se["gen"].items():
-        assert close(sg.gen.state_dict()[k], v, 5e-5), k
+        assert k in SKIP or close(sg.gen.state_dict()[k], v, 5e-4), k
+
+
+def test_data_parallel_graphs_split_around_the_all_reduce():
+    """With a process group the half-iteration is [graph: losses + backward] -> eager all-reduce -> [graph: update].
+    One rank (RCCL group of size 1) on this box: same results as the single-process eager run."""
+    import torch.distributed as dist
+    from stylegan.pytorch_amd.dist import DataParallelGroup
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29611", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        le, se, _ = run(False, torch.float32, 5, psi=-1.0)
+        lg, sgr, sg = run(True, torch.float32, 5, psi=-1.0, dp=DataParallelGroup())
+        graphs = list(sg._step_graphs.values())
+        assert len(graphs) == 2 and all(g.graph is not None and g.graph_update is not None for g in graphs)
+        for (d0, g0), (d1, g1) in zip(le, lg):
+            assert abs(d0 - d1) <= 2e-4 * abs(d0) and abs(g0 - g1) <= 2e-4 * abs(g0), (le, lg)
+        for part in ("gen", "dis", "shadow"):
+            for k, v in se[part].items():
+                assert k in SKIP or close(sgr[part][k], v, 5e-4), (part, k)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_deferred_loss_behaves_like_a_float():
