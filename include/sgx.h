@@ -77,6 +77,12 @@ int sgx_conv_config(int geo, int B, int H, int W, int Cin, int Cout, int dtype, 
 enum { SGX_PACK_S = 0, SGX_PACK_D = 1, SGX_PACK_U = 2, SGX_PACK_UF = 3 };
 int sgx_pack_weight(const float* w, void* fwd, void* adj, int O, int I, int Ipad, int mode, float scale, int dtype,
                     void* stream);
+/* the same for n parameters in ONE launch (all stale weights of a network after its optimizer step).  table: device
+ * array of n rows of SGX_PACK_ROW 64-bit words  [w, fwd, adj, O, I, Ipad, mode, scale as fp32 bits, first block, blocks],
+ * rows sorted by first block, blocks = sgx_pack_weight_blocks(O, Ipad), total_blocks = their sum; all packs in `dtype`. */
+#define SGX_PACK_ROW 10
+int sgx_pack_weight_blocks(int O, int Ipad);          /* blocks one parameter needs (32 x 32 channel tiles) */
+int sgx_pack_weight_multi(const void* table, int n, int total_blocks, int dtype, void* stream);
 /* weight gradients in the PARAMETER layout dW[O][I][3][3] (fp32): MFMA pixel-reduction into split partials (ws), then
  * one finishing kernel that sums the splits and applies the adjoint of sgx_pack_weight (autograd of F.conv2d /
  * F.conv_transpose2d w.r.t. weight composed with the reference's weight arithmetic).

@@ -67,6 +67,15 @@ class DeferredLoss:
     def __hash__(self): return hash(self.item())
 
 
+def _conv_weights(module):
+    """The 3x3 convolution parameters of a network (cached list; the module tree is static)."""
+    ws = module.__dict__.get("_sgx_conv_weights")
+    if ws is None:
+        ws = [m.weight for m in module.modules() if isinstance(m, EqualizedConv2d)]
+        module.__dict__["_sgx_conv_weights"] = ws
+    return ws
+
+
 def update_average(model_tgt, model_src, beta):
     """EMA of the generator weights into the shadow copy -- reference models/__init__.py:13-40."""
     ema_update(model_tgt, model_src, beta)
@@ -149,6 +158,7 @@ class GSynthesis(nn.Module):
 
     def forward(self, dlatents_in, depth=0, alpha=0., labels_in=None):
         assert depth < self.depth, "Requested output depth cannot be produced"
+        F.prepack(_conv_weights(self))                                      # all stale MFMA operand packs: one launch
         dl = dlatents_in.float()
         dt = self.act_dtype
         if self.structure == 'fixed':
@@ -271,6 +281,7 @@ class Discriminator(nn.Module):
 
     def forward(self, images_in, depth, alpha=1., labels_in=None):
         assert depth < self.depth, "Requested output depth cannot be produced"
+        F.prepack(_conv_weights(self))                                      # all stale MFMA operand packs: one launch
         img = F.nhwc(images_in, torch.float32)                              # [B,R,R,3] fp32
         dt = self.act_dtype
         if self.structure == 'fixed':

@@ -755,6 +755,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(FinishArgs f) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
     if (e < A * Bd) {
+#pragma unroll 4
         for (int s = sl; s < f.nsplit; s += NSL) {
             const float* p = f.ws + (size_t)s * total + e;
             if (f.mode == SGX_PACK_S) {
@@ -915,44 +916,103 @@ extern "C" int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float*
 //   D : v = 0.25*scale * sum_{a,b} w[o][i][ky-a][kx-b]                      (:159-162)
 //   U : v = scale * sum_{a,b} w[o][i][ky-a][kx-b];  UF: same on the flipped 3x3 kernel   (:146-150)
 // =====================================================================================================
-template <typename T>
-__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ adj, int O, int I, int Ip,
-                                   int mode, float scale) {
-    const int taps = mode == SGX_PACK_S ? 9 : 16;
-    const size_t n = (size_t)taps * O * Ip;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        const int i = (int)(e % Ip);
-        const int o = (int)((e / Ip) % O);
-        const int t = (int)(e / ((size_t)Ip * O));
-        float v = 0.f;
-        if (i < I) {
-            const float* wp = w + ((size_t)o * I + i) * 9;
-            if (mode == SGX_PACK_S) {
-                v = scale * wp[t];
-            } else {
-                const int ky = t >> 2, kx = t & 3;
+// One block = one 32 (o) x 32 (i) tile of the parameter: the 32 x 288 fp32 source words are read coalesced into LDS, the
+// forward pack is written with i fastest and the adjoint pack with o fastest (64-byte bf16 runs either way) -- instead
+// of one 2-byte scattered store per element.
+#define PACK_T 32
+__device__ __forceinline__ float pack_tap(const float (*raw)[PACK_T][PACK_T + 1], int r, int il, int t, int mode, float scale) {
+    if (mode == SGX_PACK_S) return scale * raw[t][r][il];
+    const int ky = t >> 2, kx = t & 3;
+    float v = 0.f;
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const int y = ky - a, x = kx - b;
-                        if (y >= 0 && y < 3 && x >= 0 && x < 3) v += wp[mode == SGX_PACK_UF ? (2 - y) * 3 + (2 - x) : y * 3 + x];
-                    }
-                v *= scale * (mode == SGX_PACK_D ? 0.25f : 1.f);
-            }
+        for (int b = 0; b < 2; ++b) {
+            const int y = ky - a, x = kx - b;
+            if (y >= 0 && y < 3 && x >= 0 && x < 3) v += raw[mode == SGX_PACK_UF ? (2 - y) * 3 + (2 - x) : y * 3 + x][r][il];
         }
-        fwd[e] = from_f<T>(v);
-        const int ta = mode == SGX_PACK_S ? 8 - t : t;
-        adj[((size_t)ta * Ip + i) * O + o] = from_f<T>(v);
+    return v * scale * (mode == SGX_PACK_D ? 0.25f : 1.f);
+}
+template <typename T>
+__device__ __forceinline__ void pack_weight_tile(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ adj, int O, int I,
+                                                 int Ip, int mode, float scale, unsigned tile) {
+    __shared__ float raw[9][PACK_T][PACK_T + 1];
+    const int tiles_i = (Ip + PACK_T - 1) / PACK_T;
+    const int o0 = (int)(tile / tiles_i) * PACK_T, i0 = (int)(tile % tiles_i) * PACK_T;
+    const int ni = (I - i0 < PACK_T ? (I - i0 > 0 ? I - i0 : 0) : PACK_T);         // real (unpadded) input channels in this tile
+    for (int idx = threadIdx.x; idx < PACK_T * PACK_T * 9; idx += blockDim.x) {
+        const int r = idx / (PACK_T * 9), c = idx % (PACK_T * 9);
+        const int il = c / 9, k = c % 9;
+        float v = 0.f;
+        if (o0 + r < O && il < ni) v = w[((size_t)(o0 + r) * I + i0) * 9 + c];
+        raw[k][r][il] = v;
     }
+    __syncthreads();
+    const int taps = mode == SGX_PACK_S ? 9 : 16;
+    constexpr int VE = 16 / (int)sizeof(T), VPR = PACK_T / VE;                    // 16-byte stores: VE elements per lane
+    const bool full = (o0 + PACK_T <= O) && (i0 + PACK_T <= Ip) && (O % VE == 0) && (Ip % VE == 0);
+    if (full) {
+        for (int e = threadIdx.x; e < taps * PACK_T * VPR; e += blockDim.x) {     // forward pack: i fastest
+            const int t = e / (PACK_T * VPR), r = (e / VPR) % PACK_T, v = e % VPR;
+            float val[VE];
+#pragma unroll
+            for (int j = 0; j < VE; ++j) val[j] = pack_tap(raw, r, v * VE + j, t, mode, scale);
+            VecTraits<T>::store(fwd + ((size_t)t * O + o0 + r) * Ip + i0 + v * VE, val);
+        }
+        for (int e = threadIdx.x; e < taps * PACK_T * VPR; e += blockDim.x) {     // adjoint pack: o fastest
+            const int t = e / (PACK_T * VPR), il = (e / VPR) % PACK_T, v = e % VPR;
+            const int ta = mode == SGX_PACK_S ? 8 - t : t;
+            float val[VE];
+#pragma unroll
+            for (int j = 0; j < VE; ++j) val[j] = pack_tap(raw, v * VE + j, il, t, mode, scale);
+            VecTraits<T>::store(adj + ((size_t)ta * Ip + i0 + il) * O + o0 + v * VE, val);
+        }
+        return;
+    }
+    for (int e = threadIdx.x; e < taps * PACK_T * PACK_T; e += blockDim.x) {      // edge tiles: element-wise
+        const int t = e / (PACK_T * PACK_T), r = (e / PACK_T) % PACK_T, il = e % PACK_T;
+        if (o0 + r < O && i0 + il < Ip)
+            fwd[((size_t)t * O + o0 + r) * Ip + i0 + il] = from_f<T>(pack_tap(raw, r, il, t, mode, scale));
+    }
+    for (int e = threadIdx.x; e < taps * PACK_T * PACK_T; e += blockDim.x) {
+        const int t = e / (PACK_T * PACK_T), il = (e / PACK_T) % PACK_T, r = e % PACK_T;
+        const int ta = mode == SGX_PACK_S ? 8 - t : t;
+        if (o0 + r < O && i0 + il < Ip)
+            adj[((size_t)ta * Ip + i0 + il) * O + o0 + r] = from_f<T>(pack_tap(raw, r, il, t, mode, scale));
+    }
+}
+static inline unsigned pack_tiles(int O, int Ip) { return (unsigned)(((O + PACK_T - 1) / PACK_T) * ((Ip + PACK_T - 1) / PACK_T)); }
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ adj, int O,
+                                                          int I, int Ip, int mode, float scale) {
+    pack_weight_tile<T>(w, fwd, adj, O, I, Ip, mode, scale, blockIdx.x);
+}
+// Every stale weight of a network in ONE launch.  tab: n rows of SGX_PACK_ROW 64-bit words
+//   [w, fwd, adj, O, I, Ipad, mode, scale (fp32 bits), first block, blocks];  blocks = sgx_pack_weight_blocks(O, Ipad)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long long* __restrict__ tab, int n) {
+    int t = 0;
+    while (t + 1 < n && (unsigned)tab[(t + 1) * SGX_PACK_ROW + 8] <= blockIdx.x) ++t;      // rows are sorted by first block
+    const long long* r = tab + (size_t)t * SGX_PACK_ROW;
+    pack_weight_tile<T>(reinterpret_cast<const float*>(r[0]), reinterpret_cast<T*>(r[1]), reinterpret_cast<T*>(r[2]), (int)r[3], (int)r[4],
+                        (int)r[5], (int)r[6], __uint_as_float((unsigned)r[7]), blockIdx.x - (unsigned)r[8]);
+}
+extern "C" int sgx_pack_weight_blocks(int O, int Ipad) { return (int)pack_tiles(O, Ipad); }
+extern "C" int sgx_pack_weight_multi(const void* table, int n, int total_blocks, int dtype, void* stream) {
+    SGX_REQUIRE(table && n > 0 && total_blocks > 0, SGX_EINVAL, "pack_weight_multi: bad args");
+    SGX_NOTE(0.0, 0.0, "pack_multi n%d", n);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const long long*)table, n);
+    else if (dtype == SGX_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<bf16_t>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const long long*)table, n);
+    else { SGX_REQUIRE(false, SGX_EINVAL, "pack_weight_multi: bad dtype"); }
+    SGX_LAUNCH_CHECK("pack_weight_multi_kernel");
+    return 0;
 }
 
 extern "C" int sgx_pack_weight(const float* w, void* fwd, void* adj, int O, int I, int Ipad, int mode, float scale, int dtype,
                                void* stream) {
     SGX_REQUIRE(mode >= SGX_PACK_S && mode <= SGX_PACK_UF && Ipad >= I && O > 0 && I > 0, SGX_EINVAL, "pack_weight: bad args");
     const size_t n = (size_t)(mode == SGX_PACK_S ? 9 : 16) * O * Ipad;
-    size_t g = (n + 255) / 256;
-    if (g > 4096) g = 4096;
+    const size_t g = pack_tiles(O, Ipad);
     SGX_NOTE(0.0, 36.0 * O * I + 2.0 * n * (dtype == SGX_F32 ? 4 : 2), "pack %dx%d m%d", O, I, mode);
     if (dtype == SGX_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, (float*)fwd, (float*)adj, O, I, Ipad, mode, scale);
     else if (dtype == SGX_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)fwd, (bf16_t*)adj, O, I, Ipad, mode, scale);

@@ -321,18 +321,17 @@ __global__ void colsum_stage1(const T* __restrict__ x, double* __restrict__ ws, 
 }
 // 32 outputs x 8 partial lanes per block: the chain over partial blocks is nblk/8 long, not nblk
 __global__ __launch_bounds__(256) void colsum_stage2(const double* __restrict__ ws, float* __restrict__ out, int nblk, int C, float scale) {
-    __shared__ double sh[8][33];
-    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double sh[64][5];                           // 4 outputs per block x 64 partial lanes
+    const int cl = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
     double s = 0.0;
     if (c < C)
-        for (int b = pl; b < nblk; b += 8) s += ws[(size_t)b * C + c];
+        for (int b = pl; b < nblk; b += 64) s += ws[(size_t)b * C + c];
     sh[pl][cl] = s;
     __syncthreads();
     if (pl == 0 && c < C) {
         double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += sh[k][cl];
+        for (int k = 0; k < 64; ++k) t += sh[k][cl];
         out[c] = (float)(t * (double)scale);
     }
 }
@@ -343,16 +342,16 @@ template <typename T, int NJ>
 __global__ __launch_bounds__(256) void colsum_vec_stage1(const T* __restrict__ x, const float* __restrict__ img, double* __restrict__ ws,
                                                          size_t npix, int C) {
     constexpr int VE = VecTraits<T>::VE;
-    extern __shared__ double sh[];                                   // [256][NJ*VE]
+    extern __shared__ float shf[];                                   // [256][NJ*VE]
     const int cv = C / VE, rows = 256 / cv;
     const int tc = threadIdx.x % cv, tr = threadIdx.x / cv;
     const size_t per = (npix + gridDim.x - 1) / gridDim.x;
     const size_t p0 = (size_t)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
-    double acc[NJ * VE];
+    // per-lane fp32 partials: a lane sums npix / (blocks * rows) values (tens to a few hundred); everything across lanes,
+    // blocks and the final total is fp64
     float part[NJ * VE];
 #pragma unroll
-    for (int k = 0; k < NJ * VE; ++k) { acc[k] = 0.0; part[k] = 0.f; }
-    int cnt = 0;
+    for (int k = 0; k < NJ * VE; ++k) part[k] = 0.f;
     auto accum = [&](const float (&v)[VE], size_t p) {
         if (NJ == 1) {
 #pragma unroll
@@ -371,11 +370,6 @@ __global__ __launch_bounds__(256) void colsum_vec_stage1(const T* __restrict__ x
         VecTraits<T>::load(x + ((p + 2 * (size_t)rows) * cv + tc) * VE, v2);
         VecTraits<T>::load(x + ((p + 3 * (size_t)rows) * cv + tc) * VE, v3);
         accum(v0, p); accum(v1, p + rows); accum(v2, p + 2 * (size_t)rows); accum(v3, p + 3 * (size_t)rows);
-        if (++cnt == 16) {                                               // fp32 over <= 64 rows, then double
-#pragma unroll
-            for (int k = 0; k < NJ * VE; ++k) { acc[k] += (double)part[k]; part[k] = 0.f; }
-            cnt = 0;
-        }
     }
     for (; p < p1; p += rows) {
         float v[VE];
@@ -383,15 +377,13 @@ __global__ __launch_bounds__(256) void colsum_vec_stage1(const T* __restrict__ x
         accum(v, p);
     }
 #pragma unroll
-    for (int k = 0; k < NJ * VE; ++k) sh[threadIdx.x * NJ * VE + k] = acc[k] + (double)part[k];
+    for (int k = 0; k < NJ * VE; ++k) shf[threadIdx.x * NJ * VE + k] = part[k];
     __syncthreads();
-    if (tr == 0) {
-#pragma unroll
-        for (int k = 0; k < NJ * VE; ++k) {
-            double s = 0.0;
-            for (int r = 0; r < rows; ++r) s += sh[(r * cv + tc) * NJ * VE + k];
-            ws[((size_t)blockIdx.x * NJ + k / VE) * C + tc * VE + (k % VE)] = s;
-        }
+    for (int o = threadIdx.x; o < cv * NJ * VE; o += 256) {             // output (channel vector, k): sum over the rows
+        const int c = o / (NJ * VE), k = o % (NJ * VE);
+        double s = 0.0;
+        for (int r = 0; r < rows; ++r) s += (double)shf[(r * cv + c) * NJ * VE + k];
+        ws[((size_t)blockIdx.x * NJ + k / VE) * C + c * VE + (k % VE)] = s;
     }
 }
 static bool colsum_vec_ok(int C, int ve) { const int cv = C / ve; return C % ve == 0 && cv >= 1 && cv <= 256 && (cv & (cv - 1)) == 0; }
@@ -406,13 +398,13 @@ extern "C" int sgx_colsum(const void* x, float* out, float scale, void* ws, size
     if (nblk > COLSUM_BLOCKS) nblk = COLSUM_BLOCKS;
     if (nblk < 1) nblk = 1;
     if (dtype == SGX_F32 && colsum_vec_ok(C, 4))
-        hipLaunchKernelGGL((colsum_vec_stage1<float, 1>), dim3(nblk), dim3(256), 256 * 4 * sizeof(double), st, (const float*)x, (const float*)nullptr, (double*)ws, npix, C);
+        hipLaunchKernelGGL((colsum_vec_stage1<float, 1>), dim3(nblk), dim3(256), 256 * 4 * sizeof(float), st, (const float*)x, (const float*)nullptr, (double*)ws, npix, C);
     else if (dtype == SGX_BF16 && colsum_vec_ok(C, 8))
-        hipLaunchKernelGGL((colsum_vec_stage1<bf16_t, 1>), dim3(nblk), dim3(256), 256 * 8 * sizeof(double), st, (const bf16_t*)x, (const float*)nullptr, (double*)ws, npix, C);
+        hipLaunchKernelGGL((colsum_vec_stage1<bf16_t, 1>), dim3(nblk), dim3(256), 256 * 8 * sizeof(float), st, (const bf16_t*)x, (const float*)nullptr, (double*)ws, npix, C);
     else if (dtype == SGX_F32) hipLaunchKernelGGL(colsum_stage1<float>, dim3(nblk), dim3(256), 256 * sizeof(double), st, (const float*)x, (double*)ws, npix, C);
     else hipLaunchKernelGGL(colsum_stage1<bf16_t>, dim3(nblk), dim3(256), 256 * sizeof(double), st, (const bf16_t*)x, (double*)ws, npix, C);
     SGX_LAUNCH_CHECK("colsum_stage1");
-    hipLaunchKernelGGL(colsum_stage2, dim3((C + 31) / 32), dim3(256), 0, st, (const double*)ws, out, nblk, C, scale);
+    hipLaunchKernelGGL(colsum_stage2, dim3((C + 3) / 4), dim3(256), 0, st, (const double*)ws, out, nblk, C, scale);
     SGX_LAUNCH_CHECK("colsum_stage2");
     return 0;
 }
@@ -556,18 +548,17 @@ extern "C" size_t sgx_rgb_wgrad_ws_bytes(size_t npix, int C) { (void)npix; retur
 // sums the per-block partials [blk][3][C] and scatters into the parameter layout dw[j*sj + c*sc]
 __global__ __launch_bounds__(256) void rgb_wgrad_stage2(const double* __restrict__ ws, float* __restrict__ dw, int nblk, int C, int sj, int sc,
                                                         float wscale) {
-    __shared__ double sh[8][33];
-    const int el = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + el;                      // e = j*C + c
+    __shared__ double sh[64][5];
+    const int el = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    const int e = blockIdx.x * 4 + el;                       // e = j*C + c
     double s = 0.0;
     if (e < 3 * C)
-        for (int b = pl; b < nblk; b += 8) s += ws[(size_t)b * 3 * C + e];
+        for (int b = pl; b < nblk; b += 64) s += ws[(size_t)b * 3 * C + e];
     sh[pl][el] = s;
     __syncthreads();
     if (pl == 0 && e < 3 * C) {
         double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += sh[k][el];
+        for (int k = 0; k < 64; ++k) t += sh[k][el];
         dw[(e / C) * sj + (e % C) * sc] = (float)(t * (double)wscale);
     }
 }
@@ -580,13 +571,13 @@ extern "C" int sgx_rgb_wgrad(const float* img, const void* f, float* dw, int sj,
     if (nblk > COLSUM_BLOCKS) nblk = COLSUM_BLOCKS;
     if (nblk < 1) nblk = 1;
     if (dtype == SGX_F32 && colsum_vec_ok(C, 4))
-        hipLaunchKernelGGL((colsum_vec_stage1<float, 3>), dim3(nblk), dim3(256), 256 * 12 * sizeof(double), st, (const float*)f, img, (double*)ws, npix, C);
+        hipLaunchKernelGGL((colsum_vec_stage1<float, 3>), dim3(nblk), dim3(256), 256 * 12 * sizeof(float), st, (const float*)f, img, (double*)ws, npix, C);
     else if (dtype == SGX_BF16 && colsum_vec_ok(C, 8))
-        hipLaunchKernelGGL((colsum_vec_stage1<bf16_t, 3>), dim3(nblk), dim3(256), 256 * 24 * sizeof(double), st, (const bf16_t*)f, img, (double*)ws, npix, C);
+        hipLaunchKernelGGL((colsum_vec_stage1<bf16_t, 3>), dim3(nblk), dim3(256), 256 * 24 * sizeof(float), st, (const bf16_t*)f, img, (double*)ws, npix, C);
     else if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_wgrad_stage1<float>, dim3(nblk), dim3(256), 768 * sizeof(double), st, img, (const float*)f, (double*)ws, npix, C);
     else hipLaunchKernelGGL(rgb_wgrad_stage1<bf16_t>, dim3(nblk), dim3(256), 768 * sizeof(double), st, img, (const bf16_t*)f, (double*)ws, npix, C);
     SGX_LAUNCH_CHECK("rgb_wgrad_stage1");
-    hipLaunchKernelGGL(rgb_wgrad_stage2, dim3((3 * C + 31) / 32), dim3(256), 0, st, (const double*)ws, dw, nblk, C, sj, sc, wscale);
+    hipLaunchKernelGGL(rgb_wgrad_stage2, dim3((3 * C + 3) / 4), dim3(256), 0, st, (const double*)ws, dw, nblk, C, sj, sc, wscale);
     SGX_LAUNCH_CHECK("rgb_wgrad_stage2");
     return 0;
 }

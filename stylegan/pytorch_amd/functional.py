@@ -14,6 +14,7 @@ epilogue, PixelNorm) and parameter gradients are first order.
 import contextlib
 import weakref
 
+import numpy as np
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -64,24 +65,72 @@ def bump_weight_generation(params=None):
         p._sgx_gen = getattr(p, "_sgx_gen", 0) + 1
 
 
+def _pack_tag(weight):
+    return (weight._version, _WEIGHT_GEN, getattr(weight, "_sgx_gen", 0), weight.data_ptr())
+
+
+def _pack_alloc(weight, sub):
+    mode, _, ipad, dtype = sub
+    taps = 9 if mode == "S" else 16
+    O = weight.shape[0]
+    return (torch.empty((taps, O, ipad), dtype=dtype, device=weight.device), torch.empty((taps, ipad, O), dtype=dtype, device=weight.device))
+
+
+def prepack(weights):
+    """Re-pack every STALE weight of ``weights`` (for all the (mode, scale, ipad, dtype) combinations it has been used
+    with) in one sgx_pack_weight_multi launch -- instead of one small launch per layer on first use after the optimizer
+    step.  Weights never used yet are left to the lazy path of ``packs``."""
+    rows, blk, dtype = [], 0, None
+    for w in weights:
+        ent = _PACKS.get(id(w))
+        if ent is None or ent[0]() is not w or not ent[3]:
+            continue
+        tag = _pack_tag(w)
+        if ent[1] == tag:
+            continue
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            raise N.SgxError("parameters must be contiguous fp32")
+        ent[1], ent[2] = tag, {}
+        for sub in ent[3]:
+            if dtype is None:
+                dtype = sub[3]
+            if sub[3] != dtype:                                   # a second activation dtype: leave it to the lazy path
+                continue
+            fwd, adj = _pack_alloc(w, sub)
+            ent[2][sub] = (fwd, adj)
+            O, I = w.shape[0], w.shape[1]
+            nb = ((O + 31) // 32) * ((sub[2] + 31) // 32)        # == sgx_pack_weight_blocks(O, Ipad)
+            rows.append([w.data_ptr(), fwd.data_ptr(), adj.data_ptr(), O, I, sub[2], MODES[sub[0]],
+                         int(np.float32(sub[1]).view(np.uint32)), blk, nb])
+            blk += nb
+    if rows:
+        table, _ = N.upload(torch.tensor(rows, dtype=torch.int64), weights[0].device)
+        N.check(N.lib().sgx_pack_weight_multi(N.ptr(table), len(rows), blk, N.F32 if dtype == torch.float32 else N.BF16, N.stream()),
+                "sgx_pack_weight_multi")
+        if not N.capturing():
+            table.record_stream(torch.cuda.current_stream())
+
+
 def packs(weight, mode, scale, ipad, dtype):
-    """(fwd, adj) operand packs of a [O][I][3][3] fp32 parameter; cached per (version, generation)."""
+    """(fwd, adj) operand packs of a [O][I][3][3] fp32 parameter; cached per (version, generation).  Entry layout:
+    [weakref, tag, {sub: (fwd, adj)} valid for the tag, {sub} ever requested (what ``prepack`` rebuilds)]."""
     key = id(weight)
     ent = _PACKS.get(key)
-    tag = (weight._version, _WEIGHT_GEN, getattr(weight, "_sgx_gen", 0), weight.data_ptr())
-    if ent is None or ent[0]() is not weight or ent[1] != tag:
-        ent = [weakref.ref(weight, lambda _r, k=key: _PACKS.pop(k, None)), tag, {}]
+    tag = _pack_tag(weight)
+    if ent is None or ent[0]() is not weight:
+        ent = [weakref.ref(weight, lambda _r, k=key: _PACKS.pop(k, None)), tag, {}, set()]
         _PACKS[key] = ent
+    elif ent[1] != tag:
+        ent[1], ent[2] = tag, {}
     sub = (mode, float(scale), int(ipad), dtype)
+    ent[3].add(sub)
     got = ent[2].get(sub)
     if got is None:
         w = _c(weight.detach())
         if w.dtype != torch.float32:
             raise N.SgxError("parameters must be fp32")
         O, I = w.shape[0], w.shape[1]
-        taps = 9 if mode == "S" else 16
-        fwd = torch.empty((taps, O, ipad), dtype=dtype, device=w.device)
-        adj = torch.empty((taps, ipad, O), dtype=dtype, device=w.device)
+        fwd, adj = _pack_alloc(w, sub)
         N.check(N.lib().sgx_pack_weight(N.ptr(w), N.ptr(fwd), N.ptr(adj), O, I, ipad, MODES[mode], float(scale),
                                         N.F32 if dtype == torch.float32 else N.BF16, N.stream()), "sgx_pack_weight")
         got = (fwd, adj)
@@ -90,7 +139,9 @@ def packs(weight, mode, scale, ipad, dtype):
 
 
 def clear_pack_cache():
-    _PACKS.clear()
+    """Forget every pack (the usage records that ``prepack`` batches by are kept)."""
+    for ent in _PACKS.values():
+        ent[1], ent[2] = None, {}
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -41,6 +41,8 @@ SIGNATURES = {
     "sgx_prof_count": (I, []),
     "sgx_prof_get": (I, [I, P, I, P, P, P, P, I]),
     "sgx_pack_weight": (I, [P, P, P, I, I, I, I, F, I, P]),
+    "sgx_pack_weight_multi": (I, [P, I, I, I, P]),
+    "sgx_pack_weight_blocks": (I, [I, I]),
     "sgx_wgrad3x3_param": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, P]),
     "sgx_wgrad4x4s2_param": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, P]),
     "sgx_bias_act": (I, [P, P, F, P, Z, I, I, I, P]),
@@ -140,6 +142,24 @@ def ptr(t):
     if not t.is_contiguous():
         raise SgxError("internal: non-contiguous tensor passed to a kernel")
     return t.data_ptr()
+
+
+# Host -> device uploads of small descriptor tables: pinned staging + non_blocking, so the copy is stream ordered and the
+# host never waits for the GPU queue.  While a hipGraph is being captured the copy becomes a graph node that re-reads the
+# pinned buffer at every replay, so the buffer is kept alive (and may be rewritten in place before a replay).
+_CAPTURE_KEEP = []
+
+
+def capturing() -> bool:
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def upload(t: torch.Tensor, device):
+    """-> (device tensor, pinned staging tensor)."""
+    pinned = t.pin_memory()
+    if capturing():
+        _CAPTURE_KEEP.append(pinned)
+    return pinned.to(device, non_blocking=True), pinned
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:

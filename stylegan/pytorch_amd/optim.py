@@ -16,18 +16,8 @@ from .functional import bump_weight_generation
 # and the host does not wait for the GPU queue to drain; pointer tables are cached (parameter / state / gradient
 # addresses are stable from step to step).
 _TABLES = {}
-_CAPTURE_KEEP = []            # pinned staging tensors that captured H2D copy nodes re-read at every graph replay
-
-
-def _capturing():
-    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
-
-
-def _to_dev(t, device):
-    pinned = t.pin_memory()
-    if _capturing():
-        _CAPTURE_KEEP.append(pinned)
-    return pinned.to(device, non_blocking=True), pinned
+_capturing = N.capturing
+_to_dev = N.upload
 
 
 def _dev_i64(vals, device):

@@ -363,3 +363,32 @@ def test_bias_gradient_fused_into_weight_gradient(mode, H, cin, cout, dt):
     gz = (g.float() * torch.where(y.float() > 0, 1.0, 0.2)).to(dt).float()          # what the wgrad kernel reads
     ref = gz.sum(dim=(0, 1, 2))
     assert_close(gb, ref, 2e-3 if dt == torch.bfloat16 else 1e-4, "fused bias gradient")
+
+
+def test_prepack_rebuilds_all_stale_packs_in_one_launch():
+    from stylegan.pytorch_amd import functional as F, native
+    torch.manual_seed(4)
+    ws = [torch.nn.Parameter(torch.randn(32, 16, 3, 3, device=DEV)), torch.nn.Parameter(torch.randn(64, 32, 3, 3, device=DEV)),
+          torch.nn.Parameter(torch.randn(16, 32, 3, 3, device=DEV))]
+    modes = ["S", "D", "U"]
+    xs = [torch.randn(2, 16, 16, w.shape[1], device=DEV).bfloat16() for w in ws]
+    ref = [F.conv(x, w, None, m, 0.07).clone() for x, w, m in zip(xs, ws, modes)]          # lazy single packs, records the usage
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(2.0)                                                                    # bumps torch's version counter
+    native.prof_start(1)
+    F.prepack(ws)
+    out = [F.conv(x, w, None, m, 0.07) for x, w, m in zip(xs, ws, modes)]
+    torch.cuda.synchronize()
+    native.prof_start(0)
+    names = [r[0] for r in native.prof_records()]
+    assert sum("pack_weight_multi_kernel" in n for n in names) == 1 and not any("pack_weight_kernel" in n for n in names), names
+    for o, r in zip(out, ref):
+        assert_close(o, 2.0 * r.float(), 1e-2, "conv after batched re-pack")               # bf16 packs of 2w vs 2 * packs of w
+    # and the adjoint packs: data gradients through the re-packed weights
+    x = xs[0].clone().requires_grad_(True)
+    y = F.conv(x, ws[0], None, "S", 0.07)
+    (gx,) = torch.autograd.grad(y, x, torch.ones_like(y))
+    wq = (ws[0].detach() * 0.07).bfloat16().float()
+    gref = TF.conv_transpose2d(torch.ones(2, 32, 16, 16, device=DEV), wq, padding=1).permute(0, 2, 3, 1)
+    assert_close(gx, gref, 1e-2, "data gradient after batched re-pack")
