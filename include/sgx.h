@@ -92,12 +92,16 @@ int sgx_pack_weight_multi(const void* table, int n, int total_blocks, int dtype,
  *                        mode D: coarse has O channels, fine has I;  mode U/UF: coarse has I, fine has O.
  *   db (nullable, fp32 [O]): also the bias gradient sum_{b,h,w} dy[.,o] (EqualizedConv2d bias, CustomLayers.py:178),
  *                        from the same pass over dy (one extra MFMA against a tile of ones) -- only where dy is the
- *                        O-channel side: adjoint=0 / mode D; otherwise SGX_EINVAL.                                  */
+ *                        O-channel side: adjoint=0 / mode D; otherwise SGX_EINVAL.
+ *   accumulate           bit 0: dW += result, bit 1: db += result (a parameter used by several passes of one backward --
+ *                        D on real and fake images, the R1 double backward -- accumulates in the finishing kernel
+ *                        instead of a separate add per contribution).                                               */
 size_t sgx_wgrad_ws_bytes(int taps, int B, int H, int W, int Ck, int Cn);
 int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, float* db, void* ws, size_t ws_bytes, int B, int H, int W,
-                       int Cx, int Cdy, int adjoint, float scale, int O, int I, int dtype, void* stream);
+                       int Cx, int Cdy, int adjoint, float scale, int O, int I, int accumulate, int dtype, void* stream);
 int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float* dW, float* db, void* ws, size_t ws_bytes, int B, int H,
-                         int W, int Cfine, int Ccoarse, int mode, float scale, int O, int I, int dtype, void* stream);
+                         int W, int Cfine, int Ccoarse, int mode, float scale, int O, int I, int accumulate, int dtype,
+                         void* stream);
 
 /* ---------------------------------------------------------------- memory-bound layer pieces
  * y = act(x + bscale*bias[c])               bias after blur / avgpool: models/CustomLayers.py:178-179; Blocks.py:142,146

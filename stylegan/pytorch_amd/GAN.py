@@ -404,7 +404,8 @@ class StyleGAN:
         self._sync_w_avg()
         loss = self.loss.dis_loss(real_samples, fake_samples, depth, alpha)
         self.dis_optim.zero_grad()
-        loss.backward()
+        with F.accumulate_param_grads():              # conv weight / bias gradients accumulate inside the finishing kernel
+            loss.backward()
         return loss.detach()
 
     def _d_reduce(self):
@@ -428,7 +429,8 @@ class StyleGAN:
         try:
             loss = self.loss.gen_loss(real_samples, fake_samples, depth, alpha)
             self.gen_optim.zero_grad()
-            loss.backward()
+            with F.accumulate_param_grads():
+                loss.backward()
         finally:
             for p in d_params:
                 p.requires_grad_(True)

@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // mode S: dW[o][i][y][x] = scale * P[y*3+x];  4x4 modes: dW[o][i][y][x] = scale * sum_{a,b in {0,1}} P[(y+a)*4 + (x+b)]
 // (x0.25 for the down kernel; spatial flip of (y,x) for the non-fused-up semantics) -- the transposes of
 // reference models/CustomLayers.py:146-150 and :159-162.
-struct FinishArgs { const float* ws; float* dw; float* db; int nsplit, O, I, Ip, mode, transposed, flip_t; float scale; };
+struct FinishArgs { const float* ws; float* dw; float* db; int nsplit, O, I, Ip, mode, transposed, flip_t; float scale; int accumulate; };
 
 // EPB consecutive workspace elements per block (consecutive in the partials' fastest dimension, so every read is
 // coalesced) x 256/EPB split lanes.  Large weights with few splits use EPB=64; tiny weights with hundreds of splits
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(FinishArgs f) {
         if (sl == 0 && o < f.O) {
             float sum = 0.f;
             for (int l = 0; l < NSL; ++l) sum += red[l][pl][0];
-            f.db[o] = sum;
+            f.db[o] = (f.accumulate & 2) ? f.db[o] + sum : sum;
         }
         return;
     }
@@ -787,7 +787,8 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(FinishArgs f) {
 #pragma unroll 8
         for (int l = 0; l < NSL; ++l) sum += red[l][el][k];
         const float c = f.scale * (f.mode == SGX_PACK_D ? 0.25f : 1.f);
-        f.dw[((size_t)o * f.I + i) * 9 + (f.mode == SGX_PACK_UF ? 8 - k : k)] = c * sum;
+        float* d = f.dw + ((size_t)o * f.I + i) * 9 + (f.mode == SGX_PACK_UF ? 8 - k : k);
+        *d = (f.accumulate & 1) ? *d + c * sum : c * sum;
     }
 }
 
@@ -853,8 +854,8 @@ static int wgrad_ch(WgradArgs& a, void* ws, size_t wsb, int* ns, hipStream_t st)
 }
 
 static int wgrad_finish(const void* ws, float* dw, float* db, int nsplit, int O, int I, int Ip, int mode, int transposed, int flip_t,
-                        float scale, hipStream_t st) {
-    FinishArgs f{static_cast<const float*>(ws), dw, db, nsplit, O, I, Ip, mode, transposed, flip_t, scale};
+                        float scale, int accumulate, hipStream_t st) {
+    FinishArgs f{static_cast<const float*>(ws), dw, db, nsplit, O, I, Ip, mode, transposed, flip_t, scale, accumulate};
     SGX_NOTE(0.0, 4.0 * ((double)nsplit * (mode == SGX_PACK_S ? 9 : 16) * O * Ip + 9.0 * O * I), "finish %dx%d m%d tr%d ns%d", O, I, mode, transposed, nsplit);
     const int ne = O * Ip, nb = db ? O : 0;                            // bias blocks trail the weight blocks
     if (nsplit <= 4) hipLaunchKernelGGL(wgrad_finish_kernel<64>, dim3((unsigned)((ne + 63) / 64 + (nb + 63) / 64)), dim3(256), 0, st, f);
@@ -873,7 +874,8 @@ extern "C" size_t sgx_wgrad_ws_bytes(int taps, int B, int H, int W, int Ck, int 
 }
 
 extern "C" int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, float* db, void* ws, size_t ws_bytes, int B, int H,
-                                  int W, int Cx, int Cdy, int adjoint, float scale, int O, int I, int dtype, void* stream) {
+                                  int W, int Cx, int Cdy, int adjoint, float scale, int O, int I, int accumulate, int dtype,
+                                  void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int Ip = adjoint ? Cdy : Cx;
     SGX_REQUIRE(!db || !adjoint, SGX_EINVAL, "wgrad3x3_param: bias gradient asked of the adjoint launch");
@@ -885,12 +887,12 @@ extern "C" int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, floa
     else if (dtype == SGX_BF16) rc = wgrad_use_tr() ? wgrad_ch<bf16_t, G3X3, 128, true>(a, ws, ws_bytes, &ns, st) : wgrad_ch<bf16_t, G3X3, 128>(a, ws, ws_bytes, &ns, st);
     else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad3x3_param: bad dtype"); }
     if (rc) return rc;
-    return wgrad_finish(ws, dW, db, ns, O, I, Ip, SGX_PACK_S, adjoint, adjoint, scale, st);
+    return wgrad_finish(ws, dW, db, ns, O, I, Ip, SGX_PACK_S, adjoint, adjoint, scale, accumulate, st);
 }
 
 extern "C" int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float* dW, float* db, void* ws, size_t ws_bytes, int B,
-                                    int H, int W, int Cfine, int Ccoarse, int mode, float scale, int O, int I, int dtype,
-                                    void* stream) {
+                                    int H, int W, int Cfine, int Ccoarse, int mode, float scale, int O, int I, int accumulate,
+                                    int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SGX_REQUIRE(H % 2 == 0 && W % 2 == 0, SGX_EINVAL, "wgrad4x4s2_param: odd fine size");
     SGX_REQUIRE(mode == SGX_PACK_D || mode == SGX_PACK_U || mode == SGX_PACK_UF, SGX_EINVAL, "wgrad4x4s2_param: bad mode %d", mode);
@@ -905,7 +907,7 @@ extern "C" int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float*
     else if (dtype == SGX_BF16) rc = wgrad_use_tr() ? wgrad_ch<bf16_t, GDOWN, 64, true>(a, ws, ws_bytes, &ns, st) : wgrad_ch<bf16_t, GDOWN, 64>(a, ws, ws_bytes, &ns, st);
     else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad4x4s2_param: bad dtype"); }
     if (rc) return rc;
-    return wgrad_finish(ws, dW, db, ns, O, I, I, mode, transposed, 0, scale, st);
+    return wgrad_finish(ws, dW, db, ns, O, I, I, mode, transposed, 0, scale, accumulate, st);
 }
 
 // =====================================================================================================

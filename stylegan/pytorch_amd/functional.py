@@ -52,6 +52,21 @@ FWD_GEO = {"S": "S", "D": "D", "U": "U", "UF": "U"}
 ADJ_GEO = {"S": "S", "D": "U", "U": "D", "UF": "D"}
 _PACKS = {}
 _WEIGHT_GEN = 0
+_ACCUM_PARAM_GRADS = False
+
+
+@contextlib.contextmanager
+def accumulate_param_grads():
+    """Inside: the backward of a convolution writes / accumulates the gradients of its LEAF weight and bias straight into
+    ``.grad`` (sgx_wgrad*_param(accumulate=...)) and hands autograd nothing for them -- for ``loss.backward()`` of the
+    training step, where a discriminator parameter collects up to three contributions.  Process-global: backward runs on
+    autograd's worker thread."""
+    global _ACCUM_PARAM_GRADS
+    prev, _ACCUM_PARAM_GRADS = _ACCUM_PARAM_GRADS, True
+    try:
+        yield
+    finally:
+        _ACCUM_PARAM_GRADS = prev
 
 
 def bump_weight_generation(params=None):
@@ -164,13 +179,17 @@ def _conv_launch(geo, x, wq, bias, act):
     return y
 
 
-def _wgrad_param(mode, adjoint, x, gy, weight, scale, want_bias=False):
+def _wgrad_param(mode, adjoint, x, gy, weight, scale, want_bias=False, into=None):
     """Gradient w.r.t. the [O][I][3][3] parameter of y = conv(x) (or of the layer's data-gradient conv if adjoint);
-    with ``want_bias`` also the bias gradient sum(gy) over batch and pixels, out of the same pass -> (dW, db|None)."""
+    with ``want_bias`` also the bias gradient sum(gy) over batch and pixels, out of the same pass -> (dW, db|None).
+    ``into`` = (dW tensor or None, db tensor or None): accumulate into these existing gradients instead."""
     L = N.lib()
     O, I = weight.shape[0], weight.shape[1]
-    dW = torch.empty((O, I, 3, 3), dtype=torch.float32, device=x.device)
-    db = torch.empty((O,), dtype=torch.float32, device=x.device) if want_bias else None
+    acc_w = into is not None and into[0] is not None
+    acc_b = want_bias and into is not None and into[1] is not None
+    dW = into[0] if acc_w else torch.empty((O, I, 3, 3), dtype=torch.float32, device=x.device)
+    db = (into[1] if acc_b else torch.empty((O,), dtype=torch.float32, device=x.device)) if want_bias else None
+    acc = (1 if acc_w else 0) | (2 if acc_b else 0)
     B = x.shape[0]
     if mode == "S":
         _, H, W, Cx = x.shape
@@ -178,7 +197,7 @@ def _wgrad_param(mode, adjoint, x, gy, weight, scale, want_bias=False):
         wsb = L.sgx_wgrad_ws_bytes(9, B, H, W, Cx, Cdy)
         ws = N.workspace(wsb, x.device)
         N.check(L.sgx_wgrad3x3_param(N.ptr(x), N.ptr(gy), N.ptr(dW), N.ptr(db), N.ptr(ws), wsb, B, H, W, Cx, Cdy, int(adjoint),
-                                     float(scale), O, I, N.dt(x), N.stream()), "sgx_wgrad3x3_param")
+                                     float(scale), O, I, acc, N.dt(x), N.stream()), "sgx_wgrad3x3_param")
         return dW, db
     launched = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]          # geometry of the convolution that ran
     fine, coarse = (x, gy) if launched == "D" else (gy, x)
@@ -187,7 +206,7 @@ def _wgrad_param(mode, adjoint, x, gy, weight, scale, want_bias=False):
     wsb = L.sgx_wgrad_ws_bytes(16, B, H, W, Cf, Cc)
     ws = N.workspace(wsb, x.device)
     N.check(L.sgx_wgrad4x4s2_param(N.ptr(fine), N.ptr(coarse), N.ptr(dW), N.ptr(db), N.ptr(ws), wsb, B, H, W, Cf, Cc, MODES[mode],
-                                   float(scale), O, I, N.dt(x), N.stream()), "sgx_wgrad4x4s2_param")
+                                   float(scale), O, I, acc, N.dt(x), N.stream()), "sgx_wgrad4x4s2_param")
     return dW, db
 
 
@@ -205,6 +224,7 @@ class ConvFn(Function):
         geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
         y = _conv_launch(geo, x, adj if adjoint else fwd, None if bias is None else _c(bias.detach()), act)
         ctx.cfg = (mode, scale, ipad, adjoint, act, bias is not None)
+        ctx.bias_ref = weakref.ref(bias) if bias is not None else (lambda: None)
         ctx.save_for_backward(x, weight, y if act else None)
         return y
 
@@ -222,7 +242,19 @@ class ConvFn(Function):
             want_b = has_bias and ctx.needs_input_grad[2]
             # the bias gradient rides along in the weight-gradient pass when gy is its O-channel side
             fuse_b = want_b and ctx.needs_input_grad[1] and not adjoint and mode in ("S", "D")
-            if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[1] and _ACCUM_PARAM_GRADS and weight.is_leaf and not torch.is_grad_enabled():
+                # training step: accumulate straight into .grad in the finishing kernel (no add kernel per contribution)
+                bias = ctx.bias_ref() if fuse_b else None
+                if fuse_b and (bias is None or not bias.is_leaf):
+                    fuse_b, bias = False, None
+                dW, db = _wgrad_param(mode, adjoint, _c(x), gy, weight, scale, fuse_b, (weight.grad, bias.grad if fuse_b else None))
+                if weight.grad is None:
+                    weight.grad = dW
+                if fuse_b:
+                    if bias.grad is None:
+                        bias.grad = db
+                    want_b = False
+            elif ctx.needs_input_grad[1]:
                 gw, gb = WgradFn.apply(x, gy, weight, mode, scale, adjoint, fuse_b)
             if want_b and not fuse_b:
                 gb = ColSumFn.apply(gy, 1.0)

@@ -43,8 +43,8 @@ SIGNATURES = {
     "sgx_pack_weight": (I, [P, P, P, I, I, I, I, F, I, P]),
     "sgx_pack_weight_multi": (I, [P, I, I, I, P]),
     "sgx_pack_weight_blocks": (I, [I, I]),
-    "sgx_wgrad3x3_param": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, P]),
-    "sgx_wgrad4x4s2_param": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, P]),
+    "sgx_wgrad3x3_param": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, I, P]),
+    "sgx_wgrad4x4s2_param": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, I, P]),
     "sgx_bias_act": (I, [P, P, F, P, Z, I, I, I, P]),
     "sgx_lrelu_bwd": (I, [P, P, P, Z, I, P]),
     "sgx_axpby": (I, [P, P, P, F, F, Z, I, P]),
