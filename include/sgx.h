@@ -118,6 +118,10 @@ int sgx_axpby_dev(const void* a, const void* b, void* out, const float* alpha_de
                   void* stream);
 /* depthwise [1,2,1]x[1,2,1]/16 blur, zero pad   BlurLayer: models/CustomLayers.py:251-276 (self-adjoint)           */
 int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+/* "LeakyReLU(0.2) then blur" (discriminator block, models/Blocks.py:140-142) with the activation folded into the blur pass:
+ * mode 0: y = blur(x);  1: y = blur(lrelu(x))  [forward];  2: y = blur(x) * slope(z)  [backward: z = the pre-activation];
+ * 3: y = blur(x * slope(z))  [backward of mode 2 w.r.t. x: the R1 double backward].  slope(z) = z > 0 ? 1 : 0.2 */
+int sgx_blur3x3_act(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, int dtype, void* stream);
 /* y = scale * (2x2 block sum)   scale .25: AvgPool2d(2) models/GAN.py:382,423; Downscale2d CustomLayers.py:60-64   */
 int sgx_pool2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream);
 /* y = scale * nearest_up2(x)    Upscale2d CustomLayers.py:27-36; F.interpolate(scale_factor=2) models/GAN.py:173     */

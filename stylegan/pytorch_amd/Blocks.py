@@ -127,8 +127,11 @@ class DiscriminatorBlock(nn.Module):
         assert _is_lrelu02(activation_layer), "the kernels fuse LeakyReLU(0.2)"
 
     def forward_nhwc(self, x):
-        x = self.conv0.forward_nhwc(x, act=ACT_LRELU)                     # bias + LeakyReLU fused in the conv store
-        x = self.blur.forward_nhwc(x)
+        z = self.conv0.forward_nhwc(x, act=ACT_NONE)                      # bias fused in the conv store; pre-activation
+        if self.blur._is_121:
+            x = F.ActBlurFn.apply(z)                                      # LeakyReLU folded into the blur pass (both ways)
+        else:
+            x = self.blur.forward_nhwc(F.BiasActFn.apply(z, None, 1.0, ACT_LRELU))
         return self.conv1_down.forward_nhwc(x, act=ACT_LRELU)
 
     def forward(self, x):

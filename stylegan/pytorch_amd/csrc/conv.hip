@@ -792,9 +792,17 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(FinishArgs f) {
     }
 }
 
-static int wgrad_nsplit(int pairs, int ntiles) {
-    int want = (1024 + pairs - 1) / pairs;           // measured: 2048 blocks is slower (partials + finish grow faster)
-    if (want > 512) want = 512;
+// Pixel splits per channel pair.  ~1024 blocks fill the chip; the 16/32-channel layers at 512^2..1024^2 (a handful of
+// channel pairs, millions of pixels, partials of a few KB per split) take 2048 blocks / up to 1024 splits -- measured:
+// 118 -> 87 us for the 1024^2 16x16 layer -- while for bigger weights more splits cost more in partial traffic than they
+// gain (measured).  SGX_WGRAD_BLOCKS / SGX_WGRAD_MAXSPLIT override both for experiments.
+static int wgrad_nsplit(int pairs, int ntiles, size_t elems_per_split) {
+    static const int env_target = [] { const char* e = getenv("SGX_WGRAD_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+    static const int env_cap = [] { const char* e = getenv("SGX_WGRAD_MAXSPLIT"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+    const bool tiny = elems_per_split <= (size_t)16 * 32 * 32;
+    const int target = env_target ? env_target : (tiny ? 2048 : 1024), cap = env_cap ? env_cap : (tiny ? 1024 : 512);
+    int want = (target + pairs - 1) / pairs;
+    if (want > cap) want = cap;
     if (want > ntiles) want = ntiles;
     if (want < 1) want = 1;
     return want;
@@ -810,7 +818,7 @@ static int launch_wgrad(WgradArgs& a, void* ws, size_t ws_bytes, int* nsplit_out
     a.tiles_y = (a.Hn + TH - 1) / TH; a.tiles_x = (a.Wn + TW - 1) / TW;
     a.ntiles = ((a.B + NI - 1) / NI) * a.tiles_y * a.tiles_x;
     const int pairs = (a.Cn / (NSUB * 16)) * (a.Ck / (KSUB * 16));
-    int nsplit = wgrad_nsplit(pairs, a.ntiles);
+    int nsplit = wgrad_nsplit(pairs, a.ntiles, (size_t)NT * a.Cn * a.Ck);
     const size_t total = (size_t)NT * a.Cn * a.Ck + a.Cn;             // per split: all taps + the n side's column sums
     size_t fit = ws_bytes / (total * sizeof(float));
     if ((size_t)nsplit > fit) nsplit = (int)fit;
@@ -858,8 +866,10 @@ static int wgrad_finish(const void* ws, float* dw, float* db, int nsplit, int O,
     FinishArgs f{static_cast<const float*>(ws), dw, db, nsplit, O, I, Ip, mode, transposed, flip_t, scale, accumulate};
     SGX_NOTE(0.0, 4.0 * ((double)nsplit * (mode == SGX_PACK_S ? 9 : 16) * O * Ip + 9.0 * O * I), "finish %dx%d m%d tr%d ns%d", O, I, mode, transposed, nsplit);
     const int ne = O * Ip, nb = db ? O : 0;                            // bias blocks trail the weight blocks
-    if (nsplit <= 4) hipLaunchKernelGGL(wgrad_finish_kernel<64>, dim3((unsigned)((ne + 63) / 64 + (nb + 63) / 64)), dim3(256), 0, st, f);
-    else if (nsplit <= 64) hipLaunchKernelGGL(wgrad_finish_kernel<16>, dim3((unsigned)((ne + 15) / 16 + (nb + 15) / 16)), dim3(256), 0, st, f);
+    // widest contiguous run per split lane (coalescing: the partials are read once per split) that still leaves >= 128 blocks
+    if (ne / 64 >= 128) hipLaunchKernelGGL(wgrad_finish_kernel<64>, dim3((unsigned)((ne + 63) / 64 + (nb + 63) / 64)), dim3(256), 0, st, f);
+    else if (ne / 16 >= 128) hipLaunchKernelGGL(wgrad_finish_kernel<16>, dim3((unsigned)((ne + 15) / 16 + (nb + 15) / 16)), dim3(256), 0, st, f);
+    else if (ne / 8 >= 128) hipLaunchKernelGGL(wgrad_finish_kernel<8>, dim3((unsigned)((ne + 7) / 8 + (nb + 7) / 8)), dim3(256), 0, st, f);
     else hipLaunchKernelGGL(wgrad_finish_kernel<4>, dim3((unsigned)((ne + 3) / 4 + (nb + 3) / 4)), dim3(256), 0, st, f);
     SGX_LAUNCH_CHECK("wgrad_finish_kernel");
     return 0;
@@ -869,7 +879,7 @@ extern "C" size_t sgx_wgrad_ws_bytes(int taps, int B, int H, int W, int Ck, int 
     size_t total = ((size_t)taps * Ck * Cn + Cn) * sizeof(float);
     int pairs = (Ck / 32 > 0 ? Ck / 32 : 1) * (Cn / 32 > 0 ? Cn / 32 : 1);
     size_t ntiles = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
-    size_t ns = (size_t)wgrad_nsplit(pairs, ntiles > (1u << 30) ? (1 << 30) : (int)ntiles);
+    size_t ns = (size_t)wgrad_nsplit(pairs, ntiles > (1u << 30) ? (1 << 30) : (int)ntiles, (size_t)taps * Ck * Cn);
     return total * ns;
 }
 

@@ -140,8 +140,12 @@ extern "C" int sgx_axpby_dev(const void* a, const void* b, void* out, const floa
 // (left / centre / right pixel; the neighbours are L1 hits of the adjacent lanes' centres) give the horizontal sum,
 // three consecutive horizontal sums give one output row: 3.75 loads per output vector instead of 9.
 #define BLUR_ROWS 8
-template <typename T>
-__global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+// MODE 0: y = blur(x)            1: y = blur(lrelu(x))            2: y = blur(x) * slope(z)            3: y = blur(x * slope(z))
+// 1..3 are the forward, backward and double-backward of "LeakyReLU then blur" (discriminator block: conv0 -> act -> blur)
+// with the activation folded into the blur pass: no separate activation-backward pass over the tensor.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, const T* __restrict__ z, T* __restrict__ y, int B, int H,
+                                                      int W, int C) {
     constexpr int VE = VecTraits<T>::VE;
     const int cv = C / VE;
     const int strips = (H + BLUR_ROWS - 1) / BLUR_ROWS;
@@ -154,8 +158,20 @@ __global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, T
         const int b = (int)(p / strips);
         const int h0 = sidx * BLUR_ROWS;
         const bool hasl = w > 0, hasr = w + 1 < W;
-        const T* col = x + (((size_t)b * H * W + w) * cv + c) * VE;          // (b, row 0, w, c)
+        const size_t col = (((size_t)b * H * W + w) * cv + c) * VE;          // (b, row 0, w, c)
         const size_t rstride = (size_t)W * cv * VE;
+        auto fetch = [&](size_t off, float (&v)[VE]) {                       // one input vector, with the mode's pre-op
+            VecTraits<T>::load(x + off, v);
+            if (MODE == 1) {
+#pragma unroll
+                for (int j = 0; j < VE; ++j) v[j] = lrelu(v[j]);
+            } else if (MODE == 3) {
+                float m[VE];
+                VecTraits<T>::load(z + off, m);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) v[j] *= lrelu_slope(m[j]);
+            }
+        };
         float ha[VE], hb[VE], hc[VE];                                         // horizontal sums of rows r-2, r-1, r
 #pragma unroll
         for (int j = 0; j < VE; ++j) { ha[j] = 0.f; hb[j] = 0.f; }
@@ -163,11 +179,11 @@ __global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, T
         for (int k = 0; k < BLUR_ROWS + 2; ++k) {
             const int r = h0 - 1 + k;                                         // input row
             if ((unsigned)r < (unsigned)H) {
-                const T* src = col + (size_t)r * rstride;
+                const size_t src = col + (size_t)r * rstride;
                 float l[VE], m[VE], rr[VE];
-                VecTraits<T>::load(src, m);
-                if (hasl) VecTraits<T>::load(src - cv * VE, l);
-                if (hasr) VecTraits<T>::load(src + cv * VE, rr);
+                fetch(src, m);
+                if (hasl) fetch(src - cv * VE, l);
+                if (hasr) fetch(src + cv * VE, rr);
 #pragma unroll
                 for (int j = 0; j < VE; ++j) hc[j] = (hasl ? l[j] : 0.f) + 2.f * m[j] + (hasr ? rr[j] : 0.f);
             } else {
@@ -177,10 +193,17 @@ __global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, T
             if (k >= 2) {
                 const int ro = r - 1;                                         // output row
                 if (ro < H) {
+                    const size_t dst = (((size_t)b * H + ro) * W + w) * cv * VE + c * VE;
                     float o[VE];
 #pragma unroll
                     for (int j = 0; j < VE; ++j) o[j] = (ha[j] + 2.f * hb[j] + hc[j]) * (1.f / 16.f);
-                    VecTraits<T>::store(y + (((size_t)b * H + ro) * W + w) * cv * VE + c * VE, o);
+                    if (MODE == 2) {
+                        float m[VE];
+                        VecTraits<T>::load(z + dst, m);
+#pragma unroll
+                        for (int j = 0; j < VE; ++j) o[j] *= lrelu_slope(m[j]);
+                    }
+                    VecTraits<T>::store(y + dst, o);
                 }
             }
 #pragma unroll
@@ -188,18 +211,30 @@ __global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, T
         }
     }
 }
-extern "C" int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    SGX_NOTE(0.0, 2.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * C, "blur B%d %dx%d C%d", B, H, W, C);
-    if (dtype == SGX_F32) {
-        SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "blur: C %% 4");
-        hipLaunchKernelGGL(blur3x3_kernel<float>, dim3(grid_for((size_t)B * ((H + BLUR_ROWS - 1) / BLUR_ROWS) * W * C / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C);
-    } else {
-        SGX_REQUIRE(C % 8 == 0, SGX_EUNSUPPORTED, "blur: C %% 8");
-        hipLaunchKernelGGL(blur3x3_kernel<bf16_t>, dim3(grid_for((size_t)B * ((H + BLUR_ROWS - 1) / BLUR_ROWS) * W * C / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+template <typename T>
+static void blur_launch(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, hipStream_t st) {
+    constexpr int VE = VecTraits<T>::VE;
+    const dim3 grid(grid_for((size_t)B * ((H + BLUR_ROWS - 1) / BLUR_ROWS) * W * C / VE)), block(256);
+    const T* xp = (const T*)x; const T* zp = (const T*)z; T* yp = (T*)y;
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((blur3x3_kernel<T, 0>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        case 1: hipLaunchKernelGGL((blur3x3_kernel<T, 1>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        case 2: hipLaunchKernelGGL((blur3x3_kernel<T, 2>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        default: hipLaunchKernelGGL((blur3x3_kernel<T, 3>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
     }
+}
+extern "C" int sgx_blur3x3_act(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SGX_REQUIRE(mode >= 0 && mode <= 3 && (mode < 2 || z), SGX_EINVAL, "blur3x3_act: mode %d", mode);
+    SGX_REQUIRE(dtype == SGX_F32 ? C % 4 == 0 : C % 8 == 0, SGX_EUNSUPPORTED, "blur: C=%d", C);
+    SGX_NOTE(0.0, (mode >= 2 ? 3.0 : 2.0) * (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * C, "blur%d B%d %dx%d C%d", mode, B, H, W, C);
+    if (dtype == SGX_F32) blur_launch<float>(x, z, y, B, H, W, C, mode, st);
+    else blur_launch<bf16_t>(x, z, y, B, H, W, C, mode, st);
     SGX_LAUNCH_CHECK("blur3x3");
     return 0;
+}
+extern "C" int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+    return sgx_blur3x3_act(x, nullptr, y, B, H, W, C, 0, dtype, stream);
 }
 
 // ---------------------------------------------------------------- 2x2 pooling / nearest upsample.  C generic (RGB has C=3):

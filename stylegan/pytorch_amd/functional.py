@@ -434,6 +434,57 @@ class BlurFn(Function):
         return BlurFn.apply(g)
 
 
+def _blur_act(x, z, mode):
+    x = _c(x)
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    N.check(N.lib().sgx_blur3x3_act(N.ptr(x), None if z is None else N.ptr(z), N.ptr(y), B, H, W, C, mode, N.dt(x), N.stream()), "sgx_blur3x3_act")
+    return y
+
+
+class ActBlurFn(Function):
+    """blur(lrelu(z)): the discriminator block's activation folded into its blur pass (one kernel forward, one backward)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        z = _c(z)
+        ctx.save_for_backward(z)
+        return _blur_act(z, None, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        return BlurMaskFn.apply(g, z)
+
+
+class BlurMaskFn(Function):
+    """blur(g) * slope(z): backward of ActBlurFn.  Linear in g; z only selects the slope."""
+
+    @staticmethod
+    def forward(ctx, g, z):
+        ctx.save_for_backward(z)
+        return _blur_act(g, z, 2)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (z,) = ctx.saved_tensors
+        return MaskBlurFn.apply(gg, z), None
+
+
+class MaskBlurFn(Function):
+    """blur(g * slope(z)): adjoint of BlurMaskFn in g (the blur is self-adjoint)."""
+
+    @staticmethod
+    def forward(ctx, g, z):
+        ctx.save_for_backward(z)
+        return _blur_act(g, z, 3)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (z,) = ctx.saved_tensors
+        return BlurMaskFn.apply(gg, z), None
+
+
 class Pool2Fn(Function):
     """scale * (2x2 block sum); adjoint = scale * nearest-up."""
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "sgx_axpby": (I, [P, P, P, F, F, Z, I, P]),
     "sgx_axpby_dev": (I, [P, P, P, P, P, Z, I, P]),
     "sgx_blur3x3": (I, [P, P, I, I, I, I, I, P]),
+    "sgx_blur3x3_act": (I, [P, P, P, I, I, I, I, I, I, P]),
     "sgx_pool2": (I, [P, P, I, I, I, I, F, I, P]),
     "sgx_up2": (I, [P, P, I, I, I, I, F, I, P]),
     "sgx_colsum_ws_bytes": (Z, [Z, I]),

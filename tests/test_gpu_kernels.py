@@ -392,3 +392,36 @@ def test_prepack_rebuilds_all_stale_packs_in_one_launch():
     wq = (ws[0].detach() * 0.07).bfloat16().float()
     gref = TF.conv_transpose2d(torch.ones(2, 32, 16, 16, device=DEV), wq, padding=1).permute(0, 2, 3, 1)
     assert_close(gx, gref, 1e-2, "data gradient after batched re-pack")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_act_blur_first_and_second_order(dt):
+    """blur(lrelu(z)) as one op: forward, backward and the double backward the R1 term needs, vs torch fp32."""
+    from stylegan.pytorch_amd import functional as F
+    torch.manual_seed(8)
+    B, H, C = 2, 24, 32
+    z = torch.randn(B, H, H, C, device=DEV).to(dt).requires_grad_(True)
+    k = torch.tensor([1., 2., 1.], device=DEV); k = (k[:, None] * k[None, :] / 16.0)[None, None].repeat(C, 1, 1, 1)
+
+    def ref(zz):
+        a = TF.leaky_relu(zz.float().permute(0, 3, 1, 2), 0.2)
+        return TF.conv2d(a, k, padding=1, groups=C).permute(0, 2, 3, 1)
+
+    y = F.ActBlurFn.apply(z)
+    zr = z.detach().float().requires_grad_(True)
+    yr = ref(zr)
+    tol = 1e-5 if dt == torch.float32 else 8e-3
+    assert_close(y, yr, tol, "act_blur forward")
+    g = torch.randn_like(y)
+    (gz,) = torch.autograd.grad(y, z, g, create_graph=True)
+    (gzr,) = torch.autograd.grad(yr, zr, g.float(), create_graph=True)
+    assert_close(gz, gzr, tol, "act_blur backward")
+    # second order: d/dg of <gz, v> (the path R1 differentiates: linear in g)
+    v = torch.randn_like(gz)
+    gg = g.clone().requires_grad_(True)
+    (gz2,) = torch.autograd.grad(F.ActBlurFn.apply(z), z, gg, create_graph=True)
+    (dg,) = torch.autograd.grad(gz2, gg, v)
+    ggr = g.float().clone().requires_grad_(True)
+    (gz2r,) = torch.autograd.grad(ref(zr), zr, ggr, create_graph=True)
+    (dgr,) = torch.autograd.grad(gz2r, ggr, v.float())
+    assert_close(dg, dgr, tol, "act_blur double backward")
