@@ -182,6 +182,16 @@ int sgx_scale_dev_f32(const float* x, const float* s, float alpha, float* out, s
 size_t sgx_gemm_ws_bytes(int M, int N, int K);
 int sgx_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, int ta, int tb, float alpha,
                  void* ws, size_t ws_bytes, void* stream);
+/* EqualizedLinear (models/CustomLayers.py:64-103) of the mapping network and the style affines, three launches:
+ *   sgx_linear_fwd      : y[B][N] = act(w_mul * x[B][K] W[N][K]^T + b_mul * bias)        (bias nullable)
+ *   sgx_linear_bwd_data : gx[B][K] = w_mul * gz W,  gz = gy * slope(y_act) (y_act nullable: no activation)
+ *   sgx_linear_bwd_param: dW[N][K] = w_mul * gz^T x,  db[N] = b_mul * sum_b gz            (db nullable)           */
+int sgx_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int N, int K, float w_mul, float b_mul,
+                   int act, void* stream);
+int sgx_linear_bwd_data(const float* gy, const float* y_act, const float* w, float* gx, int B, int N, int K, float w_mul,
+                        void* stream);
+int sgx_linear_bwd_param(const float* gy, const float* y_act, const float* x, float* dw, float* db, int B, int N, int K, float w_mul,
+                         float b_mul, void* stream);
 
 /* ---------------------------------------------------------------- optimizer step (multi-tensor, fp32)
  * torch.optim.Adam step (models/GAN.py:529-533, 616-618, 652) over n tensors described by DEVICE arrays of

@@ -28,6 +28,7 @@ class InputBlock(nn.Module):
             self.bias = nn.Parameter(torch.ones(nf))
         else:
             self.dense = EqualizedLinear(dlatent_size, nf * 16, gain=gain / 4, use_wscale=use_wscale)
+            self.dense.first_order_only = True
         self.epi1 = LayerEpilogue(nf, dlatent_size, use_wscale, use_noise, use_pixel_norm, use_instance_norm,
                                   use_styles, activation_layer)
         self.conv = EqualizedConv2d(nf, nf, 3, gain=gain, use_wscale=use_wscale)

@@ -112,6 +112,10 @@ class Downscale2d(nn.Module):
 class EqualizedLinear(nn.Module):
     """Linear layer with equalized learning rate -- reference models/CustomLayers.py:79-103."""
 
+    # True (set by the generator's modules): nothing differentiates twice through this layer, so it runs as the fused
+    # three-launch LinearFn; False: the differentiable composite (the discriminator head sits under the R1 double backward)
+    first_order_only = False
+
     def __init__(self, input_size, output_size, gain=2 ** 0.5, use_wscale=False, lrmul=1, bias=True):
         super().__init__()
         he_std = gain * input_size ** (-0.5)
@@ -133,6 +137,8 @@ class EqualizedLinear(nn.Module):
         """``act`` fuses the LeakyReLU that follows the layer in the mapping network / D head; ``weight``
         substitutes a re-ordered view of the weight (D dense0 consumes NHWC-flattened features)."""
         w = self.weight if weight is None else weight
+        if self.first_order_only and x.dim() == 2:
+            return F.linear_fused(x.float(), w, self.bias, self.w_mul, self.b_mul, act)
         return F.linear(x.float(), w, self.bias, self.w_mul, self.b_mul, act)
 
 
@@ -243,6 +249,7 @@ class StyleMod(nn.Module):
     def __init__(self, latent_size, channels, use_wscale):
         super().__init__()
         self.lin = EqualizedLinear(latent_size, channels * 2, gain=1.0, use_wscale=use_wscale)
+        self.lin.first_order_only = True
 
     def style(self, latent):
         return self.lin(latent)                                           # [B, 2C] fp32

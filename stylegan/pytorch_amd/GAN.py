@@ -108,6 +108,9 @@ class GMapping(nn.Module):
             layers.append(('dense{:d}_act'.format(layer_idx), act))
         self.map = nn.Sequential(OrderedDict(layers))
         self.mapping_layers = mapping_layers
+        for m in self.map.modules():
+            if isinstance(m, EqualizedLinear):
+                m.first_order_only = True                 # fused three-launch linear (no double backward reaches G)
 
     def forward(self, x):
         x = x.float()
@@ -225,15 +228,20 @@ class Generator(nn.Module):
         if self.conditional:
             assert labels_in is not None, "Conditional discriminatin requires labels"
             latents_in = torch.cat([latents_in, self.class_embedding(labels_in)], 1)
-        dlatents_in = self.g_mapping(latents_in)
+        mixing = self.training and self.style_mixing_prob is not None and self.style_mixing_prob > 0
+        if mixing:
+            # host RNG (CPU randn first, then the mixing coin and cutoff: models/GAN.py:282-287) -- or the values a
+            # captured-step wrapper drew in that same order and staged in static device tensors.  The mapping network is
+            # row-wise, so both latent sets go through it as ONE batch of 2B rows (half the launches, same rows).
+            latents2, mixing_cutoff = self._mixing_override or self.draw_mixing(latents_in.shape, depth, latents_in.device)
+            both = self.g_mapping(torch.cat([latents_in, latents2.to(latents_in.dtype)], 0))
+            dlatents_in, dlatents2 = both[:latents_in.shape[0]], both[latents_in.shape[0]:]
+        else:
+            dlatents_in = self.g_mapping(latents_in)
         if self.training:
             if self.truncation is not None:
                 self.truncation.update(dlatents_in[0, 0].detach())                       # sample 0 only (:278)
-            if self.style_mixing_prob is not None and self.style_mixing_prob > 0:
-                # host RNG (CPU randn first, then the mixing coin and cutoff: models/GAN.py:282-287) -- or the values a
-                # captured-step wrapper drew in that same order and staged in static device tensors
-                latents2, mixing_cutoff = self._mixing_override or self.draw_mixing(latents_in.shape, depth, latents_in.device)
-                dlatents2 = self.g_mapping(latents2)
+            if mixing:
                 layer_idx = torch.arange(self.num_layers, device=latents_in.device).view(1, -1, 1)
                 dlatents_in = torch.where(layer_idx < mixing_cutoff, dlatents_in, dlatents2)
             if self.truncation is not None:

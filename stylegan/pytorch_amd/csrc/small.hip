@@ -186,8 +186,14 @@ extern "C" int sgx_mbstd_bwd2(const void* ggx, const void* dy, const void* x, vo
 // C[M][N] = alpha * op(A)[M][K] * op(B)[K][N].  One 16x16 output tile per block; the block's 4 waves split K and
 // reduce through LDS (fixed order: deterministic).  Operand fragments are read straight from global memory: these
 // GEMMs have M = batch (4..64) and are weight-bandwidth/latency bound.
+// Optional fusions for the EqualizedLinear layers (mapping network, style affines):
+//   amask  : A is read as A * slope(amask) (same layout as A) -- the LeakyReLU backward folded into the operand load
+//   bias   : C = act(alpha * A B + bscale * bias[column])      -- bias and LeakyReLU folded into the store
+//   colsum : colsum[row of C] = cscale * sum_k A'[row][k]      -- with A = gy^T this is the bias gradient, out of the
+//            same launch as the weight gradient (written by the blocks of column tile 0)
+struct GemmFuse { const float* amask; const float* bias; float bscale; int act; float* colsum; float cscale; };
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ Cm,
-                                                       int M, int N, int K, int ta, int tb, float alpha) {
+                                                       int M, int N, int K, int ta, int tb, float alpha, GemmFuse fu) {
     __shared__ float red[4][16][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, l15 = lane & 15;
     const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
@@ -213,9 +219,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             if (va && kk + 3 < ke) {
                 const float4 t = *reinterpret_cast<const float4*>(A + i * sa_i + kk);
                 a4[0] = t.x; a4[1] = t.y; a4[2] = t.z; a4[3] = t.w;
+                if (fu.amask) {
+                    const float4 m = *reinterpret_cast<const float4*>(fu.amask + i * sa_i + kk);
+                    a4[0] *= lrelu_slope(m.x); a4[1] *= lrelu_slope(m.y); a4[2] *= lrelu_slope(m.z); a4[3] *= lrelu_slope(m.w);
+                }
             } else {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) if (kk + s < ke) a4[s] = A[i * sa_i + (kk + s) * sa_k];
+                for (int s = 0; s < 4; ++s)
+                    if (kk + s < ke) {
+                        const size_t o = i * sa_i + (kk + s) * sa_k;
+                        a4[s] = A[o];
+                        if (fu.amask) a4[s] *= lrelu_slope(fu.amask[o]);
+                    }
             }
         }
         if (j < N) {
@@ -236,7 +251,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     if (threadIdx.x < 256 && i0 + r < M && j0 + c < N) {
         const float s = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
-        Cm[(size_t)(i0 + r) * N + j0 + c] = alpha * s;
+        float v = alpha * s;
+        if (fu.bias) v += fu.bscale * fu.bias[j0 + c];
+        if (fu.act == SGX_ACT_LRELU) v = lrelu(v);
+        Cm[(size_t)(i0 + r) * N + j0 + c] = v;
+    }
+    if (fu.colsum && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x < 16 && i0 + (int)threadIdx.x < M) {
+        const int row = i0 + threadIdx.x;                     // sum over the whole K axis of row `row` of op(A) (masked)
+        float t = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const size_t o = row * sa_i + k * sa_k;
+            t += fu.amask ? A[o] * lrelu_slope(fu.amask[o]) : A[o];
+        }
+        fu.colsum[row] = fu.cscale * t;
     }
 }
 __global__ void gemm_splitk_reduce(const float* __restrict__ part, float* __restrict__ Cm, int MN, int splits, float alpha) {
@@ -259,23 +286,46 @@ extern "C" size_t sgx_gemm_ws_bytes(int M, int N, int K) {
     const int s = gemm_splits(M, N, K);
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
-extern "C" int sgx_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, int ta, int tb, float alpha, void* ws,
-                            size_t ws_bytes, void* stream) {
+static int gemm_launch(const float* A, const float* Bm, float* C, int M, int N, int K, int ta, int tb, float alpha, GemmFuse fu, void* ws,
+                       size_t ws_bytes, hipStream_t st) {
     SGX_REQUIRE(M > 0 && N > 0 && K > 0, SGX_EINVAL, "gemm: bad shape %d %d %d", M, N, K);
-    hipStream_t st = (hipStream_t)stream;
     int splits = gemm_splits(M, N, K);
-    if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float))) splits = 1;   // no workspace: plain path
-    SGX_NOTE(2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N), "gemm %dx%dx%d t%d%d", M, N, K, ta, tb);
+    if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float) || fu.bias || fu.act || fu.colsum)) splits = 1;
+    SGX_NOTE(2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N), "gemm %dx%dx%d t%d%d%s", M, N, K, ta, tb,
+             fu.amask || fu.bias || fu.colsum ? " fused" : "");
     if (splits == 1) {
-        hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16, 1), dim3(256), 0, st, A, Bm, C, M, N, K, ta, tb, alpha);
+        hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16, 1), dim3(256), 0, st, A, Bm, C, M, N, K, ta, tb, alpha, fu);
         SGX_LAUNCH_CHECK("gemm_f32");
         return 0;
     }
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16, splits), dim3(256), 0, st, A, Bm, (float*)ws, M, N, K, ta, tb, 1.0f);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16, splits), dim3(256), 0, st, A, Bm, (float*)ws, M, N, K, ta, tb, 1.0f, fu);
     SGX_LAUNCH_CHECK("gemm_f32");
     hipLaunchKernelGGL(gemm_splitk_reduce, dim3((M * N + 255) / 256), dim3(256), 0, st, (const float*)ws, C, M * N, splits, alpha);
     SGX_LAUNCH_CHECK("gemm_splitk_reduce");
     return 0;
+}
+extern "C" int sgx_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, int ta, int tb, float alpha, void* ws,
+                            size_t ws_bytes, void* stream) {
+    return gemm_launch(A, Bm, C, M, N, K, ta, tb, alpha, GemmFuse{nullptr, nullptr, 0.f, SGX_ACT_NONE, nullptr, 0.f}, ws, ws_bytes,
+                       (hipStream_t)stream);
+}
+// EqualizedLinear (models/CustomLayers.py:64-103) as three launches instead of nine:
+//   forward : y[B][N] = act(w_mul * x[B][K] W[N][K]^T + b_mul * bias)
+//   backward: gz = gy * slope(y) (if act) folded into the operand loads of both
+//             gx[B][K] = w_mul * gz W        and        dW[N][K] = w_mul * gz^T x,  db[N] = b_mul * sum_b gz
+extern "C" int sgx_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int N, int K, float w_mul, float b_mul,
+                              int act, void* stream) {
+    return gemm_launch(x, w, y, B, N, K, 0, 1, w_mul, GemmFuse{nullptr, bias, b_mul, act, nullptr, 0.f}, nullptr, 0, (hipStream_t)stream);
+}
+extern "C" int sgx_linear_bwd_data(const float* gy, const float* y_act, const float* w, float* gx, int B, int N, int K, float w_mul,
+                                   void* stream) {
+    return gemm_launch(gy, w, gx, B, K, N, 0, 0, w_mul, GemmFuse{y_act, nullptr, 0.f, SGX_ACT_NONE, nullptr, 0.f}, nullptr, 0,
+                       (hipStream_t)stream);
+}
+extern "C" int sgx_linear_bwd_param(const float* gy, const float* y_act, const float* x, float* dw, float* db, int B, int N, int K,
+                                    float w_mul, float b_mul, void* stream) {
+    return gemm_launch(gy, x, dw, N, K, B, 1, 0, w_mul, GemmFuse{y_act, nullptr, 0.f, SGX_ACT_NONE, db, b_mul}, nullptr, 0,
+                       (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------- R1 penalty head: out[0] = sum(x^2)   (models/Losses.py:210)

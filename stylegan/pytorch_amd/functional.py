@@ -784,6 +784,51 @@ class MatMulFn(Function):
 
 
 # ---------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """EqualizedLinear with everything fused: one launch forward (GEMM + bias + LeakyReLU), two backward (data gradient;
+    weight gradient + bias gradient), the activation backward folded into their operand loads.  First order only: used
+    by the generator's mapping network and style affines, which no double backward reaches (the discriminator's dense
+    layers sit under R1 and keep the differentiable composite ``linear``)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w_mul, b_mul, act):
+        x, weight = _c(x), _c(weight)
+        assert x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
+        B, K = x.shape
+        Nn = weight.shape[0]
+        assert weight.shape[1] == K
+        y = torch.empty((B, Nn), dtype=torch.float32, device=x.device)
+        N.check(N.lib().sgx_linear_fwd(N.ptr(x), N.ptr(weight), None if bias is None else N.ptr(_c(bias.detach())), N.ptr(y), B, Nn, K,
+                                       float(w_mul), float(b_mul), int(act), N.stream()), "sgx_linear_fwd")
+        ctx.cfg = (float(w_mul), float(b_mul), int(act), bias is not None)
+        ctx.save_for_backward(x, weight, y if act else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        w_mul, b_mul, act, has_bias = ctx.cfg
+        gy = _c(gy)
+        B, K = x.shape
+        Nn = weight.shape[0]
+        L = N.lib()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            N.check(L.sgx_linear_bwd_data(N.ptr(gy), N.ptr(y), N.ptr(weight), N.ptr(gx), B, Nn, K, w_mul, N.stream()), "sgx_linear_bwd_data")
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            gw = torch.empty_like(weight)
+            gb = torch.empty((Nn,), dtype=torch.float32, device=x.device) if has_bias else None
+            N.check(L.sgx_linear_bwd_param(N.ptr(gy), N.ptr(y), N.ptr(x), N.ptr(gw), N.ptr(gb), B, Nn, K, w_mul, b_mul, N.stream()),
+                    "sgx_linear_bwd_param")
+        return gx, gw, gb, None, None, None
+
+
+def linear_fused(x, weight, bias, w_mul, b_mul, act=N.ACT_NONE):
+    return LinearFn.apply(x, weight, bias, float(w_mul), float(b_mul), int(act))
+
+
 def linear(x, weight, bias, w_mul, b_mul, act=N.ACT_NONE):
     """EqualizedLinear: F.linear(x, W*w_mul, b*b_mul) (+ LeakyReLU).  x fp32 [B, in]; parameters read in place."""
     y = MatMulFn.apply(x, weight, 0, 1, w_mul)

@@ -72,6 +72,9 @@ SIGNATURES = {
     "sgx_scale_dev_f32": (I, [P, P, F, P, Z, P]),
     "sgx_gemm_ws_bytes": (Z, [I, I, I]),
     "sgx_gemm_f32": (I, [P, P, P, I, I, I, I, I, F, P, Z, P]),
+    "sgx_linear_fwd": (I, [P, P, P, P, I, I, I, F, F, I, P]),
+    "sgx_linear_bwd_data": (I, [P, P, P, P, I, I, I, F, P]),
+    "sgx_linear_bwd_param": (I, [P, P, P, P, P, I, I, I, F, F, P]),
     "sgx_adam_multi": (I, [P, P, P, P, P, I, F, F, F, P, P, P, P]),
     "sgx_ema_multi": (I, [P, P, P, I, F, P]),
     "sgx_gradnorm_clip_coef": (I, [P, P, I, F, P, P, P]),

@@ -425,3 +425,26 @@ def test_act_blur_first_and_second_order(dt):
     (gz2r,) = torch.autograd.grad(ref(zr), zr, ggr, create_graph=True)
     (dgr,) = torch.autograd.grad(gz2r, ggr, v.float())
     assert_close(dg, dgr, tol, "act_blur double backward")
+
+
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("B,K,Nn", [(4, 512, 512), (8, 512, 1024), (4, 512, 32), (3, 100, 36)])
+def test_fused_linear_matches_torch(B, K, Nn, act):
+    from stylegan.pytorch_amd import functional as F
+    torch.manual_seed(B + K + Nn)
+    x = torch.randn(B, K, device=DEV, requires_grad=True)
+    w = torch.nn.Parameter(torch.randn(Nn, K, device=DEV)); b = torch.nn.Parameter(torch.randn(Nn, device=DEV))
+    w_mul, b_mul = 0.37, 0.5
+    y = F.linear_fused(x, w, b, w_mul, b_mul, act)
+    yr = TF.linear(x, w * w_mul, b * b_mul)
+    if act:
+        yr = TF.leaky_relu(yr, 0.2)
+    assert_close(y, yr, 1e-5, "linear fwd")
+    g = torch.randn_like(y)
+    got = torch.autograd.grad(y, (x, w, b), g)
+    ref = torch.autograd.grad(yr, (x, w, b), g)
+    for a, r, n in zip(got, ref, ("gx", "gw", "gb")):
+        assert_close(a, r, 1e-5, n)
+    y2 = F.linear_fused(x, w, None, w_mul, b_mul, act)                      # no bias
+    yr2 = TF.linear(x, w * w_mul)
+    assert_close(y2, TF.leaky_relu(yr2, 0.2) if act else yr2, 1e-5, "linear fwd no bias")
