@@ -153,10 +153,31 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    calib = None
     if graphs:                                               # setup, not warmup: two eager calls, then the capture
         for i in range(3):
             step(i)
         graphs = sg.use_graphs                               # a failed capture falls back to eager for good
+    if graphs and a.graphs == "auto":
+        # Launch mode by measurement: hipGraph replay removes the host from the loop but costs the ROCm runtime more per
+        # node than stream launches do; which one wins depends on whether the host keeps up with the GPU.  4 steps each.
+        def timed(n):
+            barrier(); torch.cuda.synchronize(); t = time.perf_counter()
+            for i in range(n):
+                step(i)
+            torch.cuda.synchronize(); barrier()
+            return (time.perf_counter() - t) / n * 1e3
+        sg.use_graphs = False
+        timed(1); t_eager = timed(4)
+        sg.use_graphs = True
+        timed(1); t_graph = timed(4)
+        if world > 1:                                        # one decision for all ranks
+            tt = torch.tensor([t_eager, t_graph], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            t_eager, t_graph = float(tt[0]), float(tt[1])
+        graphs = t_graph < t_eager
+        sg.use_graphs = graphs
+        calib = {"eager_ms_per_step": round(t_eager, 3), "graph_ms_per_step": round(t_graph, 3)}
     for i in range(a.warmup):
         step(i)
     # Roofline leg, part 1 (untimed): ONE surveyed step with the library's per-launch profiler on every kernel, to find
@@ -244,7 +265,7 @@ def main():
                                       f"alpha {a.alpha}, batch {B}/GPU, global batch {B * world}",
                           "global_batch": B * world, "parallelism": f"dp{world}"},
                "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
-               "hip_graphs": bool(graphs),
+               "hip_graphs": bool(graphs), "launch_mode_calibration": calib,
                "useful_tflops": value * cfg["flops_per_img"] / 1e12,
                "mfma_frac_of_step": value * cfg["flops_per_img"] / (PEAK[a.dtype] * world)}
         if roof:

@@ -18,6 +18,7 @@ from . import Losses
 from . import functional as F
 from .Blocks import DiscriminatorBlock, DiscriminatorTop, GSynthesisBlock, InputBlock
 from .CustomLayers import EqualizedConv2d, EqualizedLinear, PixelNormLayer, Truncation
+from . import native
 from .native import ACT_LRELU
 from .optim import FusedAdam, clip_and_step, ema_update
 
@@ -399,6 +400,16 @@ class StyleGAN:
         if self.dp is not None and self.gen.truncation is not None:
             self.dp.broadcast(self.gen.truncation.avg_latent, src=0)
 
+    def _param_stream(self):
+        """Side stream for the weight-gradient kernels (one per StyleGAN; they serialise among themselves)."""
+        import os
+        if os.environ.get("SGX_PARAM_STREAM", "1") in ("0", ""):          # A/B switch (profiling)
+            return None
+        st = self.__dict__.get("_param_side_stream")
+        if st is None:
+            st = self.__dict__["_param_side_stream"] = torch.cuda.Stream(device=self.device)
+        return st
+
     def _graphable(self, labels):
         # with data parallelism the all-reduce stays eager between two graphs; the W-average broadcast cannot
         return (self.use_graphs and labels is None and self.d_repeats == 1 and self.structure == "linear"
@@ -412,8 +423,12 @@ class StyleGAN:
         self._sync_w_avg()
         loss = self.loss.dis_loss(real_samples, fake_samples, depth, alpha)
         self.dis_optim.zero_grad()
-        with F.accumulate_param_grads():              # conv weight / bias gradients accumulate inside the finishing kernel
+        side = self._param_stream()
+        # conv weight / bias gradients accumulate inside the finishing kernel, on a side stream next to the backward chain
+        with F.accumulate_param_grads(), F.param_grad_stream(side):
             loss.backward()
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         return loss.detach()
 
     def _d_reduce(self):
@@ -437,8 +452,11 @@ class StyleGAN:
         try:
             loss = self.loss.gen_loss(real_samples, fake_samples, depth, alpha)
             self.gen_optim.zero_grad()
-            with F.accumulate_param_grads():
+            side = self._param_stream()
+            with F.accumulate_param_grads(), F.param_grad_stream(side):
                 loss.backward()
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
         finally:
             for p in d_params:
                 p.requires_grad_(True)
@@ -578,6 +596,7 @@ class _StepGraph:
                         self.graph = self.graph_update = None
                         sg.use_graphs = False
                         torch.cuda.synchronize()
+                        native.lib().sgx_clear_error()                             # the failed capture leaves a sticky error
                         out = DeferredLoss(self._body())
                         self.done.record()
                         self.calls += 1
@@ -607,6 +626,7 @@ class _StepGraph:
         sg = self.sg
         opt = sg.dis_optim if self.kind == "d" else sg.gen_optim
         opt.ensure_state()
+        native.reserve_capture_staging(1 << 20)                # descriptor tables are staged in pre-allocated pinned memory
         F.clear_pack_cache()                                   # the graph packs every weight it uses itself
         torch.cuda.synchronize()
         opt._capture_log = []

@@ -127,3 +127,4 @@ extern "C" int sgx_prof_get(int i, char* name, int name_cap, float* ms, double* 
 
 extern "C" int sgx_version(void) { return SGX_VERSION; }
 extern "C" const char* sgx_last_error(void) { return g_err; }
+extern "C" int sgx_clear_error(void) { g_err[0] = 0; return (int)hipGetLastError(); }   // also resets HIP's sticky last-error

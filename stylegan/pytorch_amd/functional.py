@@ -53,6 +53,39 @@ ADJ_GEO = {"S": "S", "D": "U", "U": "D", "UF": "D"}
 _PACKS = {}
 _WEIGHT_GEN = 0
 _ACCUM_PARAM_GRADS = False
+_PARAM_GRAD_STREAM = None
+
+
+@contextlib.contextmanager
+def param_grad_stream(stream):
+    """Inside: convolution weight/bias gradient kernels are issued on ``stream`` (a side stream) instead of the stream the
+    backward chain runs on.  Nothing in the backward chain depends on them, so they overlap with the data-gradient
+    convolutions of the earlier layers -- which matters exactly where kernels are launch/latency bound (the 4x4..64x64
+    layers at batch 4).  The caller joins ``stream`` before it reads the gradients.  Process-global, like the others."""
+    global _PARAM_GRAD_STREAM
+    prev, _PARAM_GRAD_STREAM = _PARAM_GRAD_STREAM, stream
+    try:
+        yield
+    finally:
+        _PARAM_GRAD_STREAM = prev
+
+
+def _param_grads(mode, adjoint, x, gy, weight, scale, want_bias, into):
+    """_wgrad_param on the side stream of ``param_grad_stream`` if one is set (with the allocator told about every tensor
+    the side stream touches), else inline."""
+    side = _PARAM_GRAD_STREAM
+    if side is None:
+        return _wgrad_param(mode, adjoint, x, gy, weight, scale, want_bias, into)
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)                                   # gy (and x) are complete on the backward stream
+    with torch.cuda.stream(side):
+        dW, db = _wgrad_param(mode, adjoint, x, gy, weight, scale, want_bias, into)
+    for t in (x, gy):
+        t.record_stream(side)
+    for t in (dW, db):
+        if t is not None:
+            t.record_stream(cur)
+    return dW, db
 
 
 @contextlib.contextmanager
@@ -247,7 +280,7 @@ class ConvFn(Function):
                 bias = ctx.bias_ref() if fuse_b else None
                 if fuse_b and (bias is None or not bias.is_leaf):
                     fuse_b, bias = False, None
-                dW, db = _wgrad_param(mode, adjoint, _c(x), gy, weight, scale, fuse_b, (weight.grad, bias.grad if fuse_b else None))
+                dW, db = _param_grads(mode, adjoint, _c(x), gy, weight, scale, fuse_b, (weight.grad, bias.grad if fuse_b else None))
                 if weight.grad is None:
                     weight.grad = dW
                 if fuse_b:

@@ -31,6 +31,7 @@ P, I, F, Z = c_void_p, c_int, c_float, c_size_t
 SIGNATURES = {
     "sgx_version": (I, []),
     "sgx_last_error": (ctypes.c_char_p, []),
+    "sgx_clear_error": (I, []),
     "sgx_conv3x3": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_down": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_up": (I, [P, P, P, I, I, I, I, I, I, P]),
@@ -151,18 +152,44 @@ def ptr(t):
 # Host -> device uploads of small descriptor tables: pinned staging + non_blocking, so the copy is stream ordered and the
 # host never waits for the GPU queue.  While a hipGraph is being captured the copy becomes a graph node that re-reads the
 # pinned buffer at every replay, so the buffer is kept alive (and may be rewritten in place before a replay).
-_CAPTURE_KEEP = []
+_ARENA = []                     # [pinned uint8 chunk, bytes used]: staging for copies captured into hipGraphs
 
 
 def capturing() -> bool:
     return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
-def upload(t: torch.Tensor, device):
-    """-> (device tensor, pinned staging tensor)."""
-    pinned = t.pin_memory()
+def reserve_capture_staging(nbytes: int = 1 << 20):
+    """Make sure ``nbytes`` of pinned staging exist BEFORE a capture starts: allocating pinned memory while a stream is
+    capturing (hipHostMalloc synchronises) invalidates the capture -- seen as a timing-dependent capture failure when
+    torch's pinned-block cache happened to be empty."""
     if capturing():
-        _CAPTURE_KEEP.append(pinned)
+        return
+    if not _ARENA or _ARENA[-1][0].numel() - _ARENA[-1][1] < nbytes:
+        _ARENA.append([torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory(), 0])
+
+
+def _arena_take(nbytes: int) -> torch.Tensor:
+    nbytes = (nbytes + 63) // 64 * 64
+    if not _ARENA or _ARENA[-1][0].numel() - _ARENA[-1][1] < nbytes:
+        if capturing():
+            raise SgxError("pinned staging exhausted during hipGraph capture (reserve_capture_staging() before capturing)")
+        reserve_capture_staging(nbytes)
+    chunk = _ARENA[-1]
+    out = chunk[0][chunk[1]:chunk[1] + nbytes]
+    chunk[1] += nbytes
+    return out
+
+
+def upload(t: torch.Tensor, device):
+    """-> (device tensor, pinned staging tensor).  Outside a capture: a pinned temporary from torch's cache.  Inside: a
+    slice of the pre-reserved arena that lives as long as the process (the graph re-reads it at every replay)."""
+    if capturing():
+        nbytes = t.numel() * t.element_size()
+        pinned = _arena_take(nbytes)[:nbytes].view(t.dtype).view(t.shape)
+        pinned.copy_(t)
+    else:
+        pinned = t.pin_memory()
     return pinned.to(device, non_blocking=True), pinned
 
 
