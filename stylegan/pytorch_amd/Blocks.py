@@ -15,6 +15,11 @@ def _is_lrelu02(act):
     return isinstance(act, nn.LeakyReLU) and abs(act.negative_slope - 0.2) < 1e-12
 
 
+def _lat(d, k):
+    """Layer k of a block's pair of dlatents: a [B, 2, D] tensor (reference signature) or a pair of [B, D] tensors."""
+    return d[k] if isinstance(d, (tuple, list)) else d[:, k]
+
+
 class InputBlock(nn.Module):
     """The 4x4 block: learned constant (+bias) -> epilogue -> conv3x3 -> epilogue -- reference models/Blocks.py:17-60."""
 
@@ -36,17 +41,17 @@ class InputBlock(nn.Module):
                                   use_styles, activation_layer)
 
     def forward_nhwc(self, dlatents_in_range, dtype=torch.float32):
-        b = dlatents_in_range.size(0)
+        b = _lat(dlatents_in_range, 0).size(0)
         if self.const_input_layer:
             # const [1,C,4,4] -> NHWC [B,4,4,C]; its bias is folded into the epilogue kernel (Blocks.py:51-52)
             x = self.const.permute(0, 2, 3, 1).to(dtype).expand(b, -1, -1, -1).contiguous()
             bias = self.bias
         else:
-            x = self.dense(dlatents_in_range[:, 0]).view(b, self.nf, 4, 4).permute(0, 2, 3, 1).to(dtype).contiguous()
+            x = self.dense(_lat(dlatents_in_range, 0)).view(b, self.nf, 4, 4).permute(0, 2, 3, 1).to(dtype).contiguous()
             bias = None
-        x = self.epi1.forward_nhwc(x, dlatents_in_range[:, 0], conv_bias=bias)
+        x = self.epi1.forward_nhwc(x, _lat(dlatents_in_range, 0), conv_bias=bias)
         x = self.conv.forward_nhwc(x, skip_bias=True)
-        return self.epi2.forward_nhwc(x, dlatents_in_range[:, 1], conv_bias=self.conv.scaled_bias())
+        return self.epi2.forward_nhwc(x, _lat(dlatents_in_range, 1), conv_bias=self.conv.scaled_bias())
 
     def forward(self, dlatents_in_range):
         return F.nchw_view(self.forward_nhwc(dlatents_in_range))
@@ -69,9 +74,9 @@ class GSynthesisBlock(nn.Module):
 
     def forward_nhwc(self, x, dlatents_in_range):
         x = self.conv0_up.forward_nhwc(x, skip_bias=True)                 # transposed conv + blur; bias folded below
-        x = self.epi1.forward_nhwc(x, dlatents_in_range[:, 0], conv_bias=self.conv0_up.scaled_bias())
+        x = self.epi1.forward_nhwc(x, _lat(dlatents_in_range, 0), conv_bias=self.conv0_up.scaled_bias())
         x = self.conv1.forward_nhwc(x, skip_bias=True)
-        return self.epi2.forward_nhwc(x, dlatents_in_range[:, 1], conv_bias=self.conv1.scaled_bias())
+        return self.epi2.forward_nhwc(x, _lat(dlatents_in_range, 1), conv_bias=self.conv1.scaled_bias())
 
     def forward(self, x, dlatents_in_range):
         return F.nchw_view(self.forward_nhwc(F.nhwc(x), dlatents_in_range))

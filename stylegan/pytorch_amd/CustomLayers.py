@@ -235,6 +235,8 @@ class NoiseLayer(nn.Module):
         if self.noise is not None:
             return self.noise
         b, h, w, _ = x_nhwc_shape
+        if F.NOISE_ARENA is not None:
+            return F.NOISE_ARENA.take(b, h, w)                      # slice of the forward's single randn
         return torch.randn(b, 1, h, w, device=device, dtype=torch.float32)
 
     def forward(self, x, noise=None):

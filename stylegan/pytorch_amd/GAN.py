@@ -163,23 +163,41 @@ class GSynthesis(nn.Module):
     def forward(self, dlatents_in, depth=0, alpha=0., labels_in=None):
         assert depth < self.depth, "Requested output depth cannot be produced"
         F.prepack(_conv_weights(self))                                      # all stale MFMA operand packs: one launch
-        dl = dlatents_in.float()
+        dl = F.SplitLayersFn.apply(dlatents_in.float())                     # L contiguous [B, D] tensors, one copy
         dt = self.act_dtype
+        nblocks = len(self.blocks) if self.structure == 'fixed' else depth
+        prev_arena = F.NOISE_ARENA
+        if any(m.noise is None for m in self._noise_layers()):
+            b = dlatents_in.shape[0]                                         # one randn for all the per-layer noise maps
+            F.NOISE_ARENA = F.NoiseArena(b * sum(2 * (4 << k) ** 2 for k in range(nblocks + 1)), dlatents_in.device)
+        try:
+            return self._forward(dl, dt, depth, alpha)
+        finally:
+            F.NOISE_ARENA = prev_arena
+
+    def _noise_layers(self):
+        ls = self.__dict__.get("_sgx_noise_layers")
+        if ls is None:
+            from .CustomLayers import NoiseLayer
+            ls = self.__dict__["_sgx_noise_layers"] = [m for m in self.modules() if isinstance(m, NoiseLayer)]
+        return ls
+
+    def _forward(self, dl, dt, depth, alpha):
         if self.structure == 'fixed':
-            x = self.init_block.forward_nhwc(dl[:, 0:2], dt)
+            x = self.init_block.forward_nhwc(dl[0:2], dt)
             for i, block in enumerate(self.blocks):
-                x = block.forward_nhwc(x, dl[:, 2 * (i + 1):2 * (i + 2)])
+                x = block.forward_nhwc(x, dl[2 * (i + 1):2 * (i + 2)])
             images = self.to_rgb[-1].forward_nhwc(x)
         elif self.structure == 'linear':
-            x = self.init_block.forward_nhwc(dl[:, 0:2], dt)
+            x = self.init_block.forward_nhwc(dl[0:2], dt)
             if depth > 0:
                 for i, block in enumerate(self.blocks[:depth - 1]):
-                    x = block.forward_nhwc(x, dl[:, 2 * (i + 1):2 * (i + 2)])
+                    x = block.forward_nhwc(x, dl[2 * (i + 1):2 * (i + 2)])
                 # reference GAN.py:199 applies to_rgb AFTER the nearest upsample; a 1x1 conv commutes with
                 # replication, so convert at the low resolution (4x fewer bytes) and upsample the RGB image.
                 residual = F.Up2Fn.apply(self.to_rgb[depth - 1].forward_nhwc(x), 1.0)
                 straight = self.to_rgb[depth].forward_nhwc(
-                    self.blocks[depth - 1].forward_nhwc(x, dl[:, 2 * depth:2 * (depth + 1)]))
+                    self.blocks[depth - 1].forward_nhwc(x, dl[2 * depth:2 * (depth + 1)]))
                 images = F.fade(straight, residual, alpha)                                        # GAN.py:202
             else:
                 images = self.to_rgb[0].forward_nhwc(x)

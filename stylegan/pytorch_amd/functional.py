@@ -862,6 +862,41 @@ def linear_fused(x, weight, bias, w_mul, b_mul, act=N.ACT_NONE):
     return LinearFn.apply(x, weight, bias, float(w_mul), float(b_mul), int(act))
 
 
+class SplitLayersFn(Function):
+    """dlatents [B, L, D] -> L contiguous [B, D] tensors (one transposing copy); backward: one stack.  Replaces L strided
+    slices (a copy kernel each) whose autograd backward is L zero-fills + L scatters + L-1 adds."""
+
+    @staticmethod
+    def forward(ctx, dl):
+        lm = dl.transpose(0, 1).contiguous()                      # [L, B, D]
+        ctx.L = lm.shape[0]
+        return tuple(lm.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next(g for g in grads if g is not None)
+        return torch.stack([g if g is not None else torch.zeros_like(ref) for g in grads], dim=1)
+
+
+class NoiseArena:
+    """One device randn per generator forward; the per-layer noise maps [B,1,H,W] are consecutive slices of it."""
+
+    def __init__(self, numel, device):
+        self.buf = torch.randn(int(numel), device=device, dtype=torch.float32)
+        self.off = 0
+
+    def take(self, b, h, w):
+        n = b * h * w
+        if self.off + n > self.buf.numel():
+            return torch.randn(b, 1, h, w, device=self.buf.device, dtype=torch.float32)
+        out = self.buf[self.off:self.off + n].view(b, 1, h, w)
+        self.off += n
+        return out
+
+
+NOISE_ARENA = None                  # set by GSynthesis.forward for the duration of one forward
+
+
 def linear(x, weight, bias, w_mul, b_mul, act=N.ACT_NONE):
     """EqualizedLinear: F.linear(x, W*w_mul, b*b_mul) (+ LeakyReLU).  x fp32 [B, in]; parameters read in place."""
     y = MatMulFn.apply(x, weight, 0, 1, w_mul)
