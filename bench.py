@@ -235,8 +235,17 @@ def main():
         else:
             bound, achieved, peak, unit = "hbm", nb / (ms * 1e-3) / 1e9, peak_b / 1e9, "GB/s"
         per_kernel = sorted(((k, v[0], v[1]) for k, v in agg.items()), key=lambda kv: -kv[1])
+        traffic, traffic_src = None, None
+        if a.config == "ffhq1024" and a.dtype == "bf16" and B == 4:
+            # HBM bytes per launch of this instantiation from the committed PMC passes of this same workload (rocprofv3
+            # cannot run inside the benchmark): tools/gpu_pmc.sh -> tools/pmc_traffic.py, corrected as the guide prescribes
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_bf16_b4.json")
+            if os.path.exists(pmc):
+                ent = json.load(open(pmc))["kernels"].get(dom_name)
+                if ent:
+                    traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic_bf16_b4.json"
         roof = {"bound": bound, "kernel": dom_name, "launches": len(recs), "avg_us": ms * 1e3 / len(recs),
-                "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak if (fl or nb) else None, "traffic": None,
+                "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak if (fl or nb) else None, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": nb / len(recs), "flops_per_launch": fl / len(recs),
                 "library_kernels_ms_per_step": round(sum(v[0] for v in agg.values()), 3),
                 "library_launches_per_step": len(survey),
