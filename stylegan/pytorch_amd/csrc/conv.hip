@@ -496,6 +496,8 @@ struct WgradArgs {
     const void* kside; const void* nside; float* out;     // out: [nsplit][NT][Cn][Ck] partials (or dw when nsplit==1)
     int B, Hk, Wk, Hn, Wn, Ck, Cn, tiles_x, tiles_y, ntiles;
     int want_bias;                                        // also emit column sums of the n side (the bias gradient)
+    // direct epilogue (one pixel split): the block folds / scales / re-lays-out its own tile and writes dW (and db) itself
+    int direct; float* dw; float* db; int O, I, mode, transposed, flip_t, accumulate; float scale;
 };
 
 template <typename T> struct WFrag;
@@ -694,6 +696,56 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             }
         }
     }
+    if (a.direct) {
+        // One pixel split: no partials.  The 4 waves hold different taps of the same NCH x KCH channel tile; gather them in
+        // LDS, then every thread produces parameter-layout outputs: the 3x3 fold of the 4x4 taps (stride-2 pair), the
+        // equalized-lr scale, the (o,i) orientation, optionally += into the existing gradient.  Same arithmetic and
+        // association as wgrad_finish_kernel with one split, so both paths give the same bits.
+        constexpr int KP = KCH + 1;
+        float* accl = reinterpret_cast<float*>(smem);                 // [NT][NCH][KP]
+        __syncthreads();                                              // operand tiles are dead
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int t = wave + 4 * i;
+            if (t < NT) {
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+                    for (int kk = 0; kk < KSUB; ++kk)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accl[(t * NCH + ns * 16 + q * 4 + r) * KP + kk * 16 + l15] = acc[i][ns][kk][r];
+            }
+        }
+        __syncthreads();
+        const float c = a.scale * (a.mode == SGX_PACK_D ? 0.25f : 1.f);
+        for (int idx = tid; idx < NCH * KCH * 9; idx += 256) {
+            const int tap = idx % 9, kl = (idx / 9) % KCH, nl = idx / (9 * KCH);
+            const int n = n0 + nl, k = kc0 + kl;
+            const int o = a.transposed ? k : n, i = a.transposed ? n : k;
+            if (i >= a.I || o >= a.O) continue;                       // padded channels carry no parameter
+            float v;
+            if (NT == 9) {
+                v = accl[((a.flip_t ? 8 - tap : tap) * NCH + nl) * KP + kl];
+            } else {
+                const int y = tap / 3, x = tap % 3;
+                const float* pp = accl + nl * KP + kl;
+                v = (pp[(y * 4 + x) * NCH * KP] + pp[(y * 4 + x + 1) * NCH * KP]) +
+                    (pp[((y + 1) * 4 + x) * NCH * KP] + pp[((y + 1) * 4 + x + 1) * NCH * KP]);
+            }
+            float* d = a.dw + ((size_t)o * a.I + i) * 9 + (a.mode == SGX_PACK_UF ? 8 - tap : tap);
+            *d = (a.accumulate & 1) ? *d + c * v : c * v;
+        }
+        if (do_bias && l15 == 0) {
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* d = a.db + n0 + ns * 16 + q * 4 + r;
+                    *d = (a.accumulate & 2) ? *d + bacc[ns][r] : bacc[ns][r];
+                }
+        }
+        return;
+    }
     // partial store: out[split][t][n][k]; lane holds rows n = q*4+r, column k = l15
     float* out = a.out + (size_t)blockIdx.y * ((size_t)NT * a.Cn * a.Ck + a.Cn);
     if (do_bias && l15 == 0) {                             // every column of bacc holds the same sums
@@ -802,6 +854,10 @@ static int wgrad_nsplit(int pairs, int ntiles, size_t elems_per_split) {
     const bool tiny = elems_per_split <= (size_t)16 * 32 * 32;
     const int target = env_target ? env_target : (tiny ? 2048 : 1024), cap = env_cap ? env_cap : (tiny ? 1024 : 512);
     int want = (target + pairs - 1) / pairs;
+    // big weights at low resolution (512x512 channels at 4^2..32^2): with >= 512 channel pairs the grid is full without
+    // pixel splits, and one split means no partials at all (the block writes the parameter gradient itself) -- partial
+    // traffic was 4-8x the weight size there.
+    if (!env_target && pairs >= 512 && ntiles <= 64) want = 1;
     if (want > cap) want = cap;
     if (want > ntiles) want = ntiles;
     if (want < 1) want = 1;
@@ -813,7 +869,9 @@ static int launch_wgrad(WgradArgs& a, void* ws, size_t ws_bytes, int* nsplit_out
     using F = WFrag<T>;
     constexpr int IS = Geo<GEO>::IS, TK = Geo<GEO>::TK, NT = TK * TK;
     constexpr int PH = (TH - 1) * IS + TK, PW = (TW - 1) * IS + TK, NI = BP / (TH * TW);
-    constexpr int LDS = BP * F::row_bytes(NSUB * 16) + NI * PH * PW * F::row_bytes(KSUB * 16);
+    constexpr int OPER = BP * F::row_bytes(NSUB * 16) + NI * PH * PW * F::row_bytes(KSUB * 16);
+    constexpr int FOLD = NT * NSUB * 16 * (KSUB * 16 + 1) * 4;          // direct epilogue: all taps of the tile, fp32
+    constexpr int LDS = OPER > FOLD ? OPER : FOLD;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     a.tiles_y = (a.Hn + TH - 1) / TH; a.tiles_x = (a.Wn + TW - 1) / TW;
     a.ntiles = ((a.B + NI - 1) / NI) * a.tiles_y * a.tiles_x;
@@ -824,6 +882,7 @@ static int launch_wgrad(WgradArgs& a, void* ws, size_t ws_bytes, int* nsplit_out
     if ((size_t)nsplit > fit) nsplit = (int)fit;
     SGX_REQUIRE(nsplit >= 1, SGX_EWORKSPACE, "wgrad: workspace too small (%zu bytes, need >= %zu)", ws_bytes, total * sizeof(float));
     a.out = static_cast<float*>(ws);
+    a.direct = (nsplit == 1 && a.dw != nullptr) ? 1 : 0;
     auto kern = wgrad_kernel<T, GEO, TH, TW, BP, NSUB, KSUB, TR>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -855,7 +914,9 @@ static int wgrad_ch(WgradArgs& a, void* ws, size_t wsb, int* ns, hipStream_t st)
         if (n32) return wgrad_tile<T, GEO, BP, 2, 1, TR>(a, ws, wsb, ns, st);
         return wgrad_tile<T, GEO, BP, 1, 1, TR>(a, ws, wsb, ns, st);
     }
-    if (n32 && k32) return wgrad_tile<T, GEO, BP, 2, 2, TR>(a, ws, wsb, ns, st);
+    const long npix = (long)a.B * a.Hn * a.Wn;
+    const bool lowres_big = npix <= 64L * BP && (long)(a.Cn / 32) * (a.Ck / 32) < 512 && (long)(a.Cn / 32) * (a.Ck / 16) >= 512;
+    if (n32 && k32 && !lowres_big) return wgrad_tile<T, GEO, BP, 2, 2, TR>(a, ws, wsb, ns, st);
     if (n32) return wgrad_tile<T, GEO, BP, 2, 1, TR>(a, ws, wsb, ns, st);
     if (k32) return wgrad_tile<T, GEO, BP, 1, 2, TR>(a, ws, wsb, ns, st);
     return wgrad_tile<T, GEO, BP, 1, 1, TR>(a, ws, wsb, ns, st);
@@ -890,13 +951,15 @@ extern "C" int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, floa
     const int Ip = adjoint ? Cdy : Cx;
     SGX_REQUIRE(!db || !adjoint, SGX_EINVAL, "wgrad3x3_param: bias gradient asked of the adjoint launch");
     SGX_REQUIRE((adjoint ? Cx : Cdy) == O && Ip >= I, SGX_EINVAL, "wgrad3x3_param: channel mismatch (Cx=%d Cdy=%d O=%d I=%d adj=%d)", Cx, Cdy, O, I, adjoint);
-    WgradArgs a{x, dy, nullptr, B, H, W, H, W, Cx, Cdy, 0, 0, 0, db ? 1 : 0};
+    WgradArgs a{x, dy, nullptr, B, H, W, H, W, Cx, Cdy, 0, 0, 0, db ? 1 : 0,
+                0, dW, db, O, I, SGX_PACK_S, adjoint, adjoint, accumulate, scale};
     SGX_NOTE(2.0 * 9 * Cx * Cdy * B * H * W, (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * (Cx + Cdy), "wgradS B%d %dx%d %dx%d", B, H, W, Cx, Cdy);
     int ns = 0, rc;
     if (dtype == SGX_F32) rc = wgrad_ch<float, G3X3, 128>(a, ws, ws_bytes, &ns, st);
     else if (dtype == SGX_BF16) rc = wgrad_use_tr() ? wgrad_ch<bf16_t, G3X3, 128, true>(a, ws, ws_bytes, &ns, st) : wgrad_ch<bf16_t, G3X3, 128>(a, ws, ws_bytes, &ns, st);
     else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad3x3_param: bad dtype"); }
     if (rc) return rc;
+    if (a.direct) return 0;
     return wgrad_finish(ws, dW, db, ns, O, I, Ip, SGX_PACK_S, adjoint, adjoint, scale, accumulate, st);
 }
 
@@ -910,13 +973,15 @@ extern "C" int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float*
     SGX_REQUIRE(!db || !transposed, SGX_EINVAL, "wgrad4x4s2_param: bias gradient only for mode D (dy is the coarse side)");
     SGX_REQUIRE(transposed ? (Ccoarse == I && Cfine == O) : (Ccoarse == O && Cfine == I), SGX_EINVAL,
                 "wgrad4x4s2_param: channel mismatch (fine %d coarse %d O %d I %d mode %d)", Cfine, Ccoarse, O, I, mode);
-    WgradArgs a{fine, coarse, nullptr, B, H, W, H / 2, W / 2, Cfine, Ccoarse, 0, 0, 0, db ? 1 : 0};
+    WgradArgs a{fine, coarse, nullptr, B, H, W, H / 2, W / 2, Cfine, Ccoarse, 0, 0, 0, db ? 1 : 0,
+                0, dW, db, O, I, mode, transposed, 0, accumulate, scale};
     SGX_NOTE(2.0 * 16 * Cfine * Ccoarse * B * (H / 2) * (W / 2), (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * (Cfine + Ccoarse / 4.0), "wgradD B%d fine%dx%d %dx%d", B, H, W, Cfine, Ccoarse);
     int ns = 0, rc;
     if (dtype == SGX_F32) rc = wgrad_ch<float, GDOWN, 64>(a, ws, ws_bytes, &ns, st);
     else if (dtype == SGX_BF16) rc = wgrad_use_tr() ? wgrad_ch<bf16_t, GDOWN, 64, true>(a, ws, ws_bytes, &ns, st) : wgrad_ch<bf16_t, GDOWN, 64>(a, ws, ws_bytes, &ns, st);
     else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad4x4s2_param: bad dtype"); }
     if (rc) return rc;
+    if (a.direct) return 0;
     return wgrad_finish(ws, dW, db, ns, O, I, I, mode, transposed, 0, scale, accumulate, st);
 }
 
