@@ -135,9 +135,9 @@ class DiscriminatorBlock(nn.Module):
     def forward_nhwc(self, x):
         z = self.conv0.forward_nhwc(x, act=ACT_NONE)                      # bias fused in the conv store; pre-activation
         if self.blur._is_121:
-            x = F.ActBlurFn.apply(z)                                      # LeakyReLU folded into the blur pass (both ways)
+            x = F.call(F.ActBlurFn, z)                                      # LeakyReLU folded into the blur pass (both ways)
         else:
-            x = self.blur.forward_nhwc(F.BiasActFn.apply(z, None, 1.0, ACT_LRELU))
+            x = self.blur.forward_nhwc(F.call(F.BiasActFn, z, None, 1.0, ACT_LRELU))
         return self.conv1_down.forward_nhwc(x, act=ACT_LRELU)
 
     def forward(self, x):

@@ -27,9 +27,9 @@ class PixelNormLayer(nn.Module):
     def forward(self, x):
         assert abs(self.epsilon - 1e-8) < 1e-20, "kernel is built for the reference's epsilon"
         if x.dim() == 2:
-            return F.PixelNormFn.apply(x)
+            return F.call(F.PixelNormFn, x)
         shape = x.shape                                         # [B, C, ...] -> rows of C
-        y = F.PixelNormFn.apply(x.movedim(1, -1).reshape(-1, shape[1]))
+        y = F.call(F.PixelNormFn, x.movedim(1, -1).reshape(-1, shape[1]))
         return y.reshape(shape[0], *shape[2:], shape[1]).movedim(-1, 1)
 
 
@@ -48,7 +48,7 @@ class Upscale2d(nn.Module):
         if factor == 1:
             return x * gain if gain != 1 else x
         assert factor == 2, "the kernel implements the factor-2 case the networks use"
-        return F.nchw_view(F.Up2Fn.apply(F.nhwc(x), float(gain)))
+        return F.nchw_view(F.call(F.Up2Fn, F.nhwc(x), float(gain)))
 
     def forward(self, x):
         return self.upscale2d(x, factor=self.factor, gain=self.gain)
@@ -77,9 +77,9 @@ class BlurLayer(nn.Module):
 
     def forward_nhwc(self, x):
         if self._is_121:
-            return F.BlurFn.apply(x)
+            return F.call(F.BlurFn, x)
         if self._is_box2:
-            return F.Pool2Fn.apply(x, 0.25)
+            return F.call(F.Pool2Fn, x, 0.25)
         raise NotImplementedError("BlurLayer: only the [1,2,1] blur and the 2x2 box (Downscale2d) are built")
 
     def forward(self, x):
@@ -102,7 +102,7 @@ class Downscale2d(nn.Module):
 
     def forward_nhwc(self, x):
         assert self.factor == 2, "the kernel implements the factor-2 case the networks use"
-        return F.Pool2Fn.apply(x, 0.25 * float(self.gain))
+        return F.call(F.Pool2Fn, x, 0.25 * float(self.gain))
 
     def forward(self, x):
         assert x.dim() == 4
@@ -190,12 +190,12 @@ class EqualizedConv2d(nn.Module):
         if self.kernel_size == 1:
             assert self.upscale is None and self.downscale is None and self.intermediate is None
             if cin == 3 and x.shape[3] == 3:
-                y = F.RgbInFn.apply(x.float(), self.weight, bias, self.w_mul, out_dtype or torch.float32)
+                y = F.call(F.RgbInFn, x.float(), self.weight, bias, self.w_mul, out_dtype or torch.float32)
             elif cout == 3:
-                y = F.RgbOutFn.apply(x, self.weight, bias, self.w_mul)
+                y = F.call(F.RgbOutFn, x, self.weight, bias, self.w_mul)
             else:
                 raise NotImplementedError("1x1 EqualizedConv2d is built for the to_rgb / from_rgb layers (3 channels on one side)")
-            return F.BiasActFn.apply(y, None, 1.0, act) if act else y
+            return F.call(F.BiasActFn, y, None, 1.0, act) if act else y
         assert self.kernel_size == 3
         if self.upscale is not None:
             fused = min(x.shape[1], x.shape[2]) * 2 >= 128                # reference :143
@@ -203,7 +203,7 @@ class EqualizedConv2d(nn.Module):
             if self.intermediate is not None:
                 y = self.intermediate.forward_nhwc(y)
             if bias is not None or act:
-                y = F.BiasActFn.apply(y, bias, 1.0, act)                  # bias after the blur (:178-179)
+                y = F.call(F.BiasActFn, y, bias, 1.0, act)                  # bias after the blur (:178-179)
             return y
         if self.downscale is not None:
             assert self.intermediate is None                              # reference :167
@@ -211,7 +211,7 @@ class EqualizedConv2d(nn.Module):
         if self.intermediate is None:
             return F.conv(x, self.weight, bias, "S", self.w_mul, act, ipad=x.shape[3])
         y = self.intermediate.forward_nhwc(F.conv(x, self.weight, None, "S", self.w_mul))
-        return F.BiasActFn.apply(y, bias, 1.0, act) if (bias is not None or act) else y
+        return F.call(F.BiasActFn, y, bias, 1.0, act) if (bias is not None or act) else y
 
     def forward(self, x):
         if self.kernel_size == 1 and self.weight.shape[0] == 3:
@@ -289,7 +289,7 @@ class LayerEpilogue(nn.Module):
         noise_layer = self.top_epi.noise
         noise = noise_layer.sample(x.shape, x.device)
         style = self.style_mod.style(dlatents_in_slice)
-        return F.GEpilogueFn.apply(x, conv_bias, noise, noise_layer.weight, style)
+        return F.call(F.GEpilogueFn, x, conv_bias, noise, noise_layer.weight, style)
 
     def forward(self, x, dlatents_in_slice=None):
         return F.nchw_view(self.forward_nhwc(F.nhwc(x), dlatents_in_slice))
@@ -318,7 +318,7 @@ class StddevLayer(nn.Module):
         """[B,H,W,C] -> [B,H,W,C+MBSTD_CPAD]; channel C is the statistic, the rest is zero padding."""
         if self.group_size != 4 or self.num_new_features != 1:
             raise NotImplementedError("StddevLayer: the kernel implements group_size=4, num_new_features=1")
-        return F.MbstdFn.apply(x, x.shape[3] + MBSTD_CPAD)
+        return F.call(F.MbstdFn, x, x.shape[3] + MBSTD_CPAD)
 
     def forward(self, x):
         y = self.forward_nhwc(F.nhwc(x))

@@ -158,12 +158,12 @@ class GSynthesis(nn.Module):
             rgb_converters.append(EqualizedConv2d(channels, num_channels, 1, gain=1, use_wscale=use_wscale))
         self.blocks = nn.ModuleList(blocks)
         self.to_rgb = nn.ModuleList(rgb_converters)
-        self.temporaryUpsampler = lambda x: F.nchw_view(F.Up2Fn.apply(F.nhwc(x), 1.0))
+        self.temporaryUpsampler = lambda x: F.nchw_view(F.call(F.Up2Fn, F.nhwc(x), 1.0))
 
     def forward(self, dlatents_in, depth=0, alpha=0., labels_in=None):
         assert depth < self.depth, "Requested output depth cannot be produced"
         F.prepack(_conv_weights(self))                                      # all stale MFMA operand packs: one launch
-        dl = F.SplitLayersFn.apply(dlatents_in.float())                     # L contiguous [B, D] tensors, one copy
+        dl = F.call(F.SplitLayersFn, dlatents_in.float())                     # L contiguous [B, D] tensors, one copy
         dt = self.act_dtype
         nblocks = len(self.blocks) if self.structure == 'fixed' else depth
         prev_arena = F.NOISE_ARENA
@@ -195,7 +195,7 @@ class GSynthesis(nn.Module):
                     x = block.forward_nhwc(x, dl[2 * (i + 1):2 * (i + 2)])
                 # reference GAN.py:199 applies to_rgb AFTER the nearest upsample; a 1x1 conv commutes with
                 # replication, so convert at the low resolution (4x fewer bytes) and upsample the RGB image.
-                residual = F.Up2Fn.apply(self.to_rgb[depth - 1].forward_nhwc(x), 1.0)
+                residual = F.call(F.Up2Fn, self.to_rgb[depth - 1].forward_nhwc(x), 1.0)
                 straight = self.to_rgb[depth].forward_nhwc(
                     self.blocks[depth - 1].forward_nhwc(x, dl[2 * depth:2 * (depth + 1)]))
                 images = F.fade(straight, residual, alpha)                                        # GAN.py:202
@@ -304,7 +304,7 @@ class Discriminator(nn.Module):
                                             activation_layer=act)
         from_rgb.append(EqualizedConv2d(num_channels, nf(2), kernel_size=1, gain=gain, use_wscale=use_wscale))
         self.from_rgb = nn.ModuleList(from_rgb)
-        self.temporaryDownsampler = lambda x: F.nchw_view(F.Pool2Fn.apply(F.nhwc(x), 0.25))
+        self.temporaryDownsampler = lambda x: F.nchw_view(F.call(F.Pool2Fn, F.nhwc(x), 0.25))
 
     def forward(self, images_in, depth, alpha=1., labels_in=None):
         assert depth < self.depth, "Requested output depth cannot be produced"
@@ -317,7 +317,7 @@ class Discriminator(nn.Module):
                 x = block.forward_nhwc(x)
         elif self.structure == 'linear':
             if depth > 0:
-                residual = self.from_rgb[self.depth - depth].forward_nhwc(F.Pool2Fn.apply(img, 0.25), out_dtype=dt)
+                residual = self.from_rgb[self.depth - depth].forward_nhwc(F.call(F.Pool2Fn, img, 0.25), out_dtype=dt)
                 straight = self.blocks[self.depth - depth - 1].forward_nhwc(
                     self.from_rgb[self.depth - depth - 1].forward_nhwc(img, out_dtype=dt))
                 x = F.fade(straight, residual, alpha)                                      # GAN.py:427
@@ -402,9 +402,9 @@ class StyleGAN:
         x = F.nhwc(real_batch, torch.float32)
         levels = self.depth - depth - 1                         # AvgPool2d(2**levels) == levels x (2x2 mean)
         for _ in range(levels):
-            x = F.Pool2Fn.apply(x, 0.25)
+            x = F.call(F.Pool2Fn, x, 0.25)
         if depth > 0:
-            prior = F.Up2Fn.apply(F.Pool2Fn.apply(x, 0.25), 1.0)
+            prior = F.call(F.Up2Fn, F.call(F.Pool2Fn, x, 0.25), 1.0)
             x = F.fade(x, prior, alpha)
         else:
             x = F.fade(x, x, alpha)                                       # prior == current at depth 0 (:583-584)

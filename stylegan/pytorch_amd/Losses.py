@@ -69,7 +69,7 @@ class LogisticGAN(GANLoss):
             real_grads = torch.autograd.grad(outputs=real_logit, inputs=real_img,
                                              grad_outputs=torch.ones_like(real_logit),
                                              create_graph=True, retain_graph=True)[0]
-        return F.SumSqFn.apply(real_grads)            # SUM over batch and pixels (:210)
+        return F.call(F.SumSqFn, real_grads)            # SUM over batch and pixels (:210)
 
     def R1Penalty(self, real_img, height, alpha):
         real_img = real_img.detach().requires_grad_(True)

@@ -42,6 +42,29 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class _NoGradCtx:
+    """Stand-in for the autograd context when nothing needs a gradient (``call``)."""
+    needs_input_grad = (False,) * 16
+    saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+def call(fn, *args):
+    """``fn.apply(*args)`` -- or, when no gradient can flow (``torch.no_grad()``: the D-step generator forward; or no
+    input requires one), ``fn.forward`` directly: the kernels are launched without the ~10 us of autograd bookkeeping
+    per op that makes the eager step host-bound."""
+    if torch.is_grad_enabled():
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.requires_grad:
+                return fn.apply(*args)
+    return fn.forward(_NoGradCtx(), *args)
+
+
 # ---------------------------------------------------------------------------------------------------
 # packed-weight cache.  mode: 'S' plain 3x3 | 'D' fused down | 'U' fused up | 'UF' non-fused-up semantics.
 # One sgx_pack_weight launch per (parameter, version) produces both MFMA operand packs in the activation dtype;
@@ -308,7 +331,7 @@ class WgradFn(Function):
 
 
 def conv(x, weight, bias, mode, scale, act=N.ACT_NONE, ipad=None):
-    return ConvFn.apply(x, weight, bias, mode, float(scale), int(ipad if ipad is not None else weight.shape[1]), False, act)
+    return call(ConvFn, x, weight, bias, mode, float(scale), int(ipad if ipad is not None else weight.shape[1]), False, act)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -447,8 +470,8 @@ class FadeFn(Function):
 def fade(a, b, alpha):
     """alpha*a + (1-alpha)*b.  ``alpha``: python float, or a device fp32 tensor [alpha, 1-alpha] (graph replay)."""
     if isinstance(alpha, torch.Tensor):
-        return FadeFn.apply(a, b, alpha)
-    return AxpbyFn.apply(a, b, float(alpha), float(1 - alpha))
+        return call(FadeFn, a, b, alpha)
+    return call(AxpbyFn, a, b, float(alpha), float(1 - alpha))
 
 
 class BlurFn(Function):
@@ -859,7 +882,7 @@ class LinearFn(Function):
 
 
 def linear_fused(x, weight, bias, w_mul, b_mul, act=N.ACT_NONE):
-    return LinearFn.apply(x, weight, bias, float(w_mul), float(b_mul), int(act))
+    return call(LinearFn, x, weight, bias, float(w_mul), float(b_mul), int(act))
 
 
 class SplitLayersFn(Function):
@@ -899,10 +922,10 @@ NOISE_ARENA = None                  # set by GSynthesis.forward for the duration
 
 def linear(x, weight, bias, w_mul, b_mul, act=N.ACT_NONE):
     """EqualizedLinear: F.linear(x, W*w_mul, b*b_mul) (+ LeakyReLU).  x fp32 [B, in]; parameters read in place."""
-    y = MatMulFn.apply(x, weight, 0, 1, w_mul)
+    y = call(MatMulFn, x, weight, 0, 1, w_mul)
     if bias is None and act == N.ACT_NONE:
         return y
-    return BiasActFn.apply(y, bias, b_mul, act)
+    return call(BiasActFn, y, bias, b_mul, act)
 
 
 def nhwc(x_nchw, dtype=None):
