@@ -436,10 +436,20 @@ class StyleGAN:
     def _d_grads(self, noise, real_batch, depth, alpha, labels=None):
         """Discriminator half-iteration, part 1: losses and local gradients; returns the (device) loss."""
         real_samples = self.progressive_down_sampling(real_batch, depth, alpha)
-        with torch.no_grad():                         # the reference builds and drops this graph (.detach(), :607)
-            fake_samples = self.gen(noise, depth, alpha, labels)
-        self._sync_w_avg()
-        loss = self.loss.dis_loss(real_samples, fake_samples, depth, alpha)
+
+        def fake_samples():
+            self._wait_update("g")                    # data parallel: G's all-reduce + Adam + EMA may still be in flight
+            with torch.no_grad():                     # the reference builds and drops this graph (.detach(), :607)
+                out = self.gen(noise, depth, alpha, labels)
+            self._sync_w_avg()
+            return out
+
+        self._wait_update("d")
+        # LogisticGAN evaluates D(real) first and only then asks for the fakes (no host RNG is consumed in between, so the
+        # draws keep the reference's order): with data parallelism the generator update of the previous iteration overlaps
+        # the D(real) forward.  Other losses get the tensor up front.
+        lazy = isinstance(self.loss, Losses.LogisticGAN)
+        loss = self.loss.dis_loss(real_samples, fake_samples if lazy else fake_samples(), depth, alpha)
         self.dis_optim.zero_grad()
         side = self._param_stream()
         # conv weight / bias gradients accumulate inside the finishing kernel, on a side stream next to the backward chain
@@ -460,8 +470,10 @@ class StyleGAN:
         real_samples = None
         if not isinstance(self.loss, (Losses.LogisticGAN, Losses.HingeGAN)):
             real_samples = self.progressive_down_sampling(real_batch, depth, alpha)   # only the relativistic loss reads it
+        self._wait_update("g")
         fake_samples = self.gen(noise, depth, alpha, labels)
         self._sync_w_avg()
+        self._wait_update("d")                        # data parallel: D's all-reduce + Adam overlapped the G forward above
         # the reference also back-propagates into D's parameters here and discards the result at the next
         # dis_optim.zero_grad(); skipping those weight gradients changes no observable value
         d_params = [p for p in self.dis.parameters() if p.requires_grad]
@@ -489,19 +501,48 @@ class StyleGAN:
         if self.use_ema:
             self.ema_updater(self.gen_shadow, self.gen, self.ema_decay)
 
+    # Data parallel, eager mode: the gradient all-reduce and the parameter update of one network run on their own stream
+    # while the main stream already works on the part of the next half-iteration that does not read those parameters
+    # (D's update || the generator forward of the G step;  G's update + EMA || D(real) forward of the next D step).
+    # Whoever reads the parameters next waits for the event (`_wait_update`).  Gradient tensors stay alive until the next
+    # zero_grad of the same optimizer, which comes after that wait.
+    def _async_update(self, kind):
+        upd = self.__dict__.get("_update_stream")
+        if upd is None:
+            upd = self.__dict__["_update_stream"] = torch.cuda.Stream(device=self.device)
+        upd.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(upd):
+            (self._d_reduce if kind == "d" else self._g_reduce)()
+            (self._d_update if kind == "d" else self._g_update)()
+        ev = torch.cuda.Event()
+        ev.record(upd)
+        self.__dict__.setdefault("_pending_updates", {})[kind] = ev
+
+    def _wait_update(self, kind):
+        ev = self.__dict__.get("_pending_updates", {}).pop(kind, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def _d_body(self, noise, real_batch, depth, alpha, labels=None):
         loss = self._d_grads(noise, real_batch, depth, alpha, labels)
-        self._d_reduce()
-        self._d_update()
+        if self.dp is not None and not torch.cuda.is_current_stream_capturing():
+            self._async_update("d")
+        else:
+            self._d_reduce()
+            self._d_update()
         return loss
 
     def _g_body(self, noise, real_batch, depth, alpha, labels=None):
         loss = self._g_grads(noise, real_batch, depth, alpha, labels)
-        self._g_reduce()
-        self._g_update()
+        if self.dp is not None and not torch.cuda.is_current_stream_capturing():
+            self._async_update("g")
+        else:
+            self._g_reduce()
+            self._g_update()
         return loss
 
     def _graphed(self, kind, noise, real_batch, depth, alpha):
+        self._wait_update("d"); self._wait_update("g")          # leftovers of eager calls (the graphs update in line)
         key = (kind, int(depth), tuple(noise.shape), tuple(real_batch.shape), tuple(real_batch.stride()), real_batch.dtype)
         g = self._step_graphs.get(key)
         if g is None:

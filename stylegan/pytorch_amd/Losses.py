@@ -85,6 +85,8 @@ class LogisticGAN(GANLoss):
             r_preds = self.dis(real, height, alpha)
         else:
             r_preds = self.dis(real_samps, height, alpha)
+        if callable(fake_samps):                      # produced lazily, after D(real): see StyleGAN._d_grads
+            fake_samps = fake_samps()
         f_preds = self.dis(fake_samps, height, alpha)
         loss = (torch.mean(TF.softplus(f_preds)) + torch.mean(TF.softplus(-r_preds))) * self.mean_scale
         if r1_gamma != 0.0:

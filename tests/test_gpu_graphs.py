@@ -111,11 +111,15 @@ def test_data_parallel_graphs_split_around_the_all_reduce():
         lg, sgr, sg = run(True, torch.float32, 5, psi=-1.0, dp=DataParallelGroup())
         graphs = list(sg._step_graphs.values())
         assert len(graphs) == 2 and all(g.graph is not None and g.graph_update is not None for g in graphs)
-        for (d0, g0), (d1, g1) in zip(le, lg):
-            assert abs(d0 - d1) <= 2e-4 * abs(d0) and abs(g0 - g1) <= 2e-4 * abs(g0), (le, lg)
-        for part in ("gen", "dis", "shadow"):
-            for k, v in se[part].items():
-                assert k in SKIP or close(sgr[part][k], v, 5e-4), (part, k)
+        # eager with a process group: all-reduce + update run on their own stream, overlapped with the next half-iteration
+        la, sa, sga = run(False, torch.float32, 5, psi=-1.0, dp=DataParallelGroup())
+        assert "_update_stream" in sga.__dict__
+        for other_l, other_s in ((lg, sgr), (la, sa)):
+            for (d0, g0), (d1, g1) in zip(le, other_l):
+                assert abs(d0 - d1) <= 2e-4 * abs(d0) and abs(g0 - g1) <= 2e-4 * abs(g0), (le, other_l)
+            for part in ("gen", "dis", "shadow"):
+                for k, v in se[part].items():
+                    assert k in SKIP or close(other_s[part][k], v, 5e-4), (part, k)
     finally:
         dist.destroy_process_group()
 
