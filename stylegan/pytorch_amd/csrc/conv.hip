@@ -110,7 +110,8 @@ template <> struct Geo<GUP> { static constexpr int IS = 1, TK = 2, NCLS = 4; };
 #ifndef SGX_CONV_OCC_SMALL
 #define SGX_CONV_OCC_SMALL 3
 #endif
-constexpr int conv_min_waves(int tsize, int CT, int BP, int GEO) {
+constexpr int conv_min_waves(int tsize, int CT, int BP, int GEO, int KC) {
+    if (KC > 32) return 2;                                   // deep K-chunks: LDS allows two blocks per CU anyway
     if (CT * BP >= 1024 || GEO == GDOWN) return 1;
     if (tsize == 2 && CT * BP <= 256) return SGX_CONV_OCC_SMALL;
     return 2;
@@ -119,15 +120,21 @@ template <typename T, int KC, int GEO, int TH, int TW, int BP, int CT>
 // Register budget: two waves per SIMD (<= 256 VGPR+AGPR) except for the 64-channel x 256-pixel tile, whose prefetch
 // registers would spill at that bound -- and a spilled descriptor reload (scratch_load + s_waitcnt vmcnt) serialises
 // the whole global prefetch behind it (seen in the ISA), which is far worse than one wave per SIMD.
-__global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO)) void conv_kernel(ConvArgs a) {
-    using F = Frag<T, KC>;
+__global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) void conv_kernel(ConvArgs a) {
+    // bf16 K-chunks deeper than one MFMA k-step (KC = 64 / 128, the 512-channel layers at 4^2..16^2: 4x fewer
+    // load -> LDS -> barrier -> MFMA stages per tile, which is what bounds those launches) are staged as KC/32 PLANES, each
+    // laid out exactly like the KC = 32 tile (64-byte swizzled rows), so all fragment addressing stays as it is.
+    constexpr int FK = (sizeof(T) == 2 && KC > 32) ? 32 : KC;
+    constexpr int NPL = KC / FK;
+    using F = Frag<T, FK>;
     constexpr int IS = Geo<GEO>::IS, TK = Geo<GEO>::TK, NT = TK * TK;
     constexpr int PH = (TH - 1) * IS + TK, PW = (TW - 1) * IS + TK, PWP = F::pad_pw(PW, IS);
     constexpr int NI = BP / (TH * TW), SPW = BP / 64, BCO = CT * 16;
-    constexpr int VE = 16 / (int)sizeof(T), VPP = KC / VE;
+    constexpr int VE = 16 / (int)sizeof(T), VPP = KC / VE, VPR = FK / VE;
     constexpr int ROWI = F::rowb_in(IS), ROWW = F::rowb_w();
     constexpr bool SWI = F::swz_in(IS), SWW = F::swz_w();
-    constexpr int IN_BYTES = (NI * PH * PWP * ROWI + 15) / 16 * 16;
+    constexpr int IN_PLANE = (NI * PH * PWP * ROWI + 15) / 16 * 16, W_PLANE = NT * BCO * ROWW;
+    constexpr int IN_BYTES = NPL * IN_PLANE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* in_lds = smem;
     char* w_lds = smem + IN_BYTES;
@@ -143,7 +150,8 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO)) void c
     // it per chunk cost 3-8 VALU instructions per MFMA and made the kernel issue-bound.)
     constexpr int NIN = (NI * PH * PW * VPP + 255) / 256, NWT = (NT * BCO * VPP + 255) / 256;
     int in_rel[NIN], in_pos[NIN], in_dst[NIN], w_rel[NWT];
-    const int w_dst0 = F::lds_off(tid / VPP, ROWW, SWW, tid % VPP);   // descriptor j sits 256/VPP rows further (swizzle-neutral)
+    // descriptor j sits 256/VPP rows further (swizzle-neutral)
+    const int w_dst0 = ((tid % VPP) / VPR) * W_PLANE + F::lds_off(tid / VPP, ROWW, SWW, (tid % VPP) % VPR);
 #pragma unroll
     for (int j = 0; j < NIN; ++j) {
         const int idx = tid + j * 256;
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO)) void c
         const bool in_range = idx < NI * PH * PW * VPP;
         in_rel[j] = ((il * a.H + pr) * a.W + pc) * a.Cin + v * VE;
         in_pos[j] = in_range ? ((il << 20) | (pr << 10) | pc) : -1;
-        in_dst[j] = F::lds_off((il * PH + pr) * PWP + pc, ROWI, SWI, v);
+        in_dst[j] = (v / VPR) * IN_PLANE + F::lds_off((il * PH + pr) * PWP + pc, ROWI, SWI, v % VPR);
     }
 #pragma unroll
     for (int j = 0; j < NWT; ++j) {
@@ -251,12 +259,14 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO)) void c
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
             for (int kk = 0; kk < F::NK; ++kk) {
                 typename F::frag_t fa[CT], fb[SPW];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) fa[ct] = F::ld(w_lds + woff + (t * BCO + ct * 16) * ROWW, kk);
+                for (int ct = 0; ct < CT; ++ct) fa[ct] = F::ld(w_lds + pl * W_PLANE + woff + (t * BCO + ct * 16) * ROWW, kk);
 #pragma unroll
-                for (int s = 0; s < SPW; ++s) fb[s] = F::ld(in_lds + inoff[s][t % TK] + (t / TK) * PWP * ROWI, kk);
+                for (int s = 0; s < SPW; ++s) fb[s] = F::ld(in_lds + pl * IN_PLANE + inoff[s][t % TK] + (t / TK) * PWP * ROWI, kk);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -343,11 +353,12 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO)) void c
 
 template <typename T, int KC, int GEO, int TH, int TW, int BP, int CT>
 static int launch_conv(ConvArgs& a, int ngroups, hipStream_t st) {
-    using F = Frag<T, KC>;
+    constexpr int FK = (sizeof(T) == 2 && KC > 32) ? 32 : KC, NPL = KC / FK;
+    using F = Frag<T, FK>;
     constexpr int IS = Geo<GEO>::IS, TK = Geo<GEO>::TK;
     constexpr int PH = (TH - 1) * IS + TK, PW = (TW - 1) * IS + TK, NI = BP / (TH * TW);
     constexpr int IN_BYTES = (NI * PH * F::pad_pw(PW, IS) * F::rowb_in(IS) + 15) / 16 * 16;
-    constexpr int OPER = IN_BYTES + TK * TK * CT * 16 * F::rowb_w();
+    constexpr int OPER = NPL * (IN_BYTES + TK * TK * CT * 16 * F::rowb_w());
     constexpr int OUTB = (sizeof(T) == 2 && CT >= 2) ? BP * (CT * 32 + 16) : 0;     // LDS-transposed bf16 epilogue tile
     constexpr int LDS = OPER > OUTB ? OPER : OUTB;
     static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -415,6 +426,15 @@ static ConvCfg pick_cfg(int geo, int B, int ohc, int owc, int Cout) {
     return best;
 }
 
+// Deep K-chunks (128 input channels per LDS stage) for the layers whose launch is 64-pixel tiles: many input channels, few
+// pixels -- their time is the number of load/barrier/MFMA stages, not bytes or FLOPs.  SGX_CONV_DEEPK=0 switches it off.
+static bool conv_deep_k(int geo, int B, int ohc, int owc, int Cin, int Cout) {
+    static const int on = [] { const char* e = getenv("SGX_CONV_DEEPK"); return e ? atoi(e) : 1; }();
+    if (!on || Cin % 128 != 0 || geo == GDOWN) return false;
+    const ConvCfg c = pick_cfg(geo, B, ohc, owc, Cout);
+    return c.bp == 64 && (c.ct == 1 || c.ct == 2);
+}
+
 template <typename T, int KC, int GEO, int BP, int CT>
 static int dispatch_tile(ConvArgs& a, const ConvCfg& c, hipStream_t st) {
     a.tiles_y = (a.OHc + c.th - 1) / c.th; a.tiles_x = (a.OWc + c.tw - 1) / c.tw;
@@ -446,6 +466,13 @@ static int dispatch_conv(ConvArgs& a, int dtype, hipStream_t st) {
     SGX_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0, SGX_EINVAL, "conv: bad shape");
     if (dtype == SGX_F32) return dispatch_cfg<float, 16, GEO>(a, st);
     if (dtype == SGX_BF16) {
+        if constexpr (GEO != GDOWN) {                          // (the stride-2 patch x 4 planes does not fit the LDS)
+            if (conv_deep_k(GEO, a.B, a.OHc, a.OWc, a.Cin, a.Cout)) {
+                const ConvCfg c = pick_cfg(GEO, a.B, a.OHc, a.OWc, a.Cout);
+                if (c.ct == 2) return dispatch_tile<bf16_t, 128, GEO, 64, 2>(a, c, st);
+                return dispatch_tile<bf16_t, 128, GEO, 64, 1>(a, c, st);
+            }
+        }
         if (a.Cin % 32 == 0) return dispatch_cfg<bf16_t, 32, GEO>(a, st);
         return dispatch_cfg<bf16_t, 16, GEO>(a, st);
     }
@@ -456,7 +483,7 @@ extern "C" int sgx_conv_config(int geo, int B, int H, int W, int Cin, int Cout, 
     SGX_REQUIRE(geo >= 0 && geo <= 2 && cfg5, SGX_EINVAL, "conv_config: bad args");
     const int ohc = geo == GDOWN ? H / 2 : H, owc = geo == GDOWN ? W / 2 : W;
     const ConvCfg c = pick_cfg(geo, B, ohc, owc, Cout);
-    cfg5[0] = dtype == SGX_F32 ? 16 : (Cin % 32 == 0 ? 32 : 16);
+    cfg5[0] = dtype == SGX_F32 ? 16 : (conv_deep_k(geo, B, ohc, owc, Cin, Cout) ? 128 : (Cin % 32 == 0 ? 32 : 16));
     cfg5[1] = c.th; cfg5[2] = c.tw; cfg5[3] = c.bp; cfg5[4] = c.ct;
     return 0;
 }

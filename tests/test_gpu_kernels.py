@@ -64,7 +64,11 @@ def test_conv_forward_backward(mode, cin, cout, B, H):
 
 @pytest.mark.parametrize("mode,cin,cout,B,H", [("plain", 16, 16, 2, 32), ("plain", 64, 32, 3, 16), ("plain", 32, 64, 5, 8),
                                                 ("plain", 32, 32, 4, 4), ("up", 32, 16, 2, 16), ("up", 64, 64, 3, 4),
-                                                ("down", 16, 32, 2, 32), ("down", 64, 64, 5, 8), ("down", 32, 32, 2, 64)])
+                                                ("down", 16, 32, 2, 32), ("down", 64, 64, 5, 8), ("down", 32, 32, 2, 64),
+                                                # 128-channel K-chunks (deep-K variant): forward S/U and, as data gradients, U/D
+                                                ("plain", 512, 512, 4, 8), ("plain", 256, 128, 2, 16), ("plain", 512, 512, 4, 4),
+                                                ("up", 512, 512, 4, 4), ("up", 256, 256, 2, 8), ("down", 512, 512, 4, 8),
+                                                ("plain", 128, 512, 1, 16)])
 def test_conv_bf16_storage(mode, cin, cout, B, H):
     """bf16 activations / operand packs, fp32 accumulation.  Inputs are bf16-exact, so the only error sources are the
     bf16 rounding of the packed weights (y, dx: ~4e-3) and of the stored outputs; dW sees neither (x and dy exact, fp32
