@@ -418,6 +418,16 @@ class StyleGAN:
         if self.dp is not None and self.gen.truncation is not None:
             self.dp.broadcast(self.gen.truncation.avg_latent, src=0)
 
+    def _aux_stream(self):
+        """Second compute stream for work that is independent of the main chain (the D-step generator forward)."""
+        import os
+        if os.environ.get("SGX_AUX_STREAM", "1") in ("0", ""):            # A/B switch (profiling)
+            return None
+        st = self.__dict__.get("_aux_compute_stream")
+        if st is None:
+            st = self.__dict__["_aux_compute_stream"] = torch.cuda.Stream(device=self.device)
+        return st
+
     def _param_stream(self):
         """Side stream for the weight-gradient kernels (one per StyleGAN; they serialise among themselves)."""
         import os
@@ -437,18 +447,32 @@ class StyleGAN:
         """Discriminator half-iteration, part 1: losses and local gradients; returns the (device) loss."""
         real_samples = self.progressive_down_sampling(real_batch, depth, alpha)
 
-        def fake_samples():
+        def make_fakes():
             self._wait_update("g")                    # data parallel: G's all-reduce + Adam + EMA may still be in flight
             with torch.no_grad():                     # the reference builds and drops this graph (.detach(), :607)
                 out = self.gen(noise, depth, alpha, labels)
             self._sync_w_avg()
             return out
 
-        self._wait_update("d")
-        # LogisticGAN evaluates D(real) first and only then asks for the fakes (no host RNG is consumed in between, so the
-        # draws keep the reference's order): with data parallelism the generator update of the previous iteration overlaps
-        # the D(real) forward.  Other losses get the tensor up front.
+        # The generator forward that makes the fakes and the D(real) forward are independent chains of (at batch 4, mostly
+        # latency-bound) kernels: the first is issued on an auxiliary stream -- in the reference's program order, so the
+        # host RNG draws keep their order -- and the main stream only joins it when LogisticGAN asks for the fakes, after
+        # D(real).  Other losses get the tensor up front.
+        aux = self._aux_stream()
         lazy = isinstance(self.loss, Losses.LogisticGAN)
+        if aux is not None and lazy:
+            cur = torch.cuda.current_stream()
+            aux.wait_stream(cur)
+            with torch.cuda.stream(aux):
+                fakes = make_fakes()
+
+            def fake_samples():
+                cur.wait_stream(aux)
+                fakes.record_stream(cur)
+                return fakes
+        else:
+            fake_samples = make_fakes
+        self._wait_update("d")
         loss = self.loss.dis_loss(real_samples, fake_samples if lazy else fake_samples(), depth, alpha)
         self.dis_optim.zero_grad()
         side = self._param_stream()
