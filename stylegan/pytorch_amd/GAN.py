@@ -460,20 +460,24 @@ class StyleGAN:
         # D(real).  Other losses get the tensor up front.
         aux = self._aux_stream()
         lazy = isinstance(self.loss, Losses.LogisticGAN)
+        self._wait_update("d")
         if aux is not None and lazy:
+            # the whole fake branch -- generator forward AND D(fake) forward, hence also D(fake)'s backward, which autograd
+            # runs on the stream of its forward -- lives on the auxiliary stream; the real branch (D(real), the R1
+            # gradient pass, their backward) on the main one.  D's operand packs are made before the fork.
+            F.prepack(_conv_weights(self.dis))
             cur = torch.cuda.current_stream()
             aux.wait_stream(cur)
             with torch.cuda.stream(aux):
-                fakes = make_fakes()
+                f_preds = self.dis(make_fakes(), depth, alpha)
 
-            def fake_samples():
+            def fake_logits():
                 cur.wait_stream(aux)
-                fakes.record_stream(cur)
-                return fakes
+                f_preds.record_stream(cur)
+                return f_preds
+            loss = self.loss.dis_loss(real_samples, None, depth, alpha, fake_logits=fake_logits)
         else:
-            fake_samples = make_fakes
-        self._wait_update("d")
-        loss = self.loss.dis_loss(real_samples, fake_samples if lazy else fake_samples(), depth, alpha)
+            loss = self.loss.dis_loss(real_samples, make_fakes if lazy else make_fakes(), depth, alpha)
         self.dis_optim.zero_grad()
         side = self._param_stream()
         # conv weight / bias gradients accumulate inside the finishing kernel, on a side stream next to the backward chain

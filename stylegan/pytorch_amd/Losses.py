@@ -75,23 +75,28 @@ class LogisticGAN(GANLoss):
         real_img = real_img.detach().requires_grad_(True)
         return self._r1_from_logit(self.dis(real_img, height, alpha), real_img)
 
-    def dis_loss(self, real_samps, fake_samps, height, alpha, r1_gamma=10.0):
+    def dis_loss(self, real_samps, fake_samps, height, alpha, r1_gamma=10.0, fake_logits=None):
         # The reference evaluates D(real) twice -- once for the logistic term (:216) and once more inside R1Penalty
         # (:201) -- with identical results (D is deterministic).  Here ONE forward of D(real) feeds both terms, and
         # the final backward walks that graph once with the two upstream gradients summed: same loss, same
         # gradients, one D forward and one D backward less per iteration.
+        # ``fake_logits``: a callable returning D(fake) that the caller evaluates on another stream (StyleGAN._d_grads);
+        # it is asked for as late as possible so that the D(real) forward and the R1 gradient pass overlap it.
         if r1_gamma != 0.0:
             real = real_samps.detach().requires_grad_(True)
             r_preds = self.dis(real, height, alpha)
+            r1 = self._r1_from_logit(r_preds, real) * (r1_gamma * 0.5)
         else:
             r_preds = self.dis(real_samps, height, alpha)
-        if callable(fake_samps):                      # produced lazily, after D(real): see StyleGAN._d_grads
-            fake_samps = fake_samps()
-        f_preds = self.dis(fake_samps, height, alpha)
+            r1 = None
+        if fake_logits is not None:
+            f_preds = fake_logits()
+        else:
+            if callable(fake_samps):                  # produced lazily, after D(real)
+                fake_samps = fake_samps()
+            f_preds = self.dis(fake_samps, height, alpha)
         loss = (torch.mean(TF.softplus(f_preds)) + torch.mean(TF.softplus(-r_preds))) * self.mean_scale
-        if r1_gamma != 0.0:
-            loss = loss + self._r1_from_logit(r_preds, real) * (r1_gamma * 0.5)
-        return loss
+        return loss if r1 is None else loss + r1
 
     def gen_loss(self, _, fake_samps, height, alpha):
         f_preds = self.dis(fake_samps, height, alpha)

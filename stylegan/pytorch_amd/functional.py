@@ -147,11 +147,19 @@ def _pack_alloc(weight, sub):
     return (torch.empty((taps, O, ipad), dtype=dtype, device=weight.device), torch.empty((taps, ipad, O), dtype=dtype, device=weight.device))
 
 
+def _pack_mark():
+    """(event recorded after the pack kernel, raw handle of the stream it ran on): a consumer on ANOTHER stream (the step
+    runs its independent branches on several) waits for the event before it reads the packs."""
+    ev = torch.cuda.Event()
+    ev.record()
+    return (ev, N.stream())
+
+
 def prepack(weights):
     """Re-pack every STALE weight of ``weights`` (for all the (mode, scale, ipad, dtype) combinations it has been used
     with) in one sgx_pack_weight_multi launch -- instead of one small launch per layer on first use after the optimizer
     step.  Weights never used yet are left to the lazy path of ``packs``."""
-    rows, blk, dtype = [], 0, None
+    rows, blk, dtype, touched = [], 0, None, []
     for w in weights:
         ent = _PACKS.get(id(w))
         if ent is None or ent[0]() is not w or not ent[3]:
@@ -162,6 +170,7 @@ def prepack(weights):
         if w.dtype != torch.float32 or not w.is_contiguous():
             raise N.SgxError("parameters must be contiguous fp32")
         ent[1], ent[2] = tag, {}
+        touched.append(ent)
         for sub in ent[3]:
             if dtype is None:
                 dtype = sub[3]
@@ -180,6 +189,9 @@ def prepack(weights):
                 "sgx_pack_weight_multi")
         if not N.capturing():
             table.record_stream(torch.cuda.current_stream())
+        mark = _pack_mark()
+        for ent in touched:
+            ent[4] = mark
 
 
 def packs(weight, mode, scale, ipad, dtype):
@@ -189,13 +201,15 @@ def packs(weight, mode, scale, ipad, dtype):
     ent = _PACKS.get(key)
     tag = _pack_tag(weight)
     if ent is None or ent[0]() is not weight:
-        ent = [weakref.ref(weight, lambda _r, k=key: _PACKS.pop(k, None)), tag, {}, set()]
+        ent = [weakref.ref(weight, lambda _r, k=key: _PACKS.pop(k, None)), tag, {}, set(), None]
         _PACKS[key] = ent
     elif ent[1] != tag:
         ent[1], ent[2] = tag, {}
     sub = (mode, float(scale), int(ipad), dtype)
     ent[3].add(sub)
     got = ent[2].get(sub)
+    if got is not None and ent[4] is not None and ent[4][1] != N.stream():
+        torch.cuda.current_stream().wait_event(ent[4][0])      # packed on another stream
     if got is None:
         w = _c(weight.detach())
         if w.dtype != torch.float32:
@@ -206,6 +220,7 @@ def packs(weight, mode, scale, ipad, dtype):
                                         N.F32 if dtype == torch.float32 else N.BF16, N.stream()), "sgx_pack_weight")
         got = (fwd, adj)
         ent[2][sub] = got
+        ent[4] = _pack_mark()
     return got
 
 
