@@ -19,7 +19,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-enum { G3X3 = 0, GDOWN = 1, GUP = 2 };
+enum { G3X3 = 0, GDOWN = 1, GUP = 2, GUPA = 3 };   // GUPA: GUP with all four parity classes in one block (bf16)
 
 // LDS operand tiles are arrays of rows (one pixel, or one (tap, output channel) weight row) holding KC channels.
 // rowb_*: row pitch in bytes; load(): the lane's MFMA fragment (k = kk-step, q = lane>>4); lstore(): one 16-byte chunk.
@@ -104,6 +104,10 @@ template <int GEO> struct Geo;
 template <> struct Geo<G3X3> { static constexpr int IS = 1, TK = 3, NCLS = 1; };
 template <> struct Geo<GDOWN> { static constexpr int IS = 2, TK = 4, NCLS = 1; };
 template <> struct Geo<GUP> { static constexpr int IS = 1, TK = 2, NCLS = 4; };
+// all four output-parity classes of the transposed conv in ONE block: the coarse input patch (halo 1 on every side, i.e.
+// the 3x3 patch geometry) is staged once instead of once per class, and the block owns complete 2x2 output quads, so its
+// stores are whole contiguous rows of the fine image instead of every other pixel.
+template <> struct Geo<GUPA> { static constexpr int IS = 1, TK = 3, NCLS = 1; };
 
 // Small tiles of the HBM-bound layers (16/32 channels at 512^2..1024^2) want MANY resident blocks: a block has one
 // tile's loads in flight, and bytes in flight per CU -- not MFMA rate -- set their speed.
@@ -112,6 +116,7 @@ template <> struct Geo<GUP> { static constexpr int IS = 1, TK = 2, NCLS = 4; };
 #endif
 constexpr int conv_min_waves(int tsize, int CT, int BP, int GEO, int KC) {
     if (KC > 32) return 2;                                   // deep K-chunks: LDS allows two blocks per CU anyway
+    if (GEO == GUPA) return CT * BP >= 512 ? 1 : 2;          // four classes of accumulators
     if (CT * BP >= 1024 || GEO == GDOWN) return 1;
     if (tsize == 2 && CT * BP <= 256) return SGX_CONV_OCC_SMALL;
     return 2;
@@ -133,7 +138,10 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
     constexpr int VE = 16 / (int)sizeof(T), VPP = KC / VE, VPR = FK / VE;
     constexpr int ROWI = F::rowb_in(IS), ROWW = F::rowb_w();
     constexpr bool SWI = F::swz_in(IS), SWW = F::swz_w();
-    constexpr int IN_PLANE = (NI * PH * PWP * ROWI + 15) / 16 * 16, W_PLANE = NT * BCO * ROWW;
+    constexpr bool UPA = GEO == GUPA;
+    constexpr int NTW = UPA ? 16 : NT;                             // weight taps staged in LDS
+    constexpr int NCL = UPA ? 4 : 1;                               // output-parity classes accumulated by this block
+    constexpr int IN_PLANE = (NI * PH * PWP * ROWI + 15) / 16 * 16, W_PLANE = NTW * BCO * ROWW;
     constexpr int IN_BYTES = NPL * IN_PLANE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* in_lds = smem;
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
     // Per-thread staging descriptors, computed ONCE: the index arithmetic of the global->LDS copy (which element of
     // the halo patch / weight tile this thread moves) does not depend on the tile or the K-chunk.  (Measured: doing
     // it per chunk cost 3-8 VALU instructions per MFMA and made the kernel issue-bound.)
-    constexpr int NIN = (NI * PH * PW * VPP + 255) / 256, NWT = (NT * BCO * VPP + 255) / 256;
+    constexpr int NIN = (NI * PH * PW * VPP + 255) / 256, NWT = (NTW * BCO * VPP + 255) / 256;
     int in_rel[NIN], in_pos[NIN], in_dst[NIN], w_rel[NWT];
     // descriptor j sits 256/VPP rows further (swizzle-neutral)
     const int w_dst0 = ((tid % VPP) / VPR) * W_PLANE + F::lds_off(tid / VPP, ROWW, SWW, (tid % VPP) % VPR);
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
         const int n = row % BCO, t = row / BCO;
         int tg = t;
         if (GEO == GUP) tg = (3 - py - 2 * (t >> 1)) * 4 + (3 - px - 2 * (t & 1));
-        w_rel[j] = (idx < NT * BCO * VPP) ? ((tg * a.Cout + co0 + n) * a.Cin + v * VE) : -1;
+        w_rel[j] = (idx < NTW * BCO * VPP) ? ((tg * a.Cout + co0 + n) * a.Cin + v * VE) : -1;
     }
     int img0, ty0, tx0;                                // coordinates of the tile being PREFETCHED (gload) ...
     long in_base = 0;                                  // element offset of its patch origin (may be negative: halo)
@@ -206,16 +214,20 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
         for (int tx = 0; tx < TK; ++tx) inoff[s][tx] = F::rd_off((il * PH + r * IS) * PWP + c * IS + tx, ROWI, SWI, q);
     }
     const int woff = F::rd_off(l15, ROWW, SWW, q);
-    f32x4 acc[CT][SPW];
+    f32x4 acc[NCL * CT][SPW];                          // [class * CT + channel sub-tile][pixel sub-tile]
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int ct = 0; ct < NCL * CT; ++ct)
 #pragma unroll
         for (int s = 0; s < SPW; ++s) acc[ct][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // Staging is software pipelined through registers: the global loads of K-chunk c+1 (or of the next tile's first
     // chunk) are issued before the MFMAs of chunk c and written to LDS after them, so HBM/L2 latency hides under them.
     uint4 rin[NIN], rwt[NWT];
-    const bool w_static = (a.Cin == KC);              // one K-chunk: the weight tile is the same for every pixel tile
+    // one K-chunk: the weight tile is the same for every pixel tile and is staged once -- unless this block's output
+    // staging (GUPA: the whole fine tile) reaches into the weight region of the LDS, then it is re-staged per tile
+    constexpr bool OUT_CLOBBERS_W = (UPA && 4 * BP * (BCO * 2 + 16) > IN_BYTES) ||
+                                    (!UPA && sizeof(T) == 2 && CT >= 2 && BP * (BCO * 2 + 16) > IN_BYTES);
+    const bool w_static = (a.Cin == KC) && !OUT_CLOBBERS_W;
     auto gload = [&](int k0, bool with_w) {
         const T* src0 = xg + in_base + k0;
 #pragma unroll
@@ -255,6 +267,34 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
         if (a.dbg & 2) { if (k0 + KC >= a.Cin && tile + (int)gridDim.x < a.ntiles) set_tile(tile + gridDim.x); }
         else if (k0 + KC < a.Cin) gload(k0 + KC, true);    // in flight during the MFMAs below
         else if (tile + (int)gridDim.x < a.ntiles) { set_tile(tile + gridDim.x); gload(0, !w_static); }
+        if constexpr (UPA) {
+            // position-major: each of the 9 patch positions (dy, dx) is read once and feeds every class that has a tap
+            // there -- class (py, px) uses tap (a, b) = (dy - py, dx - px) when both are 0 or 1, with the weight tap
+            // (3 - py - 2a, 3 - px - 2b) of the 4x4 kernel (same mapping as the per-class GUP kernel).
+#pragma unroll
+            for (int pos = 0; pos < 9; ++pos) {
+                const int dy = pos / 3, dx = pos % 3;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    typename F::frag_t fb[SPW];
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) fb[s] = F::ld(in_lds + pl * IN_PLANE + inoff[s][dx] + dy * PWP * ROWI, 0);
+#pragma unroll
+                    for (int cls = 0; cls < 4; ++cls) {
+                        const int py_ = cls >> 1, px_ = cls & 1, ta = dy - py_, tb = dx - px_;
+                        if (ta >= 0 && ta <= 1 && tb >= 0 && tb <= 1) {
+                            const int tg = (3 - py_ - 2 * ta) * 4 + (3 - px_ - 2 * tb);
+#pragma unroll
+                            for (int ct = 0; ct < CT; ++ct) {
+                                const typename F::frag_t fa = F::ld(w_lds + pl * W_PLANE + woff + (tg * BCO + ct * 16) * ROWW, 0);
+#pragma unroll
+                                for (int s = 0; s < SPW; ++s) acc[cls * CT + ct][s] = F::mma(fa, fb[s], acc[cls * CT + ct][s]);
+                            }
+                        }
+                    }
+                }
+            }
+        } else
         if (!(a.dbg & 1))
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -278,6 +318,38 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
     // bf16 with >= 32 output channels per block: a lane's natural store is 8 bytes and a wave instruction writes 32-byte
     // pieces (measured: 14 of 43 us on the 256^2 64->64 layer).  Transpose the tile through LDS instead and write whole
     // BCO*2-byte channel rows with 16 bytes per lane.
+    if constexpr (UPA) {
+        // the block owns the complete (2 TH) x (2 TW) fine tile: stage it in LDS pixel-major and write whole rows
+        static_assert(sizeof(T) == 2, "GUPA is the bf16 path");
+        constexpr int OROW = BCO * 2 + 16, VPO = BCO * 2 / 16, FW = 2 * TW, FH = 2 * TH;
+        __syncthreads();                                  // every wave is done reading this tile's operands
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            const int m = (wave * SPW + s) * 16 + l15;
+            const int il = m / (TH * TW), r = (m / TW) % TH, c = m % TW;
+#pragma unroll
+            for (int cls = 0; cls < 4; ++cls) {
+                const int fp = (il * FH + 2 * r + (cls >> 1)) * FW + 2 * c + (cls & 1);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const f32x4 v = acc[cls * CT + ct][s];
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(smem + fp * OROW + (ct * 16 + q * 4) * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 4 * BP * VPO; idx += 256) {
+            const int fp = idx / VPO, v = idx % VPO;
+            const int il = fp / (FH * FW), fy = (fp / FW) % FH, fx = fp % FW;
+            const int b = c_img0 + il, oy = 2 * c_ty0 + fy, ox = 2 * c_tx0 + fx;
+            if (b >= a.B || oy >= a.OH || ox >= a.OW) continue;
+            T* dst = yg + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(smem + fp * OROW + v * 16);
+        }
+    } else
     if constexpr (sizeof(T) == 2 && CT >= 2) {
         constexpr int OROW = BCO * 2 + 16, VPR = BCO * 2 / 16;
         __syncthreads();                                  // every wave is done reading this tile's operands
@@ -345,7 +417,7 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
     tile += gridDim.x;
     if (tile >= a.ntiles) break;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int ct = 0; ct < NCL * CT; ++ct)
 #pragma unroll
         for (int s = 0; s < SPW; ++s) acc[ct][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -358,8 +430,10 @@ static int launch_conv(ConvArgs& a, int ngroups, hipStream_t st) {
     constexpr int IS = Geo<GEO>::IS, TK = Geo<GEO>::TK;
     constexpr int PH = (TH - 1) * IS + TK, PW = (TW - 1) * IS + TK, NI = BP / (TH * TW);
     constexpr int IN_BYTES = (NI * PH * F::pad_pw(PW, IS) * F::rowb_in(IS) + 15) / 16 * 16;
-    constexpr int OPER = NPL * (IN_BYTES + TK * TK * CT * 16 * F::rowb_w());
-    constexpr int OUTB = (sizeof(T) == 2 && CT >= 2) ? BP * (CT * 32 + 16) : 0;     // LDS-transposed bf16 epilogue tile
+    constexpr int NTW = GEO == GUPA ? 16 : TK * TK;
+    constexpr int OPER = NPL * (IN_BYTES + NTW * CT * 16 * F::rowb_w());
+    constexpr int OUTB = GEO == GUPA ? 4 * BP * (CT * 32 + 16)                      // the whole fine tile
+                                     : ((sizeof(T) == 2 && CT >= 2) ? BP * (CT * 32 + 16) : 0);   // LDS-transposed bf16 epilogue tile
     constexpr int LDS = OPER > OUTB ? OPER : OUTB;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kern = conv_kernel<T, KC, GEO, TH, TW, BP, CT>;
@@ -407,8 +481,9 @@ static void tile_shape(int bp, int ohc, int owc, ConvCfg& c) {
 static ConvCfg pick_cfg(int geo, int B, int ohc, int owc, int Cout) {
     static const int cand_su[][2] = {{256, 4}, {256, 2}, {128, 4}, {256, 1}, {128, 2}, {128, 1}, {64, 2}, {64, 1}};
     static const int cand_d[][2] = {{128, 2}, {128, 1}, {64, 2}, {64, 1}};
-    const int (*cand)[2] = geo == GDOWN ? cand_d : cand_su;
-    const int n = geo == GDOWN ? 4 : 8;
+    static const int cand_ua[][2] = {{256, 2}, {256, 1}, {128, 2}, {128, 1}, {64, 2}, {64, 1}};   // 4 classes of accumulators: ct <= 2
+    const int (*cand)[2] = geo == GDOWN ? cand_d : (geo == GUPA ? cand_ua : cand_su);
+    const int n = geo == GDOWN ? 4 : (geo == GUPA ? 6 : 8);
     ConvCfg best{0, 0, 0, 0, 0};
     for (int i = 0; i < n; ++i) {
         static const int max_ct = [] { const char* e = getenv("SGX_CONV_MAXCT"); return e ? atoi(e) : 4; }();   // tuning knob
@@ -449,10 +524,12 @@ static int dispatch_cfg(ConvArgs& a, hipStream_t st) {
     const ConvCfg c = pick_cfg(GEO, a.B, a.OHc, a.OWc, a.Cout);
     SGX_REQUIRE(c.bp != 0, SGX_EUNSUPPORTED, "conv: no launch configuration for Cout=%d", a.Cout);
     if constexpr (GEO != GDOWN) {
-        if (c.bp == 256 && c.ct == 4) return dispatch_tile<T, KC, GEO, 256, 4>(a, c, st);
+        if constexpr (GEO != GUPA) {
+            if (c.bp == 256 && c.ct == 4) return dispatch_tile<T, KC, GEO, 256, 4>(a, c, st);
+            if (c.bp == 128 && c.ct == 4) return dispatch_tile<T, KC, GEO, 128, 4>(a, c, st);
+        }
         if (c.bp == 256 && c.ct == 2) return dispatch_tile<T, KC, GEO, 256, 2>(a, c, st);
         if (c.bp == 256 && c.ct == 1) return dispatch_tile<T, KC, GEO, 256, 1>(a, c, st);
-        if (c.bp == 128 && c.ct == 4) return dispatch_tile<T, KC, GEO, 128, 4>(a, c, st);
     }
     if (c.bp == 128 && c.ct == 2) return dispatch_tile<T, KC, GEO, 128, 2>(a, c, st);
     if (c.bp == 128 && c.ct == 1) return dispatch_tile<T, KC, GEO, 128, 1>(a, c, st);
@@ -471,6 +548,13 @@ static int dispatch_conv(ConvArgs& a, int dtype, hipStream_t st) {
                 const ConvCfg c = pick_cfg(GEO, a.B, a.OHc, a.OWc, a.Cout);
                 if (c.ct == 2) return dispatch_tile<bf16_t, 128, GEO, 64, 2>(a, c, st);
                 return dispatch_tile<bf16_t, 128, GEO, 64, 1>(a, c, st);
+            }
+        }
+        if constexpr (GEO == GUP) {
+            static const int fuse = [] { const char* e = getenv("SGX_CONV_UPA"); return e ? atoi(e) : 1; }();   // A/B switch
+            if (fuse) {
+                if (a.Cin % 32 == 0) return dispatch_cfg<bf16_t, 32, GUPA>(a, st);
+                return dispatch_cfg<bf16_t, 16, GUPA>(a, st);
             }
         }
         if (a.Cin % 32 == 0) return dispatch_cfg<bf16_t, 32, GEO>(a, st);

@@ -115,3 +115,21 @@ def test_bf16_tracks_fp32_at_1024():
         img = torch.randn(4, 3, 1024, 1024, device=DEV)
         sa, sb = sg32.dis(img, 8, 0.5), sg16.dis(img, 8, 0.5)
         assert float((sa - sb).abs().max()) <= 5e-2 * float(sa.abs().max()) + 5e-2
+
+
+@pytest.mark.parametrize("mode,B,H,ci,co", [("U", 4, 128, 128, 64), ("U", 4, 64, 256, 128), ("U", 4, 256, 64, 32), ("U", 4, 32, 512, 256),
+                                            ("U", 4, 16, 512, 512), ("U", 4, 512, 32, 16), ("U", 2, 32, 64, 64), ("U", 4, 8, 64, 64),
+                                            ("S", 4, 256, 32, 64), ("S", 4, 256, 32, 128), ("S", 4, 128, 16, 64), ("D", 4, 256, 32, 64),
+                                            ("S", 4, 16, 512, 512), ("S", 4, 1024, 16, 16), ("D", 4, 1024, 16, 32)])
+def test_bf16_conv_instantiations_against_fp32(mode, B, H, ci, co):
+    """Every bf16 tile configuration the 1024x1024 step dispatches to (persistent multi-tile blocks, weights staged once,
+    LDS-staged stores, all-parity-class transposed conv, deep-K stages) against the fp32 kernels on the same data."""
+    from stylegan.pytorch_amd import functional as F
+    torch.manual_seed(1)
+    w = torch.nn.Parameter(torch.randn(co, ci, 3, 3, device=DEV))
+    x = torch.randn(B, H, H, ci, device=DEV).bfloat16()
+    with torch.no_grad():
+        y16 = F.conv(x, w, None, mode, 0.05).float()
+        y32 = F.conv(x.float(), w, None, mode, 0.05)
+    rel = float((y16 - y32).norm() / y32.norm())
+    assert rel <= 5e-3, rel                                           # bf16 rounding of the packed weights and the output

@@ -68,7 +68,10 @@ def test_conv_forward_backward(mode, cin, cout, B, H):
                                                 # 128-channel K-chunks (deep-K variant): forward S/U and, as data gradients, U/D
                                                 ("plain", 512, 512, 4, 8), ("plain", 256, 128, 2, 16), ("plain", 512, 512, 4, 4),
                                                 ("up", 512, 512, 4, 4), ("up", 256, 256, 2, 8), ("down", 512, 512, 4, 8),
-                                                ("plain", 128, 512, 1, 16)])
+                                                ("plain", 128, 512, 1, 16),
+                                                # all-parity-classes-in-one-block transposed conv (GUPA), several tile shapes
+                                                ("up", 32, 16, 4, 64), ("up", 64, 32, 2, 32), ("up", 16, 16, 2, 32), ("up", 128, 64, 1, 16),
+                                                ("up", 32, 32, 3, 8), ("down", 32, 64, 2, 128)])
 def test_conv_bf16_storage(mode, cin, cout, B, H):
     """bf16 activations / operand packs, fp32 accumulation.  Inputs are bf16-exact, so the only error sources are the
     bf16 rounding of the packed weights (y, dx: ~4e-3) and of the stored outputs; dW sees neither (x and dy exact, fp32
