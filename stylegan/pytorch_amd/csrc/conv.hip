@@ -117,6 +117,7 @@ template <> struct Geo<GUPA> { static constexpr int IS = 1, TK = 3, NCLS = 1; };
 constexpr int conv_min_waves(int tsize, int CT, int BP, int GEO, int KC) {
     if (KC > 32) return 2;                                   // deep K-chunks: LDS allows two blocks per CU anyway
     if (GEO == GUPA) return CT * BP >= 512 ? 1 : 2;          // four classes of accumulators
+    if (GEO == GDOWN && tsize == 2 && KC == 16) return 3;   // HBM-bound 16-channel stride-2 layers (measured: 69 -> 64 us)
     if (CT * BP >= 1024 || GEO == GDOWN) return 1;
     if (tsize == 2 && CT * BP <= 256) return SGX_CONV_OCC_SMALL;
     return 2;
