@@ -426,6 +426,11 @@ class StyleGAN:
         st = self.__dict__.get("_aux_compute_stream")
         if st is None:
             st = self.__dict__["_aux_compute_stream"] = torch.cuda.Stream(device=self.device)
+            # the fake branch's gradients reach AccumulateGrad nodes that live on the main stream: intended (the engine
+            # synchronises the two), so silence torch's once-per-process note about it
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if quiet is not None:
+                quiet(False)
         return st
 
     def _param_stream(self):
