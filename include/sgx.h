@@ -193,6 +193,17 @@ int sgx_linear_bwd_data(const float* gy, const float* y_act, const float* w, flo
                         void* stream);
 int sgx_linear_bwd_param(const float* gy, const float* y_act, const float* x, float* dw, float* db, int B, int N, int K, float w_mul,
                          float b_mul, void* stream);
+/* All style affines (StyleMod.lin, models/CustomLayers.py:203-216) of one generator forward in one launch, two for the
+ * backward.  lm: layer-major dlatents [L][B][D] fp32.  table: G rows of SGX_STYLE_ROW 64-bit words
+ *   [W (fp32 [N][D]), bias (fp32 [N] or 0), N, y offset in elements (= B * sum of earlier N), first tile (16 outputs per
+ *    tile), w_mul as fp32 bits, b_mul as fp32 bits, layer index into lm];  total_tiles = sum of ceil(N/16).
+ * y / gy: flat, group g at its offset as [B][N_g].  glm: [L][B][D] (rows of layers without a group are not written).
+ * dw: flat [sum N][D], db: flat [sum N] (nullable).  B <= 32, D % 64 == 0. */
+#define SGX_STYLE_ROW 8
+int sgx_style_fwd(const float* lm, const void* table, float* y, int G, int B, int D, int total_tiles, void* stream);
+int sgx_style_bwd_data(const float* gy, const void* table, float* glm, int G, int B, int D, int max_n, void* stream);
+int sgx_style_bwd_param(const float* gy, const float* lm, const void* table, float* dw, float* db, int G, int B, int D,
+                        int total_tiles, void* stream);
 
 /* ---------------------------------------------------------------- optimizer step (multi-tensor, fp32)
  * torch.optim.Adam step (models/GAN.py:529-533, 616-618, 652) over n tensors described by DEVICE arrays of

@@ -41,7 +41,8 @@ class InputBlock(nn.Module):
                                   use_styles, activation_layer)
 
     def forward_nhwc(self, dlatents_in_range, dtype=torch.float32):
-        b = _lat(dlatents_in_range, 0).size(0)
+        first = _lat(dlatents_in_range, 0)
+        b = (first.style if isinstance(first, F.PreStyle) else first).size(0)
         if self.const_input_layer:
             # const [1,C,4,4] -> NHWC [B,4,4,C]; its bias is folded into the epilogue kernel (Blocks.py:51-52)
             x = self.const.permute(0, 2, 3, 1).to(dtype).expand(b, -1, -1, -1).contiguous()

@@ -288,7 +288,10 @@ class LayerEpilogue(nn.Module):
                                       "(noise + LeakyReLU(0.2) + instance norm + styles, no pixel norm)")
         noise_layer = self.top_epi.noise
         noise = noise_layer.sample(x.shape, x.device)
-        style = self.style_mod.style(dlatents_in_slice)
+        if isinstance(dlatents_in_slice, F.PreStyle):                   # computed with all the other layers' in one launch
+            style = dlatents_in_slice.style
+        else:
+            style = self.style_mod.style(dlatents_in_slice)
         return F.call(F.GEpilogueFn, x, conv_bias, noise, noise_layer.weight, style)
 
     def forward(self, x, dlatents_in_slice=None):

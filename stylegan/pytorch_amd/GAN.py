@@ -163,7 +163,7 @@ class GSynthesis(nn.Module):
     def forward(self, dlatents_in, depth=0, alpha=0., labels_in=None):
         assert depth < self.depth, "Requested output depth cannot be produced"
         F.prepack(_conv_weights(self))                                      # all stale MFMA operand packs: one launch
-        dl = F.call(F.SplitLayersFn, dlatents_in.float())                     # L contiguous [B, D] tensors, one copy
+        dl = self._styles(dlatents_in.float(), depth)                        # per-layer style vectors (or dlatents)
         dt = self.act_dtype
         nblocks = len(self.blocks) if self.structure == 'fixed' else depth
         prev_arena = F.NOISE_ARENA
@@ -174,6 +174,24 @@ class GSynthesis(nn.Module):
             return self._forward(dl, dt, depth, alpha)
         finally:
             F.NOISE_ARENA = prev_arena
+
+    def _styles(self, dlatents, depth):
+        """Per-layer inputs of the epilogues: with the default flags, the style vectors of all active layers from ONE
+        launch (``GroupedStyleFn``) wrapped as ``PreStyle``; otherwise the L contiguous dlatents (``SplitLayersFn``)."""
+        nblocks = len(self.blocks) if self.structure == 'fixed' else depth
+        epis = [self.init_block.epi1, self.init_block.epi2]
+        for blk in self.blocks[:nblocks]:
+            epis += [blk.epi1, blk.epi2]
+        B = dlatents.shape[0]
+        ok = (getattr(self.init_block, "const_input_layer", False) and B <= 32 and dlatents.shape[2] % 64 == 0
+              and all(getattr(e, "_fusable", False) and e.style_mod is not None for e in epis))
+        if not ok:
+            return F.call(F.SplitLayersFn, dlatents)
+        lins = [e.style_mod.lin for e in epis]
+        meta = tuple((i, float(l.w_mul), float(l.b_mul)) for i, l in enumerate(lins))
+        lm = dlatents.transpose(0, 1).contiguous()                           # [L, B, D], one copy
+        styles = F.call(F.GroupedStyleFn, lm, meta, *[l.weight for l in lins], *[l.bias for l in lins])
+        return [F.PreStyle(s) for s in styles] + [None] * (dlatents.shape[1] - len(styles))
 
     def _noise_layers(self):
         ls = self.__dict__.get("_sgx_noise_layers")

@@ -328,6 +328,188 @@ extern "C" int sgx_linear_bwd_param(const float* gy, const float* y_act, const f
                        (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------- all style affines of a generator forward in one launch
+// StyleMod.lin (models/CustomLayers.py:203-216) of every active layer: y_g[B][N_g] = w_mul_g * x_g[B][D] W_g[N_g][D]^T +
+// b_mul_g * bias_g, with x_g = lm[layer_g] (the layer-major dlatents [L][B][D]).  18 small GEMMs (M = batch) are latency, not
+// work: one launch forward, two backward.  tab: G rows of SGX_STYLE_ROW 64-bit words
+//   [W, bias, N, y offset (elements, = B * sum of earlier N), first tile, w_mul bits, b_mul bits, layer]
+#define STYLE_MAXB 32
+__device__ __forceinline__ int style_group(const long long* __restrict__ tab, int G, unsigned tile) {
+    int g = 0;
+    while (g + 1 < G && (unsigned)tab[(g + 1) * SGX_STYLE_ROW + 4] <= tile) ++g;
+    return g;
+}
+// block: 16 output columns x 16 k-lanes; x_g staged in LDS
+template <int MB>
+__global__ __launch_bounds__(256) void style_fwd_kernel(const float* __restrict__ lm, const long long* __restrict__ tab, float* __restrict__ y,
+                                                        int G, int B, int D) {
+    extern __shared__ float xs[];                                  // [B][D]
+    const int g = style_group(tab, G, blockIdx.x);
+    const long long* r = tab + (size_t)g * SGX_STYLE_ROW;
+    const float* W = reinterpret_cast<const float*>(r[0]);
+    const float* bias = reinterpret_cast<const float*>(r[1]);
+    const int N = (int)r[2], layer = (int)r[7];
+    const float w_mul = __uint_as_float((unsigned)r[5]), b_mul = __uint_as_float((unsigned)r[6]);
+    const float* x = lm + (size_t)layer * B * D;
+    for (int i = threadIdx.x; i < B * D / 4; i += 256) reinterpret_cast<float4*>(xs)[i] = reinterpret_cast<const float4*>(x)[i];
+    __syncthreads();
+    const int col = threadIdx.x >> 4, kl = threadIdx.x & 15;
+    const int n = ((int)blockIdx.x - (int)r[4]) * 16 + col;
+    float acc[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[b] = 0.f;
+    if (n < N)
+        for (int k = kl * 4; k < D; k += 64) {
+            const float4 w = *reinterpret_cast<const float4*>(W + (size_t)n * D + k);
+#pragma unroll
+            for (int b = 0; b < MB; ++b)
+                if (b < B) {
+                    const float4 v = *reinterpret_cast<const float4*>(xs + b * D + k);
+                    acc[b] += (w.x * v.x + w.y * v.y) + (w.z * v.z + w.w * v.w);
+                }
+        }
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+        if (b < B) {
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) acc[b] += __shfl_xor(acc[b], o, 64);
+        }
+    if (n < N && kl == 0) {
+        const float bb = bias ? b_mul * bias[n] : 0.f;
+        float* yo = y + (size_t)r[3] + n;
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+            if (b < B) yo[(size_t)b * N] = w_mul * acc[b] + bb;
+    }
+}
+// data gradient: glm[layer][b][k] = w_mul * sum_n gy_g[b][n] W_g[n][k].  grid (D/64, G); the 4 waves split n, LDS reduce.
+template <int MB>
+__global__ __launch_bounds__(256) void style_bwd_data_kernel(const float* __restrict__ gy, const long long* __restrict__ tab,
+                                                             float* __restrict__ glm, int G, int B, int D) {
+    extern __shared__ float sh[];                                  // gy_g [B][N] then the wave partials [4][B][64]
+    const int g = blockIdx.y;
+    const long long* r = tab + (size_t)g * SGX_STYLE_ROW;
+    const float* W = reinterpret_cast<const float*>(r[0]);
+    const int N = (int)r[2], layer = (int)r[7];
+    const float w_mul = __uint_as_float((unsigned)r[5]);
+    const float* gyg = gy + (size_t)r[3];
+    for (int i = threadIdx.x; i < B * N; i += 256) sh[i] = gyg[i];
+    __syncthreads();
+    const int kk = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+    float acc[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[b] = 0.f;
+    if (kk < D) {
+        // 16 independent weight loads in flight per lane, then the FMAs (a dependent one-load-per-iteration loop is pure latency)
+        int n = wave;
+        for (; n + 4 * 15 < N; n += 4 * 16) {
+            float w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = W[(size_t)(n + 4 * u) * D + kk];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int b = 0; b < MB; ++b)
+                    if (b < B) acc[b] += sh[b * N + n + 4 * u] * w[u];
+        }
+        for (; n < N; n += 4) {
+            const float w = W[(size_t)n * D + kk];
+#pragma unroll
+            for (int b = 0; b < MB; ++b)
+                if (b < B) acc[b] += sh[b * N + n] * w;
+        }
+    }
+    __syncthreads();
+    float* part = sh;                                              // reuse: [4][B][64]
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+        if (b < B) part[(wave * B + b) * 64 + (threadIdx.x & 63)] = acc[b];
+    __syncthreads();
+    for (int i = threadIdx.x; i < B * 64; i += 256) {
+        const int b = i / 64, kl = i % 64, k = blockIdx.x * 64 + kl;
+        if (k < D) {
+            const float sum = (part[(0 * B + b) * 64 + kl] + part[(1 * B + b) * 64 + kl]) + (part[(2 * B + b) * 64 + kl] + part[(3 * B + b) * 64 + kl]);
+            glm[((size_t)layer * B + b) * D + k] = w_mul * sum;
+        }
+    }
+}
+// parameter gradients: dW_g[n][k] = w_mul * sum_b gy_g[b][n] x_g[b][k],  db_g[n] = b_mul * sum_b gy_g[b][n].  Flat outputs
+// dw[(sum of earlier N + n) * D + k], db[sum of earlier N + n]; block = 16 rows n x all k.
+template <int MB>
+__global__ __launch_bounds__(256) void style_bwd_param_kernel(const float* __restrict__ gy, const float* __restrict__ lm,
+                                                              const long long* __restrict__ tab, float* __restrict__ dw,
+                                                              float* __restrict__ db, int G, int B, int D) {
+    __shared__ float gs[MB][16];
+    const int g = style_group(tab, G, blockIdx.x);
+    const long long* r = tab + (size_t)g * SGX_STYLE_ROW;
+    const int N = (int)r[2], layer = (int)r[7];
+    const float w_mul = __uint_as_float((unsigned)r[5]), b_mul = __uint_as_float((unsigned)r[6]);
+    const int n0 = ((int)blockIdx.x - (int)r[4]) * 16;
+    const size_t noff = (size_t)r[3] / B;                          // sum of earlier N
+    const float* gyg = gy + (size_t)r[3];
+    for (int i = threadIdx.x; i < B * 16; i += 256) {
+        const int b = i / 16, j = i % 16;
+        gs[b][j] = (n0 + j < N) ? gyg[(size_t)b * N + n0 + j] : 0.f;
+    }
+    __syncthreads();
+    const float* x = lm + (size_t)layer * B * D;
+    for (int k = threadIdx.x; k < D; k += 256) {
+        float xv[MB];
+#pragma unroll
+        for (int b = 0; b < MB; ++b) xv[b] = b < B ? x[(size_t)b * D + k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (n0 + j < N) {
+                float s = 0.f;
+#pragma unroll
+                for (int b = 0; b < MB; ++b)
+                    if (b < B) s += gs[b][j] * xv[b];
+                dw[(noff + n0 + j) * D + k] = w_mul * s;
+            }
+    }
+    if (db && threadIdx.x < 16 && n0 + (int)threadIdx.x < N) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += gs[b][threadIdx.x];
+        db[noff + n0 + threadIdx.x] = b_mul * s;
+    }
+}
+static int style_check(int G, int B, int D) {
+    SGX_REQUIRE(G > 0 && B > 0 && B <= STYLE_MAXB && D > 0 && D % 64 == 0, SGX_EUNSUPPORTED, "style affines: G=%d B=%d D=%d", G, B, D);
+    return 0;
+}
+extern "C" int sgx_style_fwd(const float* lm, const void* table, float* y, int G, int B, int D, int total_tiles, void* stream) {
+    int rc = style_check(G, B, D); if (rc) return rc;
+    SGX_NOTE(0.0, 0.0, "style_fwd G%d B%d", G, B);
+    if (B <= 4) hipLaunchKernelGGL(style_fwd_kernel<4>, dim3(total_tiles), dim3(256), (size_t)B * D * sizeof(float), (hipStream_t)stream, lm, (const long long*)table, y, G, B, D);
+    else if (B <= 8) hipLaunchKernelGGL(style_fwd_kernel<8>, dim3(total_tiles), dim3(256), (size_t)B * D * sizeof(float), (hipStream_t)stream, lm, (const long long*)table, y, G, B, D);
+    else if (B <= 16) hipLaunchKernelGGL(style_fwd_kernel<16>, dim3(total_tiles), dim3(256), (size_t)B * D * sizeof(float), (hipStream_t)stream, lm, (const long long*)table, y, G, B, D);
+    else hipLaunchKernelGGL(style_fwd_kernel<32>, dim3(total_tiles), dim3(256), (size_t)B * D * sizeof(float), (hipStream_t)stream, lm, (const long long*)table, y, G, B, D);
+    SGX_LAUNCH_CHECK("style_fwd");
+    return 0;
+}
+extern "C" int sgx_style_bwd_data(const float* gy, const void* table, float* glm, int G, int B, int D, int max_n, void* stream) {
+    int rc = style_check(G, B, D); if (rc) return rc;
+    const size_t a = (size_t)B * max_n, b = (size_t)4 * B * 64;
+    SGX_NOTE(0.0, 0.0, "style_bwd_data G%d B%d", G, B);
+    if (B <= 4) hipLaunchKernelGGL(style_bwd_data_kernel<4>, dim3(D / 64, G), dim3(256), (a > b ? a : b) * sizeof(float), (hipStream_t)stream, gy, (const long long*)table, glm, G, B, D);
+    else if (B <= 8) hipLaunchKernelGGL(style_bwd_data_kernel<8>, dim3(D / 64, G), dim3(256), (a > b ? a : b) * sizeof(float), (hipStream_t)stream, gy, (const long long*)table, glm, G, B, D);
+    else if (B <= 16) hipLaunchKernelGGL(style_bwd_data_kernel<16>, dim3(D / 64, G), dim3(256), (a > b ? a : b) * sizeof(float), (hipStream_t)stream, gy, (const long long*)table, glm, G, B, D);
+    else hipLaunchKernelGGL(style_bwd_data_kernel<32>, dim3(D / 64, G), dim3(256), (a > b ? a : b) * sizeof(float), (hipStream_t)stream, gy, (const long long*)table, glm, G, B, D);
+    SGX_LAUNCH_CHECK("style_bwd_data");
+    return 0;
+}
+extern "C" int sgx_style_bwd_param(const float* gy, const float* lm, const void* table, float* dw, float* db, int G, int B, int D,
+                                   int total_tiles, void* stream) {
+    int rc = style_check(G, B, D); if (rc) return rc;
+    SGX_NOTE(0.0, 0.0, "style_bwd_param G%d B%d", G, B);
+    if (B <= 4) hipLaunchKernelGGL(style_bwd_param_kernel<4>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, gy, lm, (const long long*)table, dw, db, G, B, D);
+    else if (B <= 8) hipLaunchKernelGGL(style_bwd_param_kernel<8>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, gy, lm, (const long long*)table, dw, db, G, B, D);
+    else if (B <= 16) hipLaunchKernelGGL(style_bwd_param_kernel<16>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, gy, lm, (const long long*)table, dw, db, G, B, D);
+    else hipLaunchKernelGGL(style_bwd_param_kernel<32>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, gy, lm, (const long long*)table, dw, db, G, B, D);
+    SGX_LAUNCH_CHECK("style_bwd_param");
+    return 0;
+}
+
 // ---------------------------------------------------------------- R1 penalty head: out[0] = sum(x^2)   (models/Losses.py:210)
 // and its backward  out = alpha * s[0] * x  with the upstream scalar s kept on the device.
 #define SUMSQ_BLOCKS 1024

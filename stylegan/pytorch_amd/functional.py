@@ -916,6 +916,72 @@ class SplitLayersFn(Function):
         return torch.stack([g if g is not None else torch.zeros_like(ref) for g in grads], dim=1)
 
 
+class PreStyle:
+    """A style vector [B, 2C] already computed (by ``GroupedStyleFn``), handed to a LayerEpilogue in place of its dlatent."""
+    __slots__ = ("style",)
+
+    def __init__(self, style):
+        self.style = style
+
+
+_STYLE_TABLES = {}
+
+
+class GroupedStyleFn(Function):
+    """All style affines of a generator forward in one launch (two for the backward): (lm [L,B,D], meta, *weights, *biases)
+    -> one [B, N_g] tensor per group.  ``meta`` = tuple of (layer index, w_mul, b_mul) per group.  First order only."""
+
+    @staticmethod
+    def forward(ctx, lm, meta, *params):
+        G = len(meta)
+        ws, bs = params[:G], params[G:]
+        lm = _c(lm)
+        L_, B, D = lm.shape
+        key = (tuple(w.data_ptr() for w in ws), tuple(b.data_ptr() for b in bs), meta, B)
+        ent = _STYLE_TABLES.get(key)
+        if ent is None:
+            if len(_STYLE_TABLES) > 32:
+                _STYLE_TABLES.clear()
+            rows, yoff, tile = [], 0, 0
+            for (layer, w_mul, b_mul), w, b in zip(meta, ws, bs):
+                n = w.shape[0]
+                assert w.shape[1] == D and w.is_contiguous() and w.dtype == torch.float32
+                rows.append([w.data_ptr(), b.data_ptr(), n, yoff, tile, int(np.float32(w_mul).view(np.uint32)),
+                             int(np.float32(b_mul).view(np.uint32)), layer])
+                yoff += B * n; tile += (n + 15) // 16
+            table, _ = N.upload(torch.tensor(rows, dtype=torch.int64), lm.device)
+            ent = _STYLE_TABLES[key] = (table, [r[2] for r in rows], [r[3] for r in rows], yoff, tile)
+        table, ns, yoffs, ytotal, tiles = ent
+        y = torch.empty(ytotal, dtype=torch.float32, device=lm.device)
+        N.check(N.lib().sgx_style_fwd(N.ptr(lm), N.ptr(table), N.ptr(y), G, B, D, tiles, N.stream()), "sgx_style_fwd")
+        ctx.ent, ctx.G, ctx.shape = ent, G, (L_, B, D)
+        ctx.save_for_backward(lm)
+        return tuple(y[o:o + B * n].view(B, n) for o, n in zip(yoffs, ns))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gys):
+        (lm,) = ctx.saved_tensors
+        table, ns, yoffs, ytotal, tiles = ctx.ent
+        L_, B, D = ctx.shape
+        G = ctx.G
+        gy = torch.cat([(g if g is not None else torch.zeros(B, n, device=lm.device)).reshape(-1) for g, n in zip(gys, ns)])
+        L = N.lib()
+        glm = None
+        if ctx.needs_input_grad[0]:
+            glm = torch.zeros_like(lm) if G < L_ else torch.empty_like(lm)
+            N.check(L.sgx_style_bwd_data(N.ptr(gy), N.ptr(table), N.ptr(glm), G, B, D, max(ns), N.stream()), "sgx_style_bwd_data")
+        ntot = sum(ns)
+        dw = torch.empty((ntot, D), dtype=torch.float32, device=lm.device)
+        db = torch.empty((ntot,), dtype=torch.float32, device=lm.device)
+        N.check(L.sgx_style_bwd_param(N.ptr(gy), N.ptr(lm), N.ptr(table), N.ptr(dw), N.ptr(db), G, B, D, tiles, N.stream()),
+                "sgx_style_bwd_param")
+        offs = [o // B for o in yoffs]
+        gws = tuple(dw[o:o + n] for o, n in zip(offs, ns))
+        gbs = tuple(db[o:o + n] for o, n in zip(offs, ns))
+        return (glm, None) + gws + gbs
+
+
 class NoiseArena:
     """One device randn per generator forward; the per-layer noise maps [B,1,H,W] are consecutive slices of it."""
 

@@ -76,6 +76,9 @@ SIGNATURES = {
     "sgx_linear_fwd": (I, [P, P, P, P, I, I, I, F, F, I, P]),
     "sgx_linear_bwd_data": (I, [P, P, P, P, I, I, I, F, P]),
     "sgx_linear_bwd_param": (I, [P, P, P, P, P, I, I, I, F, F, P]),
+    "sgx_style_fwd": (I, [P, P, P, I, I, I, I, P]),
+    "sgx_style_bwd_data": (I, [P, P, P, I, I, I, I, P]),
+    "sgx_style_bwd_param": (I, [P, P, P, P, P, I, I, I, I, P]),
     "sgx_adam_multi": (I, [P, P, P, P, P, I, F, F, F, P, P, P, P]),
     "sgx_ema_multi": (I, [P, P, P, I, F, P]),
     "sgx_gradnorm_clip_coef": (I, [P, P, I, F, P, P, P]),

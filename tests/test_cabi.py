@@ -80,3 +80,13 @@ def test_product_never_imports_the_oracle():
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+\S*oracle", src, flags=re.M), fn
             assert "stylegan_oracle" not in src, fn
+
+
+def test_integration_doc_lists_every_entry_point():
+    """INTEGRATION.md's table names every symbol include/sgx.h declares."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "sgx.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = [s for s in sorted(set(re.findall(r"\b(sgx_[a-z0-9_]+)\s*\(", header))) if s not in doc]
+    assert not missing, missing

@@ -455,3 +455,29 @@ def test_fused_linear_matches_torch(B, K, Nn, act):
     y2 = F.linear_fused(x, w, None, w_mul, b_mul, act)                      # no bias
     yr2 = TF.linear(x, w * w_mul)
     assert_close(y2, TF.leaky_relu(yr2, 0.2) if act else yr2, 1e-5, "linear fwd no bias")
+
+
+@pytest.mark.parametrize("B", [4, 8, 3])
+def test_grouped_style_affines_match_per_layer_linears(B):
+    """GroupedStyleFn (one launch for all style affines, two for their backward) against torch F.linear per layer."""
+    from stylegan.pytorch_amd import functional as F
+    torch.manual_seed(B)
+    L, D = 6, 512
+    ns = [1024, 1024, 512, 64, 32, 32]
+    ws = [torch.nn.Parameter(torch.randn(n, D, device=DEV)) for n in ns]
+    bs = [torch.nn.Parameter(torch.randn(n, device=DEV)) for n in ns]
+    lm = torch.randn(L + 2, B, D, device=DEV, requires_grad=True)           # two trailing layers have no group
+    meta = tuple((i, 0.044 + 0.001 * i, 1.0 - 0.1 * i) for i in range(L))
+    outs = F.GroupedStyleFn.apply(lm, meta, *ws, *bs)
+    lmr = lm.detach().clone().requires_grad_(True)
+    wr = [w.detach().clone().requires_grad_(True) for w in ws]; br = [b.detach().clone().requires_grad_(True) for b in bs]
+    refs = [TF.linear(lmr[i], wr[i] * meta[i][1], br[i] * meta[i][2]) for i in range(L)]
+    gs = [torch.randn_like(o) for o in outs]
+    for o, r in zip(outs, refs):
+        assert_close(o, r, 1e-5, "style fwd")
+    torch.autograd.backward(outs, gs)
+    torch.autograd.backward(refs, gs)
+    assert_close(lm.grad, lmr.grad, 1e-5, "dlatent gradient")
+    for i in range(L):
+        assert_close(ws[i].grad, wr[i].grad, 1e-5, f"dW{i}")
+        assert_close(bs[i].grad, br[i].grad, 1e-5, f"db{i}")
