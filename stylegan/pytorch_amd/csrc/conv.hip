@@ -956,7 +956,8 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(FinishArgs f) {
     }
 }
 
-// Pixel splits per channel pair.  ~1024 blocks fill the chip; the 16/32-channel layers at 512^2..1024^2 (a handful of
+// Pixel splits per channel pair.  ~512 blocks for the mid layers (measured 18.20 -> 18.05 ms/step against 1024: half the
+// partial traffic); the 16/32-channel layers at 512^2..1024^2 (a handful of
 // channel pairs, millions of pixels, partials of a few KB per split) take 2048 blocks / up to 1024 splits -- measured:
 // 118 -> 87 us for the 1024^2 16x16 layer -- while for bigger weights more splits cost more in partial traffic than they
 // gain (measured).  SGX_WGRAD_BLOCKS / SGX_WGRAD_MAXSPLIT override both for experiments.
@@ -964,7 +965,8 @@ static int wgrad_nsplit(int pairs, int ntiles, size_t elems_per_split) {
     static const int env_target = [] { const char* e = getenv("SGX_WGRAD_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
     static const int env_cap = [] { const char* e = getenv("SGX_WGRAD_MAXSPLIT"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
     const bool tiny = elems_per_split <= (size_t)16 * 32 * 32;
-    const int target = env_target ? env_target : (tiny ? 2048 : 1024), cap = env_cap ? env_cap : (tiny ? 1024 : 512);
+    static const int env_mid = [] { const char* e = getenv("SGX_WGRAD_BLOCKS_MID"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+    const int target = env_target ? env_target : (tiny ? 2048 : (env_mid ? env_mid : 512)), cap = env_cap ? env_cap : (tiny ? 1024 : 512);
     int want = (target + pairs - 1) / pairs;
     // big weights at low resolution (512x512 channels at 4^2..32^2): with >= 512 channel pairs the grid is full without
     // pixel splits, and one split means no partials at all (the block writes the parameter gradient itself) -- partial
