@@ -497,7 +497,8 @@ static ConvCfg pick_cfg(int geo, int B, int ohc, int owc, int Cout) {
         best = c;
         const long blocks = (long)((B + c.ni - 1) / c.ni) * ((ohc + c.th - 1) / c.th) * ((owc + c.tw - 1) / c.tw) *
                             (Cout / (16 * c.ct)) * (geo == GUP ? 4 : 1);
-        if (blocks >= 512) break;
+        static const long min_blocks = [] { const char* e = getenv("SGX_CONV_MINBLOCKS"); return e && atoi(e) > 0 ? atol(e) : 512L; }();
+        if (blocks >= min_blocks) break;
     }
     return best;
 }
