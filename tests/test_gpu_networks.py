@@ -208,3 +208,78 @@ def test_fails_loudly_without_gpu_tensors():
     m = EqualizedConv2d(16, 16, 3, use_wscale=True)
     with pytest.raises(native.SgxError):
         m(torch.zeros(1, 16, 8, 8))
+
+
+@pytest.mark.parametrize("depth,alpha", [(0, 1.0), (1, 0.3), (2, 0.75), (3, 0.5), (4, 0.1)])
+def test_progressive_depths_step_vs_oracle(depth, alpha):
+    """The progressive-growing sweep (BASELINE configs[4]): one full G+D iteration at every depth below the top one, with
+    the fade-in active, against the fp64 oracle -- losses and the updated parameters (incl. the blocks a depth does NOT
+    touch staying bit-unchanged)."""
+    B = 4
+    sg = make_stylegan()
+    gp, dp = mid_params(torch.float64)
+    load_into(sg.gen, gp); load_into(sg.dis, dp); load_into(sg.gen_shadow, gp)
+    sg.gen.train(); sg.dis.train()
+    noises = mid_noises(B)
+    pin_noise(sg.gen, noises)
+    z = gu.seeded((B, 512), 31 + depth); real = gu.seeded((B, 3, 128, 128), 41 + depth)
+    before = {k: v.detach().clone() for k, v in sg.dis.state_dict().items()}
+    torch.manual_seed(7 + depth); random.seed(7 + depth)
+    d_loss = sg.optimize_discriminator(z.to(DEV), real.to(DEV), depth, alpha)
+    torch.manual_seed(8 + depth); random.seed(8 + depth)
+    g_loss = sg.optimize_generator(z.to(DEV), real.to(DEV), depth, alpha)
+
+    shadow = {k: v.detach().clone() for k, v in gp.items()}
+    kw = dict(total_depth=MID_DEPTH, mapping_layers=MID["mapping_layers"], noises=noises)
+    torch.manual_seed(7 + depth); random.seed(7 + depth)
+    l2, cut = O.draw_mixing(z.shape, depth)
+    od, _ = O.d_step(gp, dp, O.AdamState(), z.double(), real.double(), depth, alpha, latents2=l2.double(), mixing_cutoff=cut, **kw)
+    torch.manual_seed(8 + depth); random.seed(8 + depth)
+    l2, cut = O.draw_mixing(z.shape, depth)
+    og, _ = O.g_step(gp, dp, O.AdamState(), z.double(), depth, alpha, latents2=l2.double(), mixing_cutoff=cut, shadow=shadow, **kw)
+    assert abs(d_loss - od) <= 1e-4 * abs(od), (float(d_loss), od)
+    assert abs(g_loss - og) <= 1e-4 * abs(og), (float(g_loss), og)
+    touched = 0
+    for k, p in sg.dis.named_parameters():
+        ref = dp[k].detach()
+        if torch.equal(ref.float(), before[k].float().cpu()):          # oracle left it alone: inactive at this depth
+            assert torch.equal(p.detach().cpu(), before[k].cpu()), k
+            continue
+        touched += 1
+        d = (p.detach().double().cpu() - ref).abs()
+        assert float((d > 1e-5 * (1 + ref.abs())).double().mean()) <= max(2e-2, 2.0 / p.numel()), k
+    assert touched >= 4
+
+
+@pytest.mark.parametrize("loss", ["hinge", "relativistic-hinge"])
+def test_other_losses_run_the_same_kernels(loss):
+    """HingeGAN / RelativisticAverageHingeGAN (models/Losses.py:136-189): the step runs on the HIP path and its losses equal
+    the formulas evaluated on the discriminator's own outputs."""
+    from stylegan.pytorch_amd.GAN import StyleGAN
+    kw = dict(learning_rate=0.003, beta_1=0, beta_2=0.99, eps=1e-8)
+    sg = StyleGAN(structure="linear", resolution=128, num_channels=3, latent_size=512,
+                  g_args=dict(latent_size=512, mapping_layers=MID["mapping_layers"], blur_filter=[1, 2, 1], truncation_psi=0.7,
+                              truncation_cutoff=8, fmap_base=MID["fmap_base"], fmap_max=MID["fmap_max"]),
+                  d_args=dict(use_wscale=True, blur_filter=[1, 2, 1], fmap_base=MID["fmap_base"], fmap_max=MID["fmap_max"]),
+                  g_opt_args=kw, d_opt_args=kw, loss=loss, d_repeats=1, use_ema=True, ema_decay=0.999, device=torch.device(DEV))
+    gp, dp = mid_params(torch.float64)
+    load_into(sg.gen, gp); load_into(sg.dis, dp); load_into(sg.gen_shadow, gp)
+    sg.gen.train(); sg.dis.train()
+    pin_noise(sg.gen, mid_noises(4))
+    sg.gen.style_mixing_prob = None
+    z = gu.seeded((4, 512), 61).to(DEV); real = gu.seeded((4, 3, 128, 128), 62).to(DEV)
+    with torch.no_grad():
+        avg = sg.gen.truncation.avg_latent.clone()                     # a training-mode forward moves the W average
+        fake = sg.gen(z, 5, 0.5)
+        sg.gen.truncation.avg_latent.copy_(avg)
+        r = sg.dis(sg.progressive_down_sampling(real, 5, 0.5), 5, 0.5).double(); f = sg.dis(fake, 5, 0.5).double()
+    if loss == "hinge":
+        want = torch.relu(1 - r).mean() + torch.relu(1 + f).mean()
+    else:
+        want = torch.relu(1 - (r - f.mean())).mean() + torch.relu(1 + (f - r.mean())).mean()
+    got = sg.optimize_discriminator(z, real, 5, 0.5)
+    assert abs(got - float(want)) <= 1e-4 * abs(float(want)) + 1e-6, (float(got), float(want))
+    g = sg.optimize_generator(z, real, 5, 0.5)
+    assert np.isfinite(float(g))
+    for p in list(sg.gen.parameters()) + list(sg.dis.parameters()):
+        assert torch.isfinite(p).all()
