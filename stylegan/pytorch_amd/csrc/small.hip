@@ -62,9 +62,10 @@ __global__ __launch_bounds__(1024) void mbstd_fwd_kernel(const T* __restrict__ x
         acc += (double)sqrtf(var / G + 1e-8f);
     }
     const float stat = (float)(block_sum_d(acc, sh) / n);
+    // every block of the slot computed the statistic (redundantly: it is a 32-KB reduction); the padded copy is split over them
     for (int g = 0; g < G; ++g) {
         const size_t b = (size_t)(g * M + m);
-        for (int i = threadIdx.x; i < HW * Cpad; i += blockDim.x) {
+        for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW * Cpad; i += gridDim.y * blockDim.x) {
             const int p = i / Cpad, c = i % Cpad;
             float v = 0.f;
             if (c < C) v = to_f(x[(b * HW + p) * C + c]);
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(1024) void mbstd_bwd_kernel(const T* __restrict__ d
         acc += (double)to_f(dy[((size_t)(g * M + m) * HW + p) * Cpad + C]);
     }
     const float k = (float)(block_sum_d(acc, sh) / n) / G;              // gy / (C*HW*G)
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
         const int p = i / C, c = i % C;
         float v[4], mu = 0.f;
         for (int g = 0; g < G; ++g) { v[g] = to_f(x[(size_t)(g * M + m) * n + i]); mu += v[g]; }
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(1024) void mbstd_bwd2_kernel(const T* __restrict__ 
     }
     const float k = (float)(block_sum_d(a_gy, sh) / n) / G;             // gy / (C*HW*G)
     const float dstat = (float)(block_sum_d(a_dd, sh) / n) / G;         // d L / d gy[m]
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
         float v[4], gg[4], mu = 0.f;
         for (int g = 0; g < G; ++g) {
             v[g] = to_f(x[(size_t)(g * M + m) * n + i]); mu += v[g];
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(1024) void mbstd_bwd2_kernel(const T* __restrict__ 
     }
     for (int g = 0; g < G; ++g) {
         const size_t b = (size_t)(g * M + m);
-        for (int i = threadIdx.x; i < HW * Cpad; i += blockDim.x) {
+        for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < HW * Cpad; i += gridDim.y * blockDim.x) {
             const int p = i / Cpad, c = i % Cpad;
             float v = 0.f;
             if (c < C) v = to_f(ggx[(b * HW + p) * C + c]);
@@ -151,6 +152,9 @@ __global__ __launch_bounds__(1024) void mbstd_bwd2_kernel(const T* __restrict__ 
     }
 }
 
+#ifndef MBSTD_NB
+#define MBSTD_NB 8                                             // blocks per slot: each recomputes the scalars, writes 1/8 of the output
+#endif
 static int mbstd_check(int B, int C, int Cpad) {
     SGX_REQUIRE(B > 0 && (B < 4 || B % 4 == 0), SGX_EINVAL, "mbstd: batch %d not divisible by group size", B);
     SGX_REQUIRE(Cpad > C, SGX_EINVAL, "mbstd: Cpad must exceed C");
@@ -159,16 +163,16 @@ static int mbstd_check(int B, int C, int Cpad) {
 extern "C" int sgx_mbstd_fwd(const void* x, void* y, int B, int HW, int C, int Cpad, int dtype, void* stream) {
     int rc = mbstd_check(B, C, Cpad); if (rc) return rc;
     const int M = B / (B < 4 ? B : 4);
-    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_fwd_kernel<float>, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, HW, C, Cpad);
-    else hipLaunchKernelGGL(mbstd_fwd_kernel<bf16_t>, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, HW, C, Cpad);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_fwd_kernel<float>, dim3(M, MBSTD_NB), dim3(1024), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, HW, C, Cpad);
+    else hipLaunchKernelGGL(mbstd_fwd_kernel<bf16_t>, dim3(M, MBSTD_NB), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, HW, C, Cpad);
     SGX_LAUNCH_CHECK("mbstd_fwd");
     return 0;
 }
 extern "C" int sgx_mbstd_bwd(const void* dy, const void* x, void* dx, int B, int HW, int C, int Cpad, int dtype, void* stream) {
     int rc = mbstd_check(B, C, Cpad); if (rc) return rc;
     const int M = B / (B < 4 ? B : 4);
-    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_bwd_kernel<float>, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, (float*)dx, B, HW, C, Cpad);
-    else hipLaunchKernelGGL(mbstd_bwd_kernel<bf16_t>, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, B, HW, C, Cpad);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_bwd_kernel<float>, dim3(M, MBSTD_NB), dim3(1024), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, (float*)dx, B, HW, C, Cpad);
+    else hipLaunchKernelGGL(mbstd_bwd_kernel<bf16_t>, dim3(M, MBSTD_NB), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, B, HW, C, Cpad);
     SGX_LAUNCH_CHECK("mbstd_bwd");
     return 0;
 }
@@ -176,8 +180,8 @@ extern "C" int sgx_mbstd_bwd2(const void* ggx, const void* dy, const void* x, vo
                               int dtype, void* stream) {
     int rc = mbstd_check(B, C, Cpad); if (rc) return rc;
     const int M = B / (B < 4 ? B : 4);
-    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_bwd2_kernel<float>, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const float*)ggx, (const float*)dy, (const float*)x, (float*)ddy, (float*)gx, B, HW, C, Cpad);
-    else hipLaunchKernelGGL(mbstd_bwd2_kernel<bf16_t>, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)ggx, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)ddy, (bf16_t*)gx, B, HW, C, Cpad);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(mbstd_bwd2_kernel<float>, dim3(M, MBSTD_NB), dim3(1024), 0, (hipStream_t)stream, (const float*)ggx, (const float*)dy, (const float*)x, (float*)ddy, (float*)gx, B, HW, C, Cpad);
+    else hipLaunchKernelGGL(mbstd_bwd2_kernel<bf16_t>, dim3(M, MBSTD_NB), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)ggx, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)ddy, (bf16_t*)gx, B, HW, C, Cpad);
     SGX_LAUNCH_CHECK("mbstd_bwd2");
     return 0;
 }
