@@ -14,10 +14,29 @@ __global__ __launch_bounds__(256) void sumsq_stage1(const float* const* __restri
     const int64_t n = sizes[t];
     double acc = 0.0;
     float part = 0.f; int cnt = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)MT_BLOCKS_X * 256) {
-        const float v = g[i];
-        part += v * v;
-        if (++cnt == 32) { acc += part; part = 0.f; cnt = 0; }
+    const int64_t gs = (int64_t)MT_BLOCKS_X * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {            // 16-byte loads, four in flight per lane
+        const int64_t nv = n / 4;
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        for (; i + 3 * gs < nv; i += 4 * gs) {
+            const float4 a = g4[i], b = g4[i + gs], c = g4[i + 2 * gs], d = g4[i + 3 * gs];
+            part += ((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w)) + ((b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w));
+            part += ((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w)) + ((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w));
+            if (++cnt == 4) { acc += part; part = 0.f; cnt = 0; }
+        }
+        for (; i < nv; i += gs) {
+            const float4 a = g4[i];
+            part += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            for (int64_t k = nv * 4; k < n; ++k) part += g[k] * g[k];
+    } else {
+        for (; i < n; i += gs) {
+            const float v = g[i];
+            part += v * v;
+            if (++cnt == 32) { acc += part; part = 0.f; cnt = 0; }
+        }
     }
     acc += part;
     acc = wave_sum_d(acc);

@@ -305,12 +305,32 @@ __global__ void up2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, in
         }
     }
 }
+// fp32 RGB images (C = 3): four consecutive floats of an output row per lane (16-byte stores; a row is 3*OW floats)
+__global__ void up2_rgb_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, float scale) {
+    const int OW = 2 * W, q4 = OW * 3 / 4;
+    const size_t n = (size_t)B * 2 * H * q4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % q4);
+        const size_t row = i / q4;                             // b * OH + oh
+        const int oh = (int)(row % (2 * H));
+        const size_t b = row / (2 * H);
+        const float* src = x + ((b * H + (oh >> 1)) * W) * 3;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = q * 4 + j;
+            v[j] = scale * src[((e / 3) >> 1) * 3 + e % 3];
+        }
+        *reinterpret_cast<float4*>(y + row * OW * 3 + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
 extern "C" int sgx_up2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SGX_NOTE(0.0, 5.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * C, "up2 B%d %dx%d C%d", B, H, W, C);
     const size_t nout = (size_t)B * H * W * 4 * C;
     if (dtype == SGX_F32) {
         if (C % 4 == 0) hipLaunchKernelGGL((up2_kernel<float, true>), dim3(grid_for(nout / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
+        else if (C == 3 && (2 * W * 3) % 4 == 0) hipLaunchKernelGGL(up2_rgb_kernel, dim3(grid_for(nout / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, scale);
         else hipLaunchKernelGGL((up2_kernel<float, false>), dim3(grid_for(nout)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
     } else {
         if (C % 8 == 0) hipLaunchKernelGGL((up2_kernel<bf16_t, true>), dim3(grid_for(nout / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, scale);

@@ -522,10 +522,18 @@ __global__ __launch_bounds__(256) void sumsq_f32_stage1(const float* __restrict_
     const size_t nvec = n / 4;
     double acc = 0.0;
     float part = 0.f; int cnt = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const size_t gs = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * gs < nvec; i += 4 * gs) {                      // four 16-byte loads in flight per lane
+        const float4 v0 = reinterpret_cast<const float4*>(x)[i], v1 = reinterpret_cast<const float4*>(x)[i + gs];
+        const float4 v2 = reinterpret_cast<const float4*>(x)[i + 2 * gs], v3 = reinterpret_cast<const float4*>(x)[i + 3 * gs];
+        part += ((v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w)) + ((v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w));
+        part += ((v2.x * v2.x + v2.y * v2.y) + (v2.z * v2.z + v2.w * v2.w)) + ((v3.x * v3.x + v3.y * v3.y) + (v3.z * v3.z + v3.w * v3.w));
+        if (++cnt == 4) { acc += (double)part; part = 0.f; cnt = 0; }
+    }
+    for (; i < nvec; i += gs) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         part += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-        if (++cnt == 16) { acc += (double)part; part = 0.f; cnt = 0; }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
         for (size_t i = nvec * 4; i < n; ++i) part += x[i] * x[i];
