@@ -1132,6 +1132,16 @@ __device__ __forceinline__ void pack_weight_tile(const float* __restrict__ w, T*
     const int tiles_i = (Ip + PACK_T - 1) / PACK_T;
     const int o0 = (int)(tile / tiles_i) * PACK_T, i0 = (int)(tile % tiles_i) * PACK_T;
     const int ni = (I - i0 < PACK_T ? (I - i0 > 0 ? I - i0 : 0) : PACK_T);         // real (unpadded) input channels in this tile
+    if (ni == PACK_T && (I * 9) % 4 == 0 && ((size_t)i0 * 9) % 4 == 0) {     // 16-byte loads: a tile row is 288 contiguous floats
+        for (int idx = threadIdx.x; idx < PACK_T * (PACK_T * 9 / 4); idx += blockDim.x) {
+            const int r = idx / (PACK_T * 9 / 4), c4 = (idx % (PACK_T * 9 / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (o0 + r < O) v = *reinterpret_cast<const float4*>(w + ((size_t)(o0 + r) * I + i0) * 9 + c4);
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) raw[(c4 + j) % 9][r][(c4 + j) / 9] = e[j];
+        }
+    } else
     for (int idx = threadIdx.x; idx < PACK_T * PACK_T * 9; idx += blockDim.x) {
         const int r = idx / (PACK_T * 9), c = idx % (PACK_T * 9);
         const int il = c / 9, k = c % 9;
