@@ -1037,8 +1037,43 @@ static int wgrad_ch(WgradArgs& a, void* ws, size_t wsb, int* ns, hipStream_t st)
     return wgrad_tile<T, GEO, BP, 1, 1, TR>(a, ws, wsb, ns, st);
 }
 
+// Pre-reduction for the many-split case (tiny weights at 512^2..1024^2: 256..1024 splits of a few KB): groups of splits are
+// summed element-wise with fully coalesced 16-byte loads into WGRAD_PRE groups, which the finishing kernel then treats as
+// its splits.  (The finishing kernel alone reads a 16..32-byte run per split: 70 us for 38 MB of partials.)
+#define WGRAD_PRE 32
+__global__ __launch_bounds__(256) void wgrad_prereduce_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t total4,
+                                                              int nsplit) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;      // float4 index inside one split
+    if (e >= total4) return;
+    const int g = blockIdx.y, per = (nsplit + WGRAD_PRE - 1) / WGRAD_PRE;
+    const int s0 = g * per, s1 = (s0 + per < nsplit) ? s0 + per : nsplit;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int sp = s0; sp < s1; ++sp) {
+        const float4 v = reinterpret_cast<const float4*>(ws)[(size_t)sp * total4 + e];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[(size_t)g * total4 + e] = acc;
+}
+static size_t wgrad_pre_bytes(size_t total_floats, int nsplit) {
+    static const int on = [] { const char* e = getenv("SGX_WGRAD_PRE"); return e ? atoi(e) : 1; }();   // A/B switch
+    return (on && nsplit >= 256 && total_floats % 4 == 0) ? (size_t)WGRAD_PRE * total_floats * sizeof(float) : 0;
+}
+
 static int wgrad_finish(const void* ws, float* dw, float* db, int nsplit, int O, int I, int Ip, int mode, int transposed, int flip_t,
-                        float scale, int accumulate, hipStream_t st) {
+                        float scale, int accumulate, hipStream_t st, size_t ws_bytes = 0) {
+    {
+        const size_t total = (size_t)(mode == SGX_PACK_S ? 9 : 16) * O * Ip + (transposed ? Ip : O);
+        const size_t pre = wgrad_pre_bytes(total, nsplit), used = (size_t)nsplit * total * sizeof(float);
+        if (pre && ws_bytes >= used + pre) {
+            float* out = reinterpret_cast<float*>(const_cast<char*>(static_cast<const char*>(ws)) + used);
+            hipLaunchKernelGGL(wgrad_prereduce_kernel, dim3((unsigned)((total / 4 + 255) / 256), WGRAD_PRE), dim3(256), 0, st,
+                               static_cast<const float*>(ws), out, total / 4, nsplit);
+            SGX_LAUNCH_CHECK("wgrad_prereduce_kernel");
+            ws = out;
+            nsplit = WGRAD_PRE;
+        }
+    }
     FinishArgs f{static_cast<const float*>(ws), dw, db, nsplit, O, I, Ip, mode, transposed, flip_t, scale, accumulate};
     SGX_NOTE(0.0, 4.0 * ((double)nsplit * (mode == SGX_PACK_S ? 9 : 16) * O * Ip + 9.0 * O * I), "finish %dx%d m%d tr%d ns%d", O, I, mode, transposed, nsplit);
     const int ne = O * Ip, nb = db ? O : 0;                            // bias blocks trail the weight blocks
@@ -1056,7 +1091,7 @@ extern "C" size_t sgx_wgrad_ws_bytes(int taps, int B, int H, int W, int Ck, int 
     int pairs = (Ck / 32 > 0 ? Ck / 32 : 1) * (Cn / 32 > 0 ? Cn / 32 : 1);
     size_t ntiles = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
     size_t ns = (size_t)wgrad_nsplit(pairs, ntiles > (1u << 30) ? (1 << 30) : (int)ntiles, (size_t)taps * Ck * Cn);
-    return total * ns;
+    return total * ns + wgrad_pre_bytes(total / sizeof(float), (int)ns);
 }
 
 extern "C" int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, float* db, void* ws, size_t ws_bytes, int B, int H,
@@ -1075,7 +1110,7 @@ extern "C" int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, floa
     else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad3x3_param: bad dtype"); }
     if (rc) return rc;
     if (a.direct) return 0;
-    return wgrad_finish(ws, dW, db, ns, O, I, Ip, SGX_PACK_S, adjoint, adjoint, scale, accumulate, st);
+    return wgrad_finish(ws, dW, db, ns, O, I, Ip, SGX_PACK_S, adjoint, adjoint, scale, accumulate, st, ws_bytes);
 }
 
 extern "C" int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float* dW, float* db, void* ws, size_t ws_bytes, int B,
@@ -1097,7 +1132,7 @@ extern "C" int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float*
     else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad4x4s2_param: bad dtype"); }
     if (rc) return rc;
     if (a.direct) return 0;
-    return wgrad_finish(ws, dW, db, ns, O, I, I, mode, transposed, 0, scale, accumulate, st);
+    return wgrad_finish(ws, dW, db, ns, O, I, I, mode, transposed, 0, scale, accumulate, st, ws_bytes);
 }
 
 // =====================================================================================================
