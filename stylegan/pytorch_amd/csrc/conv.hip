@@ -1038,14 +1038,15 @@ static int wgrad_ch(WgradArgs& a, void* ws, size_t wsb, int* ns, hipStream_t st)
 }
 
 // Pre-reduction for the many-split case (tiny weights at 512^2..1024^2: 256..1024 splits of a few KB): groups of splits are
-// summed element-wise with fully coalesced 16-byte loads into WGRAD_PRE groups, which the finishing kernel then treats as
+// summed element-wise with fully coalesced 16-byte loads into 32 groups, which the finishing kernel then treats as
 // its splits.  (The finishing kernel alone reads a 16..32-byte run per split: 70 us for 38 MB of partials.)
-#define WGRAD_PRE 32
+static int wgrad_pre_groups() { static const int v = [] { const char* e = getenv("SGX_WGRAD_PRE"); return e ? atoi(e) : 32; }(); return v; }
+static int wgrad_pre_min() { static const int v = [] { const char* e = getenv("SGX_WGRAD_PRE_MIN"); return e ? atoi(e) : 256; }(); return v; }
 __global__ __launch_bounds__(256) void wgrad_prereduce_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t total4,
                                                               int nsplit) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;      // float4 index inside one split
     if (e >= total4) return;
-    const int g = blockIdx.y, per = (nsplit + WGRAD_PRE - 1) / WGRAD_PRE;
+    const int g = blockIdx.y, per = (nsplit + (int)gridDim.y - 1) / (int)gridDim.y;
     const int s0 = g * per, s1 = (s0 + per < nsplit) ? s0 + per : nsplit;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
@@ -1056,8 +1057,8 @@ __global__ __launch_bounds__(256) void wgrad_prereduce_kernel(const float* __res
     reinterpret_cast<float4*>(out)[(size_t)g * total4 + e] = acc;
 }
 static size_t wgrad_pre_bytes(size_t total_floats, int nsplit) {
-    static const int on = [] { const char* e = getenv("SGX_WGRAD_PRE"); return e ? atoi(e) : 1; }();   // A/B switch
-    return (on && nsplit >= 256 && total_floats % 4 == 0) ? (size_t)WGRAD_PRE * total_floats * sizeof(float) : 0;
+    const int G = wgrad_pre_groups();                                  // SGX_WGRAD_PRE=0 switches the pass off (A/B)
+    return (G > 0 && nsplit >= wgrad_pre_min() && nsplit > G && total_floats % 4 == 0) ? (size_t)G * total_floats * sizeof(float) : 0;
 }
 
 static int wgrad_finish(const void* ws, float* dw, float* db, int nsplit, int O, int I, int Ip, int mode, int transposed, int flip_t,
@@ -1067,11 +1068,11 @@ static int wgrad_finish(const void* ws, float* dw, float* db, int nsplit, int O,
         const size_t pre = wgrad_pre_bytes(total, nsplit), used = (size_t)nsplit * total * sizeof(float);
         if (pre && ws_bytes >= used + pre) {
             float* out = reinterpret_cast<float*>(const_cast<char*>(static_cast<const char*>(ws)) + used);
-            hipLaunchKernelGGL(wgrad_prereduce_kernel, dim3((unsigned)((total / 4 + 255) / 256), WGRAD_PRE), dim3(256), 0, st,
+            hipLaunchKernelGGL(wgrad_prereduce_kernel, dim3((unsigned)((total / 4 + 255) / 256), wgrad_pre_groups()), dim3(256), 0, st,
                                static_cast<const float*>(ws), out, total / 4, nsplit);
             SGX_LAUNCH_CHECK("wgrad_prereduce_kernel");
             ws = out;
-            nsplit = WGRAD_PRE;
+            nsplit = wgrad_pre_groups();
         }
     }
     FinishArgs f{static_cast<const float*>(ws), dw, db, nsplit, O, I, Ip, mode, transposed, flip_t, scale, accumulate};
