@@ -158,6 +158,11 @@ def main():
         for i in range(3):
             step(i)
         graphs = sg.use_graphs                               # a failed capture falls back to eager for good
+        if world > 1:                                        # ... on every rank, or the calibration below would diverge
+            ok = torch.tensor([1.0 if graphs else 0.0], device=dev)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            graphs = bool(ok.item() > 0.5)
+            sg.use_graphs = graphs
     if graphs and a.graphs == "auto":
         # Launch mode by measurement: hipGraph replay removes the host from the loop but costs the ROCm runtime more per
         # node than stream launches do; which one wins depends on whether the host keeps up with the GPU.  4 steps each.

@@ -81,10 +81,11 @@ class DataParallelGroup:
             flats.append((flat, chunk))
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
-        for flat, chunk in flats:
-            off = 0
+        for flat, chunk in flats:                             # one multi-tensor copy per bucket, not one launch per parameter
+            views, off = [], 0
             for g in chunk:
-                g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+                views.append(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+            torch._foreach_copy_(chunk, views)
 
     @torch.no_grad()
     def broadcast(self, tensor, src: int = 0):
