@@ -32,3 +32,31 @@ for s, e, n in ev:
     a = agg[n]; a[0] += 1; a[1] += (e - s) / 1e6
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
     print(f"{t:8.2f} ms  n={c:5d}  {n[:110]}")
+
+# ---- exclusive time: how long each kernel is the ONLY one running (a proxy for the critical path when several streams
+# overlap), how long >= 2 kernels overlap, per-queue busy time
+pts = []
+for i, (s, e, n) in enumerate(ev):
+    pts.append((s, 1, i)); pts.append((e, 0, i))
+pts.sort()
+active = set(); last = pts[0][0]; excl = collections.defaultdict(float); multi = 0.0
+for t, kind, i in pts:
+    if t > last and active:
+        if len(active) == 1:
+            excl[ev[next(iter(active))][2]] += (t - last) / 1e6
+        else:
+            multi += (t - last) / 1e6
+    last = t
+    if kind: active.add(i)
+    else: active.discard(i)
+print(f"exclusive (one kernel running) {sum(excl.values()):.2f} ms, overlapped (>=2 running) {multi:.2f} ms")
+for n, t in sorted(excl.items(), key=lambda kv: -kv[1])[:25]:
+    print(f"{t:8.2f} ms exclusive  (total {agg[n][1]:6.2f}, n={agg[n][0]:4d})  {n[:100]}")
+qcol = next((c for c in ("Queue_Id", "Stream_Id") if c in rows[0]), None)
+if qcol:
+    q = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        if int(r["Start_Timestamp"]) >= cut:
+            a = q[r[qcol]]; a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    for k, (c, t) in sorted(q.items(), key=lambda kv: -kv[1][1]):
+        print(f"{qcol} {k}: {c} kernels, {t:.2f} ms busy")
