@@ -30,6 +30,10 @@ enum { SGX_EINVAL = -1, SGX_EUNSUPPORTED = -2, SGX_EWORKSPACE = -3 };
 int sgx_version(void);
 const char* sgx_last_error(void);
 int sgx_clear_error(void);          /* forget the message and HIP's sticky last error (returns it); after a failed capture */
+/* Stream ordering without a host object per fork: `waiter` waits for all work enqueued on `signaler` so far (pooled
+ * events inside the library; valid during stream capture, where it becomes a graph edge).  Replaces the
+ * torch.cuda.Stream.wait_stream calls a multi-stream implementation of models/GAN.py:595-655 would make.            */
+int sgx_stream_wait_stream(void* waiter, void* signaler);
 /* Hardware self-test of ds_read_b64_tr_b16 (the transpose read of the bf16 weight-gradient kernel): with lds[e] = e and
  * lane l addressing elements [4l,4l+4), writes the 4 int16 values each of the 64 lanes received to out256.          */
 int sgx_selftest_tr16(void* out256, void* stream);

@@ -1,5 +1,7 @@
 // Error plumbing + version of the C ABI (include/sgx.h).
 #include "common.h"
+#include <atomic>
+#include <mutex>
 
 #define SGX_VERSION 100   // 0.1.0
 
@@ -128,3 +130,25 @@ extern "C" int sgx_prof_get(int i, char* name, int name_cap, float* ms, double* 
 extern "C" int sgx_version(void) { return SGX_VERSION; }
 extern "C" const char* sgx_last_error(void) { return g_err; }
 extern "C" int sgx_clear_error(void) { g_err[0] = 0; return (int)hipGetLastError(); }   // also resets HIP's sticky last-error
+
+// waiter waits for everything enqueued on signaler so far: one event record + one stream wait on an event from a small
+// round-robin pool (a wait binds to the record that precedes it, so an event may be re-recorded while older waits are
+// still pending).  The step forks its weight-gradient launches to a side stream ~70 times per iteration; through
+// torch.cuda.Stream.wait_stream that is an event object + several Python-level device queries each time.
+extern "C" int sgx_stream_wait_stream(void* waiter, void* signaler) {
+    constexpr int NEV = 256;
+    static hipEvent_t pool[NEV];
+    static std::atomic<unsigned> next{0};
+    static std::once_flag once;
+    static int create_rc = 0;
+    std::call_once(once, [] {
+        for (int i = 0; i < NEV && !create_rc; ++i) create_rc = (int)hipEventCreateWithFlags(&pool[i], hipEventDisableTiming);
+    });
+    SGX_REQUIRE(create_rc == 0, create_rc, "stream_wait_stream: hipEventCreateWithFlags failed (%d)", create_rc);
+    if (waiter == signaler) return 0;
+    hipEvent_t ev = pool[next.fetch_add(1) % NEV];
+    hipError_t e = hipEventRecord(ev, (hipStream_t)signaler);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+    SGX_REQUIRE(e == hipSuccess, (int)e, "stream_wait_stream: %s", hipGetErrorString(e));
+    return 0;
+}

@@ -32,6 +32,7 @@ SIGNATURES = {
     "sgx_version": (I, []),
     "sgx_last_error": (ctypes.c_char_p, []),
     "sgx_clear_error": (I, []),
+    "sgx_stream_wait_stream": (I, [P, P]),
     "sgx_conv3x3": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_down": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_up": (I, [P, P, P, I, I, I, I, I, I, P]),
@@ -124,12 +125,13 @@ def check(rc: int, what: str):
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 
 
 def stream() -> int:
     """hipStream_t of torch's current stream on the current device (the raw getter: this is called once per launch)."""
     if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(_get_device())                   # torch.cuda.current_device() minus its lazy-init check
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -31,6 +31,19 @@ def main():
     for _ in range(2):
         step()
     torch.cuda.synchronize()
+    # the backward passes run on autograd's device thread, which the main thread's profiler does not see: the first
+    # backward of a convolution on that thread switches a second profiler on there
+    import threading
+    from stylegan.pytorch_amd import functional as F
+    tl, bw_profs = threading.local(), []
+    orig_bw = F.ConvFn.backward
+
+    def conv_backward(ctx, *g):
+        if not getattr(tl, "on", False) and threading.current_thread() is not threading.main_thread():
+            tl.on = True
+            p2 = cProfile.Profile(); p2.enable(); bw_profs.append(p2)
+        return orig_bw(ctx, *g)
+    F.ConvFn.backward = staticmethod(conv_backward)
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(steps):
@@ -40,6 +53,11 @@ def main():
     st = pstats.Stats(pr)
     st.sort_stats("tottime").print_stats(28)
     st.sort_stats("cumulative").print_stats(22)
+    for p2 in bw_profs:
+        print("==== autograd device thread")
+        st2 = pstats.Stats(p2)
+        st2.sort_stats("tottime").print_stats(40)
+        st2.sort_stats("cumulative").print_stats(30)
 
 
 if __name__ == "__main__":
