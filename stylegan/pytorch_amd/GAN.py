@@ -527,7 +527,10 @@ class StyleGAN:
         self._wait_update("d")                        # data parallel: D's all-reduce + Adam overlapped the G forward above
         # the reference also back-propagates into D's parameters here and discards the result at the next
         # dis_optim.zero_grad(); skipping those weight gradients changes no observable value
-        d_params = [p for p in self.dis.parameters() if p.requires_grad]
+        d_all = self.__dict__.get("_sgx_dis_params")               # the module tree is static: walk it once
+        if d_all is None:
+            d_all = self.__dict__["_sgx_dis_params"] = list(self.dis.parameters())
+        d_params = [p for p in d_all if p.requires_grad]
         for p in d_params:
             p.requires_grad_(False)
         try:

@@ -66,6 +66,12 @@ def call(fn, *args):
     return fn.forward(_NoGradCtx(), *args)
 
 
+# the Functions' own backward passes go through the same bypass: a first-order backward (grad mode off) launches its
+# kernels without building a second autograd graph node per op; under create_graph (the R1 penalty) the inputs require
+# grad and ``call`` falls through to ``apply``.  SGX_BWD_BYPASS=0: always ``apply`` (A/B).
+_bcall = call if os.environ.get("SGX_BWD_BYPASS", "1") != "0" else (lambda fn, *args: fn.apply(*args))
+
+
 # ---------------------------------------------------------------------------------------------------
 # packed-weight cache.  mode: 'S' plain 3x3 | 'D' fused down | 'U' fused up | 'UF' non-fused-up semantics.
 # One sgx_pack_weight launch per (parameter, version) produces both MFMA operand packs in the activation dtype;
@@ -338,10 +344,10 @@ class ConvFn(Function):
         mode, scale, ipad, adjoint, act, has_bias = ctx.cfg
         gy = _c(gy)
         if act:
-            gy = LReluBwdFn.apply(gy, y)
+            gy = _bcall(LReluBwdFn, gy, y)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = ConvFn.apply(gy, weight, None, mode, scale, ipad, not adjoint, 0)
+            gx = _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0)
         if not _DATA_GRAD_ONLY:
             want_b = has_bias and ctx.needs_input_grad[2]
             # the bias gradient rides along in the weight-gradient pass when gy is its O-channel side
@@ -359,9 +365,9 @@ class ConvFn(Function):
                         bias.grad = db
                     want_b = False
             elif ctx.needs_input_grad[1]:
-                gw, gb = WgradFn.apply(x, gy, weight, mode, scale, adjoint, fuse_b)
+                gw, gb = _bcall(WgradFn, x, gy, weight, mode, scale, adjoint, fuse_b)
             if want_b and not fuse_b:
-                gb = ColSumFn.apply(gy, 1.0)
+                gb = _bcall(ColSumFn, gy, 1.0)
         return gx, gw, gb, None, None, None, None, None
 
 
@@ -397,7 +403,7 @@ class LReluBwdFn(Function):
     @staticmethod
     def backward(ctx, gg):
         (y,) = ctx.saved_tensors
-        return LReluBwdFn.apply(gg, y), None
+        return _bcall(LReluBwdFn, gg, y), None
 
 
 class ColSumFn(Function):
@@ -439,10 +445,10 @@ class BiasActFn(Function):
         (y,) = ctx.saved_tensors
         g = _c(g)
         if ctx.act:
-            g = LReluBwdFn.apply(g, y)
+            g = _bcall(LReluBwdFn, g, y)
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[1] and not _DATA_GRAD_ONLY:
-            gb = ColSumFn.apply(g, ctx.bscale)
+            gb = _bcall(ColSumFn, g, ctx.bscale)
         return g, gb, None, None
 
 
@@ -457,7 +463,7 @@ class ScaleFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return ScaleFn.apply(g, ctx.s), None
+        return _bcall(ScaleFn, g, ctx.s), None
 
 
 class AxpbyFn(Function):
@@ -474,8 +480,8 @@ class AxpbyFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        ga = ScaleFn.apply(g, ctx.alpha) if ctx.needs_input_grad[0] else None
-        gb = ScaleFn.apply(g, ctx.beta) if ctx.needs_input_grad[1] else None
+        ga = _bcall(ScaleFn, g, ctx.alpha) if ctx.needs_input_grad[0] else None
+        gb = _bcall(ScaleFn, g, ctx.beta) if ctx.needs_input_grad[1] else None
         return ga, gb, None, None
 
 
@@ -492,7 +498,7 @@ class ScaleDevFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return ScaleDevFn.apply(g, ctx.s), None
+        return _bcall(ScaleDevFn, g, ctx.s), None
 
 
 class FadeFn(Function):
@@ -510,8 +516,8 @@ class FadeFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        ga = ScaleDevFn.apply(g, ctx.ab[0:1]) if ctx.needs_input_grad[0] else None
-        gb = ScaleDevFn.apply(g, ctx.ab[1:2]) if ctx.needs_input_grad[1] else None
+        ga = _bcall(ScaleDevFn, g, ctx.ab[0:1]) if ctx.needs_input_grad[0] else None
+        gb = _bcall(ScaleDevFn, g, ctx.ab[1:2]) if ctx.needs_input_grad[1] else None
         return ga, gb, None
 
 
@@ -535,7 +541,7 @@ class BlurFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return BlurFn.apply(g)
+        return _bcall(BlurFn, g)
 
 
 def _blur_act(x, z, mode):
@@ -558,7 +564,7 @@ class ActBlurFn(Function):
     @staticmethod
     def backward(ctx, g):
         (z,) = ctx.saved_tensors
-        return BlurMaskFn.apply(g, z)
+        return _bcall(BlurMaskFn, g, z)
 
 
 class BlurMaskFn(Function):
@@ -572,7 +578,7 @@ class BlurMaskFn(Function):
     @staticmethod
     def backward(ctx, gg):
         (z,) = ctx.saved_tensors
-        return MaskBlurFn.apply(gg, z), None
+        return _bcall(MaskBlurFn, gg, z), None
 
 
 class MaskBlurFn(Function):
@@ -586,7 +592,7 @@ class MaskBlurFn(Function):
     @staticmethod
     def backward(ctx, gg):
         (z,) = ctx.saved_tensors
-        return BlurMaskFn.apply(gg, z), None
+        return _bcall(BlurMaskFn, gg, z), None
 
 
 class Pool2Fn(Function):
@@ -603,7 +609,7 @@ class Pool2Fn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return Up2Fn.apply(g, ctx.scale), None
+        return _bcall(Up2Fn, g, ctx.scale), None
 
 
 class Up2Fn(Function):
@@ -620,7 +626,7 @@ class Up2Fn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return Pool2Fn.apply(g, ctx.scale), None
+        return _bcall(Pool2Fn, g, ctx.scale), None
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -660,12 +666,12 @@ class RgbInFn(Function):
         g = _c(g)
         gi = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gi = RgbOutFn.apply(g, weight, None, ctx.wscale)
+            gi = _bcall(RgbOutFn, g, weight, None, ctx.wscale)
         if not _DATA_GRAD_ONLY:
             if ctx.needs_input_grad[1]:
-                gw = RgbWgradFn.apply(img, g, weight, ctx.wscale)
+                gw = _bcall(RgbWgradFn, img, g, weight, ctx.wscale)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = ColSumFn.apply(g, 1.0)
+                gb = _bcall(ColSumFn, g, 1.0)
         return gi, gw, gb, None, None
 
 
@@ -691,12 +697,12 @@ class RgbOutFn(Function):
         g = _c(g)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = RgbInFn.apply(g, weight, None, ctx.wscale, x.dtype)
+            gx = _bcall(RgbInFn, g, weight, None, ctx.wscale, x.dtype)
         if not _DATA_GRAD_ONLY:
             if ctx.needs_input_grad[1]:
-                gw = RgbWgradFn.apply(g, x, weight, ctx.wscale)
+                gw = _bcall(RgbWgradFn, g, x, weight, ctx.wscale)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = ColSumFn.apply(g, 1.0)                   # 3 numbers
+                gb = _bcall(ColSumFn, g, 1.0)                   # 3 numbers
         return gx, gw, gb, None
 
 
@@ -797,7 +803,7 @@ class MbstdFn(Function):
     @staticmethod
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
-        return MbstdBwdFn.apply(gy, x), None
+        return _bcall(MbstdBwdFn, gy, x), None
 
 
 class MbstdBwdFn(Function):
@@ -881,9 +887,9 @@ class MatMulFn(Function):
         ta, tb, al = ctx.ta, ctx.tb, ctx.alpha
         gA = gB = None
         if ctx.needs_input_grad[0]:
-            gA = MatMulFn.apply(gC, Bm, 0, 1 - tb, al) if not ta else MatMulFn.apply(Bm, gC, tb, 1, al)
+            gA = _bcall(MatMulFn, gC, Bm, 0, 1 - tb, al) if not ta else _bcall(MatMulFn, Bm, gC, tb, 1, al)
         if ctx.needs_input_grad[1] and not _DATA_GRAD_ONLY:
-            gB = MatMulFn.apply(A, gC, 1 - ta, 0, al) if not tb else MatMulFn.apply(gC, A, 1, ta, al)
+            gB = _bcall(MatMulFn, A, gC, 1 - ta, 0, al) if not tb else _bcall(MatMulFn, gC, A, 1, ta, al)
         return gA, gB, None, None, None
 
 

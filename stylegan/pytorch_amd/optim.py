@@ -146,13 +146,15 @@ def clip_and_step(optim: FusedAdam, max_norm: float):
 @torch.no_grad()
 def ema_update(model_tgt, model_src, beta):
     """tgt = beta*tgt + (1-beta)*src over named_parameters (buffers excluded) -- reference models/__init__.py:31-36."""
-    src = dict(model_src.named_parameters())
+    pairs = model_tgt.__dict__.get("_sgx_ema_pairs")              # (source module id, [(target, source)]): walk the trees once
+    if pairs is None or pairs[0] != id(model_src):
+        src = dict(model_src.named_parameters())
+        pairs = model_tgt.__dict__["_sgx_ema_pairs"] = (id(model_src), [(p, src[name]) for name, p in model_tgt.named_parameters()])
     tg, sr, sizes = [], [], []
     dev = None
     changed = []
-    for name, p in model_tgt.named_parameters():
+    for p, q in pairs[1]:
         changed.append(p)
-        q = src[name]
         assert q is not p
         if not p.is_cuda:
             raise N.SgxError("ema_update needs GPU parameters")
