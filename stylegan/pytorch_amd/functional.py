@@ -132,6 +132,8 @@ def _param_grads(mode, adjoint, x, gy, weight, scale, want_bias, into):
                 t.record_stream(cur)
         return dW, db
     cur_raw = N.stream()
+    if side.cuda_stream == cur_raw:                         # the "side" stream is the one this backward branch runs on
+        return _wgrad_param(mode, adjoint, x, gy, weight, scale, want_bias, into)
     cur = _stream_of(cur_raw)
     N.check(N.lib().sgx_stream_wait_stream(side.cuda_stream, cur_raw), "sgx_stream_wait_stream")   # gy (and x) are complete
     _set_stream(stream_id=side.stream_id, device_index=side.device_index, device_type=side.device_type)
