@@ -127,6 +127,11 @@ int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, v
  * mode 0: y = blur(x);  1: y = blur(lrelu(x))  [forward];  2: y = blur(x) * slope(z)  [backward: z = the pre-activation];
  * 3: y = blur(x * slope(z))  [backward of mode 2 w.r.t. x: the R1 double backward].  slope(z) = z > 0 ? 1 : 0.2 */
 int sgx_blur3x3_act(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, int dtype, void* stream);
+/* Input pipeline on the device: uint8 images -> NHWC activations, (v/255 - 0.5)/0.5 in fp32 -- torchvision's
+ * ToTensor + Normalize((.5,.5,.5),(.5,.5,.5)) of data/transforms.py:20-33; flip[b] != 0 mirrors image b horizontally
+ * (RandomHorizontalFlip, decision drawn by the caller; NULL: none).  src: [B][H][W][3] bytes, or [B][3][H][W] if src_chw.
+ * W must be a multiple of 4.                                                                                          */
+int sgx_images_u8_to_nhwc(const void* src, void* dst, const int* flip, int B, int H, int W, int src_chw, int dtype, void* stream);
 /* y = scale * (2x2 block sum)   scale .25: AvgPool2d(2) models/GAN.py:382,423; Downscale2d CustomLayers.py:60-64   */
 int sgx_pool2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream);
 /* y = scale * nearest_up2(x)    Upscale2d CustomLayers.py:27-36; F.interpolate(scale_factor=2) models/GAN.py:173     */

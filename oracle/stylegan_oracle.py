@@ -305,6 +305,22 @@ def progressive_down_sampling(real: Tensor, depth: int, alpha: float, total_dept
     return alpha * ds + (1 - alpha) * prior
 
 
+def images_u8_to_float(u8_hwc: Tensor, flip: Optional[Sequence[bool]] = None) -> Tensor:
+    """uint8 [B,H,W,3] -> fp32 [B,3,H,W]: the reference's transform chain without Resize, data/transforms.py:27-32
+    (``RandomHorizontalFlip(), ToTensor(), Normalize((.5,.5,.5),(.5,.5,.5))``) with the flip decisions given.
+
+    The arithmetic lives in torchvision, which requirements.txt:4 names unpinned and which is NOT installed in this
+    image: parity for this function is therefore UNPINNED against the reference itself; it restates
+    torchvision's published semantics -- ``ToTensor``: HWC uint8 -> CHW float32 ``.div(255)``; ``Normalize``:
+    ``(t - mean) / std``; ``hflip``: reverse the width axis -- and is pinned by known values in
+    tests/test_oracle_golden.py::test_images_u8_known_values (0 -> -1, 255 -> 1, 128 -> 1/255)."""
+    x = u8_hwc
+    if flip is not None:
+        x = torch.stack([img.flip(1) if f else img for img, f in zip(x, flip)])
+    t = x.permute(0, 3, 1, 2).contiguous().to(torch.float32).div(255)
+    return (t - 0.5) / 0.5
+
+
 def r1_penalty(p: Params, real: Tensor, depth: int, alpha: float, total_depth: int) -> Tensor:
     """LogisticGAN.R1Penalty (models/Losses.py:197-211): SUM over batch and pixels of grad^2."""
     real = real.detach().requires_grad_(True)

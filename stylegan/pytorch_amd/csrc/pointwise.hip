@@ -282,6 +282,82 @@ extern "C" int sgx_pool2(const void* x, void* y, int B, int H, int W, int C, flo
     return 0;
 }
 
+// ---------------------------------------------------------------- uint8 images -> normalised NHWC activations
+// ToTensor + Normalize(0.5, 0.5) (+ RandomHorizontalFlip with host-drawn decisions) of the reference's input pipeline,
+// on the device: the batch crosses PCIe as bytes (12.6 MB at B=4, 1024^2 instead of 50 MB of fp32).  HBM-bound: 3 B in,
+// 12 B (fp32) or 6 B (bf16) out per pixel.  A lane converts 4 consecutive output pixels: 12 source bytes (three dword
+// loads from an HWC row, or one dword from each plane of a CHW image) -> 48 / 24 contiguous output bytes.
+// Arithmetic in the reference's order, fp32, IEEE division: (v / 255 - 0.5) / 0.5.
+template <typename T, bool CHW>
+__global__ void images_u8_kernel(const unsigned char* __restrict__ src, T* __restrict__ dst, const int* __restrict__ flip,
+                                 int B, int H, int W) {
+    const int wq = W / 4;
+    const size_t n = (size_t)B * H * wq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int xq = (int)(i % wq);
+        size_t p = i / wq;
+        const int y = (int)(p % H), b = (int)(p / H);
+        const bool fl = flip != nullptr && flip[b] != 0;
+        const int sx = fl ? W - 4 - 4 * xq : 4 * xq;                 // first of the 4 source pixels (mirrored block if flipped)
+        unsigned char v[4][3];                                       // [source pixel][channel]
+        if (CHW) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned w = *reinterpret_cast<const unsigned*>(src + (((size_t)b * 3 + c) * H + y) * W + sx);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k][c] = (unsigned char)(w >> (8 * k));
+            }
+        } else {
+            const unsigned* s3 = reinterpret_cast<const unsigned*>(src + (((size_t)b * H + y) * W + sx) * 3);
+            const unsigned w0 = s3[0], w1 = s3[1], w2 = s3[2];
+            const unsigned char bytes[12] = {(unsigned char)w0, (unsigned char)(w0 >> 8), (unsigned char)(w0 >> 16), (unsigned char)(w0 >> 24),
+                                             (unsigned char)w1, (unsigned char)(w1 >> 8), (unsigned char)(w1 >> 16), (unsigned char)(w1 >> 24),
+                                             (unsigned char)w2, (unsigned char)(w2 >> 8), (unsigned char)(w2 >> 16), (unsigned char)(w2 >> 24)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[k][c] = bytes[3 * k + c];
+        }
+        float o[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[3 * k + c] = (__fdiv_rn((float)v[fl ? 3 - k : k][c], 255.0f) - 0.5f) * 2.0f;   // /0.5 == *2 exactly
+        T* d = dst + (((size_t)b * H + y) * W + 4 * xq) * 3;
+        if (sizeof(T) == 4) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                reinterpret_cast<float4*>(d)[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+        } else {
+            uint2 lo, hi;
+            lo.x = pack_bf16x2(o[0], o[1]); lo.y = pack_bf16x2(o[2], o[3]);
+            hi.x = pack_bf16x2(o[4], o[5]); hi.y = pack_bf16x2(o[6], o[7]);
+            reinterpret_cast<uint2*>(d)[0] = lo; reinterpret_cast<uint2*>(d)[1] = hi;
+            uint2 t;
+            t.x = pack_bf16x2(o[8], o[9]); t.y = pack_bf16x2(o[10], o[11]);
+            reinterpret_cast<uint2*>(d)[2] = t;
+        }
+    }
+}
+extern "C" int sgx_images_u8_to_nhwc(const void* src, void* dst, const int* flip, int B, int H, int W, int src_chw, int dtype,
+                                     void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SGX_REQUIRE(B > 0 && H > 0 && W > 0 && W % 4 == 0, SGX_EINVAL, "images_u8_to_nhwc: width must be a multiple of 4 (got %dx%d)", H, W);
+    SGX_REQUIRE(dtype == SGX_F32 || dtype == SGX_BF16, SGX_EINVAL, "images_u8_to_nhwc: bad dtype");
+    SGX_NOTE(0.0, (3.0 + 3.0 * (dtype == SGX_F32 ? 4.0 : 2.0)) * B * H * W, "images_u8 B%d %dx%d", B, H, W);
+    const size_t n = (size_t)B * H * (W / 4);
+    const auto* s = static_cast<const unsigned char*>(src);
+    if (dtype == SGX_F32) {
+        if (src_chw) hipLaunchKernelGGL((images_u8_kernel<float, true>), dim3(grid_for(n)), dim3(256), 0, st, s, (float*)dst, flip, B, H, W);
+        else hipLaunchKernelGGL((images_u8_kernel<float, false>), dim3(grid_for(n)), dim3(256), 0, st, s, (float*)dst, flip, B, H, W);
+    } else {
+        if (src_chw) hipLaunchKernelGGL((images_u8_kernel<bf16_t, true>), dim3(grid_for(n)), dim3(256), 0, st, s, (bf16_t*)dst, flip, B, H, W);
+        else hipLaunchKernelGGL((images_u8_kernel<bf16_t, false>), dim3(grid_for(n)), dim3(256), 0, st, s, (bf16_t*)dst, flip, B, H, W);
+    }
+    SGX_LAUNCH_CHECK("images_u8_kernel");
+    return 0;
+}
+
 template <typename T, bool VECT>
 __global__ void up2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, float scale) {
     constexpr int VE = VECT ? VecTraits<T>::VE : 1;

@@ -1058,6 +1058,31 @@ def nhwc(x_nchw, dtype=None):
     return t.contiguous()
 
 
+def images_from_uint8(u8, flip=None, out_dtype=torch.float32, layout=None):
+    """uint8 image batch on the GPU -> the ``real_batch`` the training step takes: logical [B,3,H,W] view over NHWC storage,
+    (v/255 - 0.5)/0.5 -- the reference's ToTensor + Normalize (data/transforms.py:27-32) done on the device, so the batch
+    crosses PCIe as bytes.  ``u8``: [B,H,W,3] (decoded images; ``layout='hwc'``) or [B,3,H,W] (``'chw'``; inferred when
+    unambiguous).  ``flip``: per-image horizontal-flip decisions (RandomHorizontalFlip, drawn by the caller), or None."""
+    if not (u8.is_cuda and u8.dtype == torch.uint8 and u8.dim() == 4):
+        raise N.SgxError("images_from_uint8: need a 4-d uint8 GPU tensor")
+    if layout is None:
+        hwc, chw = u8.shape[3] == 3, u8.shape[1] == 3
+        if hwc == chw:
+            raise N.SgxError(f"images_from_uint8: cannot infer the layout of {tuple(u8.shape)}; pass layout='hwc' or 'chw'")
+        layout = "hwc" if hwc else "chw"
+    u8 = _c(u8)
+    B, H, W = (u8.shape[0], u8.shape[1], u8.shape[2]) if layout == "hwc" else (u8.shape[0], u8.shape[2], u8.shape[3])
+    fl = None
+    if flip is not None:
+        fl = torch.as_tensor(flip).to(device=u8.device, dtype=torch.int32).contiguous()
+        if fl.numel() != B:
+            raise N.SgxError("images_from_uint8: one flip decision per image")
+    out = torch.empty((B, H, W, 3), dtype=out_dtype, device=u8.device)
+    N.check(N.lib().sgx_images_u8_to_nhwc(N.ptr(u8), N.ptr(out), N.ptr(fl), B, H, W, int(layout == "chw"), N.dt(out), N.stream()),
+            "sgx_images_u8_to_nhwc")
+    return nchw_view(out)
+
+
 def nchw_view(x_nhwc):
     """Contiguous NHWC -> logical NCHW view (channels_last strides, zero copy)."""
     return x_nhwc.permute(0, 3, 1, 2)

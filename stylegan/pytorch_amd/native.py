@@ -37,6 +37,7 @@ SIGNATURES = {
     "sgx_conv4x4s2_down": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_up": (I, [P, P, P, I, I, I, I, I, I, P]),
     "sgx_wgrad_ws_bytes": (Z, [I, I, I, I, I, I]),
+    "sgx_images_u8_to_nhwc": (I, [P, P, P, I, I, I, I, I, P]),
     "sgx_selftest_tr16": (I, [P, P]),
     "sgx_conv_config": (I, [I, I, I, I, I, I, I, P]),
     "sgx_prof_start": (I, [I, I]),

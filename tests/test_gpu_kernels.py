@@ -481,3 +481,42 @@ def test_grouped_style_affines_match_per_layer_linears(B):
     for i in range(L):
         assert_close(ws[i].grad, wr[i].grad, 1e-5, f"dW{i}")
         assert_close(bs[i].grad, br[i].grad, 1e-5, f"db{i}")
+
+
+@pytest.mark.parametrize("layout", ["hwc", "chw"])
+@pytest.mark.parametrize("B,H,W", [(3, 6, 8), (2, 64, 64), (4, 1024, 1024)])
+def test_images_from_uint8(layout, B, H, W):
+    """Device-side input pipeline against the oracle: bit-exact in fp32 (same operation order, IEEE division),
+    bf16 = the fp32 result rounded to nearest even; horizontal flips by per-image decision; every byte value occurs."""
+    from stylegan.pytorch_amd import functional as F
+    g = torch.Generator().manual_seed(B * H + W)
+    hwc = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, generator=g)
+    hwc.view(-1)[:256] = torch.arange(256, dtype=torch.uint8)
+    flip = [bool(i % 2) for i in range(B)]
+    src = (hwc if layout == "hwc" else hwc.permute(0, 3, 1, 2).contiguous()).to(DEV)
+    if B * H * W <= 1 << 16:
+        ref, ref_fl = O.images_u8_to_float(hwc).to(DEV), O.images_u8_to_float(hwc, flip).to(DEV)
+    else:                                                 # full size: the oracle's 256 levels, gathered on the GPU
+        lut = O.images_u8_to_float(torch.arange(256, dtype=torch.uint8).reshape(1, 1, 256, 1).expand(1, 1, 256, 3))[0, 0, 0].to(DEV)
+        ref = lut[hwc.to(DEV).permute(0, 3, 1, 2).long()]
+        ref_fl = torch.stack([r.flip(-1) if f else r for r, f in zip(ref, flip)])
+    out = F.images_from_uint8(src, layout=layout)
+    assert out.shape == (B, 3, H, W) and out.permute(0, 2, 3, 1).is_contiguous()      # NHWC storage, NCHW view
+    assert torch.equal(out, ref)
+    assert torch.equal(F.images_from_uint8(src, flip=flip, layout=layout), ref_fl)
+    assert torch.equal(F.images_from_uint8(src, flip=flip, out_dtype=torch.bfloat16, layout=layout), ref_fl.to(torch.bfloat16))
+    with pytest.raises(Exception):
+        F.images_from_uint8(src.float(), layout=layout)
+
+
+def test_images_from_uint8_feeds_the_step():
+    """The uint8 batch drives the discriminator exactly like the float batch it stands for."""
+    from stylegan.pytorch_amd import functional as F
+    from test_gpu_graphs import make
+    sg = make(False, torch.float32)
+    u8 = torch.randint(0, 256, (4, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3))
+    as_float = O.images_u8_to_float(u8).to(DEV)
+    with torch.no_grad():
+        a = sg.dis(F.images_from_uint8(u8.to(DEV)), 5, 1.0)
+        b = sg.dis(as_float, 5, 1.0)
+    assert torch.equal(a, b)

@@ -203,3 +203,19 @@ def test_schedule_bit_exact(golden_dir):
                 marks.append(-idx)
         assert marks == [int(m) for m in g[f"c{ci}_marks"]]
         assert [r[4] for r in rows] == list(range(1, len(rows) + 1))
+
+
+def test_images_u8_known_values():
+    """Input pipeline: ToTensor + Normalize(0.5, 0.5) + horizontal flip on uint8 batches.  torchvision is not
+    installed here, so this pins the oracle to the published semantics by known values and by an independent numpy
+    evaluation in the same fp32 operation order."""
+    u8 = torch.arange(256, dtype=torch.uint8).repeat(3)[: 2 * 4 * 8 * 3].reshape(2, 4, 8, 3)
+    out = O.images_u8_to_float(u8)
+    assert out.shape == (2, 3, 4, 8) and out.dtype == torch.float32
+    lut = O.images_u8_to_float(torch.arange(256, dtype=torch.uint8).reshape(1, 1, 256, 1).expand(1, 1, 256, 3))[0, 0, 0]
+    ref = (u8.numpy().astype(np.float32) / np.float32(255) - np.float32(0.5)) / np.float32(0.5)
+    assert np.array_equal(out.numpy(), ref.transpose(0, 3, 1, 2))
+    assert float(lut[0]) == -1.0 and float(lut[255]) == 1.0 and abs(float(lut[128]) - 1.0 / 255.0) < 1e-7
+    assert torch.all(lut[1:] > lut[:-1])                                  # strictly monotone: 256 distinct levels
+    fl = O.images_u8_to_float(u8, flip=[True, False])
+    assert torch.equal(fl[0], out[0].flip(-1)) and torch.equal(fl[1], out[1])
