@@ -402,13 +402,16 @@ class StyleGAN:
         if isinstance(loss, str):
             loss = loss.lower()
             assert not self.conditional, "conditional losses are outside the accelerated path"
-            assert loss in ["logistic", "hinge", "relativistic-hinge"], "Unknown loss function"
+            assert loss in ["logistic", "hinge", "standard-gan", "relativistic-hinge"], "Unknown loss function"
             mean_scale = 1.0 / self.dp.world_size if self.dp is not None else 1.0
             if loss == "logistic":
                 return Losses.LogisticGAN(self.dis, mean_scale=mean_scale)
             if loss == "hinge":
                 assert self.dp is None, "data parallel is wired for the logistic loss"
                 return Losses.HingeGAN(self.dis)
+            if loss == "standard-gan":
+                assert self.dp is None, "data parallel is wired for the logistic loss"
+                return Losses.StandardGAN(self.dis)
             assert self.dp is None, "data parallel is wired for the logistic loss"
             return Losses.RelativisticAverageHingeGAN(self.dis)
         return loss
@@ -524,7 +527,7 @@ class StyleGAN:
 
     def _g_grads(self, noise, real_batch, depth, alpha, labels=None):
         real_samples = None
-        if not isinstance(self.loss, (Losses.LogisticGAN, Losses.HingeGAN)):
+        if not isinstance(self.loss, (Losses.LogisticGAN, Losses.HingeGAN, Losses.StandardGAN)):
             real_samples = self.progressive_down_sampling(real_batch, depth, alpha)   # only the relativistic loss reads it
         self._wait_update("g")
         fake_samples = self.gen(noise, depth, alpha, labels)

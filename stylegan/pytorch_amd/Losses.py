@@ -23,6 +23,24 @@ class GANLoss:
         raise NotImplementedError("gen_loss method has not been implemented")
 
 
+class StandardGAN(GANLoss):
+    """Binary cross entropy on the logits -- reference models/Losses.py:96-134: ``(BCE(r, 1) + BCE(f, 0)) / 2`` for the
+    discriminator, ``BCE(f, 1)`` for the generator.  The reference's ``gen_loss`` unpacks the discriminator's [B,1] output
+    into three values (``preds, _, _ = self.dis(...)``, :131), which only runs at batch 3; the evident intent -- all
+    predictions -- is what is computed here."""
+
+    def dis_loss(self, real_samps, fake_samps, height, alpha):
+        r_preds = torch.squeeze(self.dis(real_samps, height, alpha))
+        f_preds = torch.squeeze(self.dis(fake_samps, height, alpha))
+        real_loss = TF.binary_cross_entropy_with_logits(r_preds, torch.ones_like(r_preds))
+        fake_loss = TF.binary_cross_entropy_with_logits(f_preds, torch.zeros_like(f_preds))
+        return (real_loss + fake_loss) / 2
+
+    def gen_loss(self, _, fake_samps, height, alpha):
+        preds = torch.squeeze(self.dis(fake_samps, height, alpha))
+        return TF.binary_cross_entropy_with_logits(preds, torch.ones_like(preds))
+
+
 class HingeGAN(GANLoss):
     """reference models/Losses.py:136-151."""
 

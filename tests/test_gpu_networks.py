@@ -251,9 +251,9 @@ def test_progressive_depths_step_vs_oracle(depth, alpha):
     assert touched >= 4
 
 
-@pytest.mark.parametrize("loss", ["hinge", "relativistic-hinge"])
+@pytest.mark.parametrize("loss", ["hinge", "relativistic-hinge", "standard-gan"])
 def test_other_losses_run_the_same_kernels(loss):
-    """HingeGAN / RelativisticAverageHingeGAN (models/Losses.py:136-189): the step runs on the HIP path and its losses equal
+    """StandardGAN / HingeGAN / RelativisticAverageHingeGAN (models/Losses.py:96-189): the step runs on the HIP path and its losses equal
     the formulas evaluated on the discriminator's own outputs."""
     from stylegan.pytorch_amd.GAN import StyleGAN
     kw = dict(learning_rate=0.003, beta_1=0, beta_2=0.99, eps=1e-8)
@@ -275,6 +275,8 @@ def test_other_losses_run_the_same_kernels(loss):
         r = sg.dis(sg.progressive_down_sampling(real, 5, 0.5), 5, 0.5).double(); f = sg.dis(fake, 5, 0.5).double()
     if loss == "hinge":
         want = torch.relu(1 - r).mean() + torch.relu(1 + f).mean()
+    elif loss == "standard-gan":                                       # BCE(r, 1) = softplus(-r), BCE(f, 0) = softplus(f)
+        want = (torch.nn.functional.softplus(-r).mean() + torch.nn.functional.softplus(f).mean()) / 2
     else:
         want = torch.relu(1 - (r - f.mean())).mean() + torch.relu(1 + (f - r.mean())).mean()
     got = sg.optimize_discriminator(z, real, 5, 0.5)
