@@ -285,3 +285,42 @@ def test_other_losses_run_the_same_kernels(loss):
     assert np.isfinite(float(g))
     for p in list(sg.gen.parameters()) + list(sg.dis.parameters()):
         assert torch.isfinite(p).all()
+
+
+def test_fixed_structure_equals_linear_at_full_depth():
+    """structure='fixed' (reference models/GAN.py:186-190,408-411: all blocks, no fade-in) is the 'linear' network at the
+    last depth index with alpha = 1, where the fade-in blend is exactly its first operand: bit-identical outputs of both
+    networks, and a training iteration on the fixed structure matches the linear one."""
+    import random
+    from stylegan.pytorch_amd.GAN import StyleGAN
+
+    def build(structure):
+        kw = dict(learning_rate=0.003, beta_1=0, beta_2=0.99, eps=1e-8)
+        sg = StyleGAN(structure=structure, resolution=128, num_channels=3, latent_size=512,
+                      g_args=dict(latent_size=512, mapping_layers=MID["mapping_layers"], blur_filter=[1, 2, 1], truncation_psi=0.7,
+                                  truncation_cutoff=8, fmap_base=MID["fmap_base"], fmap_max=MID["fmap_max"]),
+                      d_args=dict(use_wscale=True, blur_filter=[1, 2, 1], fmap_base=MID["fmap_base"], fmap_max=MID["fmap_max"]),
+                      g_opt_args=kw, d_opt_args=kw, loss="logistic", d_repeats=1, use_ema=True, ema_decay=0.999,
+                      device=torch.device(DEV))
+        gp, dp = mid_params(torch.float64)
+        load_into(sg.gen, gp); load_into(sg.dis, dp); load_into(sg.gen_shadow, gp)
+        sg.gen.train(); sg.dis.train()
+        pin_noise(sg.gen, mid_noises(4))
+        sg.gen.style_mixing_prob = None
+        return sg
+    lin, fix = build("linear"), build("fixed")
+    z = gu.seeded((4, 512), 71).to(DEV); real = gu.seeded((4, 3, 128, 128), 72).to(DEV)
+    with torch.no_grad():
+        imgs = []
+        for sg in (lin, fix):
+            avg = sg.gen.truncation.avg_latent.clone()
+            imgs.append(sg.gen(z, 5, 1.0))
+            sg.gen.truncation.avg_latent.copy_(avg)
+        assert imgs[0].shape == (4, 3, 128, 128) and torch.equal(imgs[0], imgs[1])
+        assert torch.equal(lin.dis(real, 5, 1.0), fix.dis(real, 5, 1.0))
+    out = []
+    for sg in (lin, fix):
+        torch.manual_seed(5); random.seed(5)
+        out.append((float(sg.optimize_discriminator(z, real, 5, 1.0)), float(sg.optimize_generator(z, real, 5, 1.0))))
+    for a, b in zip(out[0], out[1]):
+        assert np.isfinite(a) and abs(a - b) <= 1e-5 * abs(a) + 1e-7, out
