@@ -43,9 +43,10 @@ class DataParallelGroup:
     """Bucketed gradient all-reduce(SUM) + buffer broadcast over a torch.distributed process group
     (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests)."""
 
-    def __init__(self, group=None, bucket_mb: float = 32.0):
+    def __init__(self, group=None, bucket_mb: float = 32.0, force_collectives: bool = False):
         assert dist.is_initialized()
         self.group = group
+        self.force_collectives = force_collectives          # tests: issue the collectives even in a group of one rank
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
@@ -63,7 +64,7 @@ class DataParallelGroup:
         """Sum ``p.grad`` over ranks for every parameter that has one (the active set is identical on all ranks:
         the progressive depth is global)."""
         grads = [p.grad for p in params if p.grad is not None]
-        if not grads or self.world_size == 1:
+        if not grads or (self.world_size == 1 and not self.force_collectives):
             return
         dev = grads[0].device
         side = self._side_stream(dev)
@@ -89,5 +90,5 @@ class DataParallelGroup:
 
     @torch.no_grad()
     def broadcast(self, tensor, src: int = 0):
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force_collectives:
             dist.broadcast(tensor, src=src, group=self.group)

@@ -149,11 +149,12 @@ def test_data_parallel_graphs_split_around_the_all_reduce():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29611", rank=0, world_size=1, device_id=torch.device(DEV))
     try:
         le, se, _ = run(False, torch.float32, 5, psi=-1.0)
-        lg, sgr, sg = run(True, torch.float32, 5, psi=-1.0, dp=DataParallelGroup())
+        # force_collectives: the bucketed RCCL all-reduce (side stream, flat buckets, multi-tensor copy-back) really runs
+        lg, sgr, sg = run(True, torch.float32, 5, psi=-1.0, dp=DataParallelGroup(force_collectives=True, bucket_mb=1.0))
         graphs = list(sg._step_graphs.values())
         assert len(graphs) == 2 and all(g.graph is not None and g.graph_update is not None for g in graphs)
         # eager with a process group: all-reduce + update run on their own stream, overlapped with the next half-iteration
-        la, sa, sga = run(False, torch.float32, 5, psi=-1.0, dp=DataParallelGroup())
+        la, sa, sga = run(False, torch.float32, 5, psi=-1.0, dp=DataParallelGroup(force_collectives=True, bucket_mb=1.0))
         assert "_update_stream" in sga.__dict__
         for other_l, other_s in ((lg, sgr), (la, sa)):
             losses_agree(le, other_l)
