@@ -172,10 +172,14 @@ def main():
                 step(i)
             torch.cuda.synchronize(); barrier()
             return (time.perf_counter() - t) / n * 1e3
-        sg.use_graphs = False
-        timed(1); t_eager = timed(4)
-        sg.use_graphs = True
-        timed(1); t_graph = timed(4)
+        # two interleaved rounds, best of each: the eager step is host-bound, and one burst of host noise during a single
+        # 4-step measurement would pick the wrong mode for the whole run
+        t_eager = t_graph = float("inf")
+        for _ in range(2):
+            sg.use_graphs = False
+            timed(1); t_eager = min(t_eager, timed(4))
+            sg.use_graphs = True
+            timed(1); t_graph = min(t_graph, timed(4))
         if world > 1:                                        # one decision for all ranks
             tt = torch.tensor([t_eager, t_graph], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
