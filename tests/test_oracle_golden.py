@@ -219,3 +219,27 @@ def test_images_u8_known_values():
     assert torch.all(lut[1:] > lut[:-1])                                  # strictly monotone: 256 distinct levels
     fl = O.images_u8_to_float(u8, flip=[True, False])
     assert torch.equal(fl[0], out[0].flip(-1)) and torch.equal(fl[1], out[1])
+
+
+def test_other_losses_against_the_reference(golden_dir):
+    """StandardGAN / HingeGAN / RelativisticAverageHingeGAN of stylegan.pytorch_amd.Losses (plain torch on the [B,1]
+    logits) against values recorded from the reference's own classes (tests/golden/make_golden_losses.py: identity
+    discriminator, so the inputs are the prediction vectors).  The reference's StandardGAN.gen_loss cannot run at any
+    batch size (models/Losses.py:131 unpacks the output into three values; the fixture records its error): ours is
+    BCE(f, 1), checked against the closed form softplus(-f)."""
+    from stylegan.pytorch_amd import Losses
+    g = np.load(os.path.join(golden_dir, "losses.npz"))
+    ident = lambda x, height, alpha: x
+    for B in (3, 4, 8):
+        r, f = torch.from_numpy(g[f"r_{B}"]), torch.from_numpy(g[f"f_{B}"])
+        for name, cls in (("standard", Losses.StandardGAN), ("hinge", Losses.HingeGAN), ("relhinge", Losses.RelativisticAverageHingeGAN)):
+            loss = cls(ident)
+            want = float(g[f"{name}_dis_{B}"])
+            assert abs(float(loss.dis_loss(r, f, 0, 1.0)) - want) <= 1e-6 * max(1.0, abs(want)), (name, B)
+            if f"{name}_gen_{B}" in g:
+                want = float(g[f"{name}_gen_{B}"])
+                assert abs(float(loss.gen_loss(r, f, 0, 1.0)) - want) <= 1e-6 * max(1.0, abs(want)), (name, B)
+            else:
+                assert "Error" in str(g[f"{name}_gen_{B}_error"]) and name == "standard"
+                want = float(torch.nn.functional.softplus(-f.double()).mean())
+                assert abs(float(loss.gen_loss(r, f, 0, 1.0)) - want) <= 1e-6
