@@ -243,3 +243,22 @@ def test_other_losses_against_the_reference(golden_dir):
                 assert "Error" in str(g[f"{name}_gen_{B}_error"]) and name == "standard"
                 want = float(torch.nn.functional.softplus(-f.double()).mean())
                 assert abs(float(loss.gen_loss(r, f, 0, 1.0)) - want) <= 1e-6
+
+
+def test_fixed_structure_against_the_reference(golden_dir):
+    """structure='fixed' (models/GAN.py:186-190, 408-411): the reference's fixed networks, recorded by
+    tests/golden/make_golden_fixed.py, equal the linear networks at the last depth index with alpha = 1 -- in the reference
+    itself (recorded difference: exactly 0) and in the oracle.  This is the equivalence the GPU test
+    test_fixed_structure_equals_linear_at_full_depth relies on."""
+    g = load(golden_dir, "networks_fixed.npz")
+    assert float(np.max(g["linear_alpha1_max_abs_diff"])) == 0.0
+    gp, dp = tiny_params(torch.float32)
+    z = gu.seeded((4, 512), 11); real = gu.seeded((4, 3, 128, 128), 65)
+    with torch.no_grad():
+        gp["truncation.avg_latent"] = gu.fill_value("truncation.avg_latent", (512,), torch.float32)
+        img, _ = O.generator(gp, z, 5, 1.0, tiny_noises(4), mapping_layers=gu.TINY["mapping_layers"], num_layers=2 * gu.TINY_DEPTH)
+        close(img[:, :, ::4, ::4], g["g_fixed_img_sub"], 2e-5, 2e-5)
+        want = g["g_fixed_img_stats"]
+        got = np.array(gu.tensor_stats(img))
+        assert np.all(np.abs(got - want) <= 1e-4 * np.abs(want) + 1e-4), (got, want)
+        close(O.discriminator(dp, real, 5, 1.0, gu.TINY_DEPTH), g["d_fixed_score"], 2e-4, 2e-4)
