@@ -56,6 +56,12 @@ int sgx_prof_get(int i, char* name, int name_cap, float* ms, double* flops, doub
  *   y[b,h,w,n] = act(bias[n] + sum_{ty,tx,k} x[b,h+ty-1,w+tx-1,k] * w[ty*3+tx][n][k])                              */
 int sgx_conv3x3(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
                 int act, int dtype, void* stream);
+/* The same convolution with the kernel generation named by the caller (A/B probes and parity tests of both):
+ *   variant 0: first-generation kernel (16x16 MFMA tiles, register-staged single LDS stage; any shape / dtype);
+ *   variant 4 / 8: second-generation bf16 kernel (32x32x16 MFMA, LDS-DMA double-buffered stages) with 4- / 8-wave blocks;
+ *   needs Cin % 32 == 0, Cout % 64 == 0, W % 32 == 0 (SGX_EUNSUPPORTED otherwise).  sgx_conv3x3 chooses by itself.       */
+int sgx_conv3x3_variant(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                        int act, int dtype, int variant, void* stream);
 /* sgx_conv4x4s2_down: fused conv+downscale, F.conv2d(x, W4, stride=2, padding=1) -- models/CustomLayers.py:158-165
  *   (== conv3x3 -> avg_pool2 of :166-168); also the data gradient of sgx_conv4x4s2_up.
  *   H,W = input size.  y[b,oy,ox,n] = act(bias[n] + sum_{ky,kx,k} x[b,2oy+ky-1,2ox+kx-1,k] * w[ky*4+kx][n][k])    */

@@ -19,7 +19,9 @@
 #include "common.h"
 #include <stdlib.h>
 
-enum { G3X3 = 0, GDOWN = 1, GUP = 2, GUPA = 3 };   // GUPA: GUP with all four parity classes in one block (bf16)
+enum { G3X3 = 0, GDOWN = 1, GUP = 2, GUPA = 3 };
+int sgx_conv2_try_3x3(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
+                      int variant, hipStream_t st, int* launched);        // conv2.hip   // GUPA: GUP with all four parity classes in one block (bf16)
 
 // LDS operand tiles are arrays of rows (one pixel, or one (tap, output channel) weight row) holding KC channels.
 // rowb_*: row pitch in bytes; load(): the lane's MFMA fragment (k = kk-step, q = lane>>4); lstore(): one 16-byte chunk.
@@ -579,7 +581,25 @@ extern "C" int sgx_conv3x3(const void* x, const void* w, const float* bias, void
     ConvArgs a{x, w, bias, y, B, H, W, H, W, H, W, Cin, Cout, act, 0, 0};
     const double es = dtype == SGX_F32 ? 4 : 2;
     SGX_NOTE(2.0 * 9 * Cin * Cout * B * H * W, es * ((double)B * H * W * (Cin + Cout) + 9.0 * Cin * Cout), "convS B%d %dx%d %d->%d", B, H, W, Cin, Cout);
+    if (dtype == SGX_BF16) {                                   // second-generation kernel (conv2.hip) where it applies
+        int launched = 0;
+        const int rc = sgx_conv2_try_3x3(x, w, bias, y, B, H, W, Cin, Cout, act, -1, (hipStream_t)stream, &launched);
+        if (rc || launched) return rc;
+    }
     return dispatch_conv<G3X3>(a, dtype, (hipStream_t)stream);
+}
+
+extern "C" int sgx_conv3x3_variant(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin,
+                                   int Cout, int act, int dtype, int variant, void* stream) {
+    ConvArgs a{x, w, bias, y, B, H, W, H, W, H, W, Cin, Cout, act, 0, 0};
+    const double es = dtype == SGX_F32 ? 4 : 2;
+    SGX_NOTE(2.0 * 9 * Cin * Cout * B * H * W, es * ((double)B * H * W * (Cin + Cout) + 9.0 * Cin * Cout), "convS/v%d B%d %dx%d %d->%d", variant, B, H, W, Cin, Cout);
+    if (variant == 0) return dispatch_conv<G3X3>(a, dtype, (hipStream_t)stream);
+    SGX_REQUIRE(dtype == SGX_BF16 && (variant == 4 || variant == 8), SGX_EINVAL, "conv3x3_variant: variant %d needs bf16 and 4 or 8 waves", variant);
+    int launched = 0;
+    const int rc = sgx_conv2_try_3x3(x, w, bias, y, B, H, W, Cin, Cout, act, variant, (hipStream_t)stream, &launched);
+    SGX_REQUIRE(rc || launched, SGX_EUNSUPPORTED, "conv3x3_variant: shape not covered by the second-generation kernel");
+    return rc;
 }
 
 extern "C" int sgx_conv4x4s2_down(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,

@@ -520,3 +520,40 @@ def test_images_from_uint8_feeds_the_step():
         a = sg.dis(F.images_from_uint8(u8.to(DEV)), 5, 1.0)
         b = sg.dis(as_float, 5, 1.0)
     assert torch.equal(a, b)
+
+
+# second-generation bf16 convolution (conv2.hip): 32x32x16 MFMA, LDS-DMA double-buffered stages.  Both block shapes
+# (4 / 8 waves) against the fp64 oracle on bf16-exact operands, and against the first-generation kernel on the same packs.
+CONV2_CASES = [
+    # (cin, cout, B, H, W)      1 / 2 / 4+ K-chunks (static vs re-staged weights), 1..4 channel blocks, ragged rows, many tiles
+    (32, 64, 2, 32, 32), (64, 64, 3, 16, 32), (64, 128, 2, 40, 64), (128, 64, 1, 64, 32), (256, 256, 2, 8, 32),
+    (32, 128, 5, 24, 96), (96, 192, 1, 33, 32), (64, 64, 9, 64, 64),
+]
+
+
+@pytest.mark.parametrize("variant", [4, 8])
+@pytest.mark.parametrize("cin,cout,B,H,W", CONV2_CASES)
+def test_conv2_variants_vs_oracle(variant, cin, cout, B, H, W):
+    from stylegan.pytorch_amd import functional as F
+    from stylegan.pytorch_amd import native as N
+    w = gu.seeded((cout, cin, 3, 3), 5).to(DEV)
+    bias = (0.5 * gu.seeded((cout,), 6)).to(DEV)
+    scale = O.he_w_mul(cin * 9, math.sqrt(2))
+    x = gu.seeded((B, cin, H, W), 7).bfloat16().float()
+    xn = F.nhwc(x.to(DEV)).bfloat16()
+    wq, _ = F.packs(w, "S", scale, cin, torch.bfloat16)
+    L = N.lib()
+    outs = {}
+    for v in (0, variant):
+        y = torch.full((B, H, W, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        N.check(L.sgx_conv3x3_variant(N.ptr(xn), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, cin, cout, 1, N.BF16, v, N.stream()), "variant")
+        outs[v] = F.nchw_view(y).float()
+    # oracle on the bf16-rounded packed weights: the only remaining error is the bf16 rounding of the stored output
+    wr = wq.float().view(3, 3, cout, cin).permute(2, 3, 0, 1).double().cpu()
+    ref = TF.leaky_relu(TF.conv2d(x.double(), wr, bias.double().cpu(), padding=1), 0.2)
+    assert torch.isfinite(outs[variant]).all()
+    assert_close(outs[variant], ref, 4e-3, f"conv2 v{variant} vs oracle (bf16 output rounding only)")
+    assert_close(outs[variant], outs[0], 4e-3, f"conv2 v{variant} vs first-generation kernel")
+    # fp32 agreement before the rounding: at most one bf16 ulp apart anywhere
+    d = (outs[variant] - ref.float().to(DEV)).abs()
+    assert float((d / (ref.float().to(DEV).abs() + 1e-3)).max()) < 2 ** -7
