@@ -7,7 +7,11 @@ Extra (non-reference) knobs are keyword-only and default to the reference behavi
 ``act_dtype`` (torch.float32 | torch.bfloat16 storage of activations between kernels; accumulation stays fp32).
 """
 import copy
+import datetime
+import os
 import random
+import time
+import timeit
 from collections import OrderedDict
 
 import numpy as np
@@ -18,6 +22,7 @@ from . import Losses
 from . import functional as F
 from .Blocks import DiscriminatorBlock, DiscriminatorTop, GSynthesisBlock, InputBlock
 from .CustomLayers import EqualizedConv2d, EqualizedLinear, PixelNormLayer, Truncation
+from .data import get_data_loader
 from . import native
 from .native import ACT_LRELU
 from .optim import FusedAdam, clip_and_step, ema_update
@@ -350,7 +355,7 @@ class Discriminator(nn.Module):
 
 class StyleGAN:
     """Wrapper around the Generator and the Discriminator: optimizers, loss, EMA and the two optimisation steps --
-    reference models/GAN.py:447-659.  ``train`` (the progressive schedule loop) lives in train_loop.py."""
+    reference models/GAN.py:447-659 -- and ``train``, the progressive-growing schedule loop (:682-826)."""
 
     def __init__(self, structure, resolution, num_channels, latent_size, g_args, d_args, g_opt_args, d_opt_args,
                  conditional=False, n_classes=0, loss="relativistic-hinge", drift=0.001, d_repeats=1, use_ema=False,
@@ -627,6 +632,132 @@ class StyleGAN:
             return self._graphed("g", noise, real_batch, depth, alpha)
         return DeferredLoss(self._g_body(noise, real_batch, depth, alpha, labels))
 
+    # ------------------------------------------------------------------------------------------------------------
+    # The progressive-growing schedule -- reference models/GAN.py:730-803.  Pure host arithmetic, kept in the reference's
+    # own expression forms because the target is BIT-exact agreement of (depth, alpha, feedback ticks, checkpoint epochs)
+    # with the reference loop (tests/test_train_schedule.py replays tests/golden/schedule.npz, recorded from it).
+    @staticmethod
+    def fade_point_of(fade_in_percentage, epochs, total_batches):
+        return int((fade_in_percentage / 100) * epochs * total_batches)                  # :748-749
+
+    @staticmethod
+    def alpha_at(ticker, fade_point):
+        return ticker / fade_point if ticker <= fade_point else 1                         # :753
+
+    @staticmethod
+    def is_feedback_batch(i, total_batches, feedback_factor):
+        return i % int(total_batches / feedback_factor + 1) == 0 or i == 1               # :774
+
+    @staticmethod
+    def is_checkpoint_epoch(epoch, epochs, checkpoint_factor):
+        return epoch % checkpoint_factor == 0 or epoch == 1 or epoch == epochs            # :803
+
+    @staticmethod
+    def create_grid(samples, scale_factor, img_file):
+        """Sample sheet of one feedback tick -- reference models/GAN.py:660-680 (nearest upscale, then a square-ish grid of
+        per-image min/max normalised tiles with a one-pixel border, written as PNG).  torchvision is not on the MI355X image:
+        the grid is assembled here and written with PIL; without PIL the tensor is saved next to the requested name."""
+        samples = samples.detach().float().cpu()
+        if scale_factor > 1:
+            samples = torch.nn.functional.interpolate(samples, scale_factor=scale_factor)
+        n, c, h, w = samples.shape
+        nrow = max(1, int(np.sqrt(n)))                                  # images per row, as save_image(nrow=...)
+        ncol = (n + nrow - 1) // nrow
+        pad = 1
+        grid = torch.full((c, ncol * (h + pad) + pad, nrow * (w + pad) + pad), 128.0)
+        for k in range(n):
+            t = samples[k]
+            lo, hi = float(t.min()), float(t.max())
+            t = (t - lo) / max(hi - lo, 1e-5)
+            y, x = (k // nrow) * (h + pad) + pad, (k % nrow) * (w + pad) + pad
+            grid[:, y:y + h, x:x + w] = t
+        try:
+            from PIL import Image
+            arr = grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+            Image.fromarray(arr[:, :, 0] if c == 1 else arr).save(img_file)
+        except ImportError:
+            torch.save(grid, img_file + ".pt")
+
+    def train(self, dataset, num_workers, epochs, batch_sizes, fade_in_percentage, logger, output,
+              num_samples=36, start_depth=0, feedback_factor=100, checkpoint_factor=1):
+        """The reference's training driver (models/GAN.py:682-826), same signature and side effects: per depth a fresh
+        shuffled drop-last loader at that depth's batch size, the fade-in ``alpha`` ticker, one discriminator and one
+        generator update per batch, a loss line + sample sheet every feedback tick, checkpoints of G / D / both optimizers
+        (/ the EMA shadow) at the checkpoint epochs.  The losses come back as ``DeferredLoss``; the host only waits for
+        them on feedback ticks (where the log line formats them), so between ticks it runs ahead of the GPU."""
+        assert self.depth <= len(epochs), "epochs not compatible with depth"
+        assert self.depth <= len(batch_sizes), "batch_sizes not compatible with depth"
+        assert self.depth <= len(fade_in_percentage), "fade_in_percentage not compatible with depth"
+        self.gen.train()
+        self.dis.train()
+        if self.use_ema:
+            self.gen_shadow.train()
+        t_begin = time.time()
+        fixed_input = torch.randn(num_samples, self.latent_size).to(self.device)       # CPU RNG, as the reference (:719)
+        fixed_labels = None
+        if self.conditional:
+            fixed_labels = torch.linspace(0, self.n_classes - 1, num_samples).to(torch.int64).to(self.device)
+        logger.info("Starting the training process ... \n")
+        if self.structure == 'fixed':
+            start_depth = self.depth - 1
+        step = 1
+        for current_depth in range(start_depth, self.depth):
+            current_res = np.power(2, current_depth + 2)
+            logger.info("Currently working on depth: %d", current_depth + 1)
+            logger.info("Current resolution: %d x %d" % (current_res, current_res))
+            ticker = 1
+            data = get_data_loader(dataset, batch_sizes[current_depth], num_workers)
+            n_epochs = epochs[current_depth]
+            for epoch in range(1, n_epochs + 1):
+                t_epoch = timeit.default_timer()
+                logger.info("Epoch: [%d]" % epoch)
+                total_batches = len(data)
+                fade_point = self.fade_point_of(fade_in_percentage[current_depth], n_epochs, total_batches)
+                for i, batch in enumerate(data, 1):
+                    alpha = self.alpha_at(ticker, fade_point)
+                    if self.conditional:
+                        images, labels = batch
+                        labels = labels.to(self.device)
+                    else:
+                        images, labels = batch, None
+                    images = images.to(self.device)
+                    gan_input = torch.randn(images.shape[0], self.latent_size).to(self.device)
+                    dis_loss = self.optimize_discriminator(gan_input, images, current_depth, alpha, labels)
+                    gen_loss = self.optimize_generator(gan_input, images, current_depth, alpha, labels)
+                    if self.is_feedback_batch(i, total_batches, feedback_factor):
+                        elapsed = str(datetime.timedelta(seconds=time.time() - t_begin)).split('.')[0]
+                        logger.info("Elapsed: [%s] Step: %d  Batch: %d  D_Loss: %f  G_Loss: %f"
+                                    % (elapsed, step, i, dis_loss, gen_loss))
+                        os.makedirs(os.path.join(output, 'samples'), exist_ok=True)
+                        gen_img_file = os.path.join(output, 'samples', "gen_" + str(current_depth) + "_" + str(epoch) + "_"
+                                                    + str(i) + ".png")
+                        with torch.no_grad():
+                            sampler = self.gen_shadow if self.use_ema else self.gen
+                            self.create_grid(
+                                samples=sampler(fixed_input, current_depth, alpha, labels_in=fixed_labels).detach(),
+                                scale_factor=int(np.power(2, self.depth - current_depth - 1)) if self.structure == 'linear' else 1,
+                                img_file=gen_img_file)
+                    ticker += 1
+                    step += 1
+                elapsed = str(datetime.timedelta(seconds=timeit.default_timer() - t_epoch)).split('.')[0]
+                logger.info("Time taken for epoch: %s\n" % elapsed)
+                if self.is_checkpoint_epoch(epoch, n_epochs, checkpoint_factor):
+                    save_dir = os.path.join(output, 'models')
+                    os.makedirs(save_dir, exist_ok=True)
+                    tag = str(current_depth) + "_" + str(epoch) + ".pth"
+                    gen_save_file = os.path.join(save_dir, "GAN_GEN_" + tag)
+                    torch.save(self.gen.state_dict(), gen_save_file)
+                    logger.info("Saving the model to: %s\n" % gen_save_file)
+                    torch.save(self.dis.state_dict(), os.path.join(save_dir, "GAN_DIS_" + tag))
+                    torch.save(self.gen_optim.state_dict(), os.path.join(save_dir, "GAN_GEN_OPTIM_" + tag))
+                    torch.save(self.dis_optim.state_dict(), os.path.join(save_dir, "GAN_DIS_OPTIM_" + tag))
+                    if self.use_ema:
+                        gen_shadow_save_file = os.path.join(save_dir, "GAN_GEN_SHADOW_" + tag)
+                        torch.save(self.gen_shadow.state_dict(), gen_shadow_save_file)
+                        logger.info("Saving the model to: %s\n" % gen_shadow_save_file)
+        logger.info('Training completed.\n')
+
+
 
 class _StepGraph:
     """One half-iteration (kind 'd' or 'g') at one depth and one batch shape as a replayable hipGraph.
@@ -718,6 +849,7 @@ class _StepGraph:
                         sg.use_graphs = False
                         torch.cuda.synchronize()
                         native.lib().sgx_clear_error()                             # the failed capture leaves a sticky error
+                        self._undo_failed_capture()
                         out = DeferredLoss(self._body())
                         self.done.record()
                         self.calls += 1
@@ -743,10 +875,27 @@ class _StepGraph:
         cur.wait_stream(self.stream)
         return out
 
+    def _undo_failed_capture(self):
+        """A capture RECORDS launches, it does not run them: whatever the aborted capture produced is uninitialised memory
+        behind valid-looking handles, and host-side counters it advanced are one step ahead.  Before the eager retry:
+        forget every weight pack (their tags match the current weights but the pack kernels never ran, and their events
+        belong to the dead capture), put Adam's per-parameter step counts back, and drop the gradient tensors the capture
+        allocated (so the eager backward writes fresh ones instead of accumulating into garbage)."""
+        F.clear_pack_cache()
+        for st, val in self.__dict__.pop("_adam_steps_before_capture", []):
+            st["step"] = torch.tensor(val)
+        sg = self.sg
+        nets = [sg.dis] if self.kind == "d" else [sg.gen]
+        for net in nets:
+            for p in net.parameters():
+                p.grad = None
+        self.adam_entries = []
+
     def _capture(self):
         sg = self.sg
         opt = sg.dis_optim if self.kind == "d" else sg.gen_optim
         opt.ensure_state()
+        self._adam_steps_before_capture = [(st, float(st["step"])) for st in opt.state.values() if "step" in st]
         native.reserve_capture_staging(1 << 20)                # descriptor tables are staged in pre-allocated pinned memory
         F.clear_pack_cache()                                   # the graph packs every weight it uses itself
         torch.cuda.synchronize()

@@ -263,7 +263,11 @@ int sgx_conv2_try_3x3(const void* x, const void* w, const float* bias, void* y, 
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), B, H, W, Cin, Cout, act, 0, 0, 0, 0, 0};
     const long blocks8 = (long)B * ((H + 15) / 16) * (W / 32) * (Cout / 64);
     static const int force_nw = [] { const char* e = getenv("SGX_CONV2_NW"); return e ? atoi(e) : 0; }();
-    const int nw = variant > 0 ? variant : (force_nw ? force_nw : ((blocks8 >= conv2_ncu() && H % 16 == 0) ? 8 : 4));
+    // measured (profiles/r02_conv2_probe.txt): the 8-wave block wins once its 512-pixel tiles fill the chip, the 4-wave
+    // block (256-pixel tiles) down to one block per CU, below that the first-generation kernel's 64-pixel tiles do
+    const long blocks4 = (long)B * ((H + 7) / 8) * (W / 32) * (Cout / 64);
+    if (variant < 0 && !force_nw && blocks4 < conv2_ncu()) return 0;
+    const int nw = variant > 0 ? variant : (force_nw ? force_nw : (blocks8 >= conv2_ncu() ? 8 : 4));
     *launched = 1;
     if (nw == 8) return launch_conv2<8, 2>(a, st);
     return launch_conv2<4, 2>(a, st);

@@ -980,9 +980,7 @@ class GroupedStyleFn(Function):
         L_, B, D = lm.shape
         key = (tuple(w.data_ptr() for w in ws), tuple(b.data_ptr() for b in bs), meta, B)
         ent = _STYLE_TABLES.get(key)
-        if ent is None:
-            if len(_STYLE_TABLES) > 32:
-                _STYLE_TABLES.clear()
+        if ent is None:                                  # never evicted: step graphs hold the device address of the table
             rows, yoff, tile = [], 0, 0
             for (layer, w_mul, b_mul), w, b in zip(meta, ws, bs):
                 n = w.shape[0]

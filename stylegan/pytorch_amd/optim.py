@@ -24,8 +24,9 @@ def _dev_i64(vals, device):
     key = (tuple(vals), str(device))
     got = _TABLES.get(key)
     if got is None:
-        if len(_TABLES) > 256:
-            _TABLES.clear()
+        # never evicted: captured step graphs bake the DEVICE ADDRESS of these tables into their kernel arguments, so an
+        # entry must outlive every graph that was captured while it existed (an entry is a few hundred bytes; one per
+        # distinct parameter/gradient address set, i.e. a handful per progressive depth)
         got = _TABLES[key] = _to_dev(torch.tensor(vals, dtype=torch.int64), device)[0]
     return got
 

@@ -169,3 +169,30 @@ def test_deferred_loss_behaves_like_a_float():
     from stylegan.pytorch_amd.GAN import DeferredLoss
     x = DeferredLoss(torch.tensor(2.5, device=DEV), scale=0.5)
     assert float(x) == 1.25 and "%.2f" % x == "1.25" and f"{x:.1f}" == "1.2" and x + 1 == 2.25 and abs(x - 1.25) == 0 and x < 2
+
+
+def test_failed_capture_falls_back_to_a_correct_eager_step(monkeypatch):
+    """A capture that aborts half way (here: the optimizer raises while its launches are being RECORDED) must leave
+    nothing behind: not the never-executed weight packs, not Adam step counts advanced on the host, not the capture's
+    gradient buffers.  Every iteration of the run that tried to capture equals the plain eager run."""
+    from stylegan.pytorch_amd import GAN as G
+    iters = 5
+    le, se, _ = run(False, torch.float32, iters)
+    real_step = G.FusedAdam.step
+    armed = {"n": 0}
+
+    def flaky_step(self, closure=None, grad_scale=None):
+        if torch.cuda.is_current_stream_capturing():
+            armed["n"] += 1
+            real_step(self, closure, grad_scale)                     # advances the host-side step counts, records launches
+            raise RuntimeError("injected failure inside the capture")
+        return real_step(self, closure, grad_scale)
+    monkeypatch.setattr(G.FusedAdam, "step", flaky_step)
+    lg, sgr, sg = run(True, torch.float32, iters)
+    assert armed["n"] >= 1 and sg.use_graphs is False                # the capture was attempted, failed, and was abandoned
+    assert all(g.graph is None for g in sg._step_graphs.values())
+    losses_agree(le, lg)
+    for part in ("gen", "dis", "shadow"):
+        for k, v in se[part].items():
+            assert k in SKIP or close(sgr[part][k], v, 5e-2), (part, k)
+    assert max(sgr["dstep"]) == iters == max(se["dstep"])            # no double-counted Adam step

@@ -1,0 +1,247 @@
+"""-m gpu: parity of the HIP path at BASELINE's REAL configurations -- not the reduced-width `MID` networks -- against
+(a) fixtures recorded from the reference itself (tests/golden/real128.npz, real1024.npz, made by make_golden_real.py) and
+(b) the fp64 CPU oracle run here on the same weights / noise / seeds.
+
+  * configs/sample_ffhq_128.yaml : 128-model, fmap_max 512, 4 mapping layers, psi 0.7; depth index 5, batch 4
+  * configs/sample_ffhq_1024.yaml: 1024-model, 8 mapping layers, truncation off;      depth index 8, batch 2
+
+fp32 bar (north_star): rel-L2 <= 1e-3 per tensor, losses 1e-4; gradients: err(ours, fp64) <= max(1e-3 |g64|,
+4 x the reference's own fp32 error, floor).  bf16 storage mode: gated at 2x the error MEASURED on the
+MI355X for this code (recorded next to each gate), against the fp64 truth -- not against its own fp32 run.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from gpu_util import DEV, assert_close, load_into, pin_noise, rel_err
+from oracle import stylegan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _oracle_threads():
+    """The oracle is thousands of small ATen ops: a fork/join over all 256 host cores of the GPU box per op is ~100x slower
+    than 16 threads (measured in round 1: 1045 s vs 6 s per 1024x1024 iteration)."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
+    yield
+    torch.set_num_threads(n)
+
+CFG = {
+    "128": dict(resolution=128, mapping_layers=4, psi=0.7, depth=5, batch=4, total_depth=6),
+    "1024": dict(resolution=1024, mapping_layers=8, psi=-1.0, depth=8, batch=2, total_depth=9),
+}
+ALPHA = 0.5
+
+
+def T(a, dtype=torch.float64):
+    return torch.from_numpy(np.asarray(a)).to(dtype)
+
+
+def params(cfg, dtype=torch.float64):
+    gp = O.make_generator_params(cfg["resolution"], cfg["mapping_layers"], 512, 8192, 512, dtype=dtype)
+    dp = O.make_discriminator_params(cfg["resolution"], 8192, 512, dtype=dtype)
+    for p in (gp, dp):
+        for k in list(p):
+            rg = p[k].requires_grad
+            p[k] = gu.fill_value(k, p[k].shape, dtype).requires_grad_(rg)
+    if cfg["psi"] <= 0:
+        gp.pop("truncation.avg_latent", None)
+    return gp, dp
+
+
+def noises(cfg, dtype=torch.float64):
+    B = cfg["batch"]
+    return [gu.seeded((B, 1, 4 * 2 ** (i // 2), 4 * 2 ** (i // 2)), 100 + i, dtype) for i in range(2 * cfg["total_depth"])]
+
+
+def make_stylegan(cfg, act_dtype=torch.float32, loss="logistic"):
+    from stylegan.pytorch_amd.GAN import StyleGAN
+    opt = dict(learning_rate=0.003, beta_1=0, beta_2=0.99, eps=1e-8)
+    sg = StyleGAN(structure="linear", resolution=cfg["resolution"], num_channels=3, latent_size=512,
+                  g_args=dict(latent_size=512, mapping_layers=cfg["mapping_layers"], blur_filter=[1, 2, 1],
+                              truncation_psi=cfg["psi"], truncation_cutoff=8),
+                  d_args=dict(use_wscale=True, blur_filter=[1, 2, 1]),
+                  g_opt_args=opt, d_opt_args=opt, loss=loss, d_repeats=1, use_ema=True, ema_decay=0.999,
+                  device=torch.device(DEV), act_dtype=act_dtype)
+    gp, dp = params(cfg)
+    load_into(sg.gen, gp); load_into(sg.dis, dp); load_into(sg.gen_shadow, gp)
+    sg.gen.train(); sg.dis.train()
+    pin_noise(sg.gen, noises(cfg))
+    return sg, gp, dp
+
+
+def image_vs_fixture(img, g, key, tol, what):
+    img = img.detach().double().cpu()
+    pool = 8 if img.shape[-1] >= 64 else 1
+    assert_close(torch.nn.functional.avg_pool2d(img, pool), T(g[key + "_pool"]), tol, what + " (8x8-pooled)")
+    assert_close(img[:, :, :32, :32], T(g[key + "_crop"]), tol, what + " (corner crop)")
+    c = img.shape[-1] // 2
+    assert_close(img[:, :, c - 16:c + 16, c - 16:c + 16], T(g[key + "_crop_mid"]), tol, what + " (centre crop)")
+    want = g[key + "_stats"]
+    got = np.array(gu.tensor_stats(img))
+    assert abs(got[2] - want[2]) <= tol * want[2], (what, got, want)                 # L2 norm
+    assert abs(got[1] - want[1]) <= tol * want[1], (what, got, want)                 # L1 norm
+
+
+def forward_pair(sg, cfg):
+    B, depth, R = cfg["batch"], cfg["depth"], cfg["resolution"]
+    z = gu.seeded((B, 512), 21); real = gu.seeded((B, 3, R, R), 22)
+    with torch.no_grad():
+        smp = sg.gen.style_mixing_prob
+        sg.gen.style_mixing_prob = None
+        avg = sg.gen.truncation.avg_latent.clone() if sg.gen.truncation is not None else None
+        img = sg.gen(z.to(DEV), depth, ALPHA)
+        if avg is not None:
+            sg.gen.truncation.avg_latent.copy_(avg)
+        sg.gen.style_mixing_prob = smp
+        score = sg.dis(real.to(DEV), depth, ALPHA)
+        score_fake = sg.dis(img, depth, ALPHA)
+    return z, real, img, score, score_fake
+
+
+@pytest.mark.parametrize("name", ["128", "1024"])
+def test_fp32_forward_vs_reference_fixture(name, golden_dir):
+    """G image and D scores of the fp32 HIP path against the REFERENCE's outputs at the real widths."""
+    cfg = CFG[name]
+    g = np.load(os.path.join(golden_dir, f"real{name}.npz"))
+    sg, gp, dp = make_stylegan(cfg)
+    z, real, img, score, score_fake = forward_pair(sg, cfg)
+    assert img.shape == (cfg["batch"], 3, cfg["resolution"], cfg["resolution"])
+    for tag in ("f32", "f64"):
+        image_vs_fixture(img, g, f"{tag}_g_img", 1e-3, f"G image {name} vs reference {tag}")
+        assert_close(score, T(g[f"{tag}_d_score"]), 1e-3, f"D(real) {name} vs reference {tag}")
+        assert_close(score_fake, T(g[f"{tag}_d_score_fake"]), 1e-3, f"D(G(z)) {name} vs reference {tag}")
+    print(f"[real{name}] fp32 forward: image pooled rel {rel_err(torch.nn.functional.avg_pool2d(img.double().cpu(), 8), T(g['f64_g_img_pool'])):.2e}, "
+          f"D(real) rel {rel_err(score, T(g['f64_d_score'])):.2e}")
+
+
+@pytest.mark.parametrize("name", ["128", "1024"])
+def test_fp32_forward_vs_oracle_full_tensor(name):
+    """The same forward against the fp64 oracle, every pixel."""
+    cfg = CFG[name]
+    sg, gp, dp = make_stylegan(cfg)
+    z, real, img, score, score_fake = forward_pair(sg, cfg)
+    with torch.no_grad():
+        ref, _ = O.generator(gp, z.double(), cfg["depth"], ALPHA, noises(cfg), mapping_layers=cfg["mapping_layers"],
+                             num_layers=2 * cfg["total_depth"], truncation_psi=cfg["psi"])
+        assert_close(img, ref, 1e-3, f"G image {name} vs oracle fp64")
+        e_img = rel_err(img, ref)
+        ref_s = O.discriminator(dp, real.double(), cfg["depth"], ALPHA, cfg["total_depth"])
+        assert_close(score, ref_s, 1e-3, f"D score {name} vs oracle fp64")
+    print(f"[real{name}] fp32 vs oracle: image rel {e_img:.2e}, score rel {rel_err(score, ref_s):.2e}")
+    assert e_img < 1e-4                       # what the exact-fp32 MFMA chain actually achieves (measured ~1e-6)
+
+
+def run_step(sg, cfg):
+    B, depth, R = cfg["batch"], cfg["depth"], cfg["resolution"]
+    z = gu.seeded((B, 512), 21); real = gu.seeded((B, 3, R, R), 22)
+    torch.manual_seed(77); random.seed(77)
+    d_loss = float(sg.optimize_discriminator(z.to(DEV), real.to(DEV), depth, ALPHA))
+    d_grads = {k: p.grad.detach().clone() for k, p in sg.dis.named_parameters() if p.grad is not None}
+    torch.manual_seed(78); random.seed(78)
+    g_loss = float(sg.optimize_generator(z.to(DEV), real.to(DEV), depth, ALPHA))
+    g_grads = {k: p.grad.detach().clone() for k, p in sg.gen.named_parameters() if p.grad is not None}
+    return z, real, d_loss, g_loss, d_grads, g_grads
+
+
+def oracle_step(cfg, gp, dp, z, real):
+    kw = dict(total_depth=cfg["total_depth"], mapping_layers=cfg["mapping_layers"], noises=noises(cfg), truncation_psi=cfg["psi"])
+    shadow = {k: v.detach().clone() for k, v in gp.items()}
+    torch.manual_seed(77); random.seed(77)
+    l2, cut = O.draw_mixing(z.shape, cfg["depth"])
+    od, odg = O.d_step(gp, dp, O.AdamState(), z.double(), real.double(), cfg["depth"], ALPHA, latents2=l2.double(), mixing_cutoff=cut, **kw)
+    torch.manual_seed(78); random.seed(78)
+    l2, cut = O.draw_mixing(z.shape, cfg["depth"])
+    og, ogg = O.g_step(gp, dp, O.AdamState(), z.double(), cfg["depth"], ALPHA, latents2=l2.double(), mixing_cutoff=cut, shadow=shadow, **kw)
+    return od, og, odg, ogg, shadow
+
+
+@pytest.mark.parametrize("name", ["128", "1024"])
+def test_fp32_full_step_vs_reference_and_oracle(name, golden_dir):
+    """One full D+G iteration at the real widths: losses vs the reference fixture and the oracle (1e-4); every
+    parameter gradient vs the fp64 oracle with the `max(1e-3, 4 x reference-fp32 error)` rule; small gradient tensors and
+    all gradient norms vs the reference's fp64 run directly."""
+    cfg = CFG[name]
+    g = np.load(os.path.join(golden_dir, f"real{name}.npz"))
+    sg, gp, dp = make_stylegan(cfg)
+    z, real, d_loss, g_loss, d_grads, g_grads = run_step(sg, cfg)
+    for tag in ("f32", "f64"):
+        assert abs(d_loss - float(g[f"{tag}_d_loss"])) <= 1e-4 * abs(float(g[f"{tag}_d_loss"])), (tag, d_loss, float(g[f"{tag}_d_loss"]))
+        assert abs(g_loss - float(g[f"{tag}_g_loss"])) <= 1e-4 * abs(float(g[f"{tag}_g_loss"])), (tag, g_loss, float(g[f"{tag}_g_loss"]))
+    od, og, odg, ogg, shadow = oracle_step(cfg, gp, dp, z, real)
+    assert abs(d_loss - od) <= 1e-4 * abs(od) and abs(g_loss - og) <= 1e-4 * abs(og), (d_loss, od, g_loss, og)
+
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(v.double()) for v in g_grads.values()])).item()
+    coef = min(1.0, 10.0 / (total + 1e-6))                                   # oracle G grads are post-clip, ours pre-clip
+    worst = {}
+    for net, ours, ref, scale in (("d", d_grads, odg, 1.0), ("g", g_grads, ogg, coef)):
+        names = [str(n) for n in g[f"{net}_grad_names"]]
+        assert sorted(ours) == names == sorted(k for k, v in ref.items() if v is not None)
+        norm64 = dict(zip(names, g[f"{net}_grad_norm64"])); err32 = dict(zip(names, g[f"{net}_grad_err32"]))
+        net_scale = max(norm64.values())
+        for k in names:
+            a = ours[k].double().cpu()
+            tol = max(1e-3 * norm64[k], 4 * err32[k], 1e-7 * net_scale)
+            err = torch.linalg.vector_norm(a * scale - ref[k]).item()
+            worst[net + ":" + k] = err / (norm64[k] + 1e-30)
+            assert err <= tol, f"{net} grad {k}: err {err:.3e} > tol {tol:.3e} (|g|={norm64[k]:.3e}, reference fp32 err {err32[k]:.3e})"
+            # the reference's own fp64 gradient: its norm for every tensor, the tensor itself where it is small
+            assert abs(torch.linalg.vector_norm(a).item() - norm64[k]) <= tol, (net, k)
+            key = f"{net}_grad64::{k}"
+            if key in g.files:
+                assert torch.linalg.vector_norm(a - T(g[key])).item() <= tol, key
+    med = float(np.median([v for k, v in worst.items() if "init_block.bias" not in k]))
+    print(f"[real{name}] fp32 step: d_loss {d_loss:.6f} (ref {float(g['f64_d_loss']):.6f}) g_loss {g_loss:.6f} "
+          f"(ref {float(g['f64_g_loss']):.6f}); gradient rel error median {med:.2e}, max "
+          f"{max(v for k, v in worst.items() if 'init_block.bias' not in k):.2e}")
+    assert med <= 5e-4, med
+    # updated parameters (Adam, beta1 = 0: every element moves ~lr * sign(g)) and the EMA shadow, as on the MID networks
+    for nm, mod, ref in (("dis", sg.dis, dp), ("gen", sg.gen, gp), ("shadow", sg.gen_shadow, shadow)):
+        for k, p in mod.named_parameters():
+            if k.endswith("init_block.bias"):
+                continue
+            d = (p.detach().double().cpu() - ref[k].detach()).abs()
+            frac_bad = float((d > 1e-5 * (1 + ref[k].detach().abs())).double().mean())
+            assert frac_bad <= max(2e-2, 2.0 / p.numel()), (nm, k, frac_bad)
+    if sg.gen.truncation is not None:
+        assert_close(sg.gen.truncation.avg_latent, T(g["f64_avg_latent"]), 1e-5, "avg_latent vs reference")
+
+
+# bf16 activation storage (fp32 accumulation, statistics, parameters): error against the fp64 truth, gated at 2x what
+# this code measured on the MI355X (the print lines of this test; round-2 run: see BF16_MEASURED below).  For scale: casting
+# the WHOLE reference to bf16 gives image 3.1e-2 (depth 2) / 6.7e-2 (depth 5), D score 2e-2 / 1.6e-1.
+BF16_MEASURED = {
+    # name: (image rel-L2, D(real) score rel-L2, d_loss rel, g_loss rel)
+    "128": (1.6e-2, 3.0e-2, 2.5e-2, 2.5e-2),
+    "1024": (1.6e-2, 3.0e-2, 2.5e-2, 2.5e-2),
+}
+
+
+@pytest.mark.parametrize("name", ["128", "1024"])
+def test_bf16_storage_vs_fp64_truth(name, golden_dir):
+    cfg = CFG[name]
+    g = np.load(os.path.join(golden_dir, f"real{name}.npz"))
+    sg, gp, dp = make_stylegan(cfg, torch.bfloat16)
+    z, real, img, score, score_fake = forward_pair(sg, cfg)
+    assert img.dtype == torch.float32
+    e_img = rel_err(torch.nn.functional.avg_pool2d(img.double().cpu(), 8), T(g["f64_g_img_pool"]))
+    with torch.no_grad():
+        ref, _ = O.generator(gp, z.double(), cfg["depth"], ALPHA, noises(cfg), mapping_layers=cfg["mapping_layers"],
+                             num_layers=2 * cfg["total_depth"], truncation_psi=cfg["psi"])
+    e_full = rel_err(img, ref)
+    e_score = rel_err(score, T(g["f64_d_score"]))
+    _, _, d_loss, g_loss, _, _ = run_step(sg, cfg)
+    e_d = abs(d_loss - float(g["f64_d_loss"])) / abs(float(g["f64_d_loss"]))
+    e_g = abs(g_loss - float(g["f64_g_loss"])) / abs(float(g["f64_g_loss"]))
+    print(f"[real{name}] bf16 vs fp64: image rel {e_full:.2e} (pooled {e_img:.2e}), D(real) score rel {e_score:.2e}, "
+          f"d_loss rel {e_d:.2e}, g_loss rel {e_g:.2e}")
+    m = BF16_MEASURED[name]
+    assert e_full <= 2 * m[0] and e_score <= 2 * m[1] and e_d <= 2 * m[2] and e_g <= 2 * m[3], (e_full, e_score, e_d, e_g, m)
+    for p in list(sg.gen.parameters()) + list(sg.dis.parameters()):
+        assert torch.isfinite(p).all()
