@@ -310,10 +310,10 @@ def images_u8_to_float(u8_hwc: Tensor, flip: Optional[Sequence[bool]] = None) ->
     (``RandomHorizontalFlip(), ToTensor(), Normalize((.5,.5,.5),(.5,.5,.5))``) with the flip decisions given.
 
     The arithmetic lives in torchvision, which requirements.txt:4 names unpinned and which is NOT installed in this
-    image: parity for this function is therefore UNPINNED against the reference itself; it restates
-    torchvision's published semantics -- ``ToTensor``: HWC uint8 -> CHW float32 ``.div(255)``; ``Normalize``:
-    ``(t - mean) / std``; ``hflip``: reverse the width axis -- and is pinned by known values in
-    tests/test_oracle_golden.py::test_images_u8_known_values (0 -> -1, 255 -> 1, 128 -> 1/255)."""
+    image -- so this function cannot be pinned against torchvision itself.  It is pinned bit-exactly
+    against tests/golden/images_u8.npz (tests/golden/make_golden_images.py: PNG bytes decoded by PIL, then torchvision's
+    published ``hflip`` / ``to_tensor`` / ``normalize`` restated operation by operation, independently of this file) and by
+    known values (0 -> -1, 255 -> 1, 128 -> 1/255): tests/test_oracle_golden.py."""
     x = u8_hwc
     if flip is not None:
         x = torch.stack([img.flip(1) if f else img for img, f in zip(x, flip)])
@@ -343,6 +343,33 @@ def logistic_d_loss(p: Params, real: Tensor, fake: Tensor, depth: int, alpha: fl
 def logistic_g_loss(p: Params, fake: Tensor, depth: int, alpha: float, total_depth: int) -> Tensor:
     """LogisticGAN.gen_loss (models/Losses.py:226-229)."""
     return F.softplus(-discriminator(p, fake, depth, alpha, total_depth)).mean()
+
+
+def gan_dis_loss(kind: str, r: Tensor, f: Tensor) -> Tensor:
+    """Discriminator loss heads of the non-default losses on the [B,1] predictions r = D(real), f = D(fake):
+    'standard-gan' (models/Losses.py:107-126: (BCE(r,1) + BCE(f,0)) / 2 on the squeezed logits), 'hinge' (:141-148),
+    'relativistic-hinge' (:159-174).  Pinned by tests/golden/losses.npz (the reference's classes on an identity D)."""
+    if kind == "standard-gan":
+        r, f = r.squeeze(), f.squeeze()
+        return (F.binary_cross_entropy_with_logits(r, torch.ones_like(r)) + F.binary_cross_entropy_with_logits(f, torch.zeros_like(f))) / 2
+    if kind == "hinge":
+        return F.relu(1 - r).mean() + F.relu(1 + f).mean()
+    if kind == "relativistic-hinge":
+        return F.relu(1 - (r - f.mean())).mean() + F.relu(1 + (f - r.mean())).mean()
+    raise KeyError(kind)
+
+
+def gan_gen_loss(kind: str, r: Optional[Tensor], f: Tensor) -> Tensor:
+    """Generator loss heads: 'standard-gan' BCE(f,1) (the evident intent of models/Losses.py:130-134, whose tuple
+    unpacking of the [B,1] output cannot execute), 'hinge' -mean(f) (:150-151), 'relativistic-hinge' (:176-189)."""
+    if kind == "standard-gan":
+        f = f.squeeze()
+        return F.binary_cross_entropy_with_logits(f, torch.ones_like(f))
+    if kind == "hinge":
+        return -f.mean()
+    if kind == "relativistic-hinge":
+        return F.relu(1 + (r - f.mean())).mean() + F.relu(1 - (f - r.mean())).mean()
+    raise KeyError(kind)
 
 
 class AdamState:
@@ -389,8 +416,9 @@ def ema_update(shadow: Params, src: Params, beta: float, names: Sequence[str]) -
 
 def d_step(gp: Params, dp: Params, d_opt: AdamState, z: Tensor, real_full: Tensor, depth: int, alpha: float, *,
            total_depth: int, mapping_layers: int, noises: List[Tensor], latents2=None, mixing_cutoff=None,
-           truncation_psi: float = 0.7) -> Tuple[float, Dict[str, Optional[Tensor]]]:
-    """StyleGAN.optimize_discriminator, d_repeats=1 (models/GAN.py:591-622)."""
+           truncation_psi: float = 0.7, loss: str = "logistic") -> Tuple[float, Dict[str, Optional[Tensor]]]:
+    """StyleGAN.optimize_discriminator, d_repeats=1 (models/GAN.py:591-622).  ``loss``: 'logistic' (+R1) or one of the
+    ``gan_dis_loss`` kinds."""
     real = progressive_down_sampling(real_full, depth, alpha, total_depth)
     fake, new_avg = generator(gp, z, depth, alpha, noises, mapping_layers=mapping_layers,
                               num_layers=2 * total_depth, latents2=latents2, mixing_cutoff=mixing_cutoff,
@@ -399,7 +427,10 @@ def d_step(gp: Params, dp: Params, d_opt: AdamState, z: Tensor, real_full: Tenso
         gp["truncation.avg_latent"] = new_avg.detach()
     fake = fake.detach()
     names = [k for k, v in dp.items() if v.requires_grad]
-    loss = logistic_d_loss(dp, real, fake, depth, alpha, total_depth)
+    if loss == "logistic":
+        loss = logistic_d_loss(dp, real, fake, depth, alpha, total_depth)
+    else:
+        loss = gan_dis_loss(loss, discriminator(dp, real, depth, alpha, total_depth), discriminator(dp, fake, depth, alpha, total_depth))
     gl = torch.autograd.grad(loss, [dp[k] for k in names], allow_unused=True)
     grads = dict(zip(names, gl))
     d_opt.step(dp, grads)
@@ -408,16 +439,23 @@ def d_step(gp: Params, dp: Params, d_opt: AdamState, z: Tensor, real_full: Tenso
 
 def g_step(gp: Params, dp: Params, g_opt: AdamState, z: Tensor, depth: int, alpha: float, *,
            total_depth: int, mapping_layers: int, noises: List[Tensor], latents2=None, mixing_cutoff=None,
-           truncation_psi: float = 0.7, shadow: Optional[Params] = None, ema_decay: float = 0.999
-           ) -> Tuple[float, Dict[str, Optional[Tensor]]]:
-    """StyleGAN.optimize_generator (models/GAN.py:624-659) incl. grad clip and EMA."""
+           truncation_psi: float = 0.7, shadow: Optional[Params] = None, ema_decay: float = 0.999,
+           loss: str = "logistic", real_full: Optional[Tensor] = None) -> Tuple[float, Dict[str, Optional[Tensor]]]:
+    """StyleGAN.optimize_generator (models/GAN.py:624-659) incl. grad clip and EMA.  ``real_full`` is read by the
+    relativistic loss only (:635-641: the real batch at the current depth)."""
     fake, new_avg = generator(gp, z, depth, alpha, noises, mapping_layers=mapping_layers,
                               num_layers=2 * total_depth, latents2=latents2, mixing_cutoff=mixing_cutoff,
                               truncation_psi=truncation_psi)
     if new_avg is not None:
         gp["truncation.avg_latent"] = new_avg.detach()
     names = [k for k, v in gp.items() if v.requires_grad]
-    loss = logistic_g_loss(dp, fake, depth, alpha, total_depth)
+    if loss == "logistic":
+        loss = logistic_g_loss(dp, fake, depth, alpha, total_depth)
+    else:
+        r = None
+        if loss == "relativistic-hinge":
+            r = discriminator(dp, progressive_down_sampling(real_full, depth, alpha, total_depth), depth, alpha, total_depth)
+        loss = gan_gen_loss(loss, r, discriminator(dp, fake, depth, alpha, total_depth))
     gl = torch.autograd.grad(loss, [gp[k] for k in names], allow_unused=True)
     grads = {k: (None if g is None else g.clone()) for k, g in zip(names, gl)}
     clip_grad_norm(grads, 10.0)

@@ -509,6 +509,22 @@ def test_images_from_uint8(layout, B, H, W):
         F.images_from_uint8(src.float(), layout=layout)
 
 
+def test_images_from_uint8_vs_transform_chain_fixture(golden_dir):
+    """The device input pipeline (sgx_images_u8_to_nhwc) against the PIL-decoded fixture of the reference's transform chain
+    (tests/golden/images_u8.npz, data/transforms.py:27-32): bit-exact, both layouts, with the fixture's flips."""
+    import os
+    import numpy as np
+    from stylegan.pytorch_amd import functional as F
+    g = np.load(os.path.join(golden_dir, "images_u8.npz"))
+    u8 = torch.from_numpy(g["u8"]).to(DEV)
+    flips = [bool(f) for f in g["flips"]]
+    want = torch.from_numpy(g["out"]).to(DEV)
+    got = F.images_from_uint8(u8, flip=flips, layout="hwc")
+    assert got.shape == want.shape and torch.equal(got, want)
+    got = F.images_from_uint8(u8.permute(0, 3, 1, 2).contiguous(), flip=flips, layout="chw")
+    assert torch.equal(got, want)
+
+
 def test_images_from_uint8_feeds_the_step():
     """The uint8 batch drives the discriminator exactly like the float batch it stands for."""
     from stylegan.pytorch_amd import functional as F

@@ -221,6 +221,15 @@ def test_images_u8_known_values():
     assert torch.equal(fl[0], out[0].flip(-1)) and torch.equal(fl[1], out[1])
 
 
+def test_images_u8_against_the_transform_chain_fixture(golden_dir):
+    """oracle.images_u8_to_float against tests/golden/images_u8.npz: PNG bytes decoded by PIL and pushed through the
+    reference's transform chain (data/transforms.py:27-32) restated operation by operation from torchvision's published
+    functional source (make_golden_images.py -- torchvision itself cannot be installed here).  Bit-exact."""
+    g = np.load(os.path.join(golden_dir, "images_u8.npz"))
+    out = O.images_u8_to_float(torch.from_numpy(g["u8"]), flip=[bool(f) for f in g["flips"]])
+    assert out.dtype == torch.float32 and np.array_equal(out.numpy(), g["out"])
+
+
 def test_other_losses_against_the_reference(golden_dir):
     """StandardGAN / HingeGAN / RelativisticAverageHingeGAN of stylegan.pytorch_amd.Losses (plain torch on the [B,1]
     logits) against values recorded from the reference's own classes (tests/golden/make_golden_losses.py: identity
@@ -243,6 +252,20 @@ def test_other_losses_against_the_reference(golden_dir):
                 assert "Error" in str(g[f"{name}_gen_{B}_error"]) and name == "standard"
                 want = float(torch.nn.functional.softplus(-f.double()).mean())
                 assert abs(float(loss.gen_loss(r, f, 0, 1.0)) - want) <= 1e-6
+
+
+def test_oracle_loss_heads_against_the_reference(golden_dir):
+    """oracle.gan_dis_loss / gan_gen_loss (what the GPU parity test of the non-default losses checks against) reproduce the
+    values recorded from the reference's own loss classes."""
+    g = np.load(os.path.join(golden_dir, "losses.npz"))
+    for B in (3, 4, 8):
+        r, f = torch.from_numpy(g[f"r_{B}"]).double(), torch.from_numpy(g[f"f_{B}"]).double()
+        for name, kind in (("standard", "standard-gan"), ("hinge", "hinge"), ("relhinge", "relativistic-hinge")):
+            want = float(g[f"{name}_dis_{B}"])
+            assert abs(float(O.gan_dis_loss(kind, r, f)) - want) <= 1e-6 * max(1.0, abs(want)), (name, B)
+            if f"{name}_gen_{B}" in g:
+                want = float(g[f"{name}_gen_{B}"])
+                assert abs(float(O.gan_gen_loss(kind, r, f)) - want) <= 1e-6 * max(1.0, abs(want)), (name, B)
 
 
 def test_fixed_structure_against_the_reference(golden_dir):
