@@ -134,6 +134,7 @@ def main():
                   device=dev, act_dtype=act_dtype, data_parallel=dp,
                   use_graphs=(a.graphs != "off"))
     graphs = sg.use_graphs
+    sg.deferred_losses = True                                # losses are not read inside the timed loop: no per-half-step host wait
     sg.gen.train(); sg.dis.train(); sg.gen_shadow.train()
 
     B, res, depth = a.batch_per_gpu, cfg["resolution"], cfg["depth"]

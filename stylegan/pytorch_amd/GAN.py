@@ -616,21 +616,30 @@ class StyleGAN:
             g = self._step_graphs[key] = _StepGraph(self, kind, depth)
         return g.run(noise, real_batch, alpha)
 
+    # What optimize_* return.  False (default): a Python ``float``, exactly as the reference's ``loss.item()`` (models/GAN.py:620,
+    # :659) -- which waits for the GPU.  True: a ``DeferredLoss`` (async copy to pinned memory, the host only waits when the
+    # value is read), so that a loop that reads the losses rarely -- ``train`` below sets it for its own duration, bench.py
+    # sets it -- enqueues the next half-iteration while the GPU still runs this one.
+    deferred_losses = False
+
+    def _loss_out(self, deferred):
+        return deferred if self.deferred_losses else deferred.item()
+
     def optimize_discriminator(self, noise, real_batch, depth, alpha, labels=None):
         """One discriminator update -- reference models/GAN.py:591-622."""
         if self._graphable(labels):
-            return self._graphed("d", noise, real_batch, depth, alpha)
+            return self._loss_out(self._graphed("d", noise, real_batch, depth, alpha))
         loss_val = None
         for _ in range(self.d_repeats):
             loss = self._d_body(noise, real_batch, depth, alpha, labels)
             loss_val = loss if loss_val is None else loss_val + loss
-        return DeferredLoss(loss_val, 1.0 / self.d_repeats)
+        return self._loss_out(DeferredLoss(loss_val, 1.0 / self.d_repeats))
 
     def optimize_generator(self, noise, real_batch, depth, alpha, labels=None):
         """One generator update incl. gradient clipping and EMA -- reference models/GAN.py:624-659."""
         if self._graphable(labels):
-            return self._graphed("g", noise, real_batch, depth, alpha)
-        return DeferredLoss(self._g_body(noise, real_batch, depth, alpha, labels))
+            return self._loss_out(self._graphed("g", noise, real_batch, depth, alpha))
+        return self._loss_out(DeferredLoss(self._g_body(noise, real_batch, depth, alpha, labels)))
 
     # ------------------------------------------------------------------------------------------------------------
     # The progressive-growing schedule -- reference models/GAN.py:730-803.  Pure host arithmetic, kept in the reference's
@@ -692,6 +701,15 @@ class StyleGAN:
         self.dis.train()
         if self.use_ema:
             self.gen_shadow.train()
+        was_deferred, self.deferred_losses = self.deferred_losses, True        # the log line of a feedback tick reads them
+        try:
+            self._train_loop(dataset, num_workers, epochs, batch_sizes, fade_in_percentage, logger, output, num_samples,
+                             start_depth, feedback_factor, checkpoint_factor)
+        finally:
+            self.deferred_losses = was_deferred
+
+    def _train_loop(self, dataset, num_workers, epochs, batch_sizes, fade_in_percentage, logger, output, num_samples,
+                    start_depth, feedback_factor, checkpoint_factor):
         t_begin = time.time()
         fixed_input = torch.randn(num_samples, self.latent_size).to(self.device)       # CPU RNG, as the reference (:719)
         fixed_labels = None
