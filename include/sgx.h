@@ -56,12 +56,6 @@ int sgx_prof_get(int i, char* name, int name_cap, float* ms, double* flops, doub
  *   y[b,h,w,n] = act(bias[n] + sum_{ty,tx,k} x[b,h+ty-1,w+tx-1,k] * w[ty*3+tx][n][k])                              */
 int sgx_conv3x3(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
                 int act, int dtype, void* stream);
-/* The same convolution with the kernel generation named by the caller (A/B probes and parity tests of both):
- *   variant 0: first-generation kernel (16x16 MFMA tiles, register-staged single LDS stage; any shape / dtype);
- *   variant 4 / 8: second-generation bf16 kernel (32x32x16 MFMA, LDS-DMA double-buffered stages) with 4- / 8-wave blocks;
- *   needs Cin % 32 == 0, Cout % 64 == 0, W % 32 == 0 (SGX_EUNSUPPORTED otherwise).  sgx_conv3x3 chooses by itself.       */
-int sgx_conv3x3_variant(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
-                        int act, int dtype, int variant, void* stream);
 /* sgx_conv4x4s2_down: fused conv+downscale, F.conv2d(x, W4, stride=2, padding=1) -- models/CustomLayers.py:158-165
  *   (== conv3x3 -> avg_pool2 of :166-168); also the data gradient of sgx_conv4x4s2_up.
  *   H,W = input size.  y[b,oy,ox,n] = act(bias[n] + sum_{ky,kx,k} x[b,2oy+ky-1,2ox+kx-1,k] * w[ky*4+kx][n][k])    */
@@ -73,6 +67,15 @@ int sgx_conv4x4s2_down(const void* x, const void* w, const float* bias, void* y,
  *   y[b,iy,ix,n] = sum over (oy,ky),(ox,kx) with 2oy+ky-1=iy, 2ox+kx-1=ix of x[b,oy,ox,k] * w[ky*4+kx][n][k]      */
 int sgx_conv4x4s2_up(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int dtype,
                      void* stream);
+/* Any of the three convolutions with the kernel generation named by the caller (A/B probes and parity tests of both).
+ *   geo 0: sgx_conv3x3, 1: sgx_conv4x4s2_down, 2: sgx_conv4x4s2_up (H, W = input size; geo 2 takes no bias / activation);
+ *   variant 0: first-generation kernel (16x16 MFMA tiles, register-staged single LDS stage; any shape / dtype);
+ *   variant 4 / 8: second-generation bf16 kernel (32x32x16 MFMA, LDS-DMA double-buffered stages; the stride-2 convolution
+ *   as four polyphase 2x2 convolutions, the transposed one with its four output-parity classes in one block) with 4- / 8-wave
+ *   blocks; needs Cin % 32 == 0, Cout % 32 == 0 (64 for geo 0) and a tile-grid width % 32 == 0 (SGX_EUNSUPPORTED otherwise).
+ *   The three entry points above choose by themselves.                                                               */
+int sgx_conv_variant(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                     int act, int dtype, int variant, void* stream);
 /* Host-only query: the launch configuration a convolution of this shape resolves to (geo 0: 3x3, 1: 4x4s2 down,
  * 2: 4x4s2 up; H,W = input size).  cfg5 = {KC, TH, TW, pixels per block, output-channel sub-tiles}: the template
  * arguments of conv_kernel<T, KC, geo, TH, TW, BP, CT> as rocprofv3 prints them.                                    */

@@ -20,8 +20,8 @@
 #include <stdlib.h>
 
 enum { G3X3 = 0, GDOWN = 1, GUP = 2, GUPA = 3 };
-int sgx_conv2_try_3x3(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
-                      int variant, hipStream_t st, int* launched);        // conv2.hip   // GUPA: GUP with all four parity classes in one block (bf16)
+int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
+                  int variant, hipStream_t st, int* launched);        // conv2.hip   // GUPA: GUP with all four parity classes in one block (bf16)
 
 // LDS operand tiles are arrays of rows (one pixel, or one (tap, output channel) weight row) holding KC channels.
 // rowb_*: row pitch in bytes; load(): the lane's MFMA fragment (k = kk-step, q = lane>>4); lstore(): one 16-byte chunk.
@@ -583,23 +583,10 @@ extern "C" int sgx_conv3x3(const void* x, const void* w, const float* bias, void
     SGX_NOTE(2.0 * 9 * Cin * Cout * B * H * W, es * ((double)B * H * W * (Cin + Cout) + 9.0 * Cin * Cout), "convS B%d %dx%d %d->%d", B, H, W, Cin, Cout);
     if (dtype == SGX_BF16) {                                   // second-generation kernel (conv2.hip) where it applies
         int launched = 0;
-        const int rc = sgx_conv2_try_3x3(x, w, bias, y, B, H, W, Cin, Cout, act, -1, (hipStream_t)stream, &launched);
+        const int rc = sgx_conv2_try(G3X3, x, w, bias, y, B, H, W, Cin, Cout, act, -1, (hipStream_t)stream, &launched);
         if (rc || launched) return rc;
     }
     return dispatch_conv<G3X3>(a, dtype, (hipStream_t)stream);
-}
-
-extern "C" int sgx_conv3x3_variant(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin,
-                                   int Cout, int act, int dtype, int variant, void* stream) {
-    ConvArgs a{x, w, bias, y, B, H, W, H, W, H, W, Cin, Cout, act, 0, 0};
-    const double es = dtype == SGX_F32 ? 4 : 2;
-    SGX_NOTE(2.0 * 9 * Cin * Cout * B * H * W, es * ((double)B * H * W * (Cin + Cout) + 9.0 * Cin * Cout), "convS/v%d B%d %dx%d %d->%d", variant, B, H, W, Cin, Cout);
-    if (variant == 0) return dispatch_conv<G3X3>(a, dtype, (hipStream_t)stream);
-    SGX_REQUIRE(dtype == SGX_BF16 && (variant == 4 || variant == 8), SGX_EINVAL, "conv3x3_variant: variant %d needs bf16 and 4 or 8 waves", variant);
-    int launched = 0;
-    const int rc = sgx_conv2_try_3x3(x, w, bias, y, B, H, W, Cin, Cout, act, variant, (hipStream_t)stream, &launched);
-    SGX_REQUIRE(rc || launched, SGX_EUNSUPPORTED, "conv3x3_variant: shape not covered by the second-generation kernel");
-    return rc;
 }
 
 extern "C" int sgx_conv4x4s2_down(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,
@@ -608,6 +595,11 @@ extern "C" int sgx_conv4x4s2_down(const void* x, const void* w, const float* bia
     ConvArgs a{x, w, bias, y, B, H, W, H / 2, W / 2, H / 2, W / 2, Cin, Cout, act, 0, 0};
     const double es = dtype == SGX_F32 ? 4 : 2;
     SGX_NOTE(2.0 * 16 * Cin * Cout * B * (H / 2) * (W / 2), es * ((double)B * H * W * (Cin + Cout / 4.0) + 16.0 * Cin * Cout), "convD B%d %dx%d %d->%d", B, H, W, Cin, Cout);
+    if (dtype == SGX_BF16) {
+        int launched = 0;
+        const int rc = sgx_conv2_try(GDOWN, x, w, bias, y, B, H, W, Cin, Cout, act, -1, (hipStream_t)stream, &launched);
+        if (rc || launched) return rc;
+    }
     return dispatch_conv<GDOWN>(a, dtype, (hipStream_t)stream);
 }
 
@@ -616,7 +608,33 @@ extern "C" int sgx_conv4x4s2_up(const void* x, const void* w, void* y, int B, in
     ConvArgs a{x, w, nullptr, y, B, H, W, 2 * H, 2 * W, H, W, Cin, Cout, SGX_ACT_NONE, 0, 0};
     const double es = dtype == SGX_F32 ? 4 : 2;
     SGX_NOTE(2.0 * 16 * Cin * Cout * B * H * W, es * ((double)B * H * W * (Cin + 4.0 * Cout) + 16.0 * Cin * Cout), "convU B%d %dx%d %d->%d", B, H, W, Cin, Cout);
+    if (dtype == SGX_BF16) {
+        int launched = 0;
+        const int rc = sgx_conv2_try(GUP, x, w, nullptr, y, B, H, W, Cin, Cout, SGX_ACT_NONE, -1, (hipStream_t)stream, &launched);
+        if (rc || launched) return rc;
+    }
     return dispatch_conv<GUP>(a, dtype, (hipStream_t)stream);
+}
+
+extern "C" int sgx_conv_variant(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin,
+                                int Cout, int act, int dtype, int variant, void* stream) {
+    SGX_REQUIRE(geo >= 0 && geo <= 2, SGX_EINVAL, "conv_variant: bad geometry %d", geo);
+    SGX_REQUIRE(geo != GDOWN || (H % 2 == 0 && W % 2 == 0), SGX_EINVAL, "conv_variant: odd input size");
+    SGX_REQUIRE(geo != GUP || (!bias && act == SGX_ACT_NONE), SGX_EINVAL, "conv_variant: the transposed convolution has no fused bias / activation");
+    const int OH = geo == GDOWN ? H / 2 : (geo == GUP ? 2 * H : H), OW = geo == GDOWN ? W / 2 : (geo == GUP ? 2 * W : W);
+    ConvArgs a{x, w, bias, y, B, H, W, OH, OW, geo == GUP ? H : OH, geo == GUP ? W : OW, Cin, Cout, act, 0, 0};
+    const double es = dtype == SGX_F32 ? 4 : 2, taps = geo == G3X3 ? 9 : 16, npix = (double)B * (geo == GDOWN ? OH * OW : H * W);
+    SGX_NOTE(2.0 * taps * Cin * Cout * npix, es * ((double)B * (H * W * Cin + OH * OW * Cout) + taps * Cin * Cout), "conv%c/v%d B%d %dx%d %d->%d", "SDU"[geo], variant, B, H, W, Cin, Cout);
+    if (variant == 0) {
+        if (geo == G3X3) return dispatch_conv<G3X3>(a, dtype, (hipStream_t)stream);
+        if (geo == GDOWN) return dispatch_conv<GDOWN>(a, dtype, (hipStream_t)stream);
+        return dispatch_conv<GUP>(a, dtype, (hipStream_t)stream);
+    }
+    SGX_REQUIRE(dtype == SGX_BF16 && (variant == 4 || variant == 8), SGX_EINVAL, "conv_variant: variant %d needs bf16 and 4 or 8 waves", variant);
+    int launched = 0;
+    const int rc = sgx_conv2_try(geo, x, w, bias, y, B, H, W, Cin, Cout, act, variant, (hipStream_t)stream, &launched);
+    SGX_REQUIRE(rc || launched, SGX_EUNSUPPORTED, "conv_variant: shape not covered by the second-generation kernel");
+    return rc;
 }
 
 // =====================================================================================================

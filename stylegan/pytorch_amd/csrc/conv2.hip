@@ -1,14 +1,24 @@
 // Second-generation bf16 convolution kernels for gfx950: v_mfma_f32_32x32x16_bf16, operands staged by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers, no ds_write pass) into TWO LDS stages, one barrier per K-chunk.
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass) into TWO LDS stages, one barrier per K-step.
 //
 // Why (round-1 profile, profiles/r01_*): the first-generation kernel (conv.hip) runs one wave per SIMD with a single LDS
 // stage -- global load -> ds_write -> barrier -> MFMA -> barrier serialise, and at 64^2..256^2 (the MFMA-bound layers) it
 // reaches 12-24 % of the matrix peak while neither LDS bandwidth (6 %) nor HBM is the limit.  Here a block is 8 waves
-// (two per SIMD) on a 16 x 32 pixel tile x 64 output channels; while the waves run the 72 MFMAs of K-chunk c out of stage
-// c&1, the DMA engine fills stage (c+1)&1 with the next chunk (or the next tile's first chunk: the block is persistent).
+// (two per SIMD; 4 for small problems) on a (2*NW) x 32 pixel tile; while the waves run the MFMAs of K-step s out of
+// stage s&1, the DMA engine fills stage (s+1)&1 with the next step (or the next tile's first: the block is persistent).
 //
-// GEMM view as in conv.hip: M = output channels (A = packed weights w[tap][n][k]), N = output pixels (B = activations),
-// K = taps x input channels, K-chunks of 32 channels.  Wave tile 64 channels x 64 pixels (2 x 2 accumulators of 32x32).
+// GEMM view as in conv.hip: M = output channels (A = packed weights w[tap][n][k]), N = pixels (B = activations),
+// K = taps x input channels in K-steps of 32 channels.  A wave owns two rows of 32 pixels x MF*32 channels.
+//
+// Three geometries share the kernel:
+//   C2_S : 3x3 stride 1 pad 1.  Patch (TH+2) x 34 pixels with halo, 9 taps per K-step.
+//   C2_D : 4x4 stride 2 pad 1, as FOUR 2x2 stride-1 convolutions over the polyphase components of the input: a K-step is
+//          (phase (py,px), 32 channels); its patch is the (TH+1) x 33 block of the phase's sub-image, its weights the four
+//          taps (ky,kx) = (2a+1-py, 2b+1-px).  An input pixel is used by 4 taps only, so nothing is gained by staging the
+//          whole 4x-larger stride-2 patch at once; this way a stage is 52 KB instead of 140.
+//   C2_U : 4x4 stride 2 pad 1 TRANSPOSED: the four output-parity classes (py,px) are 2x2 convolutions over the coarse
+//          grid; all four accumulate in one block from ONE 3x3-halo patch, class (py,px) using patch offset (dy,dx) with
+//          tap (ky,kx) = (3-py-2(dy-py), 3-px-2(dx-px)) when dy-py, dx-px are 0 or 1.  The block stores whole fine rows.
 //
 // LDS image of one stage: [patch rows][weight rows], every row = 32 channels = 64 bytes = four 16-byte slots.  The DMA
 // writes lane-linear (wave-uniform base + lane*16), so slot s of an instruction holds (row s/4, chunk (s%4) ^ swz(row)):
@@ -29,24 +39,44 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+enum { C2_S = 0, C2_D = 1, C2_U = 2 };
+
 struct Conv2Args {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y;
-    int B, H, W, Cin, Cout, act;
-    int tiles_x, tiles_y, ntiles;      // pixel tiles of one channel block: B * tiles_y * tiles_x
-    int ncb, nslots;                   // channel blocks; persistent stride over tiles
+    int B, H, W, OH, OW, Cin, Cout, act;      // H, W: input; OH, OW: output
+    int tiles_x, tiles_y, ntiles;             // tiles of the tile grid (S: the image, D: the output, U: the coarse input)
+    int ncb, nslots;                          // channel blocks; persistent stride over tiles
 };
 
-// NW waves per block, each owning 2 rows x 32 pixels; MF 32-channel accumulator rows per wave (block: MF*32 channels).
-template <int NW, int MF>
-__global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_v2_kernel(Conv2Args a) {
-    constexpr int TH = 2 * NW, TW = 32, PH = TH + 2, PW = TW + 2, BCO = MF * 32;
-    constexpr int PROWS = PH * PW;
-    constexpr int P_INSTR = (PROWS * 4 + 63) / 64, P_BYTES = P_INSTR * 1024;
-    constexpr int W_INSTR = 9 * BCO * 4 / 64, W_BYTES = W_INSTR * 1024;
-    constexpr int STAGE = P_BYTES + W_BYTES;
+template <int GEO> struct G2;
+template <> struct G2<C2_S> { static constexpr int NPH = 1, HALO = 2, IS = 1, NTW = 9, NDX = 3, NDY = 3, NCLS = 1; };
+template <> struct G2<C2_D> { static constexpr int NPH = 4, HALO = 1, IS = 2, NTW = 4, NDX = 2, NDY = 2, NCLS = 1; };
+template <> struct G2<C2_U> { static constexpr int NPH = 1, HALO = 2, IS = 1, NTW = 16, NDX = 3, NDY = 3, NCLS = 4; };
+
+template <int GEO, int NW, int MF> struct C2Lds {
+    static constexpr int TH = 2 * NW, PH = TH + G2<GEO>::HALO, PW = 32 + G2<GEO>::HALO, BCO = MF * 32;
+    static constexpr int PROWS = PH * PW;
+    static constexpr int OROW = BCO * 2 + 16;
+    static constexpr int SCRATCH = NW * (GEO == C2_U ? 64 : 32) * OROW;            // epilogue: per-wave pixel-major rows
+    static constexpr int P_RAW = ((PROWS * 4 + 63) / 64) * 1024;
+    static constexpr int P_INSTR = (PROWS * 4 + 63) / 64;
+    static constexpr int P_BYTES = ((P_RAW > SCRATCH ? P_RAW : SCRATCH) + 1023) / 1024 * 1024;
+    static constexpr int W_INSTR = G2<GEO>::NTW * BCO * 4 / 64, W_BYTES = W_INSTR * 1024;
+    static constexpr int STAGE = P_BYTES + W_BYTES;
+    static constexpr int TOTAL = 2 * STAGE;
+};
+
+// NW waves per block, each owning 2 rows x 32 pixels of the tile grid; MF 32-channel accumulator rows per wave.
+template <int GEO, int NW, int MF>
+__global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
+    using G = G2<GEO>;
+    using L = C2Lds<GEO, NW, MF>;
+    constexpr int TH = L::TH, PW = L::PW, BCO = L::BCO, PROWS = L::PROWS;
+    constexpr int P_INSTR = L::P_INSTR, P_BYTES = L::P_BYTES, W_INSTR = L::W_INSTR, STAGE = L::STAGE;
     constexpr int NPI = (P_INSTR + NW - 1) / NW, NWI = (W_INSTR + NW - 1) / NW;
-    constexpr int OROW = BCO * 2 + 16, VPR = BCO * 2 / 16;                 // epilogue scratch: pixel-major rows
-    static_assert(NW * 32 * OROW <= P_BYTES, "epilogue scratch must fit the patch region");
+    constexpr int OROW = L::OROW, VPR = BCO * 2 / 16;
+    constexpr int NPH = G::NPH, IS = G::IS, NDX = G::NDX, NDY = G::NDY, NCLS = G::NCLS;
+    static_assert(GEO != C2_U || MF == 1, "four parity classes of accumulators: one 32-channel row per wave");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -59,7 +89,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_v2_kernel(Conv2Args a
     if (slot >= a.ntiles) return;
     const int my_tiles = (a.ntiles - slot + a.nslots - 1) / a.nslots;
     const int nchunks = a.Cin >> 5;
-    const int nsteps = my_tiles * nchunks;
+    const int spt = nchunks * NPH;                        // K-steps per tile
+    const int nsteps = my_tiles * spt;
 
     // ---- per-lane DMA descriptors (tile independent)
     int prel[NPI], ppos[NPI], wrel[NWI];
@@ -67,22 +98,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_v2_kernel(Conv2Args a
     for (int jj = 0; jj < NPI; ++jj) {
         const int s = (jj * NW + wave) * 64 + lane, row = s >> 2, c = s & 3;
         const int pr = row / PW, pc = row % PW;
-        prel[jj] = (pr * a.W + pc) * a.Cin + ((c ^ ((pc >> 2) & 3)) << 3);
+        prel[jj] = (IS * pr * a.W + IS * pc) * a.Cin + ((c ^ ((pc >> 2) & 3)) << 3);
         ppos[jj] = (row < PROWS) ? ((pr << 8) | pc) : -1;
     }
 #pragma unroll
     for (int jj = 0; jj < NWI; ++jj) {
         const int s = (jj * NW + wave) * 64 + lane, row = s >> 2, c = s & 3;
-        const int tap = row / BCO, n = row % BCO;
-        wrel[jj] = ((tap * a.Cout + co0 + n) * a.Cin) + ((c ^ ((n >> 2) & 3)) << 3);
+        const int t = row / BCO, n = row % BCO;
+        const int tg0 = GEO == C2_D ? (2 * (t >> 1) + 1) * 4 + 2 * (t & 1) + 1 : t;      // phase (0,0) tap; phase shifts it
+        wrel[jj] = ((tg0 * a.Cout + co0 + n) * a.Cin) + ((c ^ ((n >> 2) & 3)) << 3);
     }
     // ---- per-lane fragment read offsets inside a stage
-    int poff[3][2], woff[2];
+    int poff[NDX][2], woff[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         woff[ks] = P_BYTES + l31 * 64 + (((hi + 2 * ks) ^ ((l31 >> 2) & 3)) << 4);
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
+        for (int dx = 0; dx < NDX; ++dx) {
             const int pc = l31 + dx;
             poff[dx][ks] = (2 * wave * PW + pc) * 64 + (((hi + 2 * ks) ^ ((pc >> 2) & 3)) << 4);
         }
@@ -95,21 +127,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_v2_kernel(Conv2Args a
     auto tile_coords = [&](int t, int& b, int& ty0, int& tx0) {
         const int tx_i = t % a.tiles_x; t /= a.tiles_x;
         const int ty_i = t % a.tiles_y;
-        b = t / a.tiles_y; ty0 = ty_i * TH; tx0 = tx_i * TW;
+        b = t / a.tiles_y; ty0 = ty_i * TH; tx0 = tx_i * 32;
     };
-    // stage `step` (tile index it, K-chunk kc) into LDS stage buffer `buf`
+    // stage K-step `step` (tile it, channel chunk kc, phase ph) into LDS stage buffer `buf`
     auto issue = [&](int step, char* buf) {
-        const int it = step / nchunks, kc = step - it * nchunks;
+        const int it = step / spt, q = step - it * spt;
+        const int kc = q / NPH, ph = q - kc * NPH, py = ph >> 1, px = ph & 1;
         int b, ty0, tx0;
         tile_coords(slot + it * a.nslots, b, ty0, tx0);
-        const int iy0 = ty0 - 1, ix0 = tx0 - 1;
+        // input pixel of patch position (pr, pc): (iy0 + IS*pr, ix0 + IS*pc)
+        const int iy0 = GEO == C2_D ? 2 * ty0 - py : ty0 - 1, ix0 = GEO == C2_D ? 2 * tx0 - px : tx0 - 1;
         const bf16_t* base = xg + (((long)b * a.H + iy0) * a.W + ix0) * a.Cin + kc * 32;
 #pragma unroll
         for (int jj = 0; jj < NPI; ++jj) {
             const int ii = jj * NW + wave;
             if (ii < P_INSTR) {
                 const int pp = ppos[jj];
-                const int gy = iy0 + (pp >> 8), gx = ix0 + (pp & 255);
+                const int gy = iy0 + IS * (pp >> 8), gx = ix0 + IS * (pp & 255);
                 // branch-free select between the patch element and the page of zeros (a ?: on pointers compiles to
                 // divergent branches around every DMA instruction)
                 const unsigned long long ok = ((pp >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W)) ? ~0ull : 0ull;
@@ -117,8 +151,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_v2_kernel(Conv2Args a
                 glds16(reinterpret_cast<const void*>(zaddr + ((pa - zaddr) & ok)), buf + ii * 1024);
             }
         }
-        if (nchunks > 2 || step < 2) {               // <= 2 chunks: chunk kc's weights live in stage kc for the whole launch
-            const bf16_t* w0 = wg + kc * 32;
+        if (spt > 2 || step < 2) {                   // <= 2 K-steps per tile: step q's weights live in stage q for the whole launch
+            const bf16_t* w0 = wg + kc * 32 - (GEO == C2_D ? (long)(4 * py + px) * a.Cout * a.Cin : 0);
 #pragma unroll
             for (int jj = 0; jj < NWI; ++jj) {
                 const int ii = jj * NW + wave;
@@ -127,10 +161,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_v2_kernel(Conv2Args a
         }
     };
 
-    f32x16 acc[MF][2];
+    f32x16 acc[NCLS * MF][2];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int m = 0; m < MF; ++m)
+        for (int m = 0; m < NCLS * MF; ++m)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -143,29 +177,54 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_v2_kernel(Conv2Args a
         char* cur = smem + (step & 1) * STAGE;
         __syncthreads();                         // (vmcnt(0) first) stage `step` landed; everyone is done with step-1
         if (step + 1 < nsteps) issue(step + 1, smem + ((step + 1) & 1) * STAGE);
-        // ---- 72 MFMAs in 18 sub-steps (column shift dx, k-step ks, row shift dy).  Per (dx, ks) group the four patch rows
-        // this wave touches are read once; fragments are software-pipelined one sub-step (weights) / one group (patch rows)
-        // ahead so that the LDS latency hides under the MFMAs of the previous sub-step.
-        {
-            bf16x8 brow[2][4], af[2][MF];
-            auto ld_brow = [&](int g, bf16x8 (&dst)[4]) {
+        if constexpr (GEO == C2_U) {
+            // position-major: each of the 9 patch offsets is read once and feeds every class that has a tap there
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 brow[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) brow[r] = *reinterpret_cast<const bf16x8*>(cur + poff[dx][ks] + r * PW * 64);
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+                        for (int cls = 0; cls < 4; ++cls) {
+                            const int py = cls >> 1, px = cls & 1, ta = dy - py, tb = dx - px;
+                            if (ta >= 0 && ta <= 1 && tb >= 0 && tb <= 1) {
+                                const int tg = (3 - py - 2 * ta) * 4 + (3 - px - 2 * tb);
+                                const bf16x8 af = *reinterpret_cast<const bf16x8*>(cur + woff[ks] + (tg * BCO) * 64);
+#pragma unroll
+                                for (int f = 0; f < 2; ++f)
+                                    acc[cls][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, brow[f + dy], acc[cls][f], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            // NDX*2 groups (column shift dx, k-step ks) x NDY row shifts.  Per group the NDY+1 patch rows this wave touches
+            // are read once; fragments are software-pipelined one sub-step (weights) / one group (patch rows) ahead.
+            constexpr int NG = NDX * 2, NSUB = NG * NDY;
+            bf16x8 brow[2][NDY + 1], af[2][MF];
+            auto ld_brow = [&](int g, bf16x8 (&dst)[NDY + 1]) {
                 const int dx = g >> 1, ks = g & 1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[r] = *reinterpret_cast<const bf16x8*>(cur + poff[dx][ks] + r * PW * 64);
+                for (int r = 0; r < NDY + 1; ++r) dst[r] = *reinterpret_cast<const bf16x8*>(cur + poff[dx][ks] + r * PW * 64);
             };
             auto ld_af = [&](int sub, bf16x8 (&dst)[MF]) {
-                const int g = sub / 3, dy = sub % 3, dx = g >> 1, ks = g & 1;
+                const int g = sub / NDY, dy = sub % NDY, dx = g >> 1, ks = g & 1;
 #pragma unroll
                 for (int m = 0; m < MF; ++m)
-                    dst[m] = *reinterpret_cast<const bf16x8*>(cur + woff[ks] + ((dy * 3 + dx) * BCO + m * 32) * 64);
+                    dst[m] = *reinterpret_cast<const bf16x8*>(cur + woff[ks] + ((dy * NDX + dx) * BCO + m * 32) * 64);
             };
             ld_brow(0, brow[0]);
             ld_af(0, af[0]);
 #pragma unroll
-            for (int sub = 0; sub < 18; ++sub) {
-                const int g = sub / 3, dy = sub % 3;
-                if (sub + 1 < 18) ld_af(sub + 1, af[(sub + 1) & 1]);
-                if (dy == 0 && g + 1 < 6) ld_brow(g + 1, brow[(g + 1) & 1]);
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const int g = sub / NDY, dy = sub % NDY;
+                if (sub + 1 < NSUB) ld_af(sub + 1, af[(sub + 1) & 1]);
+                if (dy == 0 && g + 1 < NG) ld_brow(g + 1, brow[(g + 1) & 1]);
 #pragma unroll
                 for (int m = 0; m < MF; ++m)
 #pragma unroll
@@ -173,47 +232,78 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_v2_kernel(Conv2Args a
                         acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sub & 1][m], brow[g & 1][f + dy], acc[m][f], 0, 0, 0);
             }
         }
-        const int it = step / nchunks, kc = step - it * nchunks;
-        if (kc == nchunks - 1) {
+        const int it = step / spt, q = step - it * spt;
+        if (q == spt - 1) {
             // ---- epilogue: bias, activation, bf16; transposed through a wave-private LDS scratch (the patch region of
-            // the stage just consumed) so that every lane stores 16 bytes and 8 lanes cover a 128-byte channel row
+            // the stage just consumed) so that every lane stores 16 bytes and neighbouring lanes cover whole channel rows
             int b, ty0, tx0;
             tile_coords(slot + it * a.nslots, b, ty0, tx0);
-            float4 bv[MF][4];
+            if constexpr (GEO == C2_U) {
+                __syncthreads();                 // every wave is done reading this stage's patch
+                char* scr = cur + wave * (64 * OROW);
 #pragma unroll
-            for (int m = 0; m < MF; ++m)
+                for (int f = 0; f < 2; ++f) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    bv[m][g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + co0 + m * 32 + 8 * g + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
-            __syncthreads();                     // every wave is done reading this stage's patch
-            char* scr = cur + wave * (32 * OROW);
+                    for (int py = 0; py < 2; ++py) {
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
+                        for (int px = 0; px < 2; ++px) {
 #pragma unroll
-                for (int m = 0; m < MF; ++m) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int ch = m * 32 + 8 * g + 4 * hi;
-                        float v[4] = {acc[m][f][4 * g], acc[m][f][4 * g + 1], acc[m][f][4 * g + 2], acc[m][f][4 * g + 3]};
-                        v[0] += bv[m][g].x; v[1] += bv[m][g].y; v[2] += bv[m][g].z; v[3] += bv[m][g].w;
-                        if (a.act == SGX_ACT_LRELU) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i]);
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x16& v = acc[py * 2 + px][f];
+                                uint2 o;
+                                o.x = pack_bf16x2(v[4 * g], v[4 * g + 1]);
+                                o.y = pack_bf16x2(v[4 * g + 2], v[4 * g + 3]);
+                                *reinterpret_cast<uint2*>(scr + (2 * l31 + px) * OROW + (8 * g + 4 * hi) * 2) = o;
+                            }
                         }
-                        uint2 o;
-                        o.x = pack_bf16x2(v[0], v[1]);
-                        o.y = pack_bf16x2(v[2], v[3]);
-                        *reinterpret_cast<uint2*>(scr + l31 * OROW + ch * 2) = o;
+                        const int oy = 2 * (ty0 + 2 * wave + f) + py;
+#pragma unroll
+                        for (int i = 0; i < 64 * VPR / 64; ++i) {
+                            const int idx = i * 64 + lane, fpx = idx / VPR, v = idx % VPR;
+                            const uint4 val = *reinterpret_cast<const uint4*>(scr + fpx * OROW + v * 16);
+                            const int ox = 2 * tx0 + fpx;
+                            if (oy < a.OH && ox < a.OW)
+                                *reinterpret_cast<uint4*>(a.y + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8) = val;
+                        }
                     }
                 }
-                const int oy = ty0 + 2 * wave + f;
+            } else {
+                float4 bv[MF][4];
 #pragma unroll
-                for (int i = 0; i < 32 * VPR / 64; ++i) {
-                    const int idx = i * 64 + lane, px = idx / VPR, v = idx % VPR;
-                    const uint4 val = *reinterpret_cast<const uint4*>(scr + px * OROW + v * 16);
-                    const int ox = tx0 + px;
-                    if (oy < a.H && ox < a.W)
-                        *reinterpret_cast<uint4*>(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.Cout + co0 + v * 8) = val;
+                for (int m = 0; m < MF; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        bv[m][g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + co0 + m * 32 + 8 * g + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
+                __syncthreads();                 // every wave is done reading this stage's patch
+                char* scr = cur + wave * (32 * OROW);
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int ch = m * 32 + 8 * g + 4 * hi;
+                            float v[4] = {acc[m][f][4 * g], acc[m][f][4 * g + 1], acc[m][f][4 * g + 2], acc[m][f][4 * g + 3]};
+                            v[0] += bv[m][g].x; v[1] += bv[m][g].y; v[2] += bv[m][g].z; v[3] += bv[m][g].w;
+                            if (a.act == SGX_ACT_LRELU) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i]);
+                            }
+                            uint2 o;
+                            o.x = pack_bf16x2(v[0], v[1]);
+                            o.y = pack_bf16x2(v[2], v[3]);
+                            *reinterpret_cast<uint2*>(scr + l31 * OROW + ch * 2) = o;
+                        }
+                    }
+                    const int oy = ty0 + 2 * wave + f;
+#pragma unroll
+                    for (int i = 0; i < 32 * VPR / 64; ++i) {
+                        const int idx = i * 64 + lane, px = idx / VPR, v = idx % VPR;
+                        const uint4 val = *reinterpret_cast<const uint4*>(scr + px * OROW + v * 16);
+                        const int ox = tx0 + px;
+                        if (oy < a.OH && ox < a.OW)
+                            *reinterpret_cast<uint4*>(a.y + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8) = val;
+                    }
                 }
             }
             zero_acc();
@@ -230,45 +320,54 @@ static int conv2_ncu() {
     return ncu;
 }
 
-template <int NW, int MF>
+template <int GEO, int NW, int MF>
 static int launch_conv2(Conv2Args& a, hipStream_t st) {
-    constexpr int TH = 2 * NW, PH = TH + 2, PW = 34, BCO = MF * 32;
-    constexpr int P_BYTES = ((PH * PW * 4 + 63) / 64) * 1024, W_BYTES = (9 * BCO * 4 / 64) * 1024;
-    constexpr int LDS = 2 * (P_BYTES + W_BYTES);
-    static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_v2_kernel<NW, MF>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    using L = C2Lds<GEO, NW, MF>;
+    static_assert(L::TOTAL <= 160 * 1024, "LDS budget");
+    auto kern = conv2_kernel<GEO, NW, MF>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
     (void)attr;
-    a.tiles_x = (a.W + 31) / 32; a.tiles_y = (a.H + TH - 1) / TH;
+    const int gh = GEO == C2_D ? a.OH : a.H, gw = GEO == C2_D ? a.OW : a.W;       // the tile grid
+    a.tiles_x = (gw + 31) / 32; a.tiles_y = (gh + L::TH - 1) / L::TH;
     a.ntiles = a.B * a.tiles_y * a.tiles_x;
-    a.ncb = a.Cout / BCO;
+    a.ncb = a.Cout / L::BCO;
     int per = conv2_ncu() / (8 * a.ncb);                 // tile slots per XCD (one block per CU)
     const int need = (a.ntiles + 7) / 8;
     if (per > need) per = need;
     if (per < 1) per = 1;
     a.nslots = per * 8;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.ncb * per)), dim3(NW * 64), LDS, st, a);
-    SGX_LAUNCH_CHECK("conv3x3_v2_kernel");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.ncb * per)), dim3(NW * 64), L::TOTAL, st, a);
+    SGX_LAUNCH_CHECK("conv2_kernel");
     return 0;
 }
 
-// Which layers take this kernel (SGX_CONV2=0 switches it off: A/B against conv.hip).  Returns 1 if launched, 0 if the
-// shape is left to the first-generation kernel, <0 / >0 on error.
+// Which layers take this kernel (SGX_CONV2=0 switches it off: A/B against conv.hip).  geo: 0 = 3x3, 1 = 4x4 stride-2 down,
+// 2 = 4x4 stride-2 up (H, W = input size).  *launched = 1 if it ran; 0 leaves the shape to the first-generation kernel.
 // ``variant``: -1 = choose (environment switch + heuristics), 4 / 8 = force the 4- / 8-wave block (A/B probes, tests).
-int sgx_conv2_try_3x3(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
-                      int variant, hipStream_t st, int* launched) {
-    static const int on = [] { const char* e = getenv("SGX_CONV2"); return e ? atoi(e) : 1; }();
+int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
+                  int variant, hipStream_t st, int* launched) {
+    static const int on = [] { const char* e = getenv("SGX_CONV2"); return e ? atoi(e) : 1; }();      // bit 0: S, 1: D, 2: U
     *launched = 0;
-    if ((variant < 0 && !on) || Cin % 32 != 0 || Cout % 64 != 0 || W % 32 != 0 || Cout / 64 > 32 || H < 1) return 0;
-    Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), B, H, W, Cin, Cout, act, 0, 0, 0, 0, 0};
-    const long blocks8 = (long)B * ((H + 15) / 16) * (W / 32) * (Cout / 64);
+    if (variant < 0 && !((on >> geo) & 1)) return 0;
+    const int gw = geo == C2_D ? W / 2 : W, gh = geo == C2_D ? H / 2 : H;
+    const int bco = geo == C2_S ? 64 : 32;
+    if (Cin % 32 != 0 || Cout % bco != 0 || gw % 32 != 0 || Cout / bco > 32 || gh < 1 || (geo == C2_D && ((H | W) & 1))) return 0;
+    Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), B, H, W,
+                geo == C2_D ? H / 2 : (geo == C2_U ? 2 * H : H), geo == C2_D ? W / 2 : (geo == C2_U ? 2 * W : W), Cin, Cout, act, 0, 0, 0, 0, 0};
+    const bool mf2 = geo != C2_U && Cout % 64 == 0;
+    if (variant < 0 && geo == C2_D && !mf2) return 0;      // 32-channel stride-2 blocks: measured no better than the first generation
+    const int cbs = Cout / (mf2 ? 64 : 32);
+    const long blocks8 = (long)B * ((gh + 15) / 16) * (gw / 32) * cbs, blocks4 = (long)B * ((gh + 7) / 8) * (gw / 32) * cbs;
     static const int force_nw = [] { const char* e = getenv("SGX_CONV2_NW"); return e ? atoi(e) : 0; }();
     // measured (profiles/r02_conv2_probe.txt): the 8-wave block wins once its 512-pixel tiles fill the chip, the 4-wave
     // block (256-pixel tiles) down to one block per CU, below that the first-generation kernel's 64-pixel tiles do
-    const long blocks4 = (long)B * ((H + 7) / 8) * (W / 32) * (Cout / 64);
     if (variant < 0 && !force_nw && blocks4 < conv2_ncu()) return 0;
     const int nw = variant > 0 ? variant : (force_nw ? force_nw : (blocks8 >= conv2_ncu() ? 8 : 4));
     *launched = 1;
-    if (nw == 8) return launch_conv2<8, 2>(a, st);
-    return launch_conv2<4, 2>(a, st);
+    if (geo == C2_S) return nw == 8 ? launch_conv2<C2_S, 8, 2>(a, st) : launch_conv2<C2_S, 4, 2>(a, st);
+    if (geo == C2_D) {
+        if (mf2) return nw == 8 ? launch_conv2<C2_D, 8, 2>(a, st) : launch_conv2<C2_D, 4, 2>(a, st);
+        return nw == 8 ? launch_conv2<C2_D, 8, 1>(a, st) : launch_conv2<C2_D, 4, 1>(a, st);
+    }
+    return nw == 8 ? launch_conv2<C2_U, 8, 1>(a, st) : launch_conv2<C2_U, 4, 1>(a, st);
 }

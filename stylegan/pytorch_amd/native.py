@@ -34,7 +34,7 @@ SIGNATURES = {
     "sgx_clear_error": (I, []),
     "sgx_stream_wait_stream": (I, [P, P]),
     "sgx_conv3x3": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
-    "sgx_conv3x3_variant": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "sgx_conv_variant": (I, [I, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_down": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_up": (I, [P, P, P, I, I, I, I, I, I, P]),
     "sgx_wgrad_ws_bytes": (Z, [I, I, I, I, I, I]),

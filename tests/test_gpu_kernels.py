@@ -539,37 +539,51 @@ def test_images_from_uint8_feeds_the_step():
 
 
 # second-generation bf16 convolution (conv2.hip): 32x32x16 MFMA, LDS-DMA double-buffered stages.  Both block shapes
-# (4 / 8 waves) against the fp64 oracle on bf16-exact operands, and against the first-generation kernel on the same packs.
+# (4 / 8 waves), all three geometries, against the fp64 oracle on bf16-exact operands and against the first-generation kernel
+# on the same packs.
 CONV2_CASES = [
-    # (cin, cout, B, H, W)      1 / 2 / 4+ K-chunks (static vs re-staged weights), 1..4 channel blocks, ragged rows, many tiles
-    (32, 64, 2, 32, 32), (64, 64, 3, 16, 32), (64, 128, 2, 40, 64), (128, 64, 1, 64, 32), (256, 256, 2, 8, 32),
-    (32, 128, 5, 24, 96), (96, 192, 1, 33, 32), (64, 64, 9, 64, 64),
+    # (geo, cin, cout, B, H, W)   1 / 2 / 4+ K-chunks (static vs re-staged weights), 1..4 channel blocks, ragged rows, many tiles
+    ("S", 32, 64, 2, 32, 32), ("S", 64, 64, 3, 16, 32), ("S", 64, 128, 2, 40, 64), ("S", 128, 64, 1, 64, 32), ("S", 256, 256, 2, 8, 32),
+    ("S", 32, 128, 5, 24, 96), ("S", 96, 192, 1, 33, 32), ("S", 64, 64, 9, 64, 64),
+    ("D", 32, 64, 2, 64, 64), ("D", 64, 32, 3, 32, 64), ("D", 128, 128, 1, 80, 128), ("D", 32, 96, 2, 36, 64), ("D", 64, 64, 5, 128, 64),
+    ("U", 32, 32, 2, 32, 32), ("U", 64, 64, 3, 16, 32), ("U", 128, 32, 1, 40, 64), ("U", 32, 96, 2, 17, 32), ("U", 64, 32, 5, 64, 64),
 ]
 
 
 @pytest.mark.parametrize("variant", [4, 8])
-@pytest.mark.parametrize("cin,cout,B,H,W", CONV2_CASES)
-def test_conv2_variants_vs_oracle(variant, cin, cout, B, H, W):
+@pytest.mark.parametrize("geo,cin,cout,B,H,W", CONV2_CASES)
+def test_conv2_variants_vs_oracle(variant, geo, cin, cout, B, H, W):
     from stylegan.pytorch_amd import functional as F
     from stylegan.pytorch_amd import native as N
     w = gu.seeded((cout, cin, 3, 3), 5).to(DEV)
-    bias = (0.5 * gu.seeded((cout,), 6)).to(DEV)
+    bias = None if geo == "U" else (0.5 * gu.seeded((cout,), 6)).to(DEV)
     scale = O.he_w_mul(cin * 9, math.sqrt(2))
     x = gu.seeded((B, cin, H, W), 7).bfloat16().float()
     xn = F.nhwc(x.to(DEV)).bfloat16()
-    wq, _ = F.packs(w, "S", scale, cin, torch.bfloat16)
+    wq, _ = F.packs(w, geo, scale, cin, torch.bfloat16)
+    OH, OW = (H // 2, W // 2) if geo == "D" else ((2 * H, 2 * W) if geo == "U" else (H, W))
+    act = 0 if geo == "U" else 1
     L = N.lib()
     outs = {}
     for v in (0, variant):
-        y = torch.full((B, H, W, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
-        N.check(L.sgx_conv3x3_variant(N.ptr(xn), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, cin, cout, 1, N.BF16, v, N.stream()), "variant")
+        y = torch.full((B, OH, OW, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        N.check(L.sgx_conv_variant({"S": 0, "D": 1, "U": 2}[geo], N.ptr(xn), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, cin, cout, act,
+                                   N.BF16, v, N.stream()), "variant")
         outs[v] = F.nchw_view(y).float()
     # oracle on the bf16-rounded packed weights: the only remaining error is the bf16 rounding of the stored output
-    wr = wq.float().view(3, 3, cout, cin).permute(2, 3, 0, 1).double().cpu()
-    ref = TF.leaky_relu(TF.conv2d(x.double(), wr, bias.double().cpu(), padding=1), 0.2)
+    k = 3 if geo == "S" else 4
+    wr = wq.float().view(k, k, cout, cin).permute(2, 3, 0, 1).double().cpu()
+    if geo == "S":
+        ref = TF.conv2d(x.double(), wr, bias.double().cpu(), padding=1)
+    elif geo == "D":
+        ref = TF.conv2d(x.double(), wr, bias.double().cpu(), stride=2, padding=1)
+    else:
+        ref = TF.conv_transpose2d(x.double(), wr.permute(1, 0, 2, 3), stride=2, padding=1)
+    if act:
+        ref = TF.leaky_relu(ref, 0.2)
     assert torch.isfinite(outs[variant]).all()
-    assert_close(outs[variant], ref, 4e-3, f"conv2 v{variant} vs oracle (bf16 output rounding only)")
-    assert_close(outs[variant], outs[0], 4e-3, f"conv2 v{variant} vs first-generation kernel")
+    assert_close(outs[variant], ref, 4e-3, f"conv2 {geo} v{variant} vs oracle (bf16 output rounding only)")
+    assert_close(outs[variant], outs[0], 4e-3, f"conv2 {geo} v{variant} vs first-generation kernel")
     # fp32 agreement before the rounding: at most one bf16 ulp apart anywhere
     d = (outs[variant] - ref.float().to(DEV)).abs()
     assert float((d / (ref.float().to(DEV).abs() + 1e-3)).max()) < 2 ** -7

@@ -14,18 +14,24 @@ import torch  # noqa: E402
 from stylegan.pytorch_amd import functional as F  # noqa: E402
 from stylegan.pytorch_amd import native as N  # noqa: E402
 
-SHAPES = [(256, 64, 64), (128, 128, 128), (64, 256, 256), (32, 512, 512), (512, 32, 64), (128, 64, 128), (64, 128, 256)]
+SHAPES = [  # (geo, H (input), Cin, Cout)
+    ("S", 256, 64, 64), ("S", 128, 128, 128), ("S", 64, 256, 256), ("S", 32, 512, 512), ("S", 512, 32, 64),
+    ("D", 512, 32, 64), ("D", 256, 64, 128), ("D", 128, 128, 256), ("D", 64, 256, 512), ("D", 512, 32, 32),
+    ("U", 256, 64, 32), ("U", 128, 128, 64), ("U", 64, 256, 128), ("U", 32, 512, 256), ("U", 256, 32, 32),
+]
+GEO = {"S": 0, "D": 1, "U": 2}
 
 
-def run(variant, x, wq, bias, act, reps):
+def run(geo, variant, x, wq, bias, act, reps):
     B, H, W, Cin = x.shape
     Cout = wq.shape[1]
-    y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
+    oh = H // 2 if geo == "D" else (2 * H if geo == "U" else H)
+    y = torch.empty((B, oh, oh, Cout), dtype=x.dtype, device=x.device)
     L = N.lib()
 
     def go():
-        N.check(L.sgx_conv3x3_variant(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.BF16, variant, N.stream()),
-                "sgx_conv3x3_variant")
+        N.check(L.sgx_conv_variant(GEO[geo], N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.BF16, variant, N.stream()),
+                "sgx_conv_variant")
     go(); go()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,35 +48,49 @@ def main():
     ap.add_argument("--batch", type=int, nargs="+", default=[4, 32])
     ap.add_argument("--variants", type=int, nargs="+", default=[0, 4, 8])
     ap.add_argument("--check", type=int, default=1)
+    ap.add_argument("--geo", nargs="+", default=["S", "D", "U"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    only = set(a.geo)
     for B in a.batch:
-        for H, ci, co in SHAPES:
+        for geo, H, ci, co in SHAPES:
+            if geo not in only:
+                continue
             torch.manual_seed(H + ci)
             w = torch.randn(co, ci, 3, 3, device=dev)
-            bias = torch.randn(co, device=dev)
+            bias = None if geo == "U" else torch.randn(co, device=dev)
             x = torch.randn(B, H, H, ci, device=dev).bfloat16()
-            wq, _ = F.packs(w, "S", 0.05, ci, torch.bfloat16)
+            wq, _ = F.packs(w, geo, 0.05, ci, torch.bfloat16)
+            taps = 9 if geo == "S" else 16
             ref = None
             if a.check:
-                wr = wq.float().view(3, 3, co, ci).permute(2, 3, 0, 1).contiguous()          # the bf16-rounded operands
+                k = 3 if geo == "S" else 4
+                wr = wq.float().view(k, k, co, ci).permute(2, 3, 0, 1).contiguous()          # the bf16-rounded operands
                 nb = min(B, 2)
-                ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x[:nb].float().permute(0, 3, 1, 2), wr, bias, padding=1), 0.2)
+                xi = x[:nb].float().permute(0, 3, 1, 2)
+                if geo == "S":
+                    ref = torch.nn.functional.conv2d(xi, wr, bias, padding=1)
+                elif geo == "D":
+                    ref = torch.nn.functional.conv2d(xi, wr, bias, stride=2, padding=1)
+                else:
+                    ref = torch.nn.functional.conv_transpose2d(xi, wr.permute(1, 0, 2, 3), stride=2, padding=1)
+                if geo != "U":
+                    ref = torch.nn.functional.leaky_relu(ref, 0.2)
                 ref = ref.permute(0, 2, 3, 1)
-            fl = 2.0 * 9 * ci * co * B * H * H
-            line = f"convS B{B} {H}x{H} {ci}->{co}:"
+            npix = B * H * H * (0.25 if geo == "D" else 1.0)
+            fl = 2.0 * taps * ci * co * npix
+            line = f"conv{geo} B{B} {H}x{H} {ci}->{co}:"
             for v in a.variants:
                 try:
-                    y, us = run(v, x, wq, bias, 1, a.reps)
+                    y, us = run(geo, v, x, wq, bias, 0 if geo == "U" else 1, a.reps)
                 except N.SgxError as e:
-                    line += f"  v{v}: n/a ({str(e)[:40]})"
+                    line += f"  v{v}: n/a"
                     continue
                 err = ""
                 if ref is not None:
                     d = (y[:ref.shape[0]].float() - ref)
                     rel = (d.norm() / ref.norm()).item()
-                    mx = (d.abs().max() / ref.abs().max()).item()
-                    err = f" rel {rel:.1e} max {mx:.1e}"
+                    err = f" rel {rel:.1e}"
                 line += f"  v{v}: {us:7.1f} us {fl / us / 1e6:7.1f} TF{err}"
             print(line, flush=True)
 
