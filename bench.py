@@ -68,6 +68,41 @@ def cpu_baseline_subprocess(config, timeout_s):
                                          "the reference's own CPU numbers"}
 
 
+def cpu_baseline_reference(cfg, batch=1):
+    """One iteration of the REFERENCE ITSELF on this host's cores (kind "reference"), when its sources are present
+    (/root/reference: the build container; the GPU boxes do not have it -> None, and the port below is timed instead).
+    Imported with the shims of tests/golden/make_golden.py: a stub ``data`` module (models/GAN.py:25 pulls torchvision in
+    through it), no bytecode written into the read-only mount, float Adam betas (config.py:81 gives an int)."""
+    ref = os.environ.get("SGX_REFERENCE_DIR", "/root/reference")
+    if not os.path.isfile(os.path.join(ref, "models", "GAN.py")):
+        return None
+    import random
+    import types
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, ref)
+    stub = types.ModuleType("data"); stub.get_data_loader = None; sys.modules["data"] = stub
+    from models.GAN import StyleGAN as RefStyleGAN
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    res, depth = cfg["resolution"], cfg["depth"]
+    torch.manual_seed(0); random.seed(0)
+    opt = dict(learning_rate=0.003, beta_1=0.0, beta_2=0.99, eps=1e-8)
+    sg = RefStyleGAN("linear", res, 3, 512,
+                     g_args=dict(latent_size=512, mapping_layers=cfg["mapping_layers"], blur_filter=[1, 2, 1],
+                                 truncation_psi=cfg["truncation_psi"], truncation_cutoff=8),
+                     d_args=dict(use_wscale=True, blur_filter=[1, 2, 1]), g_opt_args=opt, d_opt_args=opt,
+                     loss="logistic", d_repeats=1, use_ema=True, ema_decay=0.999, device=torch.device("cpu"))
+    sg.gen.train(); sg.dis.train(); sg.gen_shadow.train()
+    z = torch.randn(batch, 512); real = torch.randn(batch, 3, res, res)
+    t0 = time.time()
+    sg.optimize_discriminator(z, real, depth, 0.5)
+    sg.optimize_generator(z, real, depth, 0.5)
+    dt = time.time() - t0
+    return {"value": batch / dt, "unit": "img/s", "cores": cores, "kind": "reference",
+            "sample": f"1 full G+D iteration of the reference's own StyleGAN.optimize_discriminator + optimize_generator "
+                      f"(models/GAN.py:591-659), batch {batch}, {res}x{res} depth index {depth}, fp32 CPU, {cores} threads, {dt:.1f} s"}
+
+
 def cpu_baseline(cfg, batch=1):
     """One iteration of the CPU oracle (fp32, torch CPU ops) at a reduced batch.  Threads are capped: the step is
     thousands of small ATen ops, and a 256-thread fork/join per op is slower than 16 threads."""
@@ -94,14 +129,19 @@ def cpu_baseline(cfg, batch=1):
     dt = time.time() - t0
     return {"value": batch / dt, "unit": "img/s", "cores": cores, "kind": "port",
             "sample": f"1 full G+D iteration, batch {batch}, {res}x{res} depth index {depth}, fp32 torch-CPU oracle "
-                      f"(oracle/stylegan_oracle.py), {dt:.1f} s"}
+                      f"(oracle/stylegan_oracle.py; the reference's sources are not on this box), {cores} threads, {dt:.1f} s"}
 
 
 def main():
     a = parse()
     cfg = CONFIGS[a.config]
     if a.cpu_baseline_child:
-        print(json.dumps(cpu_baseline(cfg)))
+        out = None
+        try:
+            out = cpu_baseline_reference(cfg)                # the reference itself where its sources exist
+        except Exception as e:                               # noqa: BLE001 -- fall back to the port, say why
+            sys.stderr.write(f"reference CPU leg failed ({type(e).__name__}: {e}); timing the port\n")
+        print(json.dumps(out or cpu_baseline(cfg)))
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -245,22 +285,45 @@ def main():
         else:
             bound, achieved, peak, unit = "hbm", nb / (ms * 1e-3) / 1e9, peak_b / 1e9, "GB/s"
         per_kernel = sorted(((k, v[0], v[1]) for k, v in agg.items()), key=lambda kv: -kv[1])
+
+        def roof_row(desc, name, n, t_ms, f, nbytes):
+            """One (layer, kernel) row of the surveyed step under its own roof: a single `frac` for an instantiation hides
+            that it serves shapes from HBM-bound to latency-bound."""
+            us = t_ms * 1e3 / n
+            mf = f / peak_f >= nbytes / peak_b
+            ach = (f / n / us / 1e6) if mf else (nbytes / n / us / 1e3)
+            pk = (peak_f / 1e12) if mf else (peak_b / 1e9)
+            return {"layer": desc, "kernel": name.split("(")[0].replace("void ", ""), "launches": n, "avg_us": round(us, 1),
+                    "bound": "mfma" if mf else "hbm", "achieved": round(ach, 1), "unit": "TFLOP/s" if mf else "GB/s",
+                    "frac": round(ach / pk, 4) if (f or nbytes) else None}
+        by_layer = {}
+        for name, t, f, n, desc in survey:
+            L = by_layer.setdefault((desc, name), [0, 0.0, 0.0, 0.0])
+            L[0] += 1; L[1] += t; L[2] += f; L[3] += n
+        rows = sorted(by_layer.items(), key=lambda kv: -kv[1][1])
+        dom_layers = [roof_row(d, nm, *v) for (d, nm), v in rows if nm == dom_name]
+        top_layers = [roof_row(d, nm, *v) for (d, nm), v in rows[:12]]
+        executed_flops = sum(r[2] for r in survey)            # what the kernels of one step actually execute (their own notes)
         traffic, traffic_src = None, None
         if a.config == "ffhq1024" and a.dtype == "bf16" and B == 4:
             # HBM bytes per launch of this instantiation from the committed PMC passes of this same workload (rocprofv3
             # cannot run inside the benchmark): tools/gpu_pmc.sh -> tools/pmc_traffic.py, corrected as the guide prescribes
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_bf16_b4.json")
-            if os.path.exists(pmc):
+            import glob
+            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_bf16_b4.json")), reverse=True):   # newest round first
                 ent = json.load(open(pmc))["kernels"].get(dom_name)
                 if ent:
-                    traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic_bf16_b4.json"
+                    traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/" + os.path.basename(pmc)
+                    break
         roof = {"bound": bound, "kernel": dom_name, "launches": len(recs), "avg_us": ms * 1e3 / len(recs),
                 "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak if (fl or nb) else None, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": nb / len(recs), "flops_per_launch": fl / len(recs),
                 "library_kernels_ms_per_step": round(sum(v[0] for v in agg.values()), 3),
                 "library_launches_per_step": len(survey),
                 "events_over": "eager re-run of the timed steps (timed region itself is hipGraph replay)" if graphs else "timed region",
-                "top_kernels_ms_per_step": {k: round(t, 3) for k, t, _ in per_kernel[:8]}}
+                "top_kernels_ms_per_step": {k: round(t, 3) for k, t, _ in per_kernel[:8]},
+                "layers": dom_layers, "top_layers": top_layers, "_executed_flops_per_step": executed_flops,
+                "layers_note": "per (layer, kernel) of ONE surveyed eager step, every launch bracketed by HIP events on its "
+                               "stream; the step's streams overlap, so a launch's duration includes sharing the GPU"}
         if a.layer_table and rank == 0:
             layers = {}
             for name, t, f, n, desc in survey:
@@ -285,8 +348,16 @@ def main():
                           "global_batch": B * world, "parallelism": f"dp{world}"},
                "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
                "hip_graphs": bool(graphs), "launch_mode_calibration": calib,
+               # useful-work convention: the reference step's algorithmic conv+GEMM FLOPs per image, whatever
+               # the kernels execute; beside it the FLOPs the kernels really execute (one D(real) forward instead of two, no
+               # D weight gradients in the G step, 4x4 stride-2 instead of 3x3 + pool) from their own per-launch notes
                "useful_tflops": value * cfg["flops_per_img"] / 1e12,
                "mfma_frac_of_step": value * cfg["flops_per_img"] / (PEAK[a.dtype] * world)}
+        if roof:
+            ex = roof.pop("_executed_flops_per_step")
+            out["executed_tflops"] = ex / (dt / a.steps) / 1e12 * world
+            out["executed_frac_of_mfma_peak"] = ex / (dt / a.steps) / PEAK[a.dtype]
+            out["executed_gflop_per_img"] = ex / B / 1e9
         if roof:
             out["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:

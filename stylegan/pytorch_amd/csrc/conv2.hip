@@ -346,7 +346,9 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
 // ``variant``: -1 = choose (environment switch + heuristics), 4 / 8 = force the 4- / 8-wave block (A/B probes, tests).
 int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
                   int variant, hipStream_t st, int* launched) {
-    static const int on = [] { const char* e = getenv("SGX_CONV2"); return e ? atoi(e) : 1; }();      // bit 0: S, 1: D, 2: U
+    // bit 0: S, 1: D, 2: U.  All three on: profiles/r02_conv2_probe.txt (S) and r02_conv2_probe_DU.txt (D, U) -- the shape
+    // heuristics below reproduce the per-shape winner of those tables
+    static const int on = [] { const char* e = getenv("SGX_CONV2"); return e ? atoi(e) : 7; }();
     *launched = 0;
     if (variant < 0 && !((on >> geo) & 1)) return 0;
     const int gw = geo == C2_D ? W / 2 : W, gh = geo == C2_D ? H / 2 : H;
