@@ -24,7 +24,10 @@ extern "C" {
 #endif
 
 enum { SGX_F32 = 0, SGX_BF16 = 1 };
-enum { SGX_ACT_NONE = 0, SGX_ACT_LRELU = 1 };          /* LeakyReLU(0.2): models/GAN.py:67-68,150-151,346-347 */
+/* LeakyReLU(0.2) / ReLU: the 'lrelu' | 'relu' nonlinearity of models/GAN.py:67-68,150-151,346-347.  The fused epilogues of
+ * the convolution / linear kernels implement NONE and LRELU (what every shipped config uses); RELU is served by
+ * sgx_bias_act + sgx_lrelu_bwd(slope 0) after the un-activated kernel.                                               */
+enum { SGX_ACT_NONE = 0, SGX_ACT_LRELU = 1, SGX_ACT_RELU = 2 };
 enum { SGX_EINVAL = -1, SGX_EUNSUPPORTED = -2, SGX_EWORKSPACE = -3 };
 
 int sgx_version(void);
@@ -122,8 +125,9 @@ int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float* dW, float*
  *   bscale = the layer's b_mul (lrmul; 0.01 in the mapping network, models/CustomLayers.py:94-95,101-102)           */
 int sgx_bias_act(const void* x, const float* bias, float bscale, void* y, size_t npix, int C, int act, int dtype,
                  void* stream);
-/* dx = dy * (y > 0 ? 1 : 0.2)               autograd of nn.LeakyReLU(0.2); y is the activation OUTPUT               */
-int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, int dtype, void* stream);
+/* dx = dy * (y > 0 ? 1 : slope)             autograd of nn.LeakyReLU(0.2) (slope 0.2) / torch.relu (slope 0); y is the
+ * activation OUTPUT                                                                                                  */
+int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, float slope, int dtype, void* stream);
 /* out = alpha*a + beta*b (b may be NULL)    fade-in lerp: models/GAN.py:202,427,586                                 */
 int sgx_axpby(const void* a, const void* b, void* out, float alpha, float beta, size_t n, int dtype, void* stream);
 /* same with the coefficients read from device memory (alpha_dev[0], beta_dev[0]): the fade-in alpha changes every
@@ -136,6 +140,12 @@ int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, v
  * mode 0: y = blur(x);  1: y = blur(lrelu(x))  [forward];  2: y = blur(x) * slope(z)  [backward: z = the pre-activation];
  * 3: y = blur(x * slope(z))  [backward of mode 2 w.r.t. x: the R1 double backward].  slope(z) = z > 0 ? 1 : 0.2 */
 int sgx_blur3x3_act(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, int dtype, void* stream);
+/* BlurLayer with any other filter (models/CustomLayers.py:251-276: kernel = outer(f,f) [/sum] [flipped], F.conv2d with
+ * groups=C, padding (K-1)//2):  y[oy][ox] = sum_{i,j} taps[i*K+j] * x[oy+i-pad][ox+j-pad], zero outside, K <= 7.
+ * taps_host: K*K floats in HOST memory (copied into the launch).  x: [B][IH][IW][C], y: [B][OH][OW][C] with
+ * OH <= IH+2*pad-K+1.  The adjoint is the same call with the taps flipped, pad' = K-1-pad and the sizes swapped.      */
+int sgx_blur_kxk(const void* x, void* y, const float* taps_host, int K, int pad, int B, int IH, int IW, int OH, int OW, int C,
+                 int dtype, void* stream);
 /* Input pipeline on the device: uint8 images -> NHWC activations, (v/255 - 0.5)/0.5 in fp32 -- torchvision's
  * ToTensor + Normalize((.5,.5,.5),(.5,.5,.5)) of data/transforms.py:20-33; flip[b] != 0 mirrors image b horizontally
  * (RandomHorizontalFlip, decision drawn by the caller; NULL: none).  src: [B][H][W][3] bytes, or [B][3][H][W] if src_chw.
@@ -170,13 +180,18 @@ int sgx_rgb_wgrad(const float* img, const void* f, float* dw, int sj, int sc, fl
  *   p = x + bias[c] + nw[c]*noise[b,hw];  a = lrelu(p);  xh = (a - mean[b,c]) * rstd[b,c]
  *   y = xh * (style[b,c] + 1) + style[b,C+c]
  * bias may be NULL.  mean/rstd ([B][C] fp32) are outputs of fwd and inputs of bwd.
- * bwd returns dx, dstyle[B][2C], dnw[C], dbias[C] (dbias may be NULL).                                               */
+ * bwd returns dx, dstyle[B][2C], dnw[C], dbias[C] (dbias may be NULL).
+ * flags select the stages the module was built with (LayerEpilogue's use_* arguments, :224-246): SGX_EPI_ACT = the
+ * LeakyReLU, SGX_EPI_NORM = the instance norm (off: mean 0 / rstd 1 are written and the backward drops the statistics
+ * terms).  use_noise=False is nw = 0, use_styles=False is style = 0 (both exact).  The default is ACT|NORM.           */
+enum { SGX_EPI_ACT = 1, SGX_EPI_NORM = 2 };
 size_t sgx_gepi_ws_bytes(int B, int HW, int C);
 int sgx_gepi_fwd(const void* x, const float* bias, const float* noise, const float* nw, const float* style, void* y,
-                 float* mean, float* rstd, void* ws, size_t ws_bytes, int B, int HW, int C, int dtype, void* stream);
+                 float* mean, float* rstd, void* ws, size_t ws_bytes, int B, int HW, int C, int flags, int dtype,
+                 void* stream);
 int sgx_gepi_bwd(const void* dy, const void* x, const float* bias, const float* noise, const float* nw,
                  const float* style, const float* mean, const float* rstd, void* dx, float* dstyle, float* dnw,
-                 float* dbias, void* ws, size_t ws_bytes, int B, int HW, int C, int dtype, void* stream);
+                 float* dbias, void* ws, size_t ws_bytes, int B, int HW, int C, int flags, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- small fp32 pieces
  * PixelNormLayer on [B][C] rows: y = x * rsqrt(mean_c(x^2) + 1e-8)      models/CustomLayers.py:22-23                 */

@@ -29,6 +29,10 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : SGX_LRELU * v; }
 __device__ __forceinline__ float lrelu_slope(float out_or_in) { return out_or_in > 0.f ? 1.f : SGX_LRELU; }
+// SGX_ACT_NONE / SGX_ACT_LRELU / SGX_ACT_RELU (the reference's 'lrelu' | 'relu' nonlinearity, models/GAN.py:67-68)
+__device__ __forceinline__ float act_apply(float v, int act) {
+    return (act == SGX_ACT_NONE || v > 0.f) ? v : (act == SGX_ACT_RELU ? 0.f : SGX_LRELU * v);
+}
 
 // 16-byte vector access, VE elements of T per vector
 template <typename T> struct VecTraits;

@@ -23,7 +23,7 @@ __global__ void bias_act_kernel(const T* __restrict__ x, const float* __restrict
 #pragma unroll
         for (int j = 0; j < VE; ++j) {
             float t = v[j] + (bias ? bscale * bias[c0 + j] : 0.f);
-            v[j] = act == SGX_ACT_LRELU ? lrelu(t) : t;
+            v[j] = act_apply(t, act);
         }
         VecTraits<T>::store(y + i * VE, v);
     }
@@ -32,11 +32,12 @@ __global__ void bias_act_scalar_kernel(const float* __restrict__ x, const float*
                                        size_t n, int C, int act) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float t = x[i] + (bias ? bscale * bias[i % C] : 0.f);
-        y[i] = act == SGX_ACT_LRELU ? lrelu(t) : t;
+        y[i] = act_apply(t, act);
     }
 }
 extern "C" int sgx_bias_act(const void* x, const float* bias, float bscale, void* y, size_t npix, int C, int act, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    SGX_REQUIRE(act >= SGX_ACT_NONE && act <= SGX_ACT_RELU, SGX_EINVAL, "bias_act: activation %d", act);
     SGX_NOTE(0.0, 2.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * npix * C, "bias_act %zux%d", npix, C);
     if (dtype == SGX_F32 && C % 4 != 0) {                    // e.g. the [B,1] discriminator output
         hipLaunchKernelGGL(bias_act_scalar_kernel, dim3(grid_for(npix * C)), dim3(256), 0, st, (const float*)x, bias, bscale, (float*)y, npix * C, C, act);
@@ -56,28 +57,28 @@ extern "C" int sgx_bias_act(const void* x, const float* bias, float bscale, void
     return 0;
 }
 
-// ---------------------------------------------------------------- dx = dy * slope(y)
+// ---------------------------------------------------------------- dx = dy * (y > 0 ? 1 : slope)   (slope 0.2: LeakyReLU; 0: ReLU)
 template <typename T>
-__global__ void lrelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, size_t nvec) {
+__global__ void lrelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, size_t nvec, float slope) {
     constexpr int VE = VecTraits<T>::VE;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
         float g[VE], a[VE];
         VecTraits<T>::load(dy + i * VE, g);
         VecTraits<T>::load(y + i * VE, a);
 #pragma unroll
-        for (int j = 0; j < VE; ++j) g[j] *= lrelu_slope(a[j]);
+        for (int j = 0; j < VE; ++j) g[j] *= a[j] > 0.f ? 1.f : slope;
         VecTraits<T>::store(dx + i * VE, g);
     }
 }
-extern "C" int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, int dtype, void* stream) {
+extern "C" int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, float slope, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SGX_NOTE(0.0, 3.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * n, "lrelu_bwd %zu", n);
     if (dtype == SGX_F32) {
         SGX_REQUIRE(n % 4 == 0, SGX_EUNSUPPORTED, "lrelu_bwd: n %% 4");
-        hipLaunchKernelGGL(lrelu_bwd_kernel<float>, dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)dx, n / 4);
+        hipLaunchKernelGGL(lrelu_bwd_kernel<float>, dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)dx, n / 4, slope);
     } else {
         SGX_REQUIRE(n % 8 == 0, SGX_EUNSUPPORTED, "lrelu_bwd: n %% 8");
-        hipLaunchKernelGGL(lrelu_bwd_kernel<bf16_t>, dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n / 8);
+        hipLaunchKernelGGL(lrelu_bwd_kernel<bf16_t>, dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n / 8, slope);
     }
     SGX_LAUNCH_CHECK("lrelu_bwd");
     return 0;
@@ -235,6 +236,63 @@ extern "C" int sgx_blur3x3_act(const void* x, const void* z, void* y, int B, int
 }
 extern "C" int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
     return sgx_blur3x3_act(x, nullptr, y, B, H, W, C, 0, dtype, stream);
+}
+
+// ---------------------------------------------------------------- depthwise K x K correlation, zero padded, any filter
+// BlurLayer with a blur_filter other than [1,2,1] (models/CustomLayers.py:251-276: kernel = outer(f, f), optionally
+// normalised / flipped; F.conv2d(groups=C, padding=(K-1)//2)):  y[oy][ox] = sum_{i,j} k[i][j] * x[oy+i-pad][ox+j-pad].
+// The same kernel serves its adjoint (flipped taps, pad' = K-1-pad, output size = the forward's input size), so the op is
+// closed under differentiation.  Not a hot path (the networks of every shipped config use [1,2,1]): one output vector per
+// lane, K*K loads.
+#define SGX_BLUR_MAXK 7
+struct BlurTaps { float k[SGX_BLUR_MAXK * SGX_BLUR_MAXK]; };
+template <typename T>
+__global__ __launch_bounds__(256) void blur_kxk_kernel(const T* __restrict__ x, T* __restrict__ y, BlurTaps taps, int K, int pad, int B,
+                                                       int IH, int IW, int OH, int OW, int C) {
+    constexpr int VE = VecTraits<T>::VE;
+    const int cv = C / VE;
+    const size_t n = (size_t)B * OH * OW * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        size_t p = i / cv;
+        const int ox = (int)(p % OW); p /= OW;
+        const int oy = (int)(p % OH);
+        const int b = (int)(p / OH);
+        float acc[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) acc[j] = 0.f;
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = oy + ky - pad;
+            if ((unsigned)iy >= (unsigned)IH) continue;
+            for (int kx = 0; kx < K; ++kx) {
+                const int ix = ox + kx - pad;
+                if ((unsigned)ix >= (unsigned)IW) continue;
+                float v[VE];
+                VecTraits<T>::load(x + ((((size_t)b * IH + iy) * IW + ix) * cv + c) * VE, v);
+                const float w = taps.k[ky * K + kx];
+#pragma unroll
+                for (int j = 0; j < VE; ++j) acc[j] += w * v[j];
+            }
+        }
+        VecTraits<T>::store(y + i * VE, acc);
+    }
+}
+extern "C" int sgx_blur_kxk(const void* x, void* y, const float* taps_host, int K, int pad, int B, int IH, int IW, int OH, int OW, int C,
+                            int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SGX_REQUIRE(taps_host && K >= 1 && K <= SGX_BLUR_MAXK && pad >= 0 && pad < K, SGX_EINVAL, "blur_kxk: K=%d pad=%d (K <= %d)", K, pad, SGX_BLUR_MAXK);
+    SGX_REQUIRE(OH >= 1 && OW >= 1 && OH <= IH + 2 * pad - K + 1 && OW <= IW + 2 * pad - K + 1, SGX_EINVAL,
+                "blur_kxk: output %dx%d does not fit input %dx%d with K=%d pad=%d", OH, OW, IH, IW, K, pad);
+    SGX_REQUIRE(dtype == SGX_F32 ? C % 4 == 0 : (dtype == SGX_BF16 && C % 8 == 0), SGX_EUNSUPPORTED, "blur_kxk: C=%d dtype=%d", C, dtype);
+    BlurTaps t;
+    for (int i = 0; i < K * K; ++i) t.k[i] = taps_host[i];
+    SGX_NOTE(0.0, (dtype == SGX_F32 ? 4.0 : 2.0) * B * C * ((double)IH * IW + (double)OH * OW), "blur_k%d B%d %dx%d C%d", K, B, IH, IW, C);
+    if (dtype == SGX_F32)
+        hipLaunchKernelGGL(blur_kxk_kernel<float>, dim3(grid_for((size_t)B * OH * OW * C / 4)), dim3(256), 0, st, (const float*)x, (float*)y, t, K, pad, B, IH, IW, OH, OW, C);
+    else
+        hipLaunchKernelGGL(blur_kxk_kernel<bf16_t>, dim3(grid_for((size_t)B * OH * OW * C / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, t, K, pad, B, IH, IW, OH, OW, C);
+    SGX_LAUNCH_CHECK("blur_kxk");
+    return 0;
 }
 
 // ---------------------------------------------------------------- 2x2 pooling / nearest upsample.  C generic (RGB has C=3):
