@@ -61,17 +61,40 @@ def leaky_relu(x: Tensor) -> Tensor:
     return F.leaky_relu(x, LRELU_SLOPE)
 
 
+def activation(x: Tensor, kind: str = "lrelu") -> Tensor:
+    """The two nonlinearities the reference names (models/GAN.py:67-68,150-151,346-347): 'lrelu' = LeakyReLU(0.2),
+    'relu'.  (The reference maps 'relu' to the function torch.relu, which its nn.Sequential containers reject at
+    construction; at layer level an nn.ReLU module works and is what tests/golden/flags.npz records.)"""
+    return leaky_relu(x) if kind == "lrelu" else torch.relu(x)
+
+
+class Flags:
+    """The non-default layer options of the networks (models/GAN.py:105-108,303-305; config.py:60-75): LayerEpilogue
+    stages, nonlinearity, blur filter.  Defaults = the reference's defaults."""
+
+    def __init__(self, use_noise=True, use_pixel_norm=False, use_instance_norm=True, use_styles=True, act="lrelu",
+                 blur_taps=(1.0, 2.0, 1.0)):
+        self.use_noise, self.use_pixel_norm, self.use_instance_norm, self.use_styles = use_noise, use_pixel_norm, use_instance_norm, use_styles
+        self.act, self.blur_taps = act, tuple(float(t) for t in blur_taps)
+
+
+DEFAULT_FLAGS = Flags()
+
+
 def upscale2d(x: Tensor) -> Tensor:
     """Nearest-neighbour x2 replicate (models/CustomLayers.py:27-36)."""
     return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
 
 
-def blur3(x: Tensor, taps: Sequence[float] = (1.0, 2.0, 1.0)) -> Tensor:
-    """Depthwise normalised binomial blur, zero padded (models/CustomLayers.py:251-276)."""
-    k = torch.tensor(taps, dtype=x.dtype)
+def blur3(x: Tensor, taps: Sequence[float] = (1.0, 2.0, 1.0), normalize: bool = True) -> Tensor:
+    """BlurLayer: depthwise outer(f, f) [normalised] correlation, zero padded by (K-1)//2 (models/CustomLayers.py:251-276;
+    default f = [1,2,1]).  (Its ``flip`` option raises in the reference, :262, and is not restated.)"""
+    k = torch.tensor(taps, dtype=torch.float32)               # the buffer is built in fp32 whatever the module dtype (:256-260)
     k = k[:, None] * k[None, :]
-    k = (k / k.sum())[None, None].expand(x.shape[1], 1, -1, -1)
-    return F.conv2d(x, k, padding=(len(taps) - 1) // 2, groups=x.shape[1])
+    if normalize:
+        k = k / k.sum()
+    k = k.to(x.dtype)[None, None].expand(x.shape[1], 1, -1, -1)
+    return F.conv2d(x, k, padding=int((len(taps) - 1) / 2), groups=x.shape[1])
 
 
 def downscale2d(x: Tensor) -> Tensor:
@@ -101,7 +124,8 @@ def fused_down_weight(w_scaled: Tensor) -> Tensor:
 
 
 def eq_conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], gain: float = SQRT2, *,
-              up: bool = False, down: bool = False, blur_after: bool = False) -> Tensor:
+              up: bool = False, down: bool = False, blur_after: bool = False,
+              blur_taps: Sequence[float] = (1.0, 2.0, 1.0)) -> Tensor:
     """EqualizedConv2d.forward, all five paths (models/CustomLayers.py:137-180).
 
     up:   conv0_up of a GSynthesisBlock (``intermediate`` = BlurLayer when blur_after)
@@ -127,7 +151,7 @@ def eq_conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], gain: float = S
     if not have_conv:                                                         # :172-173
         x = F.conv2d(x, w, None, padding=k // 2)
     if blur_after:                                                            # :175-176
-        x = blur3(x)
+        x = blur3(x, blur_taps)
     if pool_after:
         x = downscale2d(x)
     if bias is not None:                                                      # :178-179
@@ -142,13 +166,19 @@ def instance_norm(x: Tensor, eps: float = 1e-5) -> Tensor:
     return (x - mu) * torch.rsqrt(var + eps)
 
 
-def layer_epilogue(x: Tensor, noise: Tensor, noise_weight: Tensor, style_w: Tensor, style_b: Tensor,
-                   dlatent: Tensor) -> Tensor:
-    """noise -> LeakyReLU -> InstanceNorm -> StyleMod (models/CustomLayers.py:219-248, default flags
-    of models/GAN.py:108: use_noise, use_instance_norm, use_styles; no pixel norm)."""
-    x = x + noise_weight.view(1, -1, 1, 1) * noise                            # :199
-    x = leaky_relu(x)
-    x = instance_norm(x)
+def layer_epilogue(x: Tensor, noise: Optional[Tensor], noise_weight: Optional[Tensor], style_w: Optional[Tensor],
+                   style_b: Optional[Tensor], dlatent: Optional[Tensor], flags: Flags = DEFAULT_FLAGS) -> Tensor:
+    """noise -> activation -> [pixel norm] -> [instance norm] -> [style mod] (models/CustomLayers.py:219-248; default flags
+    of models/GAN.py:108: use_noise, use_instance_norm, use_styles, no pixel norm, LeakyReLU)."""
+    if flags.use_noise:
+        x = x + noise_weight.view(1, -1, 1, 1) * noise                        # :199
+    x = activation(x, flags.act)
+    if flags.use_pixel_norm:                                                  # :230-231
+        x = pixel_norm(x)
+    if flags.use_instance_norm:                                               # :232-233
+        x = instance_norm(x)
+    if not flags.use_styles:                                                  # :237-238,:246-247
+        return x
     style = eq_linear(dlatent, style_w, style_b, gain=1.0)                    # :205-207,211
     c = x.shape[1]
     s = style.view(-1, 2, c, 1, 1)                                            # :213-214
@@ -183,23 +213,23 @@ def truncation_apply(avg: Tensor, dlat: Tensor, psi: float = 0.7, max_layer: int
 # --------------------------------------------------------------------------------------
 # networks (models/GAN.py, models/Blocks.py)
 # --------------------------------------------------------------------------------------
-def g_mapping(p: Params, z: Tensor, mapping_layers: int, prefix: str = "g_mapping.map.") -> Tensor:
+def g_mapping(p: Params, z: Tensor, mapping_layers: int, prefix: str = "g_mapping.map.", act: str = "lrelu") -> Tensor:
     """GMapping.forward without the broadcast (models/GAN.py:72-96): PixelNorm, then
     mapping_layers x (EqualizedLinear lrmul=0.01 gain=sqrt2, LeakyReLU)."""
     x = pixel_norm(z)
     for i in range(mapping_layers):
-        x = leaky_relu(eq_linear(x, p[f"{prefix}dense{i}.weight"], p[f"{prefix}dense{i}.bias"],
-                                 gain=SQRT2, lrmul=0.01))
+        x = activation(eq_linear(x, p[f"{prefix}dense{i}.weight"], p[f"{prefix}dense{i}.bias"],
+                                 gain=SQRT2, lrmul=0.01), act)
     return x
 
 
-def _epi(p: Params, pre: str, x: Tensor, noise: Tensor, dlat: Tensor) -> Tensor:
-    return layer_epilogue(x, noise, p[pre + "top_epi.noise.weight"], p[pre + "style_mod.lin.weight"],
-                          p[pre + "style_mod.lin.bias"], dlat)
+def _epi(p: Params, pre: str, x: Tensor, noise: Tensor, dlat: Tensor, flags: Flags = DEFAULT_FLAGS) -> Tensor:
+    return layer_epilogue(x, noise, p.get(pre + "top_epi.noise.weight"), p.get(pre + "style_mod.lin.weight"),
+                          p.get(pre + "style_mod.lin.bias"), dlat, flags)
 
 
 def g_synthesis(p: Params, dlatents: Tensor, depth: int, alpha: float, noises: List[Tensor],
-                prefix: str = "g_synthesis.") -> Tensor:
+                prefix: str = "g_synthesis.", flags: Flags = DEFAULT_FLAGS) -> Tensor:
     """GSynthesis.forward, structure 'linear' (models/GAN.py:175-208) with InputBlock
     (models/Blocks.py:47-60) and GSynthesisBlock (models/Blocks.py:83-88).
 
@@ -208,16 +238,16 @@ def g_synthesis(p: Params, dlatents: Tensor, depth: int, alpha: float, noises: L
     b = dlatents.shape[0]
     pre = prefix + "init_block."
     x = p[pre + "const"].expand(b, -1, -1, -1) + p[pre + "bias"].view(1, -1, 1, 1)   # Blocks.py:51-52
-    x = _epi(p, pre + "epi1.", x, noises[0], dlatents[:, 0])
+    x = _epi(p, pre + "epi1.", x, noises[0], dlatents[:, 0], flags)
     x = eq_conv2d(x, p[pre + "conv.weight"], p[pre + "conv.bias"])
-    x = _epi(p, pre + "epi2.", x, noises[1], dlatents[:, 1])
+    x = _epi(p, pre + "epi2.", x, noises[1], dlatents[:, 1], flags)
 
     def block(i: int, x: Tensor) -> Tensor:
         bp = f"{prefix}blocks.{i}."
-        x = eq_conv2d(x, p[bp + "conv0_up.weight"], p[bp + "conv0_up.bias"], up=True, blur_after=True)
-        x = _epi(p, bp + "epi1.", x, noises[2 * (i + 1)], dlatents[:, 2 * (i + 1)])
+        x = eq_conv2d(x, p[bp + "conv0_up.weight"], p[bp + "conv0_up.bias"], up=True, blur_after=True, blur_taps=flags.blur_taps)
+        x = _epi(p, bp + "epi1.", x, noises[2 * (i + 1)], dlatents[:, 2 * (i + 1)], flags)
         x = eq_conv2d(x, p[bp + "conv1.weight"], p[bp + "conv1.bias"])
-        return _epi(p, bp + "epi2.", x, noises[2 * (i + 1) + 1], dlatents[:, 2 * (i + 1) + 1])
+        return _epi(p, bp + "epi2.", x, noises[2 * (i + 1) + 1], dlatents[:, 2 * (i + 1) + 1], flags)
 
     def to_rgb(i: int, x: Tensor) -> Tensor:
         return eq_conv2d(x, p[f"{prefix}to_rgb.{i}.weight"], p[f"{prefix}to_rgb.{i}.bias"], gain=1.0)
@@ -234,24 +264,26 @@ def g_synthesis(p: Params, dlatents: Tensor, depth: int, alpha: float, noises: L
 def generator(p: Params, z: Tensor, depth: int, alpha: float, noises: List[Tensor], *,
               mapping_layers: int, num_layers: int, training: bool = True,
               latents2: Optional[Tensor] = None, mixing_cutoff: Optional[int] = None,
-              truncation_psi: float = 0.7, truncation_cutoff: int = 8, dlatent_avg_beta: float = 0.995
-              ) -> Tuple[Tensor, Optional[Tensor]]:
+              truncation_psi: float = 0.7, truncation_cutoff: int = 8, dlatent_avg_beta: float = 0.995,
+              flags: Flags = DEFAULT_FLAGS, labels: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """Generator.forward (models/GAN.py:254-297).  RNG is explicit: ``latents2`` / ``mixing_cutoff``
     are the style-mixing draws of :282 / :286-288 (None = mixing disabled).  Returns
     (images, new avg_latent or None)."""
-    dl = g_mapping(p, z, mapping_layers).unsqueeze(1).expand(-1, num_layers, -1)          # GAN.py:98-99
+    if labels is not None:                                                                 # GAN.py:264-268 (conditional)
+        z = torch.cat([z, p["class_embedding.weight"][labels]], 1)
+    dl = g_mapping(p, z, mapping_layers, act=flags.act).unsqueeze(1).expand(-1, num_layers, -1)   # GAN.py:98-99
     new_avg = None
     has_trunc = truncation_psi > 0 and "truncation.avg_latent" in p
     if training:
         if has_trunc:
             new_avg = truncation_update(p["truncation.avg_latent"], dl[0, 0].detach(), dlatent_avg_beta)  # :277-278
         if latents2 is not None:
-            dl2 = g_mapping(p, latents2, mapping_layers).unsqueeze(1).expand(-1, num_layers, -1)
+            dl2 = g_mapping(p, latents2, mapping_layers, act=flags.act).unsqueeze(1).expand(-1, num_layers, -1)
             idx = torch.arange(num_layers).view(1, -1, 1)
             dl = torch.where(idx < mixing_cutoff, dl, dl2)                                 # :289
         if has_trunc:
             dl = truncation_apply(new_avg, dl, truncation_psi, truncation_cutoff)          # :292-293
-    return g_synthesis(p, dl, depth, alpha, noises), new_avg
+    return g_synthesis(p, dl, depth, alpha, noises, flags=flags), new_avg
 
 
 def draw_mixing(z_shape, depth: int, style_mixing_prob: float = 0.9) -> Tuple[Tensor, int]:
@@ -263,8 +295,15 @@ def draw_mixing(z_shape, depth: int, style_mixing_prob: float = 0.9) -> Tuple[Te
     return latents2, cutoff
 
 
+def discriminator_block(p: Params, bp: str, x: Tensor, flags: Flags = DEFAULT_FLAGS) -> Tensor:
+    """DiscriminatorBlock (models/Blocks.py:137-146): conv0 -> act -> blur -> conv1_down -> act."""
+    x = activation(eq_conv2d(x, p[bp + "conv0.weight"], p[bp + "conv0.bias"]), flags.act)
+    x = blur3(x, flags.blur_taps)
+    return activation(eq_conv2d(x, p[bp + "conv1_down.weight"], p[bp + "conv1_down.bias"], down=True), flags.act)
+
+
 def discriminator(p: Params, img: Tensor, depth: int, alpha: float, total_depth: int,
-                  prefix: str = "") -> Tensor:
+                  prefix: str = "", flags: Flags = DEFAULT_FLAGS, labels: Optional[Tensor] = None) -> Tensor:
     """Discriminator.forward, structure 'linear' (models/GAN.py:413-442), DiscriminatorBlock
     (models/Blocks.py:137-146), DiscriminatorTop (models/Blocks.py:117-134).  ``total_depth`` is
     ``self.depth`` = log2(resolution)-1; module lists are indexed from the highest resolution."""
@@ -272,11 +311,12 @@ def discriminator(p: Params, img: Tensor, depth: int, alpha: float, total_depth:
         return eq_conv2d(x, p[f"{prefix}from_rgb.{i}.weight"], p[f"{prefix}from_rgb.{i}.bias"])
 
     def block(i: int, x: Tensor) -> Tensor:
-        bp = f"{prefix}blocks.{i}."
-        x = leaky_relu(eq_conv2d(x, p[bp + "conv0.weight"], p[bp + "conv0.bias"]))
-        x = blur3(x)
-        return leaky_relu(eq_conv2d(x, p[bp + "conv1_down.weight"], p[bp + "conv1_down.bias"], down=True))
+        return discriminator_block(p, f"{prefix}blocks.{i}.", x, flags)
 
+    if labels is not None:                                                     # conditional: GAN.py:415-421 / :431-436
+        idx = total_depth - depth - 1 if depth > 0 else total_depth - 1        # embeddings[-1] at depth 0
+        emb = p[f"{prefix}embeddings.{idx}.weight"][labels].view(img.shape[0], -1, img.shape[2], img.shape[3])
+        img = torch.cat([img, emb], dim=1)
     if depth > 0:
         residual = from_rgb(total_depth - depth, F.avg_pool2d(img, 2))         # GAN.py:423-424
         straight = block(total_depth - depth - 1, from_rgb(total_depth - depth - 1, img))  # :425-426
@@ -287,9 +327,9 @@ def discriminator(p: Params, img: Tensor, depth: int, alpha: float, total_depth:
         x = from_rgb(total_depth - 1, img)                                     # :438 (from_rgb[-1])
     fp = prefix + "final_block."
     x = minibatch_stddev(x)
-    x = leaky_relu(eq_conv2d(x, p[fp + "conv.weight"], p[fp + "conv.bias"]))
+    x = activation(eq_conv2d(x, p[fp + "conv.weight"], p[fp + "conv.bias"]), flags.act)
     x = x.reshape(x.shape[0], -1)                                              # View(-1): NCHW order
-    x = leaky_relu(eq_linear(x, p[fp + "dense0.weight"], p[fp + "dense0.bias"], gain=SQRT2))
+    x = activation(eq_linear(x, p[fp + "dense0.weight"], p[fp + "dense0.bias"], gain=SQRT2), flags.act)
     return eq_linear(x, p[fp + "dense1.weight"], p[fp + "dense1.bias"], gain=1.0)
 
 
@@ -349,7 +389,7 @@ def gan_dis_loss(kind: str, r: Tensor, f: Tensor) -> Tensor:
     """Discriminator loss heads of the non-default losses on the [B,1] predictions r = D(real), f = D(fake):
     'standard-gan' (models/Losses.py:107-126: (BCE(r,1) + BCE(f,0)) / 2 on the squeezed logits), 'hinge' (:141-148),
     'relativistic-hinge' (:159-174).  Pinned by tests/golden/losses.npz (the reference's classes on an identity D)."""
-    if kind == "standard-gan":
+    if kind in ("standard-gan", "conditional-loss"):       # ConditionalGANLoss.dis_loss (models/Losses.py:61-88): the same head
         r, f = r.squeeze(), f.squeeze()
         return (F.binary_cross_entropy_with_logits(r, torch.ones_like(r)) + F.binary_cross_entropy_with_logits(f, torch.zeros_like(f))) / 2
     if kind == "hinge":
@@ -362,7 +402,7 @@ def gan_dis_loss(kind: str, r: Tensor, f: Tensor) -> Tensor:
 def gan_gen_loss(kind: str, r: Optional[Tensor], f: Tensor) -> Tensor:
     """Generator loss heads: 'standard-gan' BCE(f,1) (the evident intent of models/Losses.py:130-134, whose tuple
     unpacking of the [B,1] output cannot execute), 'hinge' -mean(f) (:150-151), 'relativistic-hinge' (:176-189)."""
-    if kind == "standard-gan":
+    if kind in ("standard-gan", "conditional-loss"):       # ConditionalGANLoss.gen_loss (models/Losses.py:90-93)
         f = f.squeeze()
         return F.binary_cross_entropy_with_logits(f, torch.ones_like(f))
     if kind == "hinge":
@@ -416,21 +456,24 @@ def ema_update(shadow: Params, src: Params, beta: float, names: Sequence[str]) -
 
 def d_step(gp: Params, dp: Params, d_opt: AdamState, z: Tensor, real_full: Tensor, depth: int, alpha: float, *,
            total_depth: int, mapping_layers: int, noises: List[Tensor], latents2=None, mixing_cutoff=None,
-           truncation_psi: float = 0.7, loss: str = "logistic") -> Tuple[float, Dict[str, Optional[Tensor]]]:
+           truncation_psi: float = 0.7, loss: str = "logistic", flags: Flags = DEFAULT_FLAGS,
+           labels: Optional[Tensor] = None) -> Tuple[float, Dict[str, Optional[Tensor]]]:
     """StyleGAN.optimize_discriminator, d_repeats=1 (models/GAN.py:591-622).  ``loss``: 'logistic' (+R1) or one of the
     ``gan_dis_loss`` kinds."""
     real = progressive_down_sampling(real_full, depth, alpha, total_depth)
     fake, new_avg = generator(gp, z, depth, alpha, noises, mapping_layers=mapping_layers,
                               num_layers=2 * total_depth, latents2=latents2, mixing_cutoff=mixing_cutoff,
-                              truncation_psi=truncation_psi)
+                              truncation_psi=truncation_psi, flags=flags, labels=labels)
     if new_avg is not None:
         gp["truncation.avg_latent"] = new_avg.detach()
     fake = fake.detach()
     names = [k for k, v in dp.items() if v.requires_grad]
     if loss == "logistic":
+        assert flags is DEFAULT_FLAGS and labels is None
         loss = logistic_d_loss(dp, real, fake, depth, alpha, total_depth)
     else:
-        loss = gan_dis_loss(loss, discriminator(dp, real, depth, alpha, total_depth), discriminator(dp, fake, depth, alpha, total_depth))
+        loss = gan_dis_loss(loss, discriminator(dp, real, depth, alpha, total_depth, flags=flags, labels=labels),
+                            discriminator(dp, fake, depth, alpha, total_depth, flags=flags, labels=labels))
     gl = torch.autograd.grad(loss, [dp[k] for k in names], allow_unused=True)
     grads = dict(zip(names, gl))
     d_opt.step(dp, grads)
@@ -440,22 +483,24 @@ def d_step(gp: Params, dp: Params, d_opt: AdamState, z: Tensor, real_full: Tenso
 def g_step(gp: Params, dp: Params, g_opt: AdamState, z: Tensor, depth: int, alpha: float, *,
            total_depth: int, mapping_layers: int, noises: List[Tensor], latents2=None, mixing_cutoff=None,
            truncation_psi: float = 0.7, shadow: Optional[Params] = None, ema_decay: float = 0.999,
-           loss: str = "logistic", real_full: Optional[Tensor] = None) -> Tuple[float, Dict[str, Optional[Tensor]]]:
+           loss: str = "logistic", real_full: Optional[Tensor] = None, flags: Flags = DEFAULT_FLAGS,
+           labels: Optional[Tensor] = None) -> Tuple[float, Dict[str, Optional[Tensor]]]:
     """StyleGAN.optimize_generator (models/GAN.py:624-659) incl. grad clip and EMA.  ``real_full`` is read by the
     relativistic loss only (:635-641: the real batch at the current depth)."""
     fake, new_avg = generator(gp, z, depth, alpha, noises, mapping_layers=mapping_layers,
                               num_layers=2 * total_depth, latents2=latents2, mixing_cutoff=mixing_cutoff,
-                              truncation_psi=truncation_psi)
+                              truncation_psi=truncation_psi, flags=flags, labels=labels)
     if new_avg is not None:
         gp["truncation.avg_latent"] = new_avg.detach()
     names = [k for k, v in gp.items() if v.requires_grad]
     if loss == "logistic":
+        assert flags is DEFAULT_FLAGS and labels is None
         loss = logistic_g_loss(dp, fake, depth, alpha, total_depth)
     else:
         r = None
         if loss == "relativistic-hinge":
-            r = discriminator(dp, progressive_down_sampling(real_full, depth, alpha, total_depth), depth, alpha, total_depth)
-        loss = gan_gen_loss(loss, r, discriminator(dp, fake, depth, alpha, total_depth))
+            r = discriminator(dp, progressive_down_sampling(real_full, depth, alpha, total_depth), depth, alpha, total_depth, flags=flags)
+        loss = gan_gen_loss(loss, r, discriminator(dp, fake, depth, alpha, total_depth, flags=flags, labels=labels))
     gl = torch.autograd.grad(loss, [gp[k] for k in names], allow_unused=True)
     grads = {k: (None if g is None else g.clone()) for k, g in zip(names, gl)}
     clip_grad_norm(grads, 10.0)

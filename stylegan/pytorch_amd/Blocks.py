@@ -7,12 +7,8 @@ import torch
 import torch.nn as nn
 
 from . import functional as F
-from .CustomLayers import (BlurLayer, EqualizedConv2d, EqualizedLinear, LayerEpilogue, StddevLayer, View)
+from .CustomLayers import (BlurLayer, EqualizedConv2d, EqualizedLinear, LayerEpilogue, StddevLayer, View, act_code, apply_act)
 from .native import ACT_LRELU, ACT_NONE
-
-
-def _is_lrelu02(act):
-    return isinstance(act, nn.LeakyReLU) and abs(act.negative_slope - 0.2) < 1e-12
 
 
 def _lat(d, k):
@@ -105,15 +101,17 @@ class DiscriminatorTop(nn.Module):
         self.act1 = activation_layer
         self.dense1 = EqualizedLinear(intermediate_channels, output_features, gain=last_gain, use_wscale=use_wscale)
         self.resolution = resolution
-        assert _is_lrelu02(activation_layer), "the kernels fuse LeakyReLU(0.2)"
+        self._act = act_code(activation_layer)        # LeakyReLU(0.2) rides in the kernels' stores; ReLU runs as its own pass
 
     def forward_nhwc(self, x):
+        fused = ACT_LRELU if self._act == ACT_LRELU else ACT_NONE
+        post = ACT_NONE if fused else self._act
         if self.stddev_layer is not None:
             x = self.stddev_layer.forward_nhwc(x)
-        x = self.conv.forward_nhwc(x, act=ACT_LRELU)                      # [B,4,4,C]
+        x = apply_act(self.conv.forward_nhwc(x, act=fused), post)        # [B,4,4,C]
         b = x.shape[0]
         flat = x.permute(0, 3, 1, 2).reshape(b, -1).float()               # View(-1) flattens NCHW (index c*16+h*4+w)
-        y = self.dense0(flat, act=ACT_LRELU)
+        y = apply_act(self.dense0(flat, act=fused), post)
         return self.dense1(y)
 
     def forward(self, x):
@@ -131,15 +129,17 @@ class DiscriminatorBlock(nn.Module):
         self.conv1_down = EqualizedConv2d(in_channels, out_channels, kernel_size=3, gain=gain, use_wscale=use_wscale,
                                           downscale=True)
         self.act1 = activation_layer
-        assert _is_lrelu02(activation_layer), "the kernels fuse LeakyReLU(0.2)"
+        self._act = act_code(activation_layer)
 
     def forward_nhwc(self, x):
         z = self.conv0.forward_nhwc(x, act=ACT_NONE)                      # bias fused in the conv store; pre-activation
-        if self.blur._is_121:
+        if self.blur._is_121 and self._act == ACT_LRELU:
             x = F.call(F.ActBlurFn, z)                                      # LeakyReLU folded into the blur pass (both ways)
-        else:
-            x = self.blur.forward_nhwc(F.call(F.BiasActFn, z, None, 1.0, ACT_LRELU))
-        return self.conv1_down.forward_nhwc(x, act=ACT_LRELU)
+        else:                                                               # ReLU / another blur filter: stage by stage
+            x = self.blur.forward_nhwc(apply_act(z, self._act))
+        if self._act == ACT_LRELU:
+            return self.conv1_down.forward_nhwc(x, act=ACT_LRELU)
+        return apply_act(self.conv1_down.forward_nhwc(x, act=ACT_NONE), self._act)
 
     def forward(self, x):
         return F.nchw_view(self.forward_nhwc(F.nhwc(x)))

@@ -11,9 +11,24 @@ import torch
 import torch.nn as nn
 
 from . import functional as F
-from .native import ACT_LRELU, ACT_NONE
+from .native import ACT_LRELU, ACT_NONE, ACT_RELU, EPI_ACT, EPI_NORM
 
 MBSTD_CPAD = 32          # the stddev channel is appended in a zero-padded group of 32 channels (MFMA K granularity)
+
+
+def act_code(activation_layer):
+    """ACT_LRELU / ACT_RELU for the two nonlinearities the reference offers (models/GAN.py:67-68,150-151,346-347:
+    ``nn.LeakyReLU(negative_slope=0.2)`` | ``torch.relu``)."""
+    if isinstance(activation_layer, nn.LeakyReLU) and abs(activation_layer.negative_slope - 0.2) < 1e-12:
+        return ACT_LRELU
+    if activation_layer is torch.relu or isinstance(activation_layer, nn.ReLU):
+        return ACT_RELU
+    raise NotImplementedError(f"activation {activation_layer!r}: the reference offers 'lrelu' (0.2) and 'relu'")
+
+
+def apply_act(x, act):
+    """Standalone activation of an NHWC tensor (the un-fused path: ReLU networks, non-default layer stacks)."""
+    return F.call(F.BiasActFn, x, None, 1.0, act) if act else x
 
 
 class PixelNormLayer(nn.Module):
@@ -74,13 +89,27 @@ class BlurLayer(nn.Module):
         self._is_121 = (list(kernel) == [1, 2, 1]) and normalize and stride == 1
         self._is_box2 = (len(kernel) == 2 and stride == 2 and abs(float(k.sum()) - 1.0) < 1e-6
                          and float((k - k.mean()).abs().max()) < 1e-7)
+        self._taps = None                        # (buffer version, K, taps tuple): host copy of ``kernel`` for the generic path
+
+    def _host_taps(self):
+        ver = self.kernel._version
+        if self._taps is None or self._taps[0] != ver:
+            k = self.kernel.detach().float().cpu()
+            self._taps = (ver, int(k.shape[2]), tuple(float(v) for v in k.reshape(-1)))
+        return self._taps[1], self._taps[2]
 
     def forward_nhwc(self, x):
         if self._is_121:
             return F.call(F.BlurFn, x)
         if self._is_box2:
             return F.call(F.Pool2Fn, x, 0.25)
-        raise NotImplementedError("BlurLayer: only the [1,2,1] blur and the 2x2 box (Downscale2d) are built")
+        if self.stride != 1:
+            raise NotImplementedError("BlurLayer: stride 2 is built for the 2x2 box of Downscale2d only")
+        K, taps = self._host_taps()                                    # any other filter: generic K x K kernel (:266-275)
+        if K > 7:
+            raise NotImplementedError("BlurLayer: filters longer than 7 taps are not built")
+        pad = int((K - 1) / 2)
+        return F.call(F.BlurGenFn, x, taps, K, pad, x.shape[1] + 2 * pad - K + 1, x.shape[2] + 2 * pad - K + 1)
 
     def forward(self, x):
         return F.nchw_view(self.forward_nhwc(F.nhwc(x)))
@@ -191,6 +220,14 @@ class EqualizedConv2d(nn.Module):
             assert self.upscale is None and self.downscale is None and self.intermediate is None
             if cin == 3 and x.shape[3] == 3:
                 y = F.call(F.RgbInFn, x.float(), self.weight, bias, self.w_mul, out_dtype or torch.float32)
+            elif cin % 3 == 0 and cin > 3 and x.shape[3] == cin and cout != 3:
+                # conditional discriminator (reference models/GAN.py:326-330,415-421): from_rgb over [image, label
+                # embedding] = the sum of the 3-channel kernels over the channel groups (the weight slices are tiny)
+                y = None
+                for k in range(0, cin, 3):
+                    part = F.call(F.RgbInFn, x[..., k:k + 3].float().contiguous(), self.weight[:, k:k + 3].contiguous(),
+                                  bias if k == 0 else None, self.w_mul, out_dtype or torch.float32)
+                    y = part if y is None else F.call(F.AxpbyFn, y, part, 1.0, 1.0)
             elif cout == 3:
                 y = F.call(F.RgbOutFn, x, self.weight, bias, self.w_mul)
             else:
@@ -279,20 +316,41 @@ class LayerEpilogue(nn.Module):
             layers.append(('instance_norm', nn.InstanceNorm2d(channels)))
         self.top_epi = nn.Sequential(OrderedDict(layers))
         self.style_mod = StyleMod(dlatent_size, channels, use_wscale=use_wscale) if use_styles else None
-        self._fusable = use_noise and use_instance_norm and use_styles and not use_pixel_norm \
-            and isinstance(activation_layer, nn.LeakyReLU) and abs(activation_layer.negative_slope - 0.2) < 1e-12
+        self._act = act_code(activation_layer)
+        self._use = (bool(use_noise), bool(use_pixel_norm), bool(use_instance_norm), bool(use_styles))
+        # the reference's default stack (models/GAN.py:108): one fused op; every other combination runs the same kernels
+        # stage by stage (forward_nhwc below)
+        self._fusable = use_noise and use_instance_norm and use_styles and not use_pixel_norm and self._act == ACT_LRELU
+
+    def _style(self, dlatents_in_slice):
+        if isinstance(dlatents_in_slice, F.PreStyle):                   # computed with all the other layers' in one launch
+            return dlatents_in_slice.style
+        return self.style_mod.style(dlatents_in_slice)
 
     def forward_nhwc(self, x, dlatents_in_slice, conv_bias=None):
-        if not self._fusable:
-            raise NotImplementedError("LayerEpilogue: the fused kernel implements the reference's default flags "
-                                      "(noise + LeakyReLU(0.2) + instance norm + styles, no pixel norm)")
-        noise_layer = self.top_epi.noise
-        noise = noise_layer.sample(x.shape, x.device)
-        if isinstance(dlatents_in_slice, F.PreStyle):                   # computed with all the other layers' in one launch
-            style = dlatents_in_slice.style
-        else:
-            style = self.style_mod.style(dlatents_in_slice)
-        return F.call(F.GEpilogueFn, x, conv_bias, noise, noise_layer.weight, style)
+        use_noise, use_pixel_norm, use_instance_norm, use_styles = self._use
+        noise = nw = None
+        if use_noise:
+            noise_layer = self.top_epi.noise
+            noise, nw = noise_layer.sample(x.shape, x.device), noise_layer.weight
+        style = self._style(dlatents_in_slice) if use_styles else None
+        if self._fusable:
+            return F.call(F.GEpilogueFn, x, conv_bias, noise, nw, style)
+        # Non-default stacks (reference :224-246: noise -> activation -> [pixel norm] -> [instance norm] -> [style]), on the
+        # same kernels: the fused op with its stages switched by flags, split in two around a ReLU / a pixel norm.
+        lrelu = self._act == ACT_LRELU
+        norm = EPI_NORM if use_instance_norm else 0
+        if lrelu and not use_pixel_norm:
+            return F.call(F.GEpilogueFn, x, conv_bias, noise, nw, style, EPI_ACT | norm)
+        x = F.call(F.GEpilogueFn, x, conv_bias, noise, nw, None, EPI_ACT if lrelu else 0)      # x + bias + noise [-> lrelu]
+        if not lrelu:
+            x = apply_act(x, self._act)
+        if use_pixel_norm:
+            shape, dt = x.shape, x.dtype
+            x = F.call(F.PixelNormFn, x.reshape(-1, shape[3])).reshape(shape).to(dt)          # over channels, per pixel (:22-23)
+        if norm or style is not None:
+            x = F.call(F.GEpilogueFn, x, None, None, None, style, norm)
+        return x
 
     def forward(self, x, dlatents_in_slice=None):
         return F.nchw_view(self.forward_nhwc(F.nhwc(x), dlatents_in_slice))

@@ -21,7 +21,7 @@ import torch.nn as nn
 from . import Losses
 from . import functional as F
 from .Blocks import DiscriminatorBlock, DiscriminatorTop, GSynthesisBlock, InputBlock
-from .CustomLayers import EqualizedConv2d, EqualizedLinear, PixelNormLayer, Truncation
+from .CustomLayers import EqualizedConv2d, EqualizedLinear, PixelNormLayer, Truncation, act_code, apply_act
 from .data import get_data_loader
 from . import native
 from .native import ACT_LRELU
@@ -73,6 +73,14 @@ class DeferredLoss:
     def __hash__(self): return hash(self.item())
 
 
+def _nonlinearity(name):
+    """(activation module, gain) of the reference's ``nonlinearity`` argument (models/GAN.py:67-68,150-151,346-347).  The
+    reference maps 'relu' to the FUNCTION ``torch.relu`` and then puts it into ``nn.Sequential`` / module attributes, which
+    raises TypeError at construction (both networks; checked against the reference) -- the evident intent, a ReLU module,
+    is what is built here."""
+    return {'relu': (nn.ReLU(), np.sqrt(2)), 'lrelu': (nn.LeakyReLU(negative_slope=0.2), np.sqrt(2))}[name]
+
+
 def _conv_weights(module):
     """The 3x3 convolution parameters of a network (cached list; the module tree is static)."""
     ws = module.__dict__.get("_sgx_conv_weights")
@@ -98,8 +106,8 @@ class GMapping(nn.Module):
         self.mapping_fmaps = mapping_fmaps
         self.dlatent_size = dlatent_size
         self.dlatent_broadcast = dlatent_broadcast
-        assert mapping_nonlinearity == 'lrelu', "the kernels fuse LeakyReLU(0.2)"
-        act, gain = nn.LeakyReLU(negative_slope=0.2), np.sqrt(2)
+        act, gain = _nonlinearity(mapping_nonlinearity)
+        self._act = act_code(act)
         layers = []
         if normalize_latents:
             layers.append(('pixel_norm', PixelNormLayer()))
@@ -123,7 +131,11 @@ class GMapping(nn.Module):
         if hasattr(self.map, 'pixel_norm'):
             x = self.map.pixel_norm(x)
         for i in range(self.mapping_layers):
-            x = getattr(self.map, 'dense{:d}'.format(i))(x, act=ACT_LRELU)   # bias + LeakyReLU fused after the GEMM
+            dense = getattr(self.map, 'dense{:d}'.format(i))
+            if self._act == ACT_LRELU:
+                x = dense(x, act=ACT_LRELU)                                  # bias + LeakyReLU fused after the GEMM
+            else:
+                x = apply_act(dense(x), self._act)
         if self.dlatent_broadcast is not None:
             x = x.unsqueeze(1).expand(-1, self.dlatent_broadcast, -1)
         return x
@@ -148,8 +160,7 @@ class GSynthesis(nn.Module):
         self.num_layers = resolution_log2 * 2 - 2
         self.num_styles = self.num_layers if use_styles else 1
         self.act_dtype = act_dtype
-        assert nonlinearity == 'lrelu', "the kernels fuse LeakyReLU(0.2)"
-        act, gain = nn.LeakyReLU(negative_slope=0.2), np.sqrt(2)
+        act, gain = _nonlinearity(nonlinearity)
 
         self.init_block = InputBlock(nf(1), dlatent_size, const_input_layer, gain, use_wscale, use_noise, use_pixel_norm,
                                      use_instance_norm, use_styles, act)
@@ -299,8 +310,10 @@ class Discriminator(nn.Module):
                  blur_filter=None, structure='linear', act_dtype=torch.float32, **kwargs):
         super().__init__()
         if conditional:
-            raise NotImplementedError("conditional discriminator (label embeddings as image channels) is outside the "
-                                      "accelerated path")
+            # reference :326-330: the label embedding joins the image as num_channels extra channels of the from_rgb input
+            assert n_classes > 0, "Conditional Discriminator requires n_class > 0"
+            num_channels *= 2
+        embeddings = []
 
         def nf(stage):
             return min(int(fmap_base / (2.0 ** (stage * fmap_decay))), fmap_max)
@@ -313,14 +326,19 @@ class Discriminator(nn.Module):
         resolution_log2 = int(np.log2(resolution))
         assert resolution == 2 ** resolution_log2 and resolution >= 4
         self.depth = resolution_log2 - 1
-        assert nonlinearity == 'lrelu', "the kernels fuse LeakyReLU(0.2)"
-        act, gain = nn.LeakyReLU(negative_slope=0.2), np.sqrt(2)
+        act, gain = _nonlinearity(nonlinearity)
 
         blocks, from_rgb = [], []
         for res in range(resolution_log2, 2, -1):
             blocks.append(DiscriminatorBlock(nf(res - 1), nf(res - 2), gain=gain, use_wscale=use_wscale,
                                              activation_layer=act, blur_kernel=blur_filter))
             from_rgb.append(EqualizedConv2d(num_channels, nf(res - 1), kernel_size=1, gain=gain, use_wscale=use_wscale))
+            if conditional:                                                 # :360-363
+                r = 2 ** res
+                embeddings.append(nn.Embedding(n_classes, (num_channels // 2) * r * r))
+        if conditional:                                                     # :365-368
+            embeddings.append(nn.Embedding(n_classes, (num_channels // 2) * 4 * 4))
+            self.embeddings = nn.ModuleList(embeddings)
         self.blocks = nn.ModuleList(blocks)
         self.final_block = DiscriminatorTop(self.mbstd_group_size, self.mbstd_num_features, in_channels=nf(2),
                                             intermediate_channels=nf(2), gain=gain, use_wscale=use_wscale,
@@ -334,6 +352,13 @@ class Discriminator(nn.Module):
         F.prepack(_conv_weights(self))                                      # all stale MFMA operand packs: one launch
         img = F.nhwc(images_in, torch.float32)                              # [B,R,R,3] fp32
         dt = self.act_dtype
+        if self.conditional:
+            # :395-400,:415-421,:431-436: embedding [B, 3*R*R] viewed as [B,3,R,R], concatenated to the image channels
+            assert labels_in is not None, "Conditional Discriminator requires labels"
+            idx = 0 if self.structure == 'fixed' else (self.depth - depth - 1 if depth > 0 else -1)
+            b, r1, r2, _ = img.shape
+            emb = self.embeddings[idx](labels_in).float().view(b, -1, r1, r2).permute(0, 2, 3, 1)
+            img = torch.cat([img, emb], dim=3).contiguous()
         if self.structure == 'fixed':
             x = self.from_rgb[0].forward_nhwc(img, out_dtype=dt)
             for block in self.blocks:
@@ -406,7 +431,10 @@ class StyleGAN:
     def __setup_loss(self, loss):
         if isinstance(loss, str):
             loss = loss.lower()
-            assert not self.conditional, "conditional losses are outside the accelerated path"
+            if self.conditional:                                            # reference :548-551
+                assert loss in ["conditional-loss"]
+                assert self.dp is None, "data parallel is wired for the logistic loss"
+                return Losses.ConditionalGANLoss(self.dis)
             assert loss in ["logistic", "hinge", "standard-gan", "relativistic-hinge"], "Unknown loss function"
             mean_scale = 1.0 / self.dp.world_size if self.dp is not None else 1.0
             if loss == "logistic":
@@ -512,6 +540,8 @@ class StyleGAN:
                 f_preds.record_stream(cur)
                 return f_preds
             loss = self.loss.dis_loss(real_samples, None, depth, alpha, fake_logits=fake_logits)
+        elif self.conditional:                                              # reference :611-613
+            loss = self.loss.dis_loss(real_samples, make_fakes(), labels, depth, alpha)
         else:
             loss = self.loss.dis_loss(real_samples, make_fakes if lazy else make_fakes(), depth, alpha)
         self.dis_optim.zero_grad()
@@ -532,7 +562,7 @@ class StyleGAN:
 
     def _g_grads(self, noise, real_batch, depth, alpha, labels=None):
         real_samples = None
-        if not isinstance(self.loss, (Losses.LogisticGAN, Losses.HingeGAN, Losses.StandardGAN)):
+        if not isinstance(self.loss, (Losses.LogisticGAN, Losses.HingeGAN, Losses.StandardGAN, Losses.ConditionalGANLoss)):
             real_samples = self.progressive_down_sampling(real_batch, depth, alpha)   # only the relativistic loss reads it
         self._wait_update("g")
         fake_samples = self.gen(noise, depth, alpha, labels)
@@ -547,7 +577,10 @@ class StyleGAN:
         for p in d_params:
             p.requires_grad_(False)
         try:
-            loss = self.loss.gen_loss(real_samples, fake_samples, depth, alpha)
+            if self.conditional:                                            # reference :644-646
+                loss = self.loss.gen_loss(real_samples, fake_samples, labels, depth, alpha)
+            else:
+                loss = self.loss.gen_loss(real_samples, fake_samples, depth, alpha)
             self.gen_optim.zero_grad()
             side = self._param_stream()
             with F.accumulate_param_grads(), F.param_grad_stream(side):

@@ -23,6 +23,25 @@ class GANLoss:
         raise NotImplementedError("gen_loss method has not been implemented")
 
 
+class ConditionalGANLoss:
+    """Binary cross entropy on the logits of the label-conditioned discriminator -- reference models/Losses.py:54-93
+    (``dis(samples, height, alpha, labels_in=labels)``)."""
+
+    def __init__(self, dis):
+        self.dis = dis
+
+    def dis_loss(self, real_samps, fake_samps, labels, height, alpha):
+        r_preds = torch.squeeze(self.dis(real_samps, height, alpha, labels_in=labels))
+        f_preds = torch.squeeze(self.dis(fake_samps, height, alpha, labels_in=labels))
+        real_loss = TF.binary_cross_entropy_with_logits(r_preds, torch.ones_like(r_preds))
+        fake_loss = TF.binary_cross_entropy_with_logits(f_preds, torch.zeros_like(f_preds))
+        return (real_loss + fake_loss) / 2
+
+    def gen_loss(self, _, fake_samps, labels, height, alpha):
+        preds = torch.squeeze(self.dis(fake_samps, height, alpha, labels_in=labels))
+        return TF.binary_cross_entropy_with_logits(preds, torch.ones_like(preds))
+
+
 class StandardGAN(GANLoss):
     """Binary cross entropy on the logits -- reference models/Losses.py:96-134: ``(BCE(r, 1) + BCE(f, 0)) / 2`` for the
     discriminator, ``BCE(f, 1)`` for the generator.  The reference's ``gen_loss`` unpacks the discriminator's [B,1] output

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
                                                  const float* __restrict__ nw, const float* __restrict__ style,
                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                  const float* __restrict__ coef, double* __restrict__ part, int HW, int C,
-                                                 int cvt, int rows, int chunk) {
+                                                 int cvt, int rows, int chunk, int act) {
     constexpr int VE = VecTraits<T>::VE;
     extern __shared__ double sh[];                                 // [256][2*VE]
     const int b = blockIdx.y, ch = blockIdx.x;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
                 if (MODE == 0) {
 #pragma unroll
                     for (int j = 0; j < VE; ++j) {
-                        const float a = lrelu(xv[j] + kb[j] + kw[j] * nz);
+                        const float a = act_apply(xv[j] + kb[j] + kw[j] * nz, act);
                         s0[j] += a; s1[j] += a * a;
                     }
                 } else {
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
                     if (MODE == 1) {
 #pragma unroll
                         for (int j = 0; j < VE; ++j) {
-                            const float xh = (lrelu(xv[j] + kb[j] + kw[j] * nz) - km[j]) * kr[j];
+                            const float xh = (act_apply(xv[j] + kb[j] + kw[j] * nz, act) - km[j]) * kr[j];
                             s0[j] += gv[j]; s1[j] += gv[j] * xh;
                         }
                     } else {
@@ -111,9 +111,9 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
 #pragma unroll
                         for (int j = 0; j < VE; ++j) {
                             const float pp = xv[j] + kb[j] + kw[j] * nz;
-                            const float xh = (lrelu(pp) - km[j]) * kr[j];
+                            const float xh = (act_apply(pp, act) - km[j]) * kr[j];
                             const float da = kr[j] * (gv[j] * ks[j] - k1[j] - xh * k2[j]);
-                            const float dp = da * lrelu_slope(pp);
+                            const float dp = act ? da * lrelu_slope(pp) : da;
                             ov[j] = dp;
                             s0[j] += dp * nz; s1[j] += dp;
                         }
@@ -143,9 +143,13 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
 
 // forward finalize: mean / rstd per (b,c); 16 lanes per output
 __global__ void gepi_fin_stats(const double* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd, int B, int C,
-                               int nchunk, int HW) {
+                               int nchunk, int HW, int norm) {
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
     const bool ok = i < B * C;
+    if (!norm) {                                                   // no instance norm: xh = a
+        if (ok && !l) { mean[i] = 0.f; rstd[i] = 1.f; }
+        return;
+    }
     const int b = ok ? i / C : 0, c = ok ? i % C : 0;
     double s = 0.0, ss = 0.0;
     if (ok)
@@ -164,7 +168,7 @@ __global__ void gepi_fin_stats(const double* __restrict__ part, float* __restric
 
 // backward finalize 1: dstyle and the two per-(b,c) coefficients of the apply pass
 __global__ void gepi_fin_bwd1(const double* __restrict__ part, const float* __restrict__ style, float* __restrict__ dstyle,
-                              float* __restrict__ coef, int B, int C, int nchunk, int HW) {
+                              float* __restrict__ coef, int B, int C, int nchunk, int HW, int norm) {
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
     const bool ok = i < B * C;
     const int b = ok ? i / C : 0, c = ok ? i % C : 0;
@@ -179,8 +183,8 @@ __global__ void gepi_fin_bwd1(const double* __restrict__ part, const float* __re
     dstyle[(size_t)b * 2 * C + c] = (float)s0;              // d/d style[:,0] = sum dy*xh
     dstyle[(size_t)b * 2 * C + C + c] = (float)s1;          // d/d style[:,1] = sum dy
     const double sc = (double)style[(size_t)b * 2 * C + c] + 1.0;
-    coef[(size_t)i * 2] = (float)(sc * s1 / HW);
-    coef[(size_t)i * 2 + 1] = (float)(sc * s0 / HW);
+    coef[(size_t)i * 2] = norm ? (float)(sc * s1 / HW) : 0.f;      // the statistics' own gradient terms (instance norm only)
+    coef[(size_t)i * 2 + 1] = norm ? (float)(sc * s0 / HW) : 0.f;
 }
 
 // backward finalize 2: d noise-weight and d bias per channel (sum over images and chunks); 16 lanes per channel
@@ -206,7 +210,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gepi_apply(const T* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ noise,
                                                   const float* __restrict__ nw, const float* __restrict__ style,
                                                   const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ y,
-                                                  int HW, int C, int cvt, int rows, int chunk) {
+                                                  int HW, int C, int cvt, int rows, int chunk, int act) {
     constexpr int VE = VecTraits<T>::VE;
     const int b = blockIdx.y, ch = blockIdx.x;
     const int tc = threadIdx.x % cvt, tr = threadIdx.x / cvt;
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256) void gepi_apply(const T* __restrict__ x, const
             VecTraits<T>::load(x + off, xv);
 #pragma unroll
             for (int j = 0; j < VE; ++j) {
-                const float a = lrelu(xv[j] + kb[j] + kw[j] * nz);
+                const float a = act_apply(xv[j] + kb[j] + kw[j] * nz, act);
                 const float xh = (a - km[j]) * kr[j];
                 xv[j] = xh * ks[j] + k1[j];
             }
@@ -245,21 +249,24 @@ __global__ __launch_bounds__(256) void gepi_apply(const T* __restrict__ x, const
 
 template <typename T>
 static int gepi_fwd_t(const void* x, const float* bias, const float* noise, const float* nw, const float* style, void* y,
-                      float* mean, float* rstd, void* ws, int B, int HW, int C, hipStream_t st) {
+                      float* mean, float* rstd, void* ws, int B, int HW, int C, int flags, hipStream_t st) {
+    const int act = (flags & SGX_EPI_ACT) ? SGX_ACT_LRELU : SGX_ACT_NONE, norm = (flags & SGX_EPI_NORM) ? 1 : 0;
     constexpr int VE = VecTraits<T>::VE;
     GepiGeom g = gepi_geom(B, HW, C, VE);
     double* part = static_cast<double*>(ws);
     const double nb = (double)sizeof(T) * B * HW * C;
-    SGX_NOTE(0.0, nb, "gepi_stats B%d HW%d C%d", B, HW, C);
-    hipLaunchKernelGGL((gepi_pass<T, 0>), dim3(g.nchunk, B), dim3(256), 256 * 2 * VE * sizeof(double), st, (const T*)x,
-                       (const T*)nullptr, (T*)nullptr, bias, noise, nw, style, mean, rstd, (const float*)nullptr, part, HW, C,
-                       g.cvt, g.rows, g.chunk);
-    SGX_LAUNCH_CHECK("gepi_stats");
-    hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 15) / 16), dim3(256), 0, st, part, mean, rstd, B, C, g.nchunk, HW);
+    if (norm) {
+        SGX_NOTE(0.0, nb, "gepi_stats B%d HW%d C%d", B, HW, C);
+        hipLaunchKernelGGL((gepi_pass<T, 0>), dim3(g.nchunk, B), dim3(256), 256 * 2 * VE * sizeof(double), st, (const T*)x,
+                           (const T*)nullptr, (T*)nullptr, bias, noise, nw, style, mean, rstd, (const float*)nullptr, part, HW, C,
+                           g.cvt, g.rows, g.chunk, act);
+        SGX_LAUNCH_CHECK("gepi_stats");
+    }
+    hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 15) / 16), dim3(256), 0, st, part, mean, rstd, B, C, g.nchunk, HW, norm);
     SGX_LAUNCH_CHECK("gepi_fin_stats");
     SGX_NOTE(0.0, 2.0 * nb, "gepi_apply B%d HW%d C%d", B, HW, C);
     hipLaunchKernelGGL(gepi_apply<T>, dim3(g.nchunk, B), dim3(256), 0, st, (const T*)x, bias, noise, nw, style, mean, rstd,
-                       (T*)y, HW, C, g.cvt, g.rows, g.chunk);
+                       (T*)y, HW, C, g.cvt, g.rows, g.chunk, act);
     SGX_LAUNCH_CHECK("gepi_apply");
     return 0;
 }
@@ -267,8 +274,9 @@ static int gepi_fwd_t(const void* x, const float* bias, const float* noise, cons
 template <typename T>
 static int gepi_bwd_t(const void* dy, const void* x, const float* bias, const float* noise, const float* nw,
                       const float* style, const float* mean, const float* rstd, void* dx, float* dstyle, float* dnw,
-                      float* dbias, void* ws, int B, int HW, int C, hipStream_t st) {
+                      float* dbias, void* ws, int B, int HW, int C, int flags, hipStream_t st) {
     constexpr int VE = VecTraits<T>::VE;
+    const int act = (flags & SGX_EPI_ACT) ? SGX_ACT_LRELU : SGX_ACT_NONE, norm = (flags & SGX_EPI_NORM) ? 1 : 0;
     GepiGeom g = gepi_geom(B, HW, C, VE);
     double* partA = static_cast<double*>(ws);
     double* partB = partA + (size_t)B * g.nchunk * C * 2;
@@ -277,13 +285,13 @@ static int gepi_bwd_t(const void* dy, const void* x, const float* bias, const fl
     const double nb = (double)sizeof(T) * B * HW * C;
     SGX_NOTE(0.0, 2.0 * nb, "gepi_bwd1 B%d HW%d C%d", B, HW, C);
     hipLaunchKernelGGL((gepi_pass<T, 1>), dim3(g.nchunk, B), dim3(256), shb, st, (const T*)x, (const T*)dy, (T*)nullptr, bias,
-                       noise, nw, style, mean, rstd, (const float*)nullptr, partA, HW, C, g.cvt, g.rows, g.chunk);
+                       noise, nw, style, mean, rstd, (const float*)nullptr, partA, HW, C, g.cvt, g.rows, g.chunk, act);
     SGX_LAUNCH_CHECK("gepi_bwd1");
-    hipLaunchKernelGGL(gepi_fin_bwd1, dim3((B * C + 15) / 16), dim3(256), 0, st, partA, style, dstyle, coef, B, C, g.nchunk, HW);
+    hipLaunchKernelGGL(gepi_fin_bwd1, dim3((B * C + 15) / 16), dim3(256), 0, st, partA, style, dstyle, coef, B, C, g.nchunk, HW, norm);
     SGX_LAUNCH_CHECK("gepi_fin_bwd1");
     SGX_NOTE(0.0, 3.0 * nb, "gepi_bwd2 B%d HW%d C%d", B, HW, C);
     hipLaunchKernelGGL((gepi_pass<T, 2>), dim3(g.nchunk, B), dim3(256), shb, st, (const T*)x, (const T*)dy, (T*)dx, bias, noise,
-                       nw, style, mean, rstd, (const float*)coef, partB, HW, C, g.cvt, g.rows, g.chunk);
+                       nw, style, mean, rstd, (const float*)coef, partB, HW, C, g.cvt, g.rows, g.chunk, act);
     SGX_LAUNCH_CHECK("gepi_bwd2");
     hipLaunchKernelGGL(gepi_fin_bwd2, dim3((C + 15) / 16), dim3(256), 0, st, partB, dnw, dbias, B, C, g.nchunk);
     SGX_LAUNCH_CHECK("gepi_fin_bwd2");
@@ -302,19 +310,20 @@ static int gepi_check(int B, int HW, int C, int dtype, size_t ws_bytes) {
 }
 
 extern "C" int sgx_gepi_fwd(const void* x, const float* bias, const float* noise, const float* nw, const float* style, void* y,
-                            float* mean, float* rstd, void* ws, size_t ws_bytes, int B, int HW, int C, int dtype, void* stream) {
+                            float* mean, float* rstd, void* ws, size_t ws_bytes, int B, int HW, int C, int flags, int dtype,
+                            void* stream) {
     int rc = gepi_check(B, HW, C, dtype, ws_bytes);
     if (rc) return rc;
-    if (dtype == SGX_F32) return gepi_fwd_t<float>(x, bias, noise, nw, style, y, mean, rstd, ws, B, HW, C, (hipStream_t)stream);
-    return gepi_fwd_t<bf16_t>(x, bias, noise, nw, style, y, mean, rstd, ws, B, HW, C, (hipStream_t)stream);
+    if (dtype == SGX_F32) return gepi_fwd_t<float>(x, bias, noise, nw, style, y, mean, rstd, ws, B, HW, C, flags, (hipStream_t)stream);
+    return gepi_fwd_t<bf16_t>(x, bias, noise, nw, style, y, mean, rstd, ws, B, HW, C, flags, (hipStream_t)stream);
 }
 
 extern "C" int sgx_gepi_bwd(const void* dy, const void* x, const float* bias, const float* noise, const float* nw,
                             const float* style, const float* mean, const float* rstd, void* dx, float* dstyle, float* dnw,
-                            float* dbias, void* ws, size_t ws_bytes, int B, int HW, int C, int dtype, void* stream) {
+                            float* dbias, void* ws, size_t ws_bytes, int B, int HW, int C, int flags, int dtype, void* stream) {
     int rc = gepi_check(B, HW, C, dtype, ws_bytes);
     if (rc) return rc;
     if (dtype == SGX_F32)
-        return gepi_bwd_t<float>(dy, x, bias, noise, nw, style, mean, rstd, dx, dstyle, dnw, dbias, ws, B, HW, C, (hipStream_t)stream);
-    return gepi_bwd_t<bf16_t>(dy, x, bias, noise, nw, style, mean, rstd, dx, dstyle, dnw, dbias, ws, B, HW, C, (hipStream_t)stream);
+        return gepi_bwd_t<float>(dy, x, bias, noise, nw, style, mean, rstd, dx, dstyle, dnw, dbias, ws, B, HW, C, flags, (hipStream_t)stream);
+    return gepi_bwd_t<bf16_t>(dy, x, bias, noise, nw, style, mean, rstd, dx, dstyle, dnw, dbias, ws, B, HW, C, flags, (hipStream_t)stream);
 }

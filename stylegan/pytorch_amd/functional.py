@@ -346,7 +346,7 @@ class ConvFn(Function):
         mode, scale, ipad, adjoint, act, has_bias = ctx.cfg
         gy = _c(gy)
         if act:
-            gy = _bcall(LReluBwdFn, gy, y)
+            gy = _bcall(LReluBwdFn, gy, y, 0.2)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0)
@@ -392,20 +392,22 @@ def conv(x, weight, bias, mode, scale, act=N.ACT_NONE, ipad=None):
 
 # ---------------------------------------------------------------------------------------------------
 class LReluBwdFn(Function):
-    """g * (y > 0 ? 1 : 0.2), y = LeakyReLU output.  Linear in g; no second derivative w.r.t. y."""
+    """g * (y > 0 ? 1 : slope), y = the activation's output (slope 0.2: LeakyReLU, 0: ReLU).  Linear in g; no second
+    derivative w.r.t. y."""
 
     @staticmethod
-    def forward(ctx, g, y):
+    def forward(ctx, g, y, slope):
         g = _c(g)
         out = torch.empty_like(g)
-        N.check(N.lib().sgx_lrelu_bwd(N.ptr(g), N.ptr(y), N.ptr(out), g.numel(), N.dt(g), N.stream()), "sgx_lrelu_bwd")
+        N.check(N.lib().sgx_lrelu_bwd(N.ptr(g), N.ptr(y), N.ptr(out), g.numel(), float(slope), N.dt(g), N.stream()), "sgx_lrelu_bwd")
+        ctx.slope = float(slope)
         ctx.save_for_backward(y)
         return out
 
     @staticmethod
     def backward(ctx, gg):
         (y,) = ctx.saved_tensors
-        return _bcall(LReluBwdFn, gg, y), None
+        return _bcall(LReluBwdFn, gg, y, ctx.slope), None, None
 
 
 class ColSumFn(Function):
@@ -429,7 +431,7 @@ class ColSumFn(Function):
 
 
 class BiasActFn(Function):
-    """y = act(x + bscale*bias[c]) on [..., C]."""
+    """y = act(x + bscale*bias[c]) on [..., C]; act: ACT_NONE | ACT_LRELU | ACT_RELU."""
 
     @staticmethod
     def forward(ctx, x, bias, bscale, act):
@@ -447,7 +449,7 @@ class BiasActFn(Function):
         (y,) = ctx.saved_tensors
         g = _c(g)
         if ctx.act:
-            g = _bcall(LReluBwdFn, g, y)
+            g = _bcall(LReluBwdFn, g, y, 0.0 if ctx.act == N.ACT_RELU else 0.2)
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[1] and not _DATA_GRAD_ONLY:
             gb = _bcall(ColSumFn, g, ctx.bscale)
@@ -544,6 +546,29 @@ class BlurFn(Function):
     @staticmethod
     def backward(ctx, g):
         return _bcall(BlurFn, g)
+
+
+class BlurGenFn(Function):
+    """Depthwise K x K correlation with zero padding for blur filters other than [1,2,1] (reference BlurLayer,
+    models/CustomLayers.py:251-276): ``taps`` = the K*K kernel as a tuple of floats (row major), ``pad`` the zero padding,
+    output [B, OH, OW, C].  Its adjoint is the same op with the taps flipped, pad' = K-1-pad and the sizes swapped, so it is
+    closed under differentiation."""
+
+    @staticmethod
+    def forward(ctx, x, taps, K, pad, OH, OW):
+        import ctypes
+        x = _c(x)
+        B, IH, IW, C = x.shape
+        y = torch.empty((B, OH, OW, C), dtype=x.dtype, device=x.device)
+        arr = (ctypes.c_float * (K * K))(*taps)
+        N.check(N.lib().sgx_blur_kxk(N.ptr(x), N.ptr(y), ctypes.addressof(arr), K, pad, B, IH, IW, OH, OW, C, N.dt(x), N.stream()), "sgx_blur_kxk")
+        ctx.cfg = (taps, K, pad, IH, IW)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        taps, K, pad, IH, IW = ctx.cfg
+        return _bcall(BlurGenFn, g, tuple(reversed(taps)), K, K - 1 - pad, IH, IW), None, None, None, None, None
 
 
 def _blur_act(x, z, mode):
@@ -731,16 +756,24 @@ class RgbWgradFn(Function):
 
 # ---------------------------------------------------------------------------------------------------
 class GEpilogueFn(Function):
-    """noise + LeakyReLU + InstanceNorm + StyleMod (reference LayerEpilogue), conv bias folded in.  First order."""
+    """noise + LeakyReLU + InstanceNorm + StyleMod (reference LayerEpilogue), conv bias folded in.  First order.
+    ``flags``: EPI_ACT | EPI_NORM select the activation / instance-norm stages (default both); ``noise``/``nw`` None = no
+    noise stage, ``style`` None = no style stage (exactly: zero noise weight / zero style)."""
 
     @staticmethod
-    def forward(ctx, x, bias, noise, nw, style):
+    def forward(ctx, x, bias, noise, nw, style, flags=N.EPI_ACT | N.EPI_NORM):
         x = _c(x)
         B, H, W, C = x.shape
-        noise = _c(noise.detach().reshape(B, H * W))
-        if noise.dtype != torch.float32:
-            noise = noise.float()
-        nw_c, style_c = _c(nw.detach()), _c(style.detach())
+        ctx.has_noise, ctx.has_style = nw is not None, style is not None
+        if nw is None:
+            noise = torch.zeros((B, H * W), dtype=torch.float32, device=x.device)
+            nw_c = torch.zeros((C,), dtype=torch.float32, device=x.device)
+        else:
+            noise = _c(noise.detach().reshape(B, H * W))
+            if noise.dtype != torch.float32:
+                noise = noise.float()
+            nw_c = _c(nw.detach())
+        style_c = _c(style.detach()) if style is not None else torch.zeros((B, 2 * C), dtype=torch.float32, device=x.device)
         bias_c = None if bias is None else _c(bias.detach())
         y = torch.empty_like(x)
         mean = torch.empty((B, C), dtype=torch.float32, device=x.device)
@@ -748,8 +781,8 @@ class GEpilogueFn(Function):
         L = N.lib()
         ws = N.workspace(L.sgx_gepi_ws_bytes(B, H * W, C), x.device)
         N.check(L.sgx_gepi_fwd(N.ptr(x), N.ptr(bias_c), N.ptr(noise), N.ptr(nw_c), N.ptr(style_c), N.ptr(y), N.ptr(mean), N.ptr(rstd),
-                               N.ptr(ws), ws.numel(), B, H * W, C, N.dt(x), N.stream()), "sgx_gepi_fwd")
-        ctx.has_bias = bias is not None
+                               N.ptr(ws), ws.numel(), B, H * W, C, int(flags), N.dt(x), N.stream()), "sgx_gepi_fwd")
+        ctx.has_bias, ctx.flags = bias is not None, int(flags)
         ctx.save_for_backward(x, bias_c, noise, nw_c, style_c, mean, rstd)
         return y
 
@@ -766,9 +799,9 @@ class GEpilogueFn(Function):
         L = N.lib()
         ws = N.workspace(L.sgx_gepi_ws_bytes(B, H * W, C), x.device)
         N.check(L.sgx_gepi_bwd(N.ptr(gy), N.ptr(x), N.ptr(bias_c), N.ptr(noise), N.ptr(nw_c), N.ptr(style_c), N.ptr(mean), N.ptr(rstd),
-                               N.ptr(dx), N.ptr(dstyle), N.ptr(dnw), N.ptr(dbias), N.ptr(ws), ws.numel(), B, H * W, C, N.dt(x),
-                               N.stream()), "sgx_gepi_bwd")
-        return dx, dbias, None, dnw, dstyle
+                               N.ptr(dx), N.ptr(dstyle), N.ptr(dnw), N.ptr(dbias), N.ptr(ws), ws.numel(), B, H * W, C, ctx.flags,
+                               N.dt(x), N.stream()), "sgx_gepi_bwd")
+        return dx, dbias, None, dnw if ctx.has_noise else None, dstyle if ctx.has_style else None, None
 
 
 class PixelNormFn(Function):

@@ -18,7 +18,8 @@ LIB_PATH = os.environ.get("SGX_HIP_LIB") or os.path.join(_HERE, "libsgx_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_LRELU = 0, 1
+ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+EPI_ACT, EPI_NORM = 1, 2
 PACK_S, PACK_D, PACK_U, PACK_UF = 0, 1, 2, 3
 
 _lib = None
@@ -50,11 +51,12 @@ SIGNATURES = {
     "sgx_wgrad3x3_param": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, I, P]),
     "sgx_wgrad4x4s2_param": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, I, P]),
     "sgx_bias_act": (I, [P, P, F, P, Z, I, I, I, P]),
-    "sgx_lrelu_bwd": (I, [P, P, P, Z, I, P]),
+    "sgx_lrelu_bwd": (I, [P, P, P, Z, F, I, P]),
     "sgx_axpby": (I, [P, P, P, F, F, Z, I, P]),
     "sgx_axpby_dev": (I, [P, P, P, P, P, Z, I, P]),
     "sgx_blur3x3": (I, [P, P, I, I, I, I, I, P]),
     "sgx_blur3x3_act": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "sgx_blur_kxk": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "sgx_pool2": (I, [P, P, I, I, I, I, F, I, P]),
     "sgx_up2": (I, [P, P, I, I, I, I, F, I, P]),
     "sgx_colsum_ws_bytes": (Z, [Z, I]),
@@ -64,8 +66,8 @@ SIGNATURES = {
     "sgx_rgb_wgrad_ws_bytes": (Z, [Z, I]),
     "sgx_rgb_wgrad": (I, [P, P, P, I, I, F, P, Z, Z, I, I, P]),
     "sgx_gepi_ws_bytes": (Z, [I, I, I]),
-    "sgx_gepi_fwd": (I, [P, P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),
-    "sgx_gepi_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),
+    "sgx_gepi_fwd": (I, [P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
+    "sgx_gepi_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
     "sgx_pixelnorm_fwd": (I, [P, P, I, I, P]),
     "sgx_pixelnorm_bwd": (I, [P, P, P, I, I, P]),
     "sgx_mbstd_fwd": (I, [P, P, I, I, I, I, I, P]),

@@ -1,0 +1,173 @@
+"""-m gpu: the NON-DEFAULT options of the reference networks on the HIP path -- LayerEpilogue stage combinations incl. the
+epilogue pixel norm, ReLU, other blur filters, the label-conditioned model -- against fixtures recorded from
+the reference itself (tests/golden/flags.npz, conditional.npz; fp64 truth + the reference's own fp32 error) and the oracle."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from gpu_util import DEV, assert_close, rel_err
+from test_oracle_flags import BLUR_CASES, EPI_CASES, FLAGS_NET, NET, NET_DEPTH, cond_nets, flag_nets, module_params
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dtype=torch.float64):
+    return torch.from_numpy(np.asarray(a)).to(dtype)
+
+
+def load_filled(module, prefix=""):
+    sd = {k: (v if k.endswith(".kernel") else gu.fill_value(prefix + k, v.shape)) for k, v in module.state_dict().items()}
+    module.load_state_dict(sd)
+    return module.to(DEV)
+
+
+def grad_gate(name, got, norm64, err32, full64=None):
+    """err(ours, fp64) <= max(1e-3 * |g64|, 4 * err(ref32, fp64)) (+ an absolute floor for pure round-off)."""
+    if full64 is not None:
+        err = torch.linalg.vector_norm(got.detach().double().cpu() - full64).item()
+    else:
+        err = abs(torch.linalg.vector_norm(got.detach().double()).item() - norm64)
+    assert err <= max(1e-3 * norm64, 4.0 * err32) + 1e-7, f"{name}: err {err:.3e}, |g64| {norm64:.3e}, ref32 err {err32:.3e}"
+
+
+def test_epilogue_stage_combinations(golden_dir):
+    from stylegan.pytorch_amd.CustomLayers import LayerEpilogue
+    g = np.load(os.path.join(golden_dir, "flags.npz"))
+    x, dl, noise, probe = (T(g[k], torch.float32).to(DEV) for k in ("x", "dlat", "noise", "probe"))
+    for name, (un, upn, uin, us, act) in EPI_CASES.items():
+        actm = torch.nn.LeakyReLU(0.2) if act == "lrelu" else torch.nn.ReLU()
+        epi = load_filled(LayerEpilogue(16, 512, True, un, upn, uin, us, actm), f"fl.{name}.")
+        if un:
+            epi.top_epi.noise.noise = noise
+        xi = x.clone().requires_grad_(True)
+        y = epi(xi, dl if us else None)
+        (y * probe).sum().backward()
+        assert_close(y, T(g[f"epi_{name}_y"]), 2e-5, name + " y")
+        assert_close(xi.grad, T(g[f"epi_{name}_dx"]), 1e-4, name + " dx")
+        for k, p in epi.named_parameters():
+            assert_close(p.grad, T(g[f"epi_{name}_g::{k}"]), 1e-4, f"{name} {k}", floor=1e-6)
+
+
+def test_blur_filters_and_relu_block(golden_dir):
+    from stylegan.pytorch_amd.Blocks import DiscriminatorBlock
+    from stylegan.pytorch_amd.CustomLayers import BlurLayer
+    g = np.load(os.path.join(golden_dir, "flags.npz"))
+    for name, (taps, normalize) in BLUR_CASES.items():
+        bl = BlurLayer(taps, normalize=normalize).to(DEV)
+        xi = T(g["x"], torch.float32).to(DEV).requires_grad_(True)
+        y = bl(xi)
+        (y * T(g[f"blur_{name}_probe"], torch.float32).to(DEV)).sum().backward()
+        assert_close(y, T(g[f"blur_{name}_y"]), 1e-5, name)
+        assert_close(xi.grad, T(g[f"blur_{name}_dx"]), 1e-5, name + " dx")
+    # the evident intent of flip=True (the reference raises, models/CustomLayers.py:262): the spatially flipped kernel
+    fl, nf = BlurLayer([1, 2, 3], flip=True).to(DEV), BlurLayer([3, 2, 1]).to(DEV)
+    xi = T(g["x"], torch.float32).to(DEV)
+    assert torch.equal(fl(xi), nf(xi))
+    blk = load_filled(DiscriminatorBlock(16, 32, gain=np.sqrt(2), use_wscale=True, activation_layer=torch.nn.ReLU(),
+                                         blur_kernel=[1, 4, 6, 4, 1]), "fl.dblk.")
+    xb = T(g["dblk_x"], torch.float32).to(DEV).requires_grad_(True)
+    yb = blk(xb)
+    (yb * T(g["dblk_probe"], torch.float32).to(DEV)).sum().backward()
+    assert_close(yb, T(g["dblk_y"]), 2e-5, "relu block y")
+    assert_close(xb.grad, T(g["dblk_dx"]), 1e-4, "relu block dx")
+    for k, p in blk.named_parameters():
+        assert_close(p.grad, T(g[f"dblk_g::{k}"]), 1e-4, "relu block " + k, floor=1e-6)
+
+
+def test_relu_networks_run_and_match_the_oracle():
+    """nonlinearity='relu' cannot be recorded from the reference (it fails to construct, see make_golden_flags.py); the HIP
+    networks are checked against the oracle, whose ReLU layers are pinned at layer / block level."""
+    from oracle import stylegan_oracle as O
+    from stylegan.pytorch_amd.GAN import Discriminator, Generator
+    kw = dict(resolution=NET["resolution"], fmap_base=NET["fmap_base"], fmap_max=NET["fmap_max"], structure="linear")
+    gen = Generator(latent_size=512, mapping_layers=2, blur_filter=[1, 2, 1], truncation_psi=0.7, nonlinearity="relu",
+                    mapping_nonlinearity="relu", **kw)
+    dis = Discriminator(num_channels=3, blur_filter=[1, 2, 1], nonlinearity="relu", **kw)
+    gp, dp = module_params(gen), module_params(dis)
+    load_filled(gen); load_filled(dis)
+    gen.train(); dis.train(); gen.style_mixing_prob = None
+    B, depth, alpha = 4, 3, 0.4
+    noises = [gu.seeded((B, 1, 4 * 2 ** (i // 2), 4 * 2 ** (i // 2)), 100 + i, torch.float64) for i in range(2 * NET_DEPTH)]
+    from gpu_util import pin_noise
+    pin_noise(gen, noises)
+    z = gu.seeded((B, 512), 11)
+    img = gen(z.to(DEV), depth, alpha)
+    score = dis(img, depth, alpha)
+    score.sum().backward()
+    fl = O.Flags(act="relu")
+    rimg, _ = O.generator(gp, z.double(), depth, alpha, noises, mapping_layers=2, num_layers=2 * NET_DEPTH, flags=fl)
+    rscore = O.discriminator(dp, rimg, depth, alpha, NET_DEPTH, flags=fl)
+    rscore.sum().backward()
+    assert_close(img, rimg, 1e-4, "relu G image"); assert_close(score, rscore, 1e-4, "relu D score")
+    for net, p in ((gen, gp), (dis, dp)):
+        for k, q in net.named_parameters():
+            if p[k].grad is not None and q.grad is not None:
+                n64 = torch.linalg.vector_norm(p[k].grad).item()
+                err = torch.linalg.vector_norm(q.grad.double().cpu() - p[k].grad).item()
+                assert err <= 5e-3 * n64 + 1e-6, (k, err, n64)
+
+
+def test_networks_with_flags(golden_dir):
+    g = np.load(os.path.join(golden_dir, "flags.npz"))
+    gen, dis = flag_nets()
+    load_filled(gen); load_filled(dis)
+    gen.train(); dis.train(); gen.style_mixing_prob = None
+    B, depth, alpha = 4, 3, 0.4
+    z = gu.seeded((B, 512), 11)
+    gen.truncation.avg_latent.copy_(gu.fill_value("truncation.avg_latent", (512,)).to(DEV))
+    img = gen(z.to(DEV), depth, alpha)
+    score = dis(img, depth, alpha)
+    score.sum().backward()
+    assert_close(img, T(g["net_f32_img"]), 1e-3, "image vs reference fp32"); assert_close(img, T(g["net_f64_img"]), 1e-4, "image vs reference fp64")
+    assert_close(score, T(g["net_f32_score"]), 1e-3, "score vs reference fp32"); assert_close(score, T(g["net_f64_score"]), 1e-4, "score vs fp64")
+    for net, mod in (("g", gen), ("d", dis)):
+        names = [str(n) for n in g[f"net_{net}_grad_names"]]
+        have = dict(mod.named_parameters())
+        assert sorted(k for k, p in have.items() if p.grad is not None) == names
+        for k, n64, e32 in zip(names, g[f"net_{net}_grad_norm64"], g[f"net_{net}_grad_err32"]):
+            full = T(g[f"net_{net}_grad64::{k}"]) if f"net_{net}_grad64::{k}" in g else None
+            grad_gate(f"{net}.{k}", have[k].grad, float(n64), float(e32), full)
+
+
+def test_conditional_step(golden_dir):
+    """One full iteration of the label-conditioned model (reference models/GAN.py:233-236,326-330,415-421; Losses.py:54-93)."""
+    from stylegan.pytorch_amd.GAN import StyleGAN
+    g = np.load(os.path.join(golden_dir, "conditional.npz"))
+    opt = dict(learning_rate=0.003, beta_1=0, beta_2=0.99, eps=1e-8)
+    sg = StyleGAN("linear", NET["resolution"], 3, 512,
+                  g_args=dict(latent_size=512, mapping_layers=NET["mapping_layers"], blur_filter=[1, 2, 1], truncation_psi=0.7,
+                              truncation_cutoff=8, fmap_base=NET["fmap_base"], fmap_max=NET["fmap_max"]),
+                  d_args=dict(use_wscale=True, blur_filter=[1, 2, 1], fmap_base=NET["fmap_base"], fmap_max=NET["fmap_max"]),
+                  g_opt_args=opt, d_opt_args=opt, conditional=True, n_classes=5, loss="conditional-loss", d_repeats=1, use_ema=True,
+                  ema_decay=0.999, device=torch.device(DEV))
+    load_filled(sg.gen); load_filled(sg.dis)
+    sg.gen_shadow.load_state_dict(sg.gen.state_dict())
+    sg.gen.train(); sg.dis.train(); sg.gen_shadow.train()
+    B, depth, alpha = 4, 3, 0.5
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+    noises = [gu.seeded((B, 1, 4 * 2 ** (i // 2), 4 * 2 ** (i // 2)), 100 + i) for i in range(2 * NET_DEPTH)]
+    from gpu_util import pin_noise
+    pin_noise(sg.gen, noises)
+    z = gu.seeded((B, 512), 21).to(DEV); real = gu.seeded((B, 3, 32, 32), 22).to(DEV)
+    torch.manual_seed(77); random.seed(77)
+    d_loss = sg.optimize_discriminator(z, real, depth, alpha, labels)
+    d_grads = {k: p.grad.detach().clone() for k, p in sg.dis.named_parameters() if p.grad is not None}
+    torch.manual_seed(78); random.seed(78)
+    g_loss = sg.optimize_generator(z, real, depth, alpha, labels)
+    g_grads = {k: p.grad.detach().clone() for k, p in sg.gen.named_parameters() if p.grad is not None}
+    assert isinstance(d_loss, float) and isinstance(g_loss, float)
+    assert abs(d_loss - float(g["f64_d_loss"])) <= 1e-4 * abs(float(g["f64_d_loss"])), (d_loss, float(g["f64_d_loss"]))
+    assert abs(g_loss - float(g["f64_g_loss"])) <= 1e-4 * abs(float(g["f64_g_loss"])), (g_loss, float(g["f64_g_loss"]))
+    assert_close(sg.gen.truncation.avg_latent, T(g["f32_avg_latent"]), 1e-5, "avg_latent")
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(v.double()) for v in g_grads.values()])).item()
+    coef = min(1.0, 10.0 / (total + 1e-6))            # the reference's .grad is post-clip (clip_grad_norm_ scales in place), ours pre-clip
+    for net, grads, scale in (("d", d_grads, 1.0), ("g", g_grads, coef)):
+        names = [str(n) for n in g[f"{net}_grad_names"]]
+        assert sorted(grads) == names, (net, sorted(set(names) ^ set(grads)))
+        for k, n64, e32 in zip(names, g[f"{net}_grad_norm64"], g[f"{net}_grad_err32"]):
+            full = T(g[f"{net}_grad64::{k}"]) if f"{net}_grad64::{k}" in g else None
+            grad_gate(f"{net}.{k}", grads[k] * scale, float(n64), float(e32), full)
