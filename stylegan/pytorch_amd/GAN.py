@@ -6,6 +6,7 @@ checkpoints interchange.  All arithmetic of the forward/backward hot path runs i
 Extra (non-reference) knobs are keyword-only and default to the reference behaviour:
 ``act_dtype`` (torch.float32 | torch.bfloat16 storage of activations between kernels; accumulation stays fp32).
 """
+import contextlib
 import copy
 import datetime
 import os
@@ -36,16 +37,18 @@ class DeferredLoss:
 
     __slots__ = ("_host", "_event", "_scale", "_value")
 
-    def __init__(self, dev_scalar, scale=1.0):
-        t = dev_scalar.detach().reshape(1).float()
+    def __init__(self, dev_scalar, scale=1.0, stream=None):
+        """``stream``: the stream the scalar is produced on, if not the current one (data parallel: the update stream)."""
         self._scale, self._value = float(scale), None
-        if t.is_cuda:
-            self._host = torch.empty(1, dtype=torch.float32).pin_memory()
-            self._host.copy_(t, non_blocking=True)
-            self._event = torch.cuda.Event()
-            self._event.record()
+        if dev_scalar.is_cuda:
+            with torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext():
+                t = dev_scalar.detach().reshape(1).float()
+                self._host = torch.empty(1, dtype=torch.float32).pin_memory()
+                self._host.copy_(t, non_blocking=True)
+                self._event = torch.cuda.Event()
+                self._event.record()
         else:
-            self._host, self._event = t.clone(), None
+            self._host, self._event = dev_scalar.detach().reshape(1).float().clone(), None
 
     def item(self):
         if self._value is None:
@@ -263,6 +266,10 @@ class Generator(nn.Module):
             self.truncation = None
 
     _mixing_override = None          # (latents2 device tensor, cutoff int or device tensor) supplied by a step graph
+    # Data parallel: called with the W-average buffer right after ``truncation.update`` and BEFORE the truncation is applied.
+    # The reference updates with GLOBAL sample 0 (:278) = rank 0's local sample 0, so every rank must truncate THIS forward's
+    # dlatents with rank 0's value (StyleGAN installs a broadcast from rank 0 here).
+    _avg_latent_hook = None
 
     def draw_mixing_host(self, shape, depth):
         """The host-side random draws of style mixing, in the reference's order: (latents2 CPU tensor, cutoff int)."""
@@ -294,6 +301,8 @@ class Generator(nn.Module):
         if self.training:
             if self.truncation is not None:
                 self.truncation.update(dlatents_in[0, 0].detach())                       # sample 0 only (:278)
+                if self._avg_latent_hook is not None:
+                    self._avg_latent_hook(self.truncation.avg_latent)
             if mixing:
                 layer_idx = torch.arange(self.num_layers, device=latents_in.device).view(1, -1, 1)
                 dlatents_in = torch.where(layer_idx < mixing_cutoff, dlatents_in, dlatents2)
@@ -421,6 +430,9 @@ class StyleGAN:
             self.gen_shadow = copy.deepcopy(self.gen)
             self.ema_updater = update_average
             self.ema_updater(self.gen_shadow, self.gen, beta=0)
+        self._grad_buckets = {}                       # (kind, depth) -> dist.GradBuckets of that network's active parameters
+        if self.dp is not None and self.gen.truncation is not None:
+            self.gen._avg_latent_hook = lambda buf: self.dp.broadcast(buf, src=0)     # (after the deepcopy: the shadow has none)
 
     def __setup_gen_optim(self, learning_rate, beta_1, beta_2, eps):
         self.gen_optim = FusedAdam(self.gen.parameters(), lr=learning_rate, betas=(float(beta_1), float(beta_2)), eps=eps)
@@ -467,10 +479,26 @@ class StyleGAN:
     # name-mangled alias so code written against the reference's private helper keeps working
     _StyleGAN__progressive_down_sampling = progressive_down_sampling
 
-    def _sync_w_avg(self):
-        """Data parallel: the W moving average follows GLOBAL sample 0 = rank 0's local sample 0 (GAN.py:278)."""
-        if self.dp is not None and self.gen.truncation is not None:
-            self.dp.broadcast(self.gen.truncation.avg_latent, src=0)
+    def _zero_grads(self, kind, depth):
+        """``optim.zero_grad()`` of the reference step (:616,:648).  Data parallel, from the second iteration at a depth on:
+        the gradients of the network's active parameters are views into flat buckets (dist.GradBuckets), zero-filled here and
+        accumulated into by the backward, so that the all-reduce runs on the buckets in place."""
+        optim = self.dis_optim if kind == "d" else self.gen_optim
+        optim.zero_grad()                                            # set_to_none: inactive resolutions keep grad None
+        gb = self._grad_buckets.get((kind, int(depth))) if self.dp is not None else None
+        if gb is not None:
+            gb.attach()
+
+    def _note_active_grads(self, kind, depth):
+        """After a backward: remember the active set of this (network, depth) as a flat bucket layout for the next iteration."""
+        if self.dp is None:
+            return
+        net = self.dis if kind == "d" else self.gen
+        active = [p for p in net.parameters() if p.grad is not None]
+        gb = self._grad_buckets.get((kind, int(depth)))
+        if active and (gb is None or not gb.matches(active)) and not torch.cuda.is_current_stream_capturing():
+            from .dist import GradBuckets
+            self._grad_buckets[(kind, int(depth))] = GradBuckets(active, self.dp.bucket_elems)
 
     def _aux_stream(self):
         """Second compute stream for work that is independent of the main chain (the D-step generator forward)."""
@@ -515,7 +543,6 @@ class StyleGAN:
             self._wait_update("g")                    # data parallel: G's all-reduce + Adam + EMA may still be in flight
             with torch.no_grad():                     # the reference builds and drops this graph (.detach(), :607)
                 out = self.gen(noise, depth, alpha, labels)
-            self._sync_w_avg()
             return out
 
         # The generator forward that makes the fakes and the D(real) forward are independent chains of (at batch 4, mostly
@@ -544,18 +571,27 @@ class StyleGAN:
             loss = self.loss.dis_loss(real_samples, make_fakes(), labels, depth, alpha)
         else:
             loss = self.loss.dis_loss(real_samples, make_fakes if lazy else make_fakes(), depth, alpha)
-        self.dis_optim.zero_grad()
+        self._zero_grads("d", depth)
         side = self._param_stream(two_branches=aux is not None and lazy)
         # conv weight / bias gradients accumulate inside the finishing kernel, on a side stream next to the backward chain
         with F.accumulate_param_grads(), F.param_grad_stream(side):
             loss.backward()
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+        self._note_active_grads("d", depth)
         return loss.detach()
 
+    def _reduce(self, kind):
+        if self.dp is None:
+            return
+        gb = next((g for (k, _), g in self._grad_buckets.items() if k == kind and g.attached()), None)
+        if gb is not None:
+            self.dp.all_reduce_buckets(gb)                           # the gradients live in the flat buckets: in place
+        else:
+            self.dp.all_reduce_grads((self.dis if kind == "d" else self.gen).parameters())
+
     def _d_reduce(self):
-        if self.dp is not None:
-            self.dp.all_reduce_grads(self.dis.parameters())
+        self._reduce("d")
 
     def _d_update(self):
         self.dis_optim.step()
@@ -566,7 +602,6 @@ class StyleGAN:
             real_samples = self.progressive_down_sampling(real_batch, depth, alpha)   # only the relativistic loss reads it
         self._wait_update("g")
         fake_samples = self.gen(noise, depth, alpha, labels)
-        self._sync_w_avg()
         self._wait_update("d")                        # data parallel: D's all-reduce + Adam overlapped the G forward above
         # the reference also back-propagates into D's parameters here and discards the result at the next
         # dis_optim.zero_grad(); skipping those weight gradients changes no observable value
@@ -581,20 +616,20 @@ class StyleGAN:
                 loss = self.loss.gen_loss(real_samples, fake_samples, labels, depth, alpha)
             else:
                 loss = self.loss.gen_loss(real_samples, fake_samples, depth, alpha)
-            self.gen_optim.zero_grad()
+            self._zero_grads("g", depth)
             side = self._param_stream()
             with F.accumulate_param_grads(), F.param_grad_stream(side):
                 loss.backward()
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
+            self._note_active_grads("g", depth)
         finally:
             for p in d_params:
                 p.requires_grad_(True)
         return loss.detach()
 
     def _g_reduce(self):
-        if self.dp is not None:
-            self.dp.all_reduce_grads(self.gen.parameters())                           # before the clip: global norm
+        self._reduce("g")                                                             # before the clip: global norm
 
     def _g_update(self):
         clip_and_step(self.gen_optim, max_norm=10.)                                   # :651-652 without a host sync
@@ -606,17 +641,23 @@ class StyleGAN:
     # (D's update || the generator forward of the G step;  G's update + EMA || D(real) forward of the next D step).
     # Whoever reads the parameters next waits for the event (`_wait_update`).  Gradient tensors stay alive until the next
     # zero_grad of the same optimizer, which comes after that wait.
-    def _async_update(self, kind):
+    def _async_update(self, kind, loss):
+        """-> the GLOBAL loss (sum of the ranks' partial losses: the mean terms carry 1/N, the R1 term is a batch sum), a
+        tensor produced on the update stream (``self._loss_stream`` tells ``optimize_*`` where to read it)."""
         upd = self.__dict__.get("_update_stream")
         if upd is None:
             upd = self.__dict__["_update_stream"] = torch.cuda.Stream(device=self.device)
         upd.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(upd):
             (self._d_reduce if kind == "d" else self._g_reduce)()
+            loss.record_stream(upd)
+            loss = self.dp.all_reduce_scalar(loss)
             (self._d_update if kind == "d" else self._g_update)()
         ev = torch.cuda.Event()
         ev.record(upd)
         self.__dict__.setdefault("_pending_updates", {})[kind] = ev
+        self.__dict__["_loss_stream"] = upd
+        return loss
 
     def _wait_update(self, kind):
         ev = self.__dict__.get("_pending_updates", {}).pop(kind, None)
@@ -626,19 +667,17 @@ class StyleGAN:
     def _d_body(self, noise, real_batch, depth, alpha, labels=None):
         loss = self._d_grads(noise, real_batch, depth, alpha, labels)
         if self.dp is not None and not torch.cuda.is_current_stream_capturing():
-            self._async_update("d")
-        else:
-            self._d_reduce()
-            self._d_update()
+            return self._async_update("d", loss)
+        self._d_reduce()
+        self._d_update()
         return loss
 
     def _g_body(self, noise, real_batch, depth, alpha, labels=None):
         loss = self._g_grads(noise, real_batch, depth, alpha, labels)
         if self.dp is not None and not torch.cuda.is_current_stream_capturing():
-            self._async_update("g")
-        else:
-            self._g_reduce()
-            self._g_update()
+            return self._async_update("g", loss)
+        self._g_reduce()
+        self._g_update()
         return loss
 
     def _graphed(self, kind, noise, real_batch, depth, alpha):
@@ -665,14 +704,17 @@ class StyleGAN:
         loss_val = None
         for _ in range(self.d_repeats):
             loss = self._d_body(noise, real_batch, depth, alpha, labels)
+            if loss_val is not None and self.__dict__.get("_loss_stream") is not None:   # data parallel and d_repeats > 1
+                torch.cuda.current_stream().wait_stream(self.__dict__.pop("_loss_stream"))
             loss_val = loss if loss_val is None else loss_val + loss
-        return self._loss_out(DeferredLoss(loss_val, 1.0 / self.d_repeats))
+        return self._loss_out(DeferredLoss(loss_val, 1.0 / self.d_repeats, stream=self.__dict__.pop("_loss_stream", None)))
 
     def optimize_generator(self, noise, real_batch, depth, alpha, labels=None):
         """One generator update incl. gradient clipping and EMA -- reference models/GAN.py:624-659."""
         if self._graphable(labels):
             return self._loss_out(self._graphed("g", noise, real_batch, depth, alpha))
-        return self._loss_out(DeferredLoss(self._g_body(noise, real_batch, depth, alpha, labels)))
+        loss = self._g_body(noise, real_batch, depth, alpha, labels)
+        return self._loss_out(DeferredLoss(loss, stream=self.__dict__.pop("_loss_stream", None)))
 
     # ------------------------------------------------------------------------------------------------------------
     # The progressive-growing schedule -- reference models/GAN.py:730-803.  Pure host arithmetic, kept in the reference's
@@ -914,12 +956,13 @@ class _StepGraph:
                         if p.grad is not g:
                             p.grad = g
                     (sg._d_reduce if self.kind == "d" else sg._g_reduce)()
+                    self.loss_global = sg.dp.all_reduce_scalar(self.loss)           # partial losses -> the global loss
                     self.graph_update.replay()
                 F.bump_weight_generation(self._changed_params())                   # eager users must re-pack these
                 for p, g in self.grads:
                     if p.grad is not g:
                         p.grad = g
-                loss = self.loss
+                loss = self.loss_global if self.graph_update is not None else self.loss
             out = DeferredLoss(loss)
             self.done.record()
         self.calls += 1

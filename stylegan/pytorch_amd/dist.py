@@ -11,7 +11,9 @@ single-device result at the GLOBAL batch:
 * ``Truncation.update`` uses global sample 0 (models/GAN.py:278) = rank 0's local sample 0: the buffer is broadcast.
 
 Collective choice for xGMI (7 point-to-point links per GPU): few large flat buckets (default 32 MiB; the D and G
-gradient sets are ~92 / ~105 MB at 1024x1024) issued on a side stream as soon as they are packed.
+gradient sets are ~92 / ~105 MB at 1024x1024).  From the second iteration at a depth on the gradients LIVE in those
+buckets (``GradBuckets``: every ``.grad`` is a view into a flat buffer), so the all-reduce runs on the buffers in place;
+the first iteration (active set still unknown) concatenates and copies back.
 """
 import torch
 import torch.distributed as dist
@@ -39,6 +41,45 @@ def bucketize(sizes, bucket_elems):
     return buckets
 
 
+class GradBuckets:
+    """Flat gradient storage for a FIXED set of parameters (the active set of one network at one progressive depth): a few
+    large fp32 buffers; every parameter's ``.grad`` is a view into one of them, so the all-reduce runs on the buffers
+    themselves -- no concatenation before, no copy back after (two passes over ~100 MB per network and step otherwise).
+    ``attach()`` zero-fills the buffers and installs the views; the backward then accumulates into them (the convolution
+    weight-gradient kernels and autograd's AccumulateGrad both add in place into an existing ``.grad``)."""
+
+    ALIGN = 64                                               # elements: every view starts on a 256-byte boundary
+
+    def __init__(self, params, bucket_elems):
+        self.params = list(params)
+        assert self.params and all(p.dtype == torch.float32 for p in self.params)
+        dev = self.params[0].device
+        pad = lambda n: (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.buckets = []
+        for idx in bucketize([pad(p.numel()) for p in self.params], bucket_elems):
+            chunk = [self.params[i] for i in idx]
+            flat = torch.zeros(sum(pad(p.numel()) for p in chunk), dtype=torch.float32, device=dev)
+            views, off = [], 0
+            for p in chunk:
+                views.append((p, flat[off:off + p.numel()].view(p.shape)))
+                off += pad(p.numel())
+            self.buckets.append((flat, views))
+
+    def matches(self, params):
+        """True if ``params`` (the parameters that received a gradient) are exactly this layout's parameters."""
+        params = list(params)
+        return len(params) == len(self.params) and all(a is b for a, b in zip(params, self.params))
+
+    def attach(self):
+        for flat, views in self.buckets:
+            flat.zero_()
+            for p, v in views:
+                p.grad = v
+
+    def attached(self):
+        return all(p.grad is v for _, views in self.buckets for p, v in views)
+
+
 class DataParallelGroup:
     """Bucketed gradient all-reduce(SUM) + buffer broadcast over a torch.distributed process group
     (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests)."""
@@ -51,6 +92,45 @@ class DataParallelGroup:
         self.rank = dist.get_rank(group)
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self._side = None
+        # "gloo" cannot reduce device memory: GPU tensors are staged through the host (the 2-process-on-one-GPU parity test
+        # of StyleGAN(data_parallel=...) runs this way; production is backend "nccl" = RCCL, device to device over xGMI)
+        self._stage_through_host = dist.get_backend(group) == "gloo"
+
+    def _all_reduce(self, t):
+        if self._stage_through_host and t.is_cuda:
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    @torch.no_grad()
+    def all_reduce_buckets(self, gb: GradBuckets):
+        """Sum the flat gradient buffers of ``gb`` over ranks, in place, on the side stream (joined before returning to the
+        caller's stream order)."""
+        if self.world_size == 1 and not self.force_collectives:
+            return
+        dev = gb.buckets[0][0].device
+        side = self._side_stream(dev)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(dev))
+        for flat, _ in gb.buckets:
+            if side is not None:
+                with torch.cuda.stream(side):
+                    self._all_reduce(flat)
+                flat.record_stream(side)
+            else:
+                self._all_reduce(flat)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+
+    @torch.no_grad()
+    def all_reduce_scalar(self, t):
+        """Sum of a (loss) scalar over ranks, as a new tensor on the current stream."""
+        out = t.detach().clone()
+        if self.world_size > 1 or self.force_collectives:
+            self._all_reduce(out)
+        return out
 
     def _side_stream(self, device):
         if device.type != "cuda":
@@ -75,10 +155,10 @@ class DataParallelGroup:
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
-                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                    self._all_reduce(flat)
                 flat.record_stream(side)
             else:
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                self._all_reduce(flat)
             flats.append((flat, chunk))
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
@@ -91,4 +171,9 @@ class DataParallelGroup:
     @torch.no_grad()
     def broadcast(self, tensor, src: int = 0):
         if self.world_size > 1 or self.force_collectives:
-            dist.broadcast(tensor, src=src, group=self.group)
+            if self._stage_through_host and tensor.is_cuda:
+                h = tensor.detach().cpu()
+                dist.broadcast(h, src=src, group=self.group)
+                tensor.copy_(h)
+            else:
+                dist.broadcast(tensor, src=src, group=self.group)

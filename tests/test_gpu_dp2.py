@@ -1,0 +1,122 @@
+"""-m gpu: TWO ranks of ``StyleGAN(data_parallel=...)`` itself, as two processes sharing the one MI355X of the test box
+(RCCL refuses two ranks on one device, so the process group is gloo and ``DataParallelGroup`` stages its collectives through
+the host -- the data-parallel LOGIC under test is the production one: ``mean_scale`` of the loss terms, the flat gradient
+buckets, the W-average broadcast inside the generator forward, ``_async_update`` / ``_wait_update`` ordering on the update
+stream, the all-reduced loss).  Target: after N-rank steps every rank holds the single-process result at the GLOBAL
+batch -- losses, gradients, parameters, W average."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+WORLD, GLOBAL_B, DEPTH, ITERS = 2, 8, 3, 2
+NET = dict(resolution=32, fmap_base=512, fmap_max=32, mapping_layers=2)
+NET_DEPTH = 4
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def build(dp):
+    from stylegan.pytorch_amd.GAN import StyleGAN
+    opt = dict(learning_rate=0.003, beta_1=0, beta_2=0.99, eps=1e-8)
+    sg = StyleGAN("linear", NET["resolution"], 3, 512,
+                  g_args=dict(latent_size=512, mapping_layers=NET["mapping_layers"], blur_filter=[1, 2, 1], truncation_psi=0.7,
+                              truncation_cutoff=8, fmap_base=NET["fmap_base"], fmap_max=NET["fmap_max"]),
+                  d_args=dict(use_wscale=True, blur_filter=[1, 2, 1], fmap_base=NET["fmap_base"], fmap_max=NET["fmap_max"]),
+                  g_opt_args=opt, d_opt_args=opt, loss="logistic", d_repeats=1, use_ema=True, ema_decay=0.999,
+                  device=torch.device("cuda:0"), data_parallel=dp)
+    for mod in (sg.gen, sg.dis):
+        mod.load_state_dict({k: (v if k.endswith(".kernel") else gu.fill_value(k, v.shape).to(v.device)) for k, v in mod.state_dict().items()})
+    sg.gen_shadow.load_state_dict(sg.gen.state_dict())
+    sg.gen.train(); sg.dis.train(); sg.gen_shadow.train()
+    return sg
+
+
+def run_steps(sg, idx):
+    """ITERS iterations on the samples ``idx`` of the global batch; every random input is pinned from global tensors."""
+    from stylegan.pytorch_amd.CustomLayers import NoiseLayer
+    dev = torch.device("cuda:0")
+    noise_mods = [m for m in sg.gen.modules() if isinstance(m, NoiseLayer)]
+    losses = []
+    for it in range(ITERS):
+        alpha = 0.5 + 0.25 * it
+        z = gu.seeded((GLOBAL_B, 512), 300 + it)[idx].to(dev)
+        real = gu.seeded((GLOBAL_B, 3, 32, 32), 400 + it)[idx].to(dev)
+        for i, m in enumerate(noise_mods):
+            r = 4 * 2 ** (i // 2)
+            m.noise = gu.seeded((GLOBAL_B, 1, r, r), 500 + 10 * it + i)[idx].to(dev)
+        for half, fn in ((0, sg.optimize_discriminator), (1, sg.optimize_generator)):
+            sg.gen._mixing_override = (gu.seeded((GLOBAL_B, 512), 600 + 2 * it + half)[idx].to(dev), 3 + it)   # latents2 of the GLOBAL batch, sliced
+            losses.append(float(fn(z, real, DEPTH, alpha)))
+    sg._wait_update("d"); sg._wait_update("g")
+    torch.cuda.synchronize()
+    out = {"losses": np.array(losses), "avg_latent": sg.gen.truncation.avg_latent.cpu().numpy()}
+    for tag, mod in (("gen", sg.gen), ("dis", sg.dis), ("shadow", sg.gen_shadow)):
+        for k, p in mod.named_parameters():
+            out[f"{tag}::{k}"] = p.detach().cpu().numpy()
+            if tag != "shadow" and p.grad is not None:
+                out[f"{tag}.grad::{k}"] = p.grad.detach().cpu().numpy()
+    out["buckets"] = np.array(sorted(f"{k}{d}" for (k, d), gb in sg._grad_buckets.items() if gb.attached()))
+    return out
+
+
+def _worker(rank, port, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        torch.cuda.set_device(0)
+        from stylegan.pytorch_amd.dist import DataParallelGroup, stddev_preserving_shard
+        sg = build(DataParallelGroup(bucket_mb=1.0))                 # several buckets per network
+        q.put((rank, run_steps(sg, stddev_preserving_shard(GLOBAL_B, WORLD, rank))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_the_global_batch_run():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(WORLD))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref = run_steps(build(None), list(range(GLOBAL_B)))              # single process, global batch
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+
+    for rank in range(WORLD):
+        r = got[rank]
+        assert list(r["buckets"]) == [f"d{DEPTH}", f"g{DEPTH}"], r["buckets"]      # iteration 2 ran on the flat buckets
+        assert np.allclose(r["losses"], ref["losses"], rtol=2e-4), (rank, r["losses"], ref["losses"])   # the GLOBAL loss on every rank
+        assert rel(r["avg_latent"], ref["avg_latent"]) <= 1e-5
+        for k, v in ref.items():
+            if ".grad::" in k:                                        # summed over ranks == global-batch gradient
+                n = np.linalg.norm(v)
+                assert np.linalg.norm(r[k] - v) <= 2e-3 * n + 1e-6 * (1 + n), (rank, k, rel(r[k], v))
+            elif "::" in k and not k.endswith("init_block.bias"):     # parameters after 2 x (Adam at beta1 = 0: +-lr per element)
+                bad = np.mean(np.abs(r[k] - v) > 1e-5 * (1 + np.abs(v)))
+                assert bad <= max(3e-2, 2.0 / v.size), (rank, k, bad)
+    for k in got[0]:
+        if "::" in k or k == "avg_latent":
+            assert np.array_equal(got[0][k], got[1][k]), k             # the replicas stay bit-identical
