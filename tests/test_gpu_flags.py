@@ -25,13 +25,14 @@ def load_filled(module, prefix=""):
     return module.to(DEV)
 
 
-def grad_gate(name, got, norm64, err32, full64=None, k32=4.0):
-    """err(ours, fp64) <= max(1e-3 * |g64|, k32 * err(ref32, fp64)) (+ an absolute floor for pure round-off), k32 = 4."""
+def grad_gate(name, got, norm64, err32, full64=None, k32=4.0, kink=0.0):
+    """err(ours, fp64) <= max(1e-3 * |g64|, k32 * err(ref32, fp64)) (+ an absolute floor for pure round-off), k32 = 4.
+    ``kink``: allowance (relative) for ONE LeakyReLU element flipping side between two fp32 evaluations (see callers)."""
     if full64 is not None:
         err = torch.linalg.vector_norm(got.detach().double().cpu() - full64).item()
     else:
         err = abs(torch.linalg.vector_norm(got.detach().double()).item() - norm64)
-    assert err <= max(1e-3 * norm64, k32 * err32) + 1e-7, f"{name}: err {err:.3e}, |g64| {norm64:.3e}, ref32 err {err32:.3e}"
+    assert err <= max(1e-3 * norm64, k32 * err32, kink * norm64) + 1e-7, f"{name}: err {err:.3e}, |g64| {norm64:.3e}, ref32 err {err32:.3e}"
 
 
 def test_epilogue_stage_combinations(golden_dir):
@@ -122,18 +123,50 @@ def test_networks_with_flags(golden_dir):
     img = gen(z.to(DEV), depth, alpha)
     score = dis(img, depth, alpha)
     score.sum().backward()
+    print(f"[flags net] image rel err vs fp64 {rel_err(img, T(g['net_f64_img'])):.2e} (reference fp32: {rel_err(T(g['net_f32_img']), T(g['net_f64_img'])):.2e}); "
+          f"score {rel_err(score, T(g['net_f64_score'])):.2e} (reference fp32: {rel_err(T(g['net_f32_score']), T(g['net_f64_score'])):.2e})")
     assert_close(img, T(g["net_f32_img"]), 1e-3, "image vs reference fp32"); assert_close(img, T(g["net_f64_img"]), 1e-4, "image vs reference fp64")
     assert_close(score, T(g["net_f32_score"]), 1e-3, "score vs reference fp32"); assert_close(score, T(g["net_f64_score"]), 1e-4, "score vs fp64")
+    bad = []
     for net, mod in (("g", gen), ("d", dis)):
         names = [str(n) for n in g[f"net_{net}_grad_names"]]
         have = dict(mod.named_parameters())
         assert sorted(k for k, p in have.items() if p.grad is not None) == names
         for k, n64, e32 in zip(names, g[f"net_{net}_grad_norm64"], g[f"net_{net}_grad_err32"]):
             full = T(g[f"net_{net}_grad64::{k}"]) if f"net_{net}_grad64::{k}" in g else None
-            # k32 = 8 here: a conv bias upstream of TWO stacked normalisations (pixel norm, then instance norm) has a
-            # cancellation-dominated gradient; measured on the MI355X: 5.9e-4 against the reference's own fp32 error 1.0e-4
-            # on g_synthesis.blocks.1.conv0_up.bias (|g64| = 0.13), every other tensor inside the 4x rule
-            grad_gate(f"{net}.{k}", have[k].grad, float(n64), float(e32), full, k32=8.0)
+            if full is not None:
+                err = torch.linalg.vector_norm(have[k].grad.detach().double().cpu() - full).item()
+                print(f"[flags net] {net}.{k}: rel err {err / (float(n64) + 1e-30):.2e} (ref32 {float(e32) / (float(n64) + 1e-30):.2e})")
+            try:
+                # The image that D sees comes from G in fp32 (1.4e-6 from fp64 here, the reference's own fp32 image 1.2e-6): an
+                # activation of the discriminator's first block that lies within that distance of zero takes the other
+                # LeakyReLU slope, and ONE flipped element of its 4x16x16x32 map moves every gradient upstream of it by
+                # 0.8 |g| / sqrt(32768) = 4.4e-3 relative (measured 2.5e-3..4.7e-3 on exactly those tensors, 3e-7 on the rest;
+                # the reference's fp32 run shows the same jumps, 1e-3, on its own set of tensors).  With a FIXED image the same
+                # gradients are tight: test_flag_discriminator_gradients_are_tight below.
+                grad_gate(f"{net}.{k}", have[k].grad, float(n64), float(e32), full, k32=8.0, kink=6e-3)
+            except AssertionError as e:
+                bad.append(str(e))
+    assert not bad, "\n".join(bad)
+
+
+def test_flag_discriminator_gradients_are_tight():
+    """The discriminator with the 5-tap blur on a FIXED image (no LeakyReLU kink can flip between the two evaluations):
+    every parameter gradient within 1e-5 of the fp64 oracle (whose flags path is pinned by tests/test_oracle_flags.py)."""
+    from oracle import stylegan_oracle as O
+    _, dis = flag_nets()
+    dp = module_params(dis)
+    load_filled(dis); dis.train()
+    B, depth, alpha = 4, 3, 0.4
+    img = gu.seeded((B, 3, 32, 32), 5)
+    ref = O.discriminator(dp, img.double(), depth, alpha, NET_DEPTH, flags=FLAGS_NET)
+    ref.sum().backward()
+    score = dis(img.to(DEV), depth, alpha)
+    score.sum().backward()
+    assert_close(score, ref, 1e-5, "score")
+    for k, q in dis.named_parameters():
+        if dp[k].grad is not None:
+            assert_close(q.grad, dp[k].grad, 1e-5, k)
 
 
 def test_conditional_step(golden_dir):

@@ -1,6 +1,6 @@
 #!/bin/bash
-# usage: tools/gpu_one.sh <tag> <pytest args...>   -- one pytest invocation on the GPU box, log merged back
+# run one pytest selection on the GPU box.   usage: tools/gpu_one.sh <tag> <pytest args...>
 tag=$1; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R
-timeout 2000 python -m pytest "$@" > $O/pytest.log 2>&1; echo "rc=$?"; grep -E "^\[|passed|failed" $O/pytest.log | tail -40
+timeout 1200 python -m pytest "$@" -q -m gpu -s > $O/pytest.log 2>&1; echo "rc=$?"; grep -E "^\[|passed|failed|Error|FAILED|assert" $O/pytest.log | tail -80
