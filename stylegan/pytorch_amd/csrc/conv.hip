@@ -20,6 +20,11 @@
 #include <stdlib.h>
 
 enum { G3X3 = 0, GDOWN = 1, GUP = 2, GUPA = 3 };
+// second-generation bf16 weight-gradient kernels (wgrad2.hip): plan = pixel splits (0: shape stays here); launch writes the
+// same per-split partials as wgrad_kernel below
+int sgx_wgrad2_plan(int geo, int B, int H, int W, int Ck, int Cn, int* nct_n, int* nct_k, int* kbw, int* ntiles);
+int sgx_wgrad2_launch(int geo, const void* kside, const void* nside, float* ws, size_t ws_bytes, int B, int H, int W, int Ck, int Cn,
+                      int want_bias, hipStream_t st, int* nsplit_out);
 int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
                   int variant, hipStream_t st, int* launched);        // conv2.hip   // GUPA: GUP with all four parity classes in one block (bf16)
 
@@ -1130,7 +1135,11 @@ extern "C" size_t sgx_wgrad_ws_bytes(int taps, int B, int H, int W, int Ck, int 
     int pairs = (Ck / 32 > 0 ? Ck / 32 : 1) * (Cn / 32 > 0 ? Cn / 32 : 1);
     size_t ntiles = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
     size_t ns = (size_t)wgrad_nsplit(pairs, ntiles > (1u << 30) ? (1 << 30) : (int)ntiles, (size_t)taps * Ck * Cn);
-    return total * ns + wgrad_pre_bytes(total / sizeof(float), (int)ns);
+    size_t need = total * ns + wgrad_pre_bytes(total / sizeof(float), (int)ns);
+    int a0, a1, a2, a3;                                             // the second-generation kernel's splits (bf16 only; harmless for fp32)
+    const int ns2 = taps == 9 ? sgx_wgrad2_plan(0, B, H, W, Ck, Cn, &a0, &a1, &a2, &a3) : sgx_wgrad2_plan(1, B, H / 2, W / 2, Ck, Cn, &a0, &a1, &a2, &a3);
+    const size_t need2 = ns2 ? total * ns2 + wgrad_pre_bytes(total / sizeof(float), ns2) : 0;
+    return need > need2 ? need : need2;
 }
 
 extern "C" int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, float* db, void* ws, size_t ws_bytes, int B, int H,
@@ -1144,6 +1153,11 @@ extern "C" int sgx_wgrad3x3_param(const void* x, const void* dy, float* dW, floa
                 0, dW, db, O, I, SGX_PACK_S, adjoint, adjoint, accumulate, scale};
     SGX_NOTE(2.0 * 9 * Cx * Cdy * B * H * W, (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * (Cx + Cdy), "wgradS B%d %dx%d %dx%d", B, H, W, Cx, Cdy);
     int ns = 0, rc;
+    if (dtype == SGX_BF16) {                                       // second-generation kernel (wgrad2.hip) where it applies
+        rc = sgx_wgrad2_launch(0, x, dy, static_cast<float*>(ws), ws_bytes, B, H, W, Cx, Cdy, db ? 1 : 0, st, &ns);
+        if (rc) return rc;
+        if (ns) return wgrad_finish(ws, dW, db, ns, O, I, Ip, SGX_PACK_S, adjoint, adjoint, scale, accumulate, st, ws_bytes);
+    }
     if (dtype == SGX_F32) rc = wgrad_ch<float, G3X3, 128>(a, ws, ws_bytes, &ns, st);
     else if (dtype == SGX_BF16) rc = wgrad_use_tr() ? wgrad_ch<bf16_t, G3X3, 128, true>(a, ws, ws_bytes, &ns, st) : wgrad_ch<bf16_t, G3X3, 128>(a, ws, ws_bytes, &ns, st);
     else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad3x3_param: bad dtype"); }
@@ -1166,6 +1180,11 @@ extern "C" int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float*
                 0, dW, db, O, I, mode, transposed, 0, accumulate, scale};
     SGX_NOTE(2.0 * 16 * Cfine * Ccoarse * B * (H / 2) * (W / 2), (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * (Cfine + Ccoarse / 4.0), "wgradD B%d fine%dx%d %dx%d", B, H, W, Cfine, Ccoarse);
     int ns = 0, rc;
+    if (dtype == SGX_BF16) {
+        rc = sgx_wgrad2_launch(1, fine, coarse, static_cast<float*>(ws), ws_bytes, B, H / 2, W / 2, Cfine, Ccoarse, db ? 1 : 0, st, &ns);
+        if (rc) return rc;
+        if (ns) return wgrad_finish(ws, dW, db, ns, O, I, I, mode, transposed, 0, scale, accumulate, st, ws_bytes);
+    }
     if (dtype == SGX_F32) rc = wgrad_ch<float, GDOWN, 64>(a, ws, ws_bytes, &ns, st);
     else if (dtype == SGX_BF16) rc = wgrad_use_tr() ? wgrad_ch<bf16_t, GDOWN, 64, true>(a, ws, ws_bytes, &ns, st) : wgrad_ch<bf16_t, GDOWN, 64>(a, ws, ws_bytes, &ns, st);
     else { SGX_REQUIRE(false, SGX_EINVAL, "wgrad4x4s2_param: bad dtype"); }

@@ -93,6 +93,39 @@ def test_conv_bf16_storage(mode, cin, cout, B, H):
     assert_close(m.weight.grad, w64.grad, 1e-4, "dW (bf16 operands, fp32 accumulate)")
 
 
+WGRAD2_CASES = [
+    # (mode, cin, cout, B, H): shapes sgx_wgrad2_plan accepts (64-multiple channels on the dy side, 32/64 on the x side, enough tiles)
+    ("plain", 64, 64, 4, 64), ("plain", 128, 64, 2, 64), ("plain", 64, 128, 4, 32), ("plain", 256, 256, 1, 64),
+    ("down", 32, 64, 2, 64), ("down", 64, 64, 2, 64), ("down", 64, 128, 2, 128), ("down", 128, 256, 1, 64),
+    ("up", 64, 64, 2, 32), ("up", 128, 32, 2, 32), ("up", 64, 64, 4, 16), ("up", 128, 64, 1, 64),
+]
+
+
+@pytest.mark.parametrize("mode,cin,cout,B,H", WGRAD2_CASES)
+def test_wgrad2_vs_oracle(mode, cin, cout, B, H):
+    """The second-generation bf16 weight-gradient kernels (32x32x16 MFMA, LDS-DMA staged, transpose reads; wgrad2.hip)
+    through the module surface: dW and db against the fp64 oracle on bf16-exact inputs (fp32 accumulation and output, so
+    the comparison is tight), and the launch really is the new kernel."""
+    from stylegan.pytorch_amd import functional as F, native
+    m = conv_module(cin, cout, upscale=(mode == "up"), downscale=(mode == "down"))
+    x = gu.seeded((B, cin, H, H), 7).bfloat16().float()
+    xg = F.nhwc(x.to(DEV)).bfloat16().requires_grad_(True)
+    y = m.forward_nhwc(xg)
+    w64 = m.weight.detach().double().cpu().requires_grad_(True)
+    b64 = m.bias.detach().double().cpu().requires_grad_(True)
+    y64 = O.eq_conv2d(x.double(), w64, b64, up=(mode == "up"), down=(mode == "down"))
+    gy = gu.seeded(y64.shape, 8).bfloat16().float()
+    native.prof_start(1)
+    y.backward(F.nhwc(gy.to(DEV)).bfloat16())
+    torch.cuda.synchronize()
+    native.prof_start(0)
+    names = [r[0] for r in native.prof_records()]
+    assert any("wgrad2_" in n for n in names), names
+    y64.backward(gy.double())
+    assert_close(m.weight.grad, w64.grad, 1e-4, "dW")
+    assert_close(m.bias.grad, b64.grad, 1e-4, "db")
+
+
 def test_lds_transpose_read_semantics():
     """ds_read_b64_tr_b16: lane i of a 16-lane group supplies row i/4, column block i%4 and receives column i."""
     from stylegan.pytorch_amd import native as N
@@ -352,7 +385,10 @@ def test_library_profiler_names_and_times_launches():
 
 @pytest.mark.parametrize("mode,H,cin,cout,dt", [("S", 64, 32, 64, torch.float32), ("D", 64, 32, 64, torch.float32),
                                                 ("S", 128, 16, 16, torch.bfloat16), ("D", 256, 16, 32, torch.bfloat16),
-                                                ("S", 8, 512, 512, torch.bfloat16)])
+                                                ("S", 8, 512, 512, torch.bfloat16),
+                                                # second-generation weight-gradient kernels (wgrad2.hip): bias sums from their MFMA-against-ones
+                                                ("S", 64, 64, 64, torch.bfloat16), ("S", 64, 128, 64, torch.bfloat16),
+                                                ("D", 64, 32, 64, torch.bfloat16), ("D", 128, 64, 128, torch.bfloat16)])
 def test_bias_gradient_fused_into_weight_gradient(mode, H, cin, cout, dt):
     """db comes out of the wgrad pass (MFMA against a tile of ones) and equals sum(gy) over batch and pixels."""
     from stylegan.pytorch_amd import functional as F, native
