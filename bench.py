@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--graphs", default="auto", choices=["auto", "on", "off"],
                     help="replay each half-iteration as captured hipGraphs (with data parallelism: two graphs around the eager all-reduce)")
+    ap.add_argument("--streams", default="auto", choices=["auto", "11", "01", "00"],
+                    help="extra streams of the step: auxiliary (fake branch) / side (weight gradients); auto = measured on this box")
     ap.add_argument("--layer-table", default=None, help="write a per-layer conv/wgrad timing table (TSV) to this path")
     return ap.parse_args()
 
@@ -173,7 +175,6 @@ def main():
                   g_opt_args=opt, d_opt_args=opt, loss="logistic", d_repeats=1, use_ema=True, ema_decay=0.999,
                   device=dev, act_dtype=act_dtype, data_parallel=dp,
                   use_graphs=(a.graphs != "off"))
-    graphs = sg.use_graphs
     sg.deferred_losses = True                                # losses are not read inside the timed loop: no per-half-step host wait
     sg.gen.train(); sg.dis.train(); sg.gen_shadow.train()
 
@@ -194,40 +195,55 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    calib = None
-    if graphs:                                               # setup, not warmup: two eager calls, then the capture
-        for i in range(3):
+    # Launch structure by measurement on THIS box (setup, not warmup).  Two knobs: hipGraph replay of each half-iteration
+    # vs stream launches, and the step's extra streams (fake branch of the D step on an auxiliary stream / weight gradients on
+    # a side stream).  Replay takes the host out of the loop but costs the ROCm runtime more per node; extra streams overlap
+    # the latency-bound low-resolution kernels but cost host time per fork -- which combination wins depends on whether this
+    # box's host keeps up with the GPU (measured on one box at batch 4: eager 19.7 ms with both streams (host-bound), 16.0
+    # with the side stream only, 16.3 with neither; replay 17.4).  Every candidate runs the same arithmetic (the parity tests
+    # pin graph vs eager and multi- vs single-stream); best of two interleaved 4-step rounds each.
+    def timed(n):
+        barrier(); torch.cuda.synchronize(); t = time.perf_counter()
+        for i in range(n):
             step(i)
-        graphs = sg.use_graphs                               # a failed capture falls back to eager for good
-        if world > 1:                                        # ... on every rank, or the calibration below would diverge
-            ok = torch.tensor([1.0 if graphs else 0.0], device=dev)
-            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
-            graphs = bool(ok.item() > 0.5)
-            sg.use_graphs = graphs
-    if graphs and a.graphs == "auto":
-        # Launch mode by measurement: hipGraph replay removes the host from the loop but costs the ROCm runtime more per
-        # node than stream launches do; which one wins depends on whether the host keeps up with the GPU.  4 steps each.
-        def timed(n):
-            barrier(); torch.cuda.synchronize(); t = time.perf_counter()
-            for i in range(n):
+        torch.cuda.synchronize(); barrier()
+        return (time.perf_counter() - t) / n * 1e3
+
+    def apply(c):
+        sg.use_graphs, sg.aux_stream, sg.param_stream = c
+
+    want_graphs = [False] if a.graphs == "off" else ([True] if a.graphs == "on" else [False, True])
+    streams = {"auto": [(True, True), (False, True), (False, False)], "11": [(True, True)], "01": [(False, True)], "00": [(False, False)]}[a.streams]
+    cands = [(g, ax, pr) for g in want_graphs for (ax, pr) in streams if not (g and (ax, pr) == (False, True))]
+    calib, best = {}, None
+    if len(cands) > 1:
+        times = {c: float("inf") for c in cands}
+        for c in cands:                                      # graphs: two eager calls, then the capture
+            apply(c)
+            for i in range(3 if c[0] else 1):
                 step(i)
-            torch.cuda.synchronize(); barrier()
-            return (time.perf_counter() - t) / n * 1e3
-        # two interleaved rounds, best of each: the eager step is host-bound, and one burst of host noise during a single
-        # 4-step measurement would pick the wrong mode for the whole run
-        t_eager = t_graph = float("inf")
+            if c[0] and not sg.use_graphs:                   # a failed capture falls back to eager for good: drop the candidate
+                times.pop(c)
         for _ in range(2):
-            sg.use_graphs = False
-            timed(1); t_eager = min(t_eager, timed(4))
-            sg.use_graphs = True
-            timed(1); t_graph = min(t_graph, timed(4))
-        if world > 1:                                        # one decision for all ranks
-            tt = torch.tensor([t_eager, t_graph], device=dev, dtype=torch.float64)
+            for c in list(times):
+                apply(c)
+                timed(1); times[c] = min(times[c], timed(4))
+        if world > 1:                                        # one decision for all ranks: the slowest rank's time per candidate
+            keys = sorted(times)
+            tt = torch.tensor([times[k] for k in keys], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            t_eager, t_graph = float(tt[0]), float(tt[1])
-        graphs = t_graph < t_eager
-        sg.use_graphs = graphs
-        calib = {"eager_ms_per_step": round(t_eager, 3), "graph_ms_per_step": round(t_graph, 3)}
+            times = {k: float(v) for k, v in zip(keys, tt)}
+        best = min(times, key=times.get)
+        calib = {("graph" if g else "eager") + f"_aux{int(ax)}_side{int(pr)}_ms_per_step": round(t, 3) for (g, ax, pr), t in sorted(times.items())}
+    else:
+        best = cands[0]
+        apply(best)
+        for i in range(3 if best[0] else 1):
+            step(i)
+        if best[0] and not sg.use_graphs:
+            best = (False,) + best[1:]
+    apply(best)
+    graphs = best[0]
     for i in range(a.warmup):
         step(i)
     # Roofline leg, part 1 (untimed): ONE surveyed step with the library's per-launch profiler on every kernel, to find
@@ -347,7 +363,8 @@ def main():
                                       f"alpha {a.alpha}, batch {B}/GPU, global batch {B * world}",
                           "global_batch": B * world, "parallelism": f"dp{world}"},
                "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
-               "hip_graphs": bool(graphs), "launch_mode_calibration": calib,
+               "hip_graphs": bool(graphs), "aux_stream": bool(sg.aux_stream), "side_stream": bool(sg.param_stream),
+               "launch_mode_calibration": calib or None,
                # useful-work convention: the reference step's algorithmic conv+GEMM FLOPs per image, whatever
                # the kernels execute; beside it the FLOPs the kernels really execute (one D(real) forward instead of two, no
                # D weight gradients in the G step, 4x4 stride-2 instead of 3x3 + pool) from their own per-launch notes

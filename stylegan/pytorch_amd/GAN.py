@@ -412,6 +412,12 @@ class StyleGAN:
         # data parallelism, with labels or with d_repeats != 1
         self.use_graphs = bool(use_graphs)
         self._step_graphs = {}
+        # Stream structure of a half-iteration (A/B and per-box calibration, bench.py): the fake branch of the D step on an
+        # auxiliary stream / the weight-gradient kernels on a side stream.  Extra streams buy GPU overlap of the latency-bound
+        # low-resolution kernels and cost host time per fork (measured on one box at batch 4, eager: 19.7 ms host-bound with
+        # both, 16.0 / 16.1 with one of them, 16.3 with neither; no effect at batch 32) -- which wins depends on the host.
+        self.aux_stream = os.environ.get("SGX_AUX_STREAM", "1") not in ("0", "")
+        self.param_stream = os.environ.get("SGX_PARAM_STREAM", "1") not in ("0", "")
         if self.device.type != "cuda":
             raise RuntimeError("stylegan.pytorch_amd runs on MI355X only: device must be a cuda (ROCm) device; the "
                                "reference's CPU path is the oracle, not a fallback of this package")
@@ -502,8 +508,7 @@ class StyleGAN:
 
     def _aux_stream(self):
         """Second compute stream for work that is independent of the main chain (the D-step generator forward)."""
-        import os
-        if os.environ.get("SGX_AUX_STREAM", "1") in ("0", ""):            # A/B switch (profiling)
+        if not self.aux_stream:
             return None
         st = self.__dict__.get("_aux_compute_stream")
         if st is None:
@@ -518,8 +523,7 @@ class StyleGAN:
     def _param_stream(self, two_branches=False):
         """Side stream for the weight-gradient kernels (one per StyleGAN; they serialise among themselves, which is what
         makes accumulating into ``.grad`` from the two branches of the D step safe)."""
-        import os
-        if os.environ.get("SGX_PARAM_STREAM", "1") in ("0", ""):          # A/B switch (profiling)
+        if not self.param_stream:
             # With two backward branches (D step: fake on the auxiliary stream, real on the main one) the accumulating
             # launches of BOTH must still share one stream: the main stream itself (only the fake branch forks to it).
             return torch.cuda.current_stream() if two_branches else None
@@ -682,7 +686,8 @@ class StyleGAN:
 
     def _graphed(self, kind, noise, real_batch, depth, alpha):
         self._wait_update("d"); self._wait_update("g")          # leftovers of eager calls (the graphs update in line)
-        key = (kind, int(depth), tuple(noise.shape), tuple(real_batch.shape), tuple(real_batch.stride()), real_batch.dtype)
+        key = (kind, int(depth), tuple(noise.shape), tuple(real_batch.shape), tuple(real_batch.stride()), real_batch.dtype,
+               self.aux_stream, self.param_stream)                     # a captured graph bakes its stream structure in
         g = self._step_graphs.get(key)
         if g is None:
             g = self._step_graphs[key] = _StepGraph(self, kind, depth)
