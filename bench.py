@@ -37,8 +37,8 @@ HBM_PEAK = 8e12                                 # HBM3E bytes/s, same guide
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="ffhq1024", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch-per-gpu", type=int, default=4)
@@ -203,11 +203,13 @@ def main():
     # with the side stream only, 16.3 with neither; replay 17.4).  Every candidate runs the same arithmetic (the parity tests
     # pin graph vs eager and multi- vs single-stream); best of two interleaved 4-step rounds each.
     def timed(n):
+        """-> (ms per step, host enqueue ms per step)"""
         barrier(); torch.cuda.synchronize(); t = time.perf_counter()
         for i in range(n):
             step(i)
+        t_host = time.perf_counter() - t
         torch.cuda.synchronize(); barrier()
-        return (time.perf_counter() - t) / n * 1e3
+        return (time.perf_counter() - t) / n * 1e3, t_host / n * 1e3
 
     def apply(c):
         sg.use_graphs, sg.aux_stream, sg.param_stream = c
@@ -215,9 +217,13 @@ def main():
     want_graphs = [False] if a.graphs == "off" else ([True] if a.graphs == "on" else [False, True])
     streams = {"auto": [(True, True), (False, True), (False, False)], "11": [(True, True)], "01": [(False, True)], "00": [(False, False)]}[a.streams]
     cands = [(g, ax, pr) for g in want_graphs for (ax, pr) in streams if not (g and (ax, pr) == (False, True))]
+    HOST_MARGIN = 1.10        # a mode whose host enqueue time is within 10 % of its step time is one host hiccup away from
+    #                           being host-bound for the whole timed region (seen: 16.6 ms calibrated, 20.1 ms timed): it is
+    #                           ranked by max(step time, 1.1 x host time), so replay / leaner stream structures win ties
     calib, best = {}, None
     if len(cands) > 1:
         times = {c: float("inf") for c in cands}
+        hosts = {c: float("inf") for c in cands}
         for c in cands:                                      # graphs: two eager calls, then the capture
             apply(c)
             for i in range(3 if c[0] else 1):
@@ -227,14 +233,19 @@ def main():
         for _ in range(2):
             for c in list(times):
                 apply(c)
-                timed(1); times[c] = min(times[c], timed(4))
+                timed(1)
+                t, h = timed(4)
+                if t < times[c]:
+                    times[c], hosts[c] = t, h
         if world > 1:                                        # one decision for all ranks: the slowest rank's time per candidate
             keys = sorted(times)
-            tt = torch.tensor([times[k] for k in keys], device=dev, dtype=torch.float64)
+            tt = torch.tensor([times[k] for k in keys] + [hosts[k] for k in keys], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            times = {k: float(v) for k, v in zip(keys, tt)}
-        best = min(times, key=times.get)
-        calib = {("graph" if g else "eager") + f"_aux{int(ax)}_side{int(pr)}_ms_per_step": round(t, 3) for (g, ax, pr), t in sorted(times.items())}
+            times = {k: float(v) for k, v in zip(keys, tt[:len(keys)])}
+            hosts = {k: float(v) for k, v in zip(keys, tt[len(keys):])}
+        best = min(times, key=lambda c: max(times[c], HOST_MARGIN * hosts[c]))
+        calib = {("graph" if g else "eager") + f"_aux{int(ax)}_side{int(pr)}": {"ms_per_step": round(t, 3), "host_ms_per_step": round(hosts[(g, ax, pr)], 3)}
+                 for (g, ax, pr), t in sorted(times.items())}
     else:
         best = cands[0]
         apply(best)
@@ -267,6 +278,8 @@ def main():
         dom_name, (dom_ms, dom_n, dom_idx) = max(agg.items(), key=lambda kv: kv[1][0])
         if not graphs:
             native.prof_start(2, dom_idx)
+    import gc
+    gc.collect(); gc.disable()                              # no collector pause inside the timed region
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -274,6 +287,7 @@ def main():
     t_enq = time.perf_counter() - t0                        # host time to enqueue the region (launch-bound if ~= dt)
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

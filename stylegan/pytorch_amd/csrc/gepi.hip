@@ -9,17 +9,20 @@
 
 #define GEPI_EPS 1e-5f
 #define GEPI_ROWS_PER_THREAD 64
+#ifndef GEPI_MIN_BLOCKS
+#define GEPI_MIN_BLOCKS 2048       // ~8 blocks per CU: the read-only reduction passes need that many loads in flight (512: 2.6 TB/s)
+#endif
 
 struct GepiGeom { int cvt, rows, chunk, nchunk; };
-// Rows per thread: 64 for the big layers (few partials), fewer for the small ones so that a launch still has ~1024
-// blocks (a 4x4..64x64 layer with 64 rows per thread is a handful of blocks walking a long serial loop).
+// Rows per thread: 64 for the big layers (few partials), fewer for the small ones so that a launch still has
+// GEPI_MIN_BLOCKS blocks (a 4x4..64x64 layer with 64 rows per thread is a handful of blocks walking a long serial loop).
 static GepiGeom gepi_geom(int B, int HW, int C, int ve) {
     GepiGeom g;
     int cv = C / ve;
     g.cvt = cv < 256 ? cv : 256;
     g.rows = 256 / g.cvt;
     int rpt = GEPI_ROWS_PER_THREAD;
-    while (rpt > 8 && (long)B * ((HW + g.rows * rpt - 1) / (g.rows * rpt)) < 512) rpt >>= 1;
+    while (rpt > 8 && (long)B * ((HW + g.rows * rpt - 1) / (g.rows * rpt)) < GEPI_MIN_BLOCKS) rpt >>= 1;
     g.chunk = g.rows * rpt;
     g.nchunk = (HW + g.chunk - 1) / g.chunk;
     return g;
@@ -125,17 +128,19 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
 #pragma unroll
         for (int j = 0; j < VE; ++j) { sh[threadIdx.x * 2 * VE + j] = (double)s0[j]; sh[threadIdx.x * 2 * VE + VE + j] = (double)s1[j]; }
         __syncthreads();
+        // fixed-order binary tree over the pixel rows of the block (rows is a power of two): log2(rows) parallel steps
+        // instead of one thread per channel vector walking all rows (a 128-step serial tail per block for C = 16)
+        for (int st = rows >> 1; st > 0; st >>= 1) {
+            if (tr < st) {
+#pragma unroll
+                for (int j = 0; j < 2 * VE; ++j) sh[threadIdx.x * 2 * VE + j] += sh[(threadIdx.x + st * cvt) * 2 * VE + j];
+            }
+            __syncthreads();
+        }
         if (tr == 0) {
             double* o = part + (((size_t)b * gridDim.x + ch) * C + c0) * 2;
 #pragma unroll
-            for (int j = 0; j < VE; ++j) {
-                double a0 = 0.0, a1 = 0.0;
-                for (int r = 0; r < rows; ++r) {
-                    a0 += sh[(r * cvt + tc) * 2 * VE + j];
-                    a1 += sh[(r * cvt + tc) * 2 * VE + VE + j];
-                }
-                o[j * 2] = a0; o[j * 2 + 1] = a1;
-            }
+            for (int j = 0; j < VE; ++j) { o[j * 2] = sh[tc * 2 * VE + j]; o[j * 2 + 1] = sh[tc * 2 * VE + VE + j]; }
         }
         __syncthreads();
     }
