@@ -10,7 +10,7 @@
 #define GEPI_EPS 1e-5f
 #define GEPI_ROWS_PER_THREAD 64
 #ifndef GEPI_MIN_BLOCKS
-#define GEPI_MIN_BLOCKS 2048       // ~8 blocks per CU: the read-only reduction passes need that many loads in flight (512: 2.6 TB/s)
+#define GEPI_MIN_BLOCKS 512        // (2048 blocks were tried for the read-only reduction passes: the per-block reduction tail costs more than the extra loads in flight gain)
 #endif
 
 struct GepiGeom { int cvt, rows, chunk, nchunk; };
@@ -88,7 +88,10 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
             for (int j = 0; j < VE; ++j) { k1[j] = kk[2 * j]; k2[j] = kk[2 * j + 1]; }
         }
         if (tr < rows) {
-#pragma unroll 4
+            // loads in flight per lane: 8 rows for the read-only statistics pass (2 blocks per CU: it is latency-bound, 2.6 ->
+            // 3.2 TB/s); 4 for the two-tensor passes (8 costs them the second wave per SIMD: 284 VGPRs, measured 2x slower)
+            constexpr int UNR = MODE == 0 ? 8 : 4;
+#pragma unroll UNR
             for (int p = p0 + tr; p < p1; p += rows) {
                 const size_t off = (((size_t)b * HW + p) * cv + v) * VE;
                 const float nz = noise[(size_t)b * HW + p];
@@ -128,19 +131,35 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
 #pragma unroll
         for (int j = 0; j < VE; ++j) { sh[threadIdx.x * 2 * VE + j] = (double)s0[j]; sh[threadIdx.x * 2 * VE + VE + j] = (double)s1[j]; }
         __syncthreads();
-        // fixed-order binary tree over the pixel rows of the block (rows is a power of two): log2(rows) parallel steps
-        // instead of one thread per channel vector walking all rows (a 128-step serial tail per block for C = 16)
-        for (int st = rows >> 1; st > 0; st >>= 1) {
-            if (tr < st) {
+        // Sum over the block's pixel rows in a fixed order.  NO = outputs of the block (channel vectors x 2*VE sums).  Few
+        // channels (C = 16: 32 outputs, 128 rows): every thread sums one output over a slice of 2*VE rows, then the first NO
+        // threads add the 256/NO slices -- instead of `cvt` threads walking all rows while 250 idle.  Many channels: one
+        // thread per channel vector walks the (few) rows.
+        const int NO = cvt * 2 * VE;
+        if (NO < 256 && rows > 1) {
+            const int o = threadIdx.x % NO, slice = threadIdx.x / NO, otc = o / (2 * VE), oj = o % (2 * VE);
+            double acc = 0.0;
 #pragma unroll
-                for (int j = 0; j < 2 * VE; ++j) sh[threadIdx.x * 2 * VE + j] += sh[(threadIdx.x + st * cvt) * 2 * VE + j];
-            }
+            for (int r = 0; r < 2 * VE; ++r) acc += sh[((slice * 2 * VE + r) * cvt + otc) * 2 * VE + oj];
+            __syncthreads();                                         // every read of the per-thread sums is done
+            sh[threadIdx.x] = acc;                                   // [slice][output]
             __syncthreads();
-        }
-        if (tr == 0) {
+            if ((int)threadIdx.x < NO) {
+                double a = 0.0;
+                for (int sl = 0; sl < 256 / NO; ++sl) a += sh[sl * NO + threadIdx.x];
+                part[(((size_t)b * gridDim.x + ch) * C + (size_t)(vb + otc) * VE + (oj % VE)) * 2 + (oj / VE)] = a;
+            }
+        } else if (tr == 0) {
             double* o = part + (((size_t)b * gridDim.x + ch) * C + c0) * 2;
 #pragma unroll
-            for (int j = 0; j < VE; ++j) { o[j * 2] = sh[tc * 2 * VE + j]; o[j * 2 + 1] = sh[tc * 2 * VE + VE + j]; }
+            for (int j = 0; j < VE; ++j) {
+                double a0 = 0.0, a1 = 0.0;
+                for (int r = 0; r < rows; ++r) {
+                    a0 += sh[(r * cvt + tc) * 2 * VE + j];
+                    a1 += sh[(r * cvt + tc) * 2 * VE + VE + j];
+                }
+                o[j * 2] = a0; o[j * 2 + 1] = a1;
+            }
         }
         __syncthreads();
     }
