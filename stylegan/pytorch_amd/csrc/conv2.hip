@@ -352,7 +352,7 @@ int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void
     *launched = 0;
     if (variant < 0 && !((on >> geo) & 1)) return 0;
     const int gw = geo == C2_D ? W / 2 : W, gh = geo == C2_D ? H / 2 : H;
-    const int bco = geo == C2_S ? 64 : 32;
+    const int bco = (geo == C2_S && Cout % 64 == 0) ? 64 : 32;       // (3x3 with 32 output channels: the MF = 1 block)
     if (Cin % 32 != 0 || Cout % bco != 0 || gw % 32 != 0 || Cout / bco > 32 || gh < 1 || (geo == C2_D && ((H | W) & 1))) return 0;
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), B, H, W,
                 geo == C2_D ? H / 2 : (geo == C2_U ? 2 * H : H), geo == C2_D ? W / 2 : (geo == C2_U ? 2 * W : W), Cin, Cout, act, 0, 0, 0, 0, 0};
@@ -366,7 +366,10 @@ int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void
     if (variant < 0 && !force_nw && blocks4 < conv2_ncu()) return 0;
     const int nw = variant > 0 ? variant : (force_nw ? force_nw : (blocks8 >= conv2_ncu() ? 8 : 4));
     *launched = 1;
-    if (geo == C2_S) return nw == 8 ? launch_conv2<C2_S, 8, 2>(a, st) : launch_conv2<C2_S, 4, 2>(a, st);
+    if (geo == C2_S) {
+        if (mf2) return nw == 8 ? launch_conv2<C2_S, 8, 2>(a, st) : launch_conv2<C2_S, 4, 2>(a, st);
+        return nw == 8 ? launch_conv2<C2_S, 8, 1>(a, st) : launch_conv2<C2_S, 4, 1>(a, st);
+    }
     if (geo == C2_D) {
         if (mf2) return nw == 8 ? launch_conv2<C2_D, 8, 2>(a, st) : launch_conv2<C2_D, 4, 2>(a, st);
         return nw == 8 ? launch_conv2<C2_D, 8, 1>(a, st) : launch_conv2<C2_D, 4, 1>(a, st);

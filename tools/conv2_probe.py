@@ -15,7 +15,7 @@ from stylegan.pytorch_amd import functional as F  # noqa: E402
 from stylegan.pytorch_amd import native as N  # noqa: E402
 
 SHAPES = [  # (geo, H (input), Cin, Cout)
-    ("S", 256, 64, 64), ("S", 128, 128, 128), ("S", 64, 256, 256), ("S", 32, 512, 512), ("S", 512, 32, 64),
+    ("S", 512, 32, 32), ("S", 256, 64, 64), ("S", 128, 128, 128), ("S", 64, 256, 256), ("S", 32, 512, 512), ("S", 512, 32, 64),
     ("D", 512, 32, 64), ("D", 256, 64, 128), ("D", 128, 128, 256), ("D", 64, 256, 512), ("D", 512, 32, 32),
     ("U", 256, 64, 32), ("U", 128, 128, 64), ("U", 64, 256, 128), ("U", 32, 512, 256), ("U", 256, 32, 32),
 ]
