@@ -377,9 +377,13 @@ int sgx_wgrad2_plan(int geo, int B, int H, int W, int Ck, int Cn, int* nct_n, in
     *nct_n = Cn / 64; *nct_k = Ck / kt;
     *ntiles = B * (H / th) * (W / tw);
     const int nct = *nct_n * *nct_k;
-    if (nct > wg2_max_ct()) return 0;              // big weights at low resolution: partial traffic would exceed the operands'
+    if (nct > 2 * wg2_max_ct()) return 0;
     int ns = wg2_ncu() / nct / 8 * 8;              // ~ one block per CU, a multiple of 8 (one split per XCD slot)
     if (ns < 8) ns = 8;
+    // big weights at low resolution (512 x 512 channels: 64 tiles, 9-17 MB of partials per split): only when every block
+    // walks >= 8 pixel tiles, i.e. the operand traffic outweighs the partials (probe at 32^2: batch 32 255 -> 160 us and
+    // 166 -> 107 us, batch 4 no gain / 31 -> 57 us: there the first generation's single-split no-partials path stays)
+    if (nct > wg2_max_ct() && *ntiles < 8 * ns) return 0;
     if (*ntiles < 2 * ns) ns = *ntiles / 2 / 8 * 8;  // small problems: fewer splits, every block still pipelines >= 2 tiles
     return ns >= 8 ? ns : 0;                        // too few pixel tiles: first generation
 }
