@@ -98,6 +98,7 @@ WGRAD2_CASES = [
     ("plain", 64, 64, 4, 64), ("plain", 128, 64, 2, 64), ("plain", 64, 128, 4, 32), ("plain", 256, 256, 1, 64),
     ("down", 32, 64, 2, 64), ("down", 64, 64, 2, 64), ("down", 64, 128, 2, 128), ("down", 128, 256, 1, 64),
     ("up", 64, 64, 2, 32), ("up", 128, 32, 2, 32), ("up", 64, 64, 4, 16), ("up", 128, 64, 1, 64),
+    ("plain", 320, 512, 16, 32), ("down", 512, 512, 16, 32),        # > 32 channel tiles: taken when a block walks >= 8 pixel tiles
 ]
 
 
