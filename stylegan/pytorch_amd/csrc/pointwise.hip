@@ -144,12 +144,12 @@ extern "C" int sgx_axpby_dev(const void* a, const void* b, void* out, const floa
 // MODE 0: y = blur(x)            1: y = blur(lrelu(x))            2: y = blur(x) * slope(z)            3: y = blur(x * slope(z))
 // 1..3 are the forward, backward and double-backward of "LeakyReLU then blur" (discriminator block: conv0 -> act -> blur)
 // with the activation folded into the blur pass: no separate activation-backward pass over the tensor.
-template <typename T, int MODE>
+template <typename T, int MODE, int ROWS = BLUR_ROWS>
 __global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, const T* __restrict__ z, T* __restrict__ y, int B, int H,
                                                       int W, int C) {
     constexpr int VE = VecTraits<T>::VE;
     const int cv = C / VE;
-    const int strips = (H + BLUR_ROWS - 1) / BLUR_ROWS;
+    const int strips = (H + ROWS - 1) / ROWS;
     const size_t nthr = (size_t)B * strips * W * cv;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nthr; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % cv);
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, c
         const int w = (int)(p % W); p /= W;
         const int sidx = (int)(p % strips);
         const int b = (int)(p / strips);
-        const int h0 = sidx * BLUR_ROWS;
+        const int h0 = sidx * ROWS;
         const bool hasl = w > 0, hasr = w + 1 < W;
         const size_t col = (((size_t)b * H * W + w) * cv + c) * VE;          // (b, row 0, w, c)
         const size_t rstride = (size_t)W * cv * VE;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, c
 #pragma unroll
         for (int j = 0; j < VE; ++j) { ha[j] = 0.f; hb[j] = 0.f; }
 #pragma unroll
-        for (int k = 0; k < BLUR_ROWS + 2; ++k) {
+        for (int k = 0; k < ROWS + 2; ++k) {
             const int r = h0 - 1 + k;                                         // input row
             if ((unsigned)r < (unsigned)H) {
                 const size_t src = col + (size_t)r * rstride;
@@ -212,17 +212,26 @@ __global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, c
         }
     }
 }
-template <typename T>
-static void blur_launch(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, hipStream_t st) {
+template <typename T, int ROWS>
+static void blur_launch_rows(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, hipStream_t st) {
     constexpr int VE = VecTraits<T>::VE;
-    const dim3 grid(grid_for((size_t)B * ((H + BLUR_ROWS - 1) / BLUR_ROWS) * W * C / VE)), block(256);
+    const dim3 grid(grid_for((size_t)B * ((H + ROWS - 1) / ROWS) * W * C / VE)), block(256);
     const T* xp = (const T*)x; const T* zp = (const T*)z; T* yp = (T*)y;
     switch (mode) {
-        case 0: hipLaunchKernelGGL((blur3x3_kernel<T, 0>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
-        case 1: hipLaunchKernelGGL((blur3x3_kernel<T, 1>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
-        case 2: hipLaunchKernelGGL((blur3x3_kernel<T, 2>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
-        default: hipLaunchKernelGGL((blur3x3_kernel<T, 3>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        case 0: hipLaunchKernelGGL((blur3x3_kernel<T, 0, ROWS>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        case 1: hipLaunchKernelGGL((blur3x3_kernel<T, 1, ROWS>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        case 2: hipLaunchKernelGGL((blur3x3_kernel<T, 2, ROWS>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        default: hipLaunchKernelGGL((blur3x3_kernel<T, 3, ROWS>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
     }
+}
+// 8-row strips amortise the vertical halo (3.75 loads per output vector) where the tensor streams from HBM; a small tensor
+// (4x4 .. 64x64 at batch 4: a few MB, L2 resident) with 8-row strips is a hundred blocks each walking a 10-row dependent
+// chain -- 16-20 us for 2 MB.  There 2-row strips give 4x the lanes and a 4-row chain.
+template <typename T>
+static void blur_launch(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, hipStream_t st) {
+    const size_t lanes8 = (size_t)B * ((H + BLUR_ROWS - 1) / BLUR_ROWS) * W * C / VecTraits<T>::VE;
+    if (lanes8 < (size_t)256 * 512) blur_launch_rows<T, 2>(x, z, y, B, H, W, C, mode, st);
+    else blur_launch_rows<T, BLUR_ROWS>(x, z, y, B, H, W, C, mode, st);
 }
 extern "C" int sgx_blur3x3_act(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
