@@ -29,6 +29,20 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : SGX_LRELU * v; }
 __device__ __forceinline__ float lrelu_slope(float out_or_in) { return out_or_in > 0.f ? 1.f : SGX_LRELU; }
+// 8 packed bf16 times the LeakyReLU slope selected by 8 packed bf16 of the activation's output: exactly the arithmetic of
+// sgx_lrelu_bwd on the stored tensor (bf16 -> fp32, multiply, round to nearest even), so fusing it into a producer's store
+// leaves every bit unchanged
+__device__ __forceinline__ uint4 lrelu_mask_bf16x8(uint4 v, uint4 m) {
+    unsigned vv[4] = {v.x, v.y, v.z, v.w};
+    const unsigned mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = __uint_as_float(vv[i] << 16) * lrelu_slope(__uint_as_float(mm[i] << 16));
+        const float hi = __uint_as_float(vv[i] & 0xffff0000u) * lrelu_slope(__uint_as_float(mm[i] & 0xffff0000u));
+        vv[i] = pack_bf16x2(lo, hi);
+    }
+    return make_uint4(vv[0], vv[1], vv[2], vv[3]);
+}
 // SGX_ACT_NONE / SGX_ACT_LRELU / SGX_ACT_RELU (the reference's 'lrelu' | 'relu' nonlinearity, models/GAN.py:67-68)
 __device__ __forceinline__ float act_apply(float v, int act) {
     return (act == SGX_ACT_NONE || v > 0.f) ? v : (act == SGX_ACT_RELU ? 0.f : SGX_LRELU * v);

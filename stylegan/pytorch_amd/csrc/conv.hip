@@ -26,7 +26,7 @@ int sgx_wgrad2_plan(int geo, int B, int H, int W, int Ck, int Cn, int* nct_n, in
 int sgx_wgrad2_launch(int geo, const void* kside, const void* nside, float* ws, size_t ws_bytes, int B, int H, int W, int Ck, int Cn,
                       int want_bias, hipStream_t st, int* nsplit_out);
 int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
-                  int variant, hipStream_t st, int* launched);        // conv2.hip   // GUPA: GUP with all four parity classes in one block (bf16)
+                  const void* mask, int variant, hipStream_t st, int* launched);        // conv2.hip   // GUPA: GUP with all four parity classes in one block (bf16)
 
 // LDS operand tiles are arrays of rows (one pixel, or one (tap, output channel) weight row) holding KC channels.
 // rowb_*: row pitch in bytes; load(): the lane's MFMA fragment (k = kk-step, q = lane>>4); lstore(): one 16-byte chunk.
@@ -104,6 +104,7 @@ template <> struct Frag<bf16_t, 16> {
 struct ConvArgs {
     const void* x; const void* w; const float* bias; void* y;
     int B, H, W, OH, OW, OHc, OWc, Cin, Cout, act, tiles_x, tiles_y, ntiles;
+    const void* mask;   // 3x3 only: y *= slope(mask) in the store (mask: a tensor shaped like y; the activation-backward of the layer below)
     int dbg;   // ablation switches (SGX_CONV_DBG, profiling only): 1 no MFMA, 2 no global loads, 4 no LDS stores, 8 no output stores
 };
 
@@ -389,8 +390,10 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
             const int b = c_img0 + il, oyc = c_ty0 + r, oxc = c_tx0 + c;
             if (b >= a.B || oyc >= a.OHc || oxc >= a.OWc) continue;
             const int oy = (GEO == GUP) ? 2 * oyc + py : oyc, ox = (GEO == GUP) ? 2 * oxc + px : oxc;
-            T* dst = yg + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8;
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(smem + m * OROW + v * 16);
+            const size_t doff = (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8;
+            uint4 val = *reinterpret_cast<const uint4*>(smem + m * OROW + v * 16);
+            if (GEO == G3X3 && a.mask) val = lrelu_mask_bf16x8(val, *reinterpret_cast<const uint4*>(static_cast<const T*>(a.mask) + doff));
+            *reinterpret_cast<uint4*>(yg + doff) = val;
         }
     } else
 #pragma unroll
@@ -413,11 +416,20 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
                 for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i]);
             }
             if (sizeof(T) == 4) {
+                if (GEO == G3X3 && a.mask) {
+                    const float4 mv = *reinterpret_cast<const float4*>(static_cast<const float*>(a.mask) + (dst - yg) + ct * 16);
+                    v[0] *= lrelu_slope(mv.x); v[1] *= lrelu_slope(mv.y); v[2] *= lrelu_slope(mv.z); v[3] *= lrelu_slope(mv.w);
+                }
                 *reinterpret_cast<float4*>(dst + ct * 16) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 uint2 o;
                 o.x = pack_bf16x2(v[0], v[1]);
                 o.y = pack_bf16x2(v[2], v[3]);
+                if (GEO == G3X3 && a.mask) {                               // on the ROUNDED value, as the separate pass would
+                    const uint2 mv = *reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(a.mask) + (dst - yg) + ct * 16);
+                    const uint4 r = lrelu_mask_bf16x8(make_uint4(o.x, o.y, 0u, 0u), make_uint4(mv.x, mv.y, 0u, 0u));
+                    o.x = r.x; o.y = r.y;
+                }
                 *reinterpret_cast<uint2*>(dst + ct * 16) = o;
             }
         }
@@ -582,13 +594,13 @@ extern "C" int sgx_conv_config(int geo, int B, int H, int W, int Cin, int Cout, 
 }
 
 extern "C" int sgx_conv3x3(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin,
-                           int Cout, int act, int dtype, void* stream) {
-    ConvArgs a{x, w, bias, y, B, H, W, H, W, H, W, Cin, Cout, act, 0, 0};
+                           int Cout, int act, const void* mask, int dtype, void* stream) {
+    ConvArgs a{x, w, bias, y, B, H, W, H, W, H, W, Cin, Cout, act, 0, 0, 0, mask};
     const double es = dtype == SGX_F32 ? 4 : 2;
     SGX_NOTE(2.0 * 9 * Cin * Cout * B * H * W, es * ((double)B * H * W * (Cin + Cout) + 9.0 * Cin * Cout), "convS B%d %dx%d %d->%d", B, H, W, Cin, Cout);
     if (dtype == SGX_BF16) {                                   // second-generation kernel (conv2.hip) where it applies
         int launched = 0;
-        const int rc = sgx_conv2_try(G3X3, x, w, bias, y, B, H, W, Cin, Cout, act, -1, (hipStream_t)stream, &launched);
+        const int rc = sgx_conv2_try(G3X3, x, w, bias, y, B, H, W, Cin, Cout, act, mask, -1, (hipStream_t)stream, &launched);
         if (rc || launched) return rc;
     }
     return dispatch_conv<G3X3>(a, dtype, (hipStream_t)stream);
@@ -602,7 +614,7 @@ extern "C" int sgx_conv4x4s2_down(const void* x, const void* w, const float* bia
     SGX_NOTE(2.0 * 16 * Cin * Cout * B * (H / 2) * (W / 2), es * ((double)B * H * W * (Cin + Cout / 4.0) + 16.0 * Cin * Cout), "convD B%d %dx%d %d->%d", B, H, W, Cin, Cout);
     if (dtype == SGX_BF16) {
         int launched = 0;
-        const int rc = sgx_conv2_try(GDOWN, x, w, bias, y, B, H, W, Cin, Cout, act, -1, (hipStream_t)stream, &launched);
+        const int rc = sgx_conv2_try(GDOWN, x, w, bias, y, B, H, W, Cin, Cout, act, nullptr, -1, (hipStream_t)stream, &launched);
         if (rc || launched) return rc;
     }
     return dispatch_conv<GDOWN>(a, dtype, (hipStream_t)stream);
@@ -615,7 +627,7 @@ extern "C" int sgx_conv4x4s2_up(const void* x, const void* w, void* y, int B, in
     SGX_NOTE(2.0 * 16 * Cin * Cout * B * H * W, es * ((double)B * H * W * (Cin + 4.0 * Cout) + 16.0 * Cin * Cout), "convU B%d %dx%d %d->%d", B, H, W, Cin, Cout);
     if (dtype == SGX_BF16) {
         int launched = 0;
-        const int rc = sgx_conv2_try(GUP, x, w, nullptr, y, B, H, W, Cin, Cout, SGX_ACT_NONE, -1, (hipStream_t)stream, &launched);
+        const int rc = sgx_conv2_try(GUP, x, w, nullptr, y, B, H, W, Cin, Cout, SGX_ACT_NONE, nullptr, -1, (hipStream_t)stream, &launched);
         if (rc || launched) return rc;
     }
     return dispatch_conv<GUP>(a, dtype, (hipStream_t)stream);
@@ -637,7 +649,7 @@ extern "C" int sgx_conv_variant(int geo, const void* x, const void* w, const flo
     }
     SGX_REQUIRE(dtype == SGX_BF16 && (variant == 4 || variant == 8), SGX_EINVAL, "conv_variant: variant %d needs bf16 and 4 or 8 waves", variant);
     int launched = 0;
-    const int rc = sgx_conv2_try(geo, x, w, bias, y, B, H, W, Cin, Cout, act, variant, (hipStream_t)stream, &launched);
+    const int rc = sgx_conv2_try(geo, x, w, bias, y, B, H, W, Cin, Cout, act, nullptr, variant, (hipStream_t)stream, &launched);
     SGX_REQUIRE(rc || launched, SGX_EUNSUPPORTED, "conv_variant: shape not covered by the second-generation kernel");
     return rc;
 }
