@@ -56,9 +56,13 @@ int sgx_prof_get(int i, char* name, int name_cap, float* ms, double* flops, doub
  *
  * sgx_conv3x3: EqualizedConv2d plain path, F.conv2d(x, W*w_mul, b, padding=1) -- models/CustomLayers.py:170-171;
  *   also its data gradient (call with the flipped/transposed pack).
- *   y[b,h,w,n] = act(bias[n] + sum_{ty,tx,k} x[b,h+ty-1,w+tx-1,k] * w[ty*3+tx][n][k])                              */
+ *   y[b,h,w,n] = act(bias[n] + sum_{ty,tx,k} x[b,h+ty-1,w+tx-1,k] * w[ty*3+tx][n][k])
+ *   mask (may be NULL; a tensor shaped and typed like y): y *= (mask > 0 ? 1 : 0.2) in the store.  As a DATA-GRADIENT launch
+ *   of a layer whose input is the LeakyReLU output of the layer below (DiscriminatorBlock conv0 after the previous block's
+ *   conv1_down + act, models/Blocks.py:140-146), that is the activation's autograd applied where the gradient is produced
+ *   instead of in a pass of its own; bit-identical to sgx_lrelu_bwd on the stored result.                              */
 int sgx_conv3x3(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
-                int act, int dtype, void* stream);
+                int act, const void* mask, int dtype, void* stream);
 /* sgx_conv4x4s2_down: fused conv+downscale, F.conv2d(x, W4, stride=2, padding=1) -- models/CustomLayers.py:158-165
  *   (== conv3x3 -> avg_pool2 of :166-168); also the data gradient of sgx_conv4x4s2_up.
  *   H,W = input size.  y[b,oy,ox,n] = act(bias[n] + sum_{ky,kx,k} x[b,2oy+ky-1,2ox+kx-1,k] * w[ky*4+kx][n][k])    */
@@ -125,9 +129,11 @@ int sgx_wgrad4x4s2_param(const void* fine, const void* coarse, float* dW, float*
  *   bscale = the layer's b_mul (lrmul; 0.01 in the mapping network, models/CustomLayers.py:94-95,101-102)           */
 int sgx_bias_act(const void* x, const float* bias, float bscale, void* y, size_t npix, int C, int act, int dtype,
                  void* stream);
-/* dx = dy * (y > 0 ? 1 : slope)             autograd of nn.LeakyReLU(0.2) (slope 0.2) / torch.relu (slope 0); y is the
- * activation OUTPUT                                                                                                  */
-int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, float slope, int dtype, void* stream);
+/* dx = scale * dy * (y > 0 ? 1 : slope)     autograd of nn.LeakyReLU(0.2) (slope 0.2) / torch.relu (slope 0); y is the
+ * activation OUTPUT.  scale (1 = none; scale_dev != NULL: read from device memory instead) folds the fade-in coefficient of
+ * the branch the activation sits on (x = alpha*straight + (1-alpha)*residual, models/GAN.py:427) into the same pass    */
+int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, float slope, float scale, const float* scale_dev, int dtype,
+                  void* stream);
 /* out = alpha*a + beta*b (b may be NULL)    fade-in lerp: models/GAN.py:202,427,586                                 */
 int sgx_axpby(const void* a, const void* b, void* out, float alpha, float beta, size_t n, int dtype, void* stream);
 /* same with the coefficients read from device memory (alpha_dev[0], beta_dev[0]): the fade-in alpha changes every

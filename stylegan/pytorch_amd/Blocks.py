@@ -131,14 +131,20 @@ class DiscriminatorBlock(nn.Module):
         self.act1 = activation_layer
         self._act = act_code(activation_layer)
 
-    def forward_nhwc(self, x):
-        z = self.conv0.forward_nhwc(x, act=ACT_NONE)                      # bias fused in the conv store; pre-activation
+    def forward_nhwc(self, x, x_masked=False, defer_out=False):
+        """``x_masked``: x is the previous block's LeakyReLU output whose activation backward was deferred to this block
+        (conv0's data gradient leaves its kernel already masked); ``defer_out``: this block's final activation backward is
+        applied by the consumer of its output (the next block, or the fade-in lerp).  Set by Discriminator.forward for the
+        LeakyReLU networks: one elementwise pass less per block and backward."""
+        x_masked = x_masked and self._act == ACT_LRELU
+        defer_out = defer_out and self._act == ACT_LRELU
+        z = self.conv0.forward_nhwc(x, act=ACT_NONE, x_masked=x_masked)   # bias fused in the conv store; pre-activation
         if self.blur._is_121 and self._act == ACT_LRELU:
             x = F.call(F.ActBlurFn, z)                                      # LeakyReLU folded into the blur pass (both ways)
         else:                                                               # ReLU / another blur filter: stage by stage
             x = self.blur.forward_nhwc(apply_act(z, self._act))
         if self._act == ACT_LRELU:
-            return self.conv1_down.forward_nhwc(x, act=ACT_LRELU)
+            return self.conv1_down.forward_nhwc(x, act=ACT_LRELU, defer_act=defer_out)
         return apply_act(self.conv1_down.forward_nhwc(x, act=ACT_NONE), self._act)
 
     def forward(self, x):

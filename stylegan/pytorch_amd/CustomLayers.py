@@ -210,8 +210,10 @@ class EqualizedConv2d(nn.Module):
             return None
         return self.bias * self.b_mul if self.b_mul != 1 else self.bias
 
-    def forward_nhwc(self, x, act=ACT_NONE, skip_bias=False, out_dtype=None):
+    def forward_nhwc(self, x, act=ACT_NONE, skip_bias=False, out_dtype=None, defer_act=False, x_masked=False):
         """x: NHWC.  ``skip_bias``: the caller folds the bias into the next kernel (generator epilogue).
+        ``defer_act`` / ``x_masked``: the LeakyReLU backward of this layer is applied by its consumer / this layer's input is
+        such an output and its data gradient leaves the kernel already masked (functional.ConvFn; discriminator chain only).
         The parameter is consumed in place: w_mul, the 3x3 -> 4x4 kernel synthesis and the MFMA operand packing run in
         sgx_pack_weight (cached per parameter version), their adjoints in the weight-gradient finishing kernel."""
         bias = None if skip_bias else self.scaled_bias()
@@ -244,9 +246,9 @@ class EqualizedConv2d(nn.Module):
             return y
         if self.downscale is not None:
             assert self.intermediate is None                              # reference :167
-            return F.conv(x, self.weight, bias, "D", self.w_mul, act)     # bias after the 2x2 mean == bias in the fused store
+            return F.conv(x, self.weight, bias, "D", self.w_mul, act, defer_act=defer_act and act == ACT_LRELU)   # bias after the 2x2 mean == bias in the fused store
         if self.intermediate is None:
-            return F.conv(x, self.weight, bias, "S", self.w_mul, act, ipad=x.shape[3])
+            return F.conv(x, self.weight, bias, "S", self.w_mul, act, ipad=x.shape[3], x_masked=x_masked)
         y = self.intermediate.forward_nhwc(F.conv(x, self.weight, None, "S", self.w_mul))
         return F.call(F.BiasActFn, y, bias, 1.0, act) if (bias is not None or act) else y
 

@@ -368,18 +368,28 @@ class Discriminator(nn.Module):
             b, r1, r2, _ = img.shape
             emb = self.embeddings[idx](labels_in).float().view(b, -1, r1, r2).permute(0, 2, 3, 1)
             img = torch.cat([img, emb], dim=3).contiguous()
+        # LeakyReLU backward without a pass of its own along the block chain (Blocks.DiscriminatorBlock.forward_nhwc): a
+        # block's final activation is un-done by the NEXT block's conv0 data-gradient kernel (mask in its store), the newest
+        # block's by the fade-in lerp's backward (one scale-and-mask pass); the last block feeds the minibatch-stddev head
+        # and keeps its own pass.
+        fuse = os.environ.get("SGX_FUSE_ACT_BWD", "1") != "0"
+
+        def chain(x, blocks, x_masked):
+            for i, block in enumerate(blocks):
+                defer = fuse and i < len(blocks) - 1 and block._act == ACT_LRELU
+                x = block.forward_nhwc(x, x_masked=x_masked, defer_out=defer)
+                x_masked = defer
+            return x
         if self.structure == 'fixed':
-            x = self.from_rgb[0].forward_nhwc(img, out_dtype=dt)
-            for block in self.blocks:
-                x = block.forward_nhwc(x)
+            x = chain(self.from_rgb[0].forward_nhwc(img, out_dtype=dt), list(self.blocks), False)
         elif self.structure == 'linear':
             if depth > 0:
                 residual = self.from_rgb[self.depth - depth].forward_nhwc(F.call(F.Pool2Fn, img, 0.25), out_dtype=dt)
                 straight = self.blocks[self.depth - depth - 1].forward_nhwc(
-                    self.from_rgb[self.depth - depth - 1].forward_nhwc(img, out_dtype=dt))
-                x = F.fade(straight, residual, alpha)                                      # GAN.py:427
-                for block in self.blocks[(self.depth - depth):]:
-                    x = block.forward_nhwc(x)
+                    self.from_rgb[self.depth - depth - 1].forward_nhwc(img, out_dtype=dt), defer_out=fuse)
+                x = F.fade(straight, residual, alpha,                                      # GAN.py:427
+                           a_act=fuse and self.blocks[self.depth - depth - 1]._act == ACT_LRELU)
+                x = chain(x, list(self.blocks[(self.depth - depth):]), False)
             else:
                 x = self.from_rgb[-1].forward_nhwc(img, out_dtype=dt)
         else:

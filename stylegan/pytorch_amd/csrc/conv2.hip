@@ -43,6 +43,7 @@ enum { C2_S = 0, C2_D = 1, C2_U = 2 };
 
 struct Conv2Args {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y;
+    const bf16_t* mask;                       // C2_S only: y *= slope(mask) in the store (shaped like y), see sgx_conv3x3
     int B, H, W, OH, OW, Cin, Cout, act;      // H, W: input; OH, OW: output
     int tiles_x, tiles_y, ntiles;             // tiles of the tile grid (S: the image, D: the output, U: the coarse input)
     int ncb, nslots;                          // channel blocks; persistent stride over tiles
@@ -299,10 +300,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
 #pragma unroll
                     for (int i = 0; i < 32 * VPR / 64; ++i) {
                         const int idx = i * 64 + lane, px = idx / VPR, v = idx % VPR;
-                        const uint4 val = *reinterpret_cast<const uint4*>(scr + px * OROW + v * 16);
+                        uint4 val = *reinterpret_cast<const uint4*>(scr + px * OROW + v * 16);
                         const int ox = tx0 + px;
-                        if (oy < a.OH && ox < a.OW)
-                            *reinterpret_cast<uint4*>(a.y + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8) = val;
+                        if (oy < a.OH && ox < a.OW) {
+                            const size_t doff = (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8;
+                            if (GEO == C2_S && a.mask) val = lrelu_mask_bf16x8(val, *reinterpret_cast<const uint4*>(a.mask + doff));
+                            *reinterpret_cast<uint4*>(a.y + doff) = val;
+                        }
                     }
                 }
             }
@@ -345,7 +349,7 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
 // 2 = 4x4 stride-2 up (H, W = input size).  *launched = 1 if it ran; 0 leaves the shape to the first-generation kernel.
 // ``variant``: -1 = choose (environment switch + heuristics), 4 / 8 = force the 4- / 8-wave block (A/B probes, tests).
 int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
-                  int variant, hipStream_t st, int* launched) {
+                  const void* mask, int variant, hipStream_t st, int* launched) {
     // bit 0: S, 1: D, 2: U.  All three on: profiles/r02_conv2_probe.txt (S) and r02_conv2_probe_DU.txt (D, U) -- the shape
     // heuristics below reproduce the per-shape winner of those tables
     static const int on = [] { const char* e = getenv("SGX_CONV2"); return e ? atoi(e) : 7; }();
@@ -354,7 +358,7 @@ int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void
     const int gw = geo == C2_D ? W / 2 : W, gh = geo == C2_D ? H / 2 : H;
     const int bco = (geo == C2_S && Cout % 64 == 0) ? 64 : 32;       // (3x3 with 32 output channels: the MF = 1 block)
     if (Cin % 32 != 0 || Cout % bco != 0 || gw % 32 != 0 || Cout / bco > 32 || gh < 1 || (geo == C2_D && ((H | W) & 1))) return 0;
-    Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), B, H, W,
+    Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
                 geo == C2_D ? H / 2 : (geo == C2_U ? 2 * H : H), geo == C2_D ? W / 2 : (geo == C2_U ? 2 * W : W), Cin, Cout, act, 0, 0, 0, 0, 0};
     const bool mf2 = geo != C2_U && Cout % 64 == 0;
     if (variant < 0 && geo == C2_D && !mf2) return 0;      // 32-channel stride-2 blocks: measured no better than the first generation

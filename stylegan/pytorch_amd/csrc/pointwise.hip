@@ -57,28 +57,33 @@ extern "C" int sgx_bias_act(const void* x, const float* bias, float bscale, void
     return 0;
 }
 
-// ---------------------------------------------------------------- dx = dy * (y > 0 ? 1 : slope)   (slope 0.2: LeakyReLU; 0: ReLU)
+// ---------------------------------------------------------------- dx = scale * dy * (y > 0 ? 1 : slope)   (slope 0.2: LeakyReLU; 0: ReLU)
+// scale (1 = exact no-op): the fade-in coefficient of the branch the activation sits on, so that "lerp backward, then
+// activation backward" on the discriminator's newest block is one pass
 template <typename T>
-__global__ void lrelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, size_t nvec, float slope) {
+__global__ void lrelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, size_t nvec, float slope, float scale,
+                                 const float* __restrict__ scale_dev) {
+    if (scale_dev) scale = scale_dev[0];
     constexpr int VE = VecTraits<T>::VE;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
         float g[VE], a[VE];
         VecTraits<T>::load(dy + i * VE, g);
         VecTraits<T>::load(y + i * VE, a);
 #pragma unroll
-        for (int j = 0; j < VE; ++j) g[j] *= a[j] > 0.f ? 1.f : slope;
+        for (int j = 0; j < VE; ++j) g[j] = (scale * g[j]) * (a[j] > 0.f ? 1.f : slope);
         VecTraits<T>::store(dx + i * VE, g);
     }
 }
-extern "C" int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, float slope, int dtype, void* stream) {
+extern "C" int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, float slope, float scale, const float* scale_dev, int dtype,
+                             void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SGX_NOTE(0.0, 3.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * n, "lrelu_bwd %zu", n);
     if (dtype == SGX_F32) {
         SGX_REQUIRE(n % 4 == 0, SGX_EUNSUPPORTED, "lrelu_bwd: n %% 4");
-        hipLaunchKernelGGL(lrelu_bwd_kernel<float>, dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)dx, n / 4, slope);
+        hipLaunchKernelGGL(lrelu_bwd_kernel<float>, dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)dx, n / 4, slope, scale, scale_dev);
     } else {
         SGX_REQUIRE(n % 8 == 0, SGX_EUNSUPPORTED, "lrelu_bwd: n %% 8");
-        hipLaunchKernelGGL(lrelu_bwd_kernel<bf16_t>, dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n / 8, slope);
+        hipLaunchKernelGGL(lrelu_bwd_kernel<bf16_t>, dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n / 8, slope, scale, scale_dev);
     }
     SGX_LAUNCH_CHECK("lrelu_bwd");
     return 0;

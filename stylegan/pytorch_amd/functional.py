@@ -272,7 +272,7 @@ def clear_pack_cache():
 
 
 # ---------------------------------------------------------------------------------------------------
-def _conv_launch(geo, x, wq, bias, act):
+def _conv_launch(geo, x, wq, bias, act, mask=None):
     B, H, W, Cin = x.shape
     taps, Cout, K = wq.shape
     if K != Cin:
@@ -280,12 +280,15 @@ def _conv_launch(geo, x, wq, bias, act):
     L = N.lib()
     if geo == "S":
         y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
-        N.check(L.sgx_conv3x3(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv3x3")
+        if mask is not None and (mask.shape != y.shape or mask.dtype != y.dtype):
+            raise N.SgxError("conv: the output mask must have the output's shape and dtype")
+        N.check(L.sgx_conv3x3(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.ptr(mask), N.dt(x), N.stream()), "sgx_conv3x3")
     elif geo == "D":
+        assert mask is None
         y = torch.empty((B, H // 2, W // 2, Cout), dtype=x.dtype, device=x.device)
         N.check(L.sgx_conv4x4s2_down(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.dt(x), N.stream()), "sgx_conv4x4s2_down")
     else:
-        assert bias is None and act == 0
+        assert bias is None and act == 0 and mask is None
         y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
         N.check(L.sgx_conv4x4s2_up(N.ptr(x), N.ptr(wq), N.ptr(y), B, H, W, Cin, Cout, N.dt(x), N.stream()), "sgx_conv4x4s2_up")
     return y
@@ -323,33 +326,40 @@ def _wgrad_param(mode, adjoint, x, gy, weight, scale, want_bias=False, into=None
 
 
 class ConvFn(Function):
-    """y = act(conv(x, pack(weight)) + bias) for one EqualizedConv2d parameter.
+    """y = act(conv(x, pack(weight)) + bias) [* slope(mask)] for one EqualizedConv2d parameter.
 
     ``adjoint=False``: the layer's own convolution (geometry by ``mode``).  ``adjoint=True``: its data-gradient
     convolution (transposed/flipped pack).  The backward of either is the other, so the op is closed under
-    differentiation; the parameter gradient comes back in the parameter's own layout."""
+    differentiation; the parameter gradient comes back in the parameter's own layout.
+
+    Activation backward without a pass of its own (discriminator chain conv1_down+LeakyReLU -> next block's conv0):
+    ``defer_act``: this layer's LeakyReLU backward is applied by whoever consumes its output -- the incoming gradient is
+    already masked; ``x_masked``: x is such an output, so the data gradient leaves the kernel multiplied by slope(x)
+    (``mask`` argument of the adjoint launch, fused in its store; bit-identical to the separate pass)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, mode, scale, ipad, adjoint, act):
+    def forward(ctx, x, weight, bias, mode, scale, ipad, adjoint, act, mask=None, defer_act=False, x_masked=False):
         x = _c(x)
         fwd, adj = packs(weight, mode, scale, ipad, x.dtype)
         geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
-        y = _conv_launch(geo, x, adj if adjoint else fwd, None if bias is None else _c(bias.detach()), act)
-        ctx.cfg = (mode, scale, ipad, adjoint, act, bias is not None)
+        y = _conv_launch(geo, x, adj if adjoint else fwd, None if bias is None else _c(bias.detach()), act, mask)
+        ctx.cfg = (mode, scale, ipad, adjoint, act, bias is not None, bool(defer_act), bool(x_masked))
         ctx.bias_ref = weakref.ref(bias) if bias is not None else (lambda: None)
-        ctx.save_for_backward(x, weight, y if act else None)
+        ctx.save_for_backward(x, weight, y if (act and not defer_act) else None, mask)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, y = ctx.saved_tensors
-        mode, scale, ipad, adjoint, act, has_bias = ctx.cfg
+        x, weight, y, mask = ctx.saved_tensors
+        mode, scale, ipad, adjoint, act, has_bias, defer_act, x_masked = ctx.cfg
         gy = _c(gy)
-        if act:
-            gy = _bcall(LReluBwdFn, gy, y, 0.2)
+        if mask is not None:                                  # adjoint of the output mask (reached by the R1 double backward only)
+            gy = _bcall(LReluBwdFn, gy, mask, 0.2, 1.0)
+        if act and not defer_act:
+            gy = _bcall(LReluBwdFn, gy, y, 0.2, 1.0)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0)
+            gx = _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0, x if x_masked else None, False, False)
         if not _DATA_GRAD_ONLY:
             want_b = has_bias and ctx.needs_input_grad[2]
             # the bias gradient rides along in the weight-gradient pass when gy is its O-channel side
@@ -370,7 +380,7 @@ class ConvFn(Function):
                 gw, gb = _bcall(WgradFn, x, gy, weight, mode, scale, adjoint, fuse_b)
             if want_b and not fuse_b:
                 gb = _bcall(ColSumFn, gy, 1.0)
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None
 
 
 class WgradFn(Function):
@@ -386,28 +396,32 @@ class WgradFn(Function):
         raise NotImplementedError("second derivative through a weight gradient is not part of the training path")
 
 
-def conv(x, weight, bias, mode, scale, act=N.ACT_NONE, ipad=None):
-    return call(ConvFn, x, weight, bias, mode, float(scale), int(ipad if ipad is not None else weight.shape[1]), False, act)
+def conv(x, weight, bias, mode, scale, act=N.ACT_NONE, ipad=None, defer_act=False, x_masked=False):
+    return call(ConvFn, x, weight, bias, mode, float(scale), int(ipad if ipad is not None else weight.shape[1]), False, act, None,
+                bool(defer_act), bool(x_masked))
 
 
 # ---------------------------------------------------------------------------------------------------
 class LReluBwdFn(Function):
-    """g * (y > 0 ? 1 : slope), y = the activation's output (slope 0.2: LeakyReLU, 0: ReLU).  Linear in g; no second
-    derivative w.r.t. y."""
+    """scale * g * (y > 0 ? 1 : slope), y = the activation's output (slope 0.2: LeakyReLU, 0: ReLU).  Linear in g; no second
+    derivative w.r.t. y.  ``scale``: 1.0, a python float, or a one-element device fp32 tensor (the fade-in coefficient of the
+    branch the activation sits on: lerp backward and activation backward in one pass)."""
 
     @staticmethod
-    def forward(ctx, g, y, slope):
+    def forward(ctx, g, y, slope, scale=1.0):
         g = _c(g)
         out = torch.empty_like(g)
-        N.check(N.lib().sgx_lrelu_bwd(N.ptr(g), N.ptr(y), N.ptr(out), g.numel(), float(slope), N.dt(g), N.stream()), "sgx_lrelu_bwd")
-        ctx.slope = float(slope)
+        dev = isinstance(scale, torch.Tensor)
+        N.check(N.lib().sgx_lrelu_bwd(N.ptr(g), N.ptr(y), N.ptr(out), g.numel(), float(slope), 1.0 if dev else float(scale),
+                                      scale.data_ptr() if dev else None, N.dt(g), N.stream()), "sgx_lrelu_bwd")
+        ctx.slope, ctx.scale = float(slope), scale
         ctx.save_for_backward(y)
         return out
 
     @staticmethod
     def backward(ctx, gg):
         (y,) = ctx.saved_tensors
-        return _bcall(LReluBwdFn, gg, y, ctx.slope), None, None
+        return _bcall(LReluBwdFn, gg, y, ctx.slope, ctx.scale), None, None, None
 
 
 class ColSumFn(Function):
@@ -449,7 +463,7 @@ class BiasActFn(Function):
         (y,) = ctx.saved_tensors
         g = _c(g)
         if ctx.act:
-            g = _bcall(LReluBwdFn, g, y, 0.0 if ctx.act == N.ACT_RELU else 0.2)
+            g = _bcall(LReluBwdFn, g, y, 0.0 if ctx.act == N.ACT_RELU else 0.2, 1.0)
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[1] and not _DATA_GRAD_ONLY:
             gb = _bcall(ColSumFn, g, ctx.bscale)
@@ -471,22 +485,28 @@ class ScaleFn(Function):
 
 
 class AxpbyFn(Function):
-    """alpha*a + beta*b (fade-in lerp)."""
+    """alpha*a + beta*b (fade-in lerp).  ``a_act``: ``a`` is a LeakyReLU output whose activation backward was deferred to its
+    consumer (ConvFn ``defer_act``): the gradient of ``a`` is alpha * g * slope(a), one pass."""
 
     @staticmethod
-    def forward(ctx, a, b, alpha, beta):
+    def forward(ctx, a, b, alpha, beta, a_act=False):
         a, b = _c(a), _c(b)
         assert a.shape == b.shape and a.dtype == b.dtype
         out = torch.empty_like(a)
         N.check(N.lib().sgx_axpby(N.ptr(a), N.ptr(b), N.ptr(out), float(alpha), float(beta), a.numel(), N.dt(a), N.stream()), "sgx_axpby")
-        ctx.alpha, ctx.beta = float(alpha), float(beta)
+        ctx.alpha, ctx.beta, ctx.a_act = float(alpha), float(beta), bool(a_act)
+        ctx.save_for_backward(a if a_act else None)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        ga = _bcall(ScaleFn, g, ctx.alpha) if ctx.needs_input_grad[0] else None
-        gb = _bcall(ScaleFn, g, ctx.beta) if ctx.needs_input_grad[1] else None
-        return ga, gb, None, None
+        (a,) = ctx.saved_tensors
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = _bcall(LReluBwdFn, g, a, 0.2, ctx.alpha) if ctx.a_act else _bcall(ScaleFn, g, ctx.alpha)
+        if ctx.needs_input_grad[1]:
+            gb = _bcall(ScaleFn, g, ctx.beta)
+        return ga, gb, None, None, None
 
 
 class ScaleDevFn(Function):
@@ -506,30 +526,37 @@ class ScaleDevFn(Function):
 
 
 class FadeFn(Function):
-    """ab[0]*a + ab[1]*b with the two coefficients in a device fp32 tensor (fade-in under graph replay)."""
+    """ab[0]*a + ab[1]*b with the two coefficients in a device fp32 tensor (fade-in under graph replay).  ``a_act`` as in
+    ``AxpbyFn``."""
 
     @staticmethod
-    def forward(ctx, a, b, ab):
+    def forward(ctx, a, b, ab, a_act=False):
         a, b = _c(a), _c(b)
         assert a.shape == b.shape and a.dtype == b.dtype and ab.dtype == torch.float32 and ab.numel() == 2 and ab.is_contiguous()
         out = torch.empty_like(a)
         N.check(N.lib().sgx_axpby_dev(N.ptr(a), N.ptr(b), N.ptr(out), ab.data_ptr(), ab.data_ptr() + 4, a.numel(), N.dt(a), N.stream()),
                 "sgx_axpby_dev")
-        ctx.ab = ab
+        ctx.ab, ctx.a_act = ab, bool(a_act)
+        ctx.save_for_backward(a if a_act else None)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        ga = _bcall(ScaleDevFn, g, ctx.ab[0:1]) if ctx.needs_input_grad[0] else None
-        gb = _bcall(ScaleDevFn, g, ctx.ab[1:2]) if ctx.needs_input_grad[1] else None
-        return ga, gb, None
+        (a,) = ctx.saved_tensors
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = _bcall(LReluBwdFn, g, a, 0.2, ctx.ab[0:1]) if ctx.a_act else _bcall(ScaleDevFn, g, ctx.ab[0:1])
+        if ctx.needs_input_grad[1]:
+            gb = _bcall(ScaleDevFn, g, ctx.ab[1:2])
+        return ga, gb, None, None
 
 
-def fade(a, b, alpha):
-    """alpha*a + (1-alpha)*b.  ``alpha``: python float, or a device fp32 tensor [alpha, 1-alpha] (graph replay)."""
+def fade(a, b, alpha, a_act=False):
+    """alpha*a + (1-alpha)*b.  ``alpha``: python float, or a device fp32 tensor [alpha, 1-alpha] (graph replay).  ``a_act``:
+    ``a`` is a LeakyReLU output with its activation backward deferred to this op."""
     if isinstance(alpha, torch.Tensor):
-        return call(FadeFn, a, b, alpha)
-    return call(AxpbyFn, a, b, float(alpha), float(1 - alpha))
+        return call(FadeFn, a, b, alpha, bool(a_act))
+    return call(AxpbyFn, a, b, float(alpha), float(1 - alpha), bool(a_act))
 
 
 class BlurFn(Function):

@@ -34,7 +34,7 @@ SIGNATURES = {
     "sgx_last_error": (ctypes.c_char_p, []),
     "sgx_clear_error": (I, []),
     "sgx_stream_wait_stream": (I, [P, P]),
-    "sgx_conv3x3": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+    "sgx_conv3x3": (I, [P, P, P, P, I, I, I, I, I, I, P, I, P]),
     "sgx_conv_variant": (I, [I, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_down": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_up": (I, [P, P, P, I, I, I, I, I, I, P]),
@@ -51,7 +51,7 @@ SIGNATURES = {
     "sgx_wgrad3x3_param": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, I, P]),
     "sgx_wgrad4x4s2_param": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, I, P]),
     "sgx_bias_act": (I, [P, P, F, P, Z, I, I, I, P]),
-    "sgx_lrelu_bwd": (I, [P, P, P, Z, F, I, P]),
+    "sgx_lrelu_bwd": (I, [P, P, P, Z, F, F, P, I, P]),
     "sgx_axpby": (I, [P, P, P, F, F, Z, I, P]),
     "sgx_axpby_dev": (I, [P, P, P, P, P, Z, I, P]),
     "sgx_blur3x3": (I, [P, P, I, I, I, I, I, P]),

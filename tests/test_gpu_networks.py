@@ -351,3 +351,43 @@ def test_fixed_structure_equals_linear_at_full_depth():
         out.append((float(sg.optimize_discriminator(z, real, 5, 1.0)), float(sg.optimize_generator(z, real, 5, 1.0))))
     for a, b in zip(out[0], out[1]):
         assert np.isfinite(a) and abs(a - b) <= 1e-5 * abs(a) + 1e-7, out
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_activation_backward_fused_into_the_data_gradient_kernels(nets, monkeypatch, dt):
+    """The discriminator chain applies each block's LeakyReLU backward in the store of the NEXT block's conv0 data-gradient
+    kernel (and the newest block's in the fade-in lerp's backward) instead of a pass of its own (SGX_FUSE_ACT_BWD=0: the
+    separate passes).  Same arithmetic on the same rounded values: fp32 results are bit-identical, first and second order;
+    bf16 differs only by the one rounding the merged scale-and-mask pass of the newest block no longer does."""
+    from stylegan.pytorch_amd import native
+    gp, dp, _, _ = nets
+    _, dis = build_mid(dt)
+    load_into(dis, dp); dis.train()
+    B = 4
+    out = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("SGX_FUSE_ACT_BWD", fuse)
+        res = []
+        for depth, alpha in [(5, 0.6), (3, 1.0), (0, 1.0)]:
+            img = gu.seeded((B, 3, 4 * 2 ** depth, 4 * 2 ** depth), 60 + depth).to(DEV).requires_grad_(True)
+            for p in dis.parameters():
+                p.grad = None
+            native.prof_start(1)
+            score = dis(img, depth, alpha)
+            (gi,) = torch.autograd.grad(score.sum(), img, create_graph=True)           # R1 structure: second order through the chain
+            ((gi * gi).sum() * 0.5 + score.sum()).backward()
+            torch.cuda.synchronize()
+            native.prof_start(0)
+            n_lrelu = sum("lrelu_bwd" in r[0] for r in native.prof_records())
+            res.append((score.detach().clone(), gi.detach().clone(), img.grad.clone(),
+                        {k: p.grad.clone() for k, p in dis.named_parameters() if p.grad is not None}, n_lrelu))
+        out[fuse] = res
+    for (s0, g0, i0, p0, n0), (s1, g1, i1, p1, n1) in zip(out["0"], out["1"]):
+        assert n1 < n0 or n0 <= 3, (n0, n1)                               # fewer activation-backward launches
+        assert torch.equal(s0, s1)
+        tol = 0.0 if dt == torch.float32 else 2e-2
+        for a, b, what in [(g0, g1, "image gradient"), (i0, i1, "second-order image gradient")] + [(p0[k], p1[k], k) for k in p0]:
+            if tol == 0.0:
+                assert torch.equal(a, b), what
+            else:
+                assert_close(b, a, tol, what, floor=1e-6)
