@@ -380,14 +380,14 @@ def test_activation_backward_fused_into_the_data_gradient_kernels(nets, monkeypa
             native.prof_start(0)
             n_lrelu = sum("lrelu_bwd" in r[0] for r in native.prof_records())
             res.append((score.detach().clone(), gi.detach().clone(), img.grad.clone(),
-                        {k: p.grad.clone() for k, p in dis.named_parameters() if p.grad is not None}, n_lrelu))
+                        {k: p.grad.clone() for k, p in dis.named_parameters() if p.grad is not None}, n_lrelu, depth))
         out[fuse] = res
-    for (s0, g0, i0, p0, n0), (s1, g1, i1, p1, n1) in zip(out["0"], out["1"]):
-        assert n1 < n0 or n0 <= 3, (n0, n1)                               # fewer activation-backward launches
+    for (s0, g0, i0, p0, n0, depth), (s1, g1, i1, p1, n1, _) in zip(out["0"], out["1"]):
+        assert (n1 < n0) if depth > 0 else (n1 == n0), (depth, n0, n1)    # fewer activation-backward launches (depth 0: only the head's)
         assert torch.equal(s0, s1)
-        tol = 0.0 if dt == torch.float32 else 2e-2
+        assert torch.equal(g0, g1) or dt != torch.float32, "image gradient (a single chain: bit-identical in fp32)"
+        # parameter gradients sum a first- and a second-order contribution in the autograd engine's order, which follows node
+        # creation order and so differs between the two graph shapes: equal up to that one fp32 re-association
+        tol = 5e-6 if dt == torch.float32 else 2e-2
         for a, b, what in [(g0, g1, "image gradient"), (i0, i1, "second-order image gradient")] + [(p0[k], p1[k], k) for k in p0]:
-            if tol == 0.0:
-                assert torch.equal(a, b), what
-            else:
-                assert_close(b, a, tol, what, floor=1e-6)
+            assert_close(b, a, tol, what, floor=1e-6)
