@@ -210,10 +210,12 @@ class EqualizedConv2d(nn.Module):
             return None
         return self.bias * self.b_mul if self.b_mul != 1 else self.bias
 
-    def forward_nhwc(self, x, act=ACT_NONE, skip_bias=False, out_dtype=None, defer_act=False, x_masked=False):
+    def forward_nhwc(self, x, act=ACT_NONE, skip_bias=False, out_dtype=None, defer_act=False, x_masked=False, out_scale=1.0):
         """x: NHWC.  ``skip_bias``: the caller folds the bias into the next kernel (generator epilogue).
         ``defer_act`` / ``x_masked``: the LeakyReLU backward of this layer is applied by its consumer / this layer's input is
         such an output and its data gradient leaves the kernel already masked (functional.ConvFn; discriminator chain only).
+        ``out_scale`` (from_rgb only): the layer's output times a python-float factor, folded into its weight scale and bias
+        (the fade-in coefficient of the residual branch: neither the forward nor the backward needs a scaling pass then).
         The parameter is consumed in place: w_mul, the 3x3 -> 4x4 kernel synthesis and the MFMA operand packing run in
         sgx_pack_weight (cached per parameter version), their adjoints in the weight-gradient finishing kernel."""
         bias = None if skip_bias else self.scaled_bias()
@@ -221,7 +223,11 @@ class EqualizedConv2d(nn.Module):
         if self.kernel_size == 1:
             assert self.upscale is None and self.downscale is None and self.intermediate is None
             if cin == 3 and x.shape[3] == 3:
-                y = F.call(F.RgbInFn, x.float(), self.weight, bias, self.w_mul, out_dtype or torch.float32)
+                if out_scale != 1.0:
+                    y = F.call(F.RgbInFn, x.float(), self.weight, None if bias is None else bias * float(out_scale),
+                               self.w_mul * float(out_scale), out_dtype or torch.float32)
+                else:
+                    y = F.call(F.RgbInFn, x.float(), self.weight, bias, self.w_mul, out_dtype or torch.float32)
             elif cin % 3 == 0 and cin > 3 and x.shape[3] == cin and cout != 3:
                 # conditional discriminator (reference models/GAN.py:326-330,415-421): from_rgb over [image, label
                 # embedding] = the sum of the 3-channel kernels over the channel groups (the weight slices are tiny)

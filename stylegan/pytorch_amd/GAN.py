@@ -384,11 +384,15 @@ class Discriminator(nn.Module):
             x = chain(self.from_rgb[0].forward_nhwc(img, out_dtype=dt), list(self.blocks), False)
         elif self.structure == 'linear':
             if depth > 0:
-                residual = self.from_rgb[self.depth - depth].forward_nhwc(F.call(F.Pool2Fn, img, 0.25), out_dtype=dt)
+                # (1-alpha) of the residual branch rides in from_rgb's weight scale and bias when alpha is a host number (under
+                # graph replay it is device memory): its backward then needs no scaling pass over the activation
+                pre = fuse and not isinstance(alpha, torch.Tensor) and not self.conditional
+                residual = self.from_rgb[self.depth - depth].forward_nhwc(F.call(F.Pool2Fn, img, 0.25), out_dtype=dt,
+                                                                          out_scale=float(1 - alpha) if pre else 1.0)
                 straight = self.blocks[self.depth - depth - 1].forward_nhwc(
                     self.from_rgb[self.depth - depth - 1].forward_nhwc(img, out_dtype=dt), defer_out=fuse)
                 x = F.fade(straight, residual, alpha,                                      # GAN.py:427
-                           a_act=fuse and self.blocks[self.depth - depth - 1]._act == ACT_LRELU)
+                           a_act=fuse and self.blocks[self.depth - depth - 1]._act == ACT_LRELU, b_prescaled=pre)
                 x = chain(x, list(self.blocks[(self.depth - depth):]), False)
             else:
                 x = self.from_rgb[-1].forward_nhwc(img, out_dtype=dt)

@@ -505,7 +505,7 @@ class AxpbyFn(Function):
         if ctx.needs_input_grad[0]:
             ga = _bcall(LReluBwdFn, g, a, 0.2, ctx.alpha) if ctx.a_act else _bcall(ScaleFn, g, ctx.alpha)
         if ctx.needs_input_grad[1]:
-            gb = _bcall(ScaleFn, g, ctx.beta)
+            gb = g if ctx.beta == 1.0 else _bcall(ScaleFn, g, ctx.beta)
         return ga, gb, None, None, None
 
 
@@ -551,12 +551,14 @@ class FadeFn(Function):
         return ga, gb, None, None
 
 
-def fade(a, b, alpha, a_act=False):
+def fade(a, b, alpha, a_act=False, b_prescaled=False):
     """alpha*a + (1-alpha)*b.  ``alpha``: python float, or a device fp32 tensor [alpha, 1-alpha] (graph replay).  ``a_act``:
-    ``a`` is a LeakyReLU output with its activation backward deferred to this op."""
+    ``a`` is a LeakyReLU output with its activation backward deferred to this op.  ``b_prescaled``: ``b`` already carries its
+    (1-alpha) (folded into the layer that produced it; python-float alpha only), so its gradient is g itself."""
     if isinstance(alpha, torch.Tensor):
+        assert not b_prescaled
         return call(FadeFn, a, b, alpha, bool(a_act))
-    return call(AxpbyFn, a, b, float(alpha), float(1 - alpha), bool(a_act))
+    return call(AxpbyFn, a, b, float(alpha), 1.0 if b_prescaled else float(1 - alpha), bool(a_act))
 
 
 class BlurFn(Function):

@@ -357,8 +357,8 @@ def test_fixed_structure_equals_linear_at_full_depth():
 def test_activation_backward_fused_into_the_data_gradient_kernels(nets, monkeypatch, dt):
     """The discriminator chain applies each block's LeakyReLU backward in the store of the NEXT block's conv0 data-gradient
     kernel (and the newest block's in the fade-in lerp's backward) instead of a pass of its own (SGX_FUSE_ACT_BWD=0: the
-    separate passes).  Same arithmetic on the same rounded values: fp32 results are bit-identical, first and second order;
-    bf16 differs only by the one rounding the merged scale-and-mask pass of the newest block no longer does."""
+    separate passes; the same switch folds the residual branch's (1-alpha) into from_rgb's weight scale).  Same arithmetic up to
+    re-association: fp32 results agree to a few ulp, first and second order; bf16 to its rounding."""
     from stylegan.pytorch_amd import native
     gp, dp, _, _ = nets
     _, dis = build_mid(dt)
@@ -384,8 +384,7 @@ def test_activation_backward_fused_into_the_data_gradient_kernels(nets, monkeypa
         out[fuse] = res
     for (s0, g0, i0, p0, n0, depth), (s1, g1, i1, p1, n1, _) in zip(out["0"], out["1"]):
         assert (n1 < n0) if depth > 0 else (n1 == n0), (depth, n0, n1)    # fewer activation-backward launches (depth 0: only the head's)
-        assert torch.equal(s0, s1)
-        assert torch.equal(g0, g1) or dt != torch.float32, "image gradient (a single chain: bit-identical in fp32)"
+        assert_close(s1, s0, 1e-6 if dt == torch.float32 else 1e-2, "score")     # (1-alpha) folded into from_rgb: a re-association
         # parameter gradients sum a first- and a second-order contribution in the autograd engine's order, which follows node
         # creation order and so differs between the two graph shapes: equal up to that one fp32 re-association
         tol = 5e-6 if dt == torch.float32 else 2e-2
