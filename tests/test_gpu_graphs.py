@@ -90,7 +90,10 @@ def close(a, b, tol):
 # 4 iterations = 2 eager warm-up calls + the capture + one pure replay: tight.  6 iterations: the sign-like Adam update
 # (beta1 = 0) amplifies the ulp-level summation-order differences by ~10x per iteration, so the bound is loose there.
 @pytest.mark.parametrize("act_dtype,iters,lscale,ptol", [(torch.float32, 4, 1.0, 3e-2), (torch.float32, 6, 1.0, 5e-2),
-                                                         (torch.bfloat16, 4, 2e3, 5e-2)])
+                                                         # bf16: eager folds the residual branch's (1-alpha) into from_rgb's weights,
+                                                         # replay (alpha in device memory) scales the bf16 activation: two roundings
+                                                         # of the same quantity, 5e-3 on the first G loss (measured)
+                                                         (torch.bfloat16, 4, 5e3, 5e-2)])
 def test_graph_replay_matches_eager(act_dtype, iters, lscale, ptol):
     le, se, _ = run(False, act_dtype, iters)                         # 2 eager warm-up calls, the capture, pure replays
     lg, sgr, sg = run(True, act_dtype, iters)
