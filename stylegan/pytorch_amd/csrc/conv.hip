@@ -711,6 +711,15 @@ __device__ __forceinline__ bf16x8 cat8(s16x4 lo, s16x4 hi) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// LDS pixel pitch of an operand tile.  Transpose-read path with pixels ONE apart (a half-wave reads 8 consecutive pixels x
+// 32 bytes): 16 channels unpadded (32 B: 256 contiguous bytes), 32 channels 96 B (chunk i at dword 24i: all 64 banks once);
+// the padded 48 / 80-byte pitches of WFrag are the conflict-free choice for the scalar path and for lanes TWO pixels apart
+// (the stride-2 fine side), and ran at 46-53 % bank conflicts on the one-apart transpose reads (r02_b_pmc_mfma_bf16_b4.json).
+template <typename T>
+constexpr int wgrad_pitch(int ch, bool tr, int is) {
+    return (tr && is == 1) ? (ch == 16 ? 32 : ch * 2 + 32) : WFrag<T>::row_bytes(ch);
+}
+
 template <typename T, int GEO, int TH, int TW, int BP, int NSUB, int KSUB, bool TR>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     using F = WFrag<T>;
@@ -718,7 +727,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     constexpr int PH = (TH - 1) * IS + TK, PW = (TW - 1) * IS + TK;
     constexpr int NI = BP / (TH * TW);
     constexpr int NCH = NSUB * 16, KCH = KSUB * 16;
-    constexpr int NROW = F::row_bytes(NCH), KROW = F::row_bytes(KCH);
+    constexpr int NROW = wgrad_pitch<T>(NCH, TR, 1), KROW = wgrad_pitch<T>(KCH, TR, IS);
     constexpr int VE = 16 / (int)sizeof(T);
     constexpr int TPW = (NT + 3) / 4;                          // taps per wave
     constexpr int PPL = F::KPS / 4;                            // pixels per lane per k-step (1 fp32, 4 bf16)
@@ -1039,7 +1048,7 @@ static int launch_wgrad(WgradArgs& a, void* ws, size_t ws_bytes, int* nsplit_out
     using F = WFrag<T>;
     constexpr int IS = Geo<GEO>::IS, TK = Geo<GEO>::TK, NT = TK * TK;
     constexpr int PH = (TH - 1) * IS + TK, PW = (TW - 1) * IS + TK, NI = BP / (TH * TW);
-    constexpr int OPER = BP * F::row_bytes(NSUB * 16) + NI * PH * PW * F::row_bytes(KSUB * 16);
+    constexpr int OPER = BP * wgrad_pitch<T>(NSUB * 16, TR, 1) + NI * PH * PW * wgrad_pitch<T>(KSUB * 16, TR, IS);
     constexpr int FOLD = NT * NSUB * 16 * (KSUB * 16 + 1) * 4;          // direct epilogue: all taps of the tile, fp32
     constexpr int LDS = OPER > FOLD ? OPER : FOLD;
     static_assert(LDS <= 160 * 1024, "LDS budget");

@@ -111,10 +111,12 @@ def test_two_ranks_equal_the_global_batch_run():
         assert np.allclose(r["losses"], ref["losses"], rtol=2e-4), (rank, r["losses"], ref["losses"])   # the GLOBAL loss on every rank
         assert rel(r["avg_latent"], ref["avg_latent"]) <= 1e-5
         for k, v in ref.items():
+            if k.endswith("init_block.bias"):                         # analytically zero gradient (it feeds an instance norm):
+                continue                                              # pure round-off, not comparable between two runs of anything
             if ".grad::" in k:                                        # summed over ranks == global-batch gradient
                 n = np.linalg.norm(v)
                 assert np.linalg.norm(r[k] - v) <= 2e-3 * n + 1e-6 * (1 + n), (rank, k, rel(r[k], v))
-            elif "::" in k and not k.endswith("init_block.bias"):     # parameters after 2 x (Adam at beta1 = 0: +-lr per element)
+            elif "::" in k:                                           # parameters after 2 x (Adam at beta1 = 0: +-lr per element)
                 bad = np.mean(np.abs(r[k] - v) > 1e-5 * (1 + np.abs(v)))
                 assert bad <= max(3e-2, 2.0 / v.size), (rank, k, bad)
     for k in got[0]:
