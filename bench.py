@@ -51,6 +51,10 @@ def parse():
                     help="replay each half-iteration as captured hipGraphs (with data parallelism: two graphs around the eager all-reduce)")
     ap.add_argument("--streams", default="auto", choices=["auto", "11", "01", "00"],
                     help="extra streams of the step: auxiliary (fake branch) / side (weight gradients); auto = measured on this box")
+    ap.add_argument("--dry-run-ranks-on-one-gpu", action="store_true",
+                    help="TEST ONLY: every rank on cuda:0 over a gloo group (RCCL refuses two ranks per device): exercises the N>1 "
+                         "control flow (calibration votes, sharded step, all-reduce, max-over-ranks timing) on a 1-GPU box; the "
+                         "printed throughput is meaningless")
     ap.add_argument("--layer-table", default=None, help="write a per-layer conv/wgrad timing table (TSV) to this path")
     return ap.parse_args()
 
@@ -150,6 +154,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE {world} (launch N>1 with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if a.dry_run_ranks_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -161,7 +167,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.dry_run_ranks_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         from stylegan.pytorch_amd.dist import DataParallelGroup
         dp = DataParallelGroup()
 
@@ -195,6 +204,12 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    def max_over_ranks(values):
+        """element-wise MAX of a list of floats over all ranks (a device tensor over RCCL; host memory in the gloo dry run)"""
+        t = torch.tensor(values, dtype=torch.float64, device="cpu" if a.dry_run_ranks_on_one_gpu else dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return [float(v) for v in t]
+
     # Launch structure by measurement on THIS box (setup, not warmup).  Two knobs: hipGraph replay of each half-iteration
     # vs stream launches, and the step's extra streams (fake branch of the D step on an auxiliary stream / weight gradients on
     # a side stream).  Replay takes the host out of the loop but costs the ROCm runtime more per node; extra streams overlap
@@ -224,14 +239,15 @@ def main():
     if len(cands) > 1:
         times = {c: float("inf") for c in cands}
         hosts = {c: float("inf") for c in cands}
+        dead = set()
         for c in cands:                                      # graphs: two eager calls, then the capture
             apply(c)
             for i in range(3 if c[0] else 1):
                 step(i)
-            if c[0] and not sg.use_graphs:                   # a failed capture falls back to eager for good: drop the candidate
-                times.pop(c)
+            if c[0] and not sg.use_graphs:                   # a failed capture falls back to eager for good: the candidate stays
+                dead.add(c)                                  # at +inf (on every rank after the MAX below: the keys never diverge)
         for _ in range(2):
-            for c in list(times):
+            for c in [c for c in cands if c not in dead]:
                 apply(c)
                 timed(1)
                 t, h = timed(4)
@@ -239,13 +255,12 @@ def main():
                     times[c], hosts[c] = t, h
         if world > 1:                                        # one decision for all ranks: the slowest rank's time per candidate
             keys = sorted(times)
-            tt = torch.tensor([times[k] for k in keys] + [hosts[k] for k in keys], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            times = {k: float(v) for k, v in zip(keys, tt[:len(keys)])}
-            hosts = {k: float(v) for k, v in zip(keys, tt[len(keys):])}
+            tt = max_over_ranks([times[k] for k in keys] + [hosts[k] for k in keys])
+            times = dict(zip(keys, tt[:len(keys)]))
+            hosts = dict(zip(keys, tt[len(keys):]))
         best = min(times, key=lambda c: max(times[c], HOST_MARGIN * hosts[c]))
         calib = {("graph" if g else "eager") + f"_aux{int(ax)}_side{int(pr)}": {"ms_per_step": round(t, 3), "host_ms_per_step": round(hosts[(g, ax, pr)], 3)}
-                 for (g, ax, pr), t in sorted(times.items())}
+                 for (g, ax, pr), t in sorted(times.items()) if t != float("inf")}
     else:
         best = cands[0]
         apply(best)
@@ -289,9 +304,7 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = max_over_ranks([dt])[0]
 
     roof = None
     if survey is not None:
