@@ -47,6 +47,7 @@ struct Conv2Args {
     int B, H, W, OH, OW, Cin, Cout, act;      // H, W: input; OH, OW: output
     int tiles_x, tiles_y, ntiles;             // tiles of the tile grid (S: the image, D: the output, U: the coarse input)
     int ncb, nslots;                          // channel blocks; persistent stride over tiles
+    int bands;                                // tile order: 0 = slot, slot + nslots, ...; 1 = each XCD walks one contiguous eighth of the raster
 };
 
 template <int GEO> struct G2;
@@ -87,8 +88,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
     const int bid = blockIdx.x, xcd = bid & 7, j8 = bid >> 3;
     const int cb = j8 % a.ncb, slot = (j8 / a.ncb) * 8 + xcd;
     const int co0 = cb * BCO;
-    if (slot >= a.ntiles) return;
-    const int my_tiles = (a.ntiles - slot + a.nslots - 1) / a.nslots;
+    // bands: XCD `xcd` owns tiles [xcd*band, (xcd+1)*band) of the raster and its per = nslots/8 tile slots walk them in order,
+    // so raster neighbours (which share halo rows / columns) run on the same L2 close in time
+    const int band = (a.ntiles + 7) >> 3, per = a.nslots >> 3, lslot = j8 / a.ncb;
+    const int band_len = a.ntiles - xcd * band < band ? a.ntiles - xcd * band : band;
+    const int tile0 = a.bands ? xcd * band + lslot : slot, tstride = a.bands ? per : a.nslots;
+    const int my_tiles = a.bands ? (lslot < band_len ? (band_len - lslot + per - 1) / per : 0)
+                                 : (slot < a.ntiles ? (a.ntiles - slot + a.nslots - 1) / a.nslots : 0);
+    if (my_tiles <= 0) return;
     const int nchunks = a.Cin >> 5;
     const int spt = nchunks * NPH;                        // K-steps per tile
     const int nsteps = my_tiles * spt;
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
         const int it = step / spt, q = step - it * spt;
         const int kc = q / NPH, ph = q - kc * NPH, py = ph >> 1, px = ph & 1;
         int b, ty0, tx0;
-        tile_coords(slot + it * a.nslots, b, ty0, tx0);
+        tile_coords(tile0 + it * tstride, b, ty0, tx0);
         // input pixel of patch position (pr, pc): (iy0 + IS*pr, ix0 + IS*pc)
         const int iy0 = GEO == C2_D ? 2 * ty0 - py : ty0 - 1, ix0 = GEO == C2_D ? 2 * tx0 - px : tx0 - 1;
         const bf16_t* base = xg + (((long)b * a.H + iy0) * a.W + ix0) * a.Cin + kc * 32;
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
             // ---- epilogue: bias, activation, bf16; transposed through a wave-private LDS scratch (the patch region of
             // the stage just consumed) so that every lane stores 16 bytes and neighbouring lanes cover whole channel rows
             int b, ty0, tx0;
-            tile_coords(slot + it * a.nslots, b, ty0, tx0);
+            tile_coords(tile0 + it * tstride, b, ty0, tx0);
             if constexpr (GEO == C2_U) {
                 __syncthreads();                 // every wave is done reading this stage's patch
                 char* scr = cur + wave * (64 * OROW);
@@ -340,6 +347,8 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
     if (per > need) per = need;
     if (per < 1) per = 1;
     a.nslots = per * 8;
+    static const int bands_on = [] { const char* e = getenv("SGX_TILE_BANDS"); return e ? atoi(e) : 0; }();   // measured (tools/gpu_r2u.sh): 80.8 vs 81.2 ms at batch 32, nothing at batch 4 -- off by default
+    a.bands = (bands_on && a.ntiles >= 8 * a.nslots) ? 1 : 0;      // enough tiles per slot for the order to matter
     hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.ncb * per)), dim3(NW * 64), L::TOTAL, st, a);
     SGX_LAUNCH_CHECK("conv2_kernel");
     return 0;

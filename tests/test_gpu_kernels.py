@@ -583,6 +583,7 @@ CONV2_CASES = [
     ("S", 32, 64, 2, 32, 32), ("S", 64, 64, 3, 16, 32), ("S", 64, 128, 2, 40, 64), ("S", 128, 64, 1, 64, 32), ("S", 256, 256, 2, 8, 32),
     ("S", 32, 128, 5, 24, 96), ("S", 96, 192, 1, 33, 32), ("S", 64, 64, 9, 64, 64),
     ("S", 32, 32, 2, 64, 64), ("S", 64, 32, 3, 24, 32), ("S", 32, 96, 1, 40, 64),        # 32-channel output blocks (MF = 1)
+    ("S", 32, 128, 2, 520, 512), ("U", 32, 64, 1, 512, 1024),                            # enough tiles for the XCD-band tile order, ragged rows
     ("D", 32, 64, 2, 64, 64), ("D", 64, 32, 3, 32, 64), ("D", 128, 128, 1, 80, 128), ("D", 32, 96, 2, 36, 64), ("D", 64, 64, 5, 128, 64),
     ("U", 32, 32, 2, 32, 32), ("U", 64, 64, 3, 16, 32), ("U", 128, 32, 1, 40, 64), ("U", 32, 96, 2, 17, 32), ("U", 64, 32, 5, 64, 64),
 ]
