@@ -123,8 +123,10 @@ def test_two_ranks_equal_the_global_batch_run():
                 # an element whose gradient is ~0 flips sign on round-off and then differs by 2 lr -- a few per cent of a big
                 # tensor; on the small ones (biases, noise weights: tens of elements) the fraction is noise, and what pins the
                 # data-parallel arithmetic there is the gradient comparison above
+                # (measured 1..5.4 % after two iterations; a missing rank in the all-reduce or a wrong loss scale shows in the
+                # gradient comparison above as a factor, and here as ~half of the elements)
                 bad = np.mean(np.abs(r[k] - v) > 1e-5 * (1 + np.abs(v)))
-                assert bad <= 5e-2, (rank, k, bad)
+                assert bad <= 0.15, (rank, k, bad)
     for k in got[0]:
         if "::" in k or k == "avg_latent":
             assert np.array_equal(got[0][k], got[1][k]), k             # the replicas stay bit-identical
