@@ -52,13 +52,14 @@ class GradBuckets:
 
     def __init__(self, params, bucket_elems):
         self.params = list(params)
-        assert self.params and all(p.dtype == torch.float32 for p in self.params)
+        dtype = self.params[0].dtype                        # fp32 in the product (parameters and their gradients are fp32)
+        assert self.params and all(p.dtype == dtype for p in self.params)
         dev = self.params[0].device
         pad = lambda n: (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.buckets = []
         for idx in bucketize([pad(p.numel()) for p in self.params], bucket_elems):
             chunk = [self.params[i] for i in idx]
-            flat = torch.zeros(sum(pad(p.numel()) for p in chunk), dtype=torch.float32, device=dev)
+            flat = torch.zeros(sum(pad(p.numel()) for p in chunk), dtype=dtype, device=dev)
             views, off = [], 0
             for p in chunk:
                 views.append((p, flat[off:off + p.numel()].view(p.shape)))

@@ -15,7 +15,7 @@ import torch.nn.functional as TF
 
 import golden_util as gu
 from oracle import stylegan_oracle as O
-from stylegan.pytorch_amd.dist import DataParallelGroup, bucketize, stddev_preserving_shard
+from stylegan.pytorch_amd.dist import DataParallelGroup, GradBuckets, bucketize, stddev_preserving_shard
 
 WORLD = 2
 RES, DEPTH_TOTAL, DEPTH, ALPHA, B = 16, 3, 2, 0.5, 16      # tiny D: 16x16, 8 channels
@@ -79,6 +79,21 @@ def _worker(rank, port, out_q):
         extra = torch.nn.Parameter(torch.zeros(3))           # inactive resolution: grad None on every rank, skipped
         group.all_reduce_grads(params + [extra])
         assert extra.grad is None
+        # flat gradient buckets (what StyleGAN(data_parallel=...) uses from the second iteration at a depth on): the gradients
+        # live in the buckets, the all-reduce runs on the buckets in place
+        active = [p for p in params if p.grad is not None]
+        gb = GradBuckets(active, group.bucket_elems)
+        assert len(gb.buckets) > 1 and gb.matches(active) and not gb.matches(active[:-1])
+        want = [p.grad.clone() for p in active]                          # (already the all-reduced sums)
+        gb.attach()
+        assert gb.attached() and all(float(p.grad.abs().sum()) == 0.0 for p in active)
+        for p, w in zip(active, want):
+            p.grad.add_(w * (0.25 if rank == 0 else 0.75))               # a "backward" accumulating into the views
+        group.all_reduce_buckets(gb)
+        for p, w in zip(active, want):
+            assert torch.allclose(p.grad, w, rtol=1e-12, atol=0), "bucket all-reduce"
+        loss_part = torch.tensor(1.5 + rank, dtype=torch.float64)
+        assert float(group.all_reduce_scalar(loss_part)) == 4.0 and float(loss_part) == 1.5 + rank    # a new tensor; the input is untouched
         avg = torch.full((4,), float(rank + 1))
         group.broadcast(avg, src=0)
         # numpy payloads are pickled by value (torch tensors would travel as shared-memory handles of a dying process)
