@@ -518,6 +518,9 @@ class StyleGAN:
         gb = self._grad_buckets.get((kind, int(depth)))
         if active and (gb is None or not gb.matches(active)) and not torch.cuda.is_current_stream_capturing():
             from .dist import GradBuckets
+            for key in [k for k in self._grad_buckets if k[0] == kind and k[1] != int(depth)
+                        and not any(g.depth == k[1] and g.graph is not None for g in self._step_graphs.values())]:
+                del self._grad_buckets[key]                    # progressive growing moves on: drop the previous depth's ~100 MB
             self._grad_buckets[(kind, int(depth))] = GradBuckets(active, self.dp.bucket_elems)
 
     def _aux_stream(self):
