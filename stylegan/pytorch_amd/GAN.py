@@ -463,22 +463,21 @@ class StyleGAN:
     def __setup_loss(self, loss):
         if isinstance(loss, str):
             loss = loss.lower()
+            # data parallel: every head is a batch mean -> 1/world under the gradient all-reduce(SUM)
+            mean_scale = 1.0 / self.dp.world_size if self.dp is not None else 1.0
             if self.conditional:                                            # reference :548-551
                 assert loss in ["conditional-loss"]
-                assert self.dp is None, "data parallel is wired for the logistic loss"
-                return Losses.ConditionalGANLoss(self.dis)
+                return Losses.ConditionalGANLoss(self.dis, mean_scale=mean_scale)
             assert loss in ["logistic", "hinge", "standard-gan", "relativistic-hinge"], "Unknown loss function"
-            mean_scale = 1.0 / self.dp.world_size if self.dp is not None else 1.0
             if loss == "logistic":
                 return Losses.LogisticGAN(self.dis, mean_scale=mean_scale)
             if loss == "hinge":
-                assert self.dp is None, "data parallel is wired for the logistic loss"
-                return Losses.HingeGAN(self.dis)
+                return Losses.HingeGAN(self.dis, mean_scale=mean_scale)
             if loss == "standard-gan":
-                assert self.dp is None, "data parallel is wired for the logistic loss"
-                return Losses.StandardGAN(self.dis)
-            assert self.dp is None, "data parallel is wired for the logistic loss"
-            return Losses.RelativisticAverageHingeGAN(self.dis)
+                return Losses.StandardGAN(self.dis, mean_scale=mean_scale)
+            # the relativistic loss subtracts the mean prediction of the WHOLE batch: a differentiable all-reduce
+            return Losses.RelativisticAverageHingeGAN(self.dis, mean_scale=mean_scale,
+                                                      batch_mean=self.dp.global_mean if self.dp is not None else None)
         return loss
 
     def progressive_down_sampling(self, real_batch, depth, alpha):
@@ -554,7 +553,8 @@ class StyleGAN:
     def _graphable(self, labels):
         # with data parallelism the all-reduce stays eager between two graphs; the W-average broadcast cannot
         return (self.use_graphs and labels is None and self.d_repeats == 1 and self.structure == "linear"
-                and (self.dp is None or self.gen.truncation is None))
+                and (self.dp is None or (self.gen.truncation is None                     # (neither can the relativistic
+                                         and not isinstance(self.loss, Losses.RelativisticAverageHingeGAN))))  # loss's mean)
 
     def _d_grads(self, noise, real_batch, depth, alpha, labels=None):
         """Discriminator half-iteration, part 1: losses and local gradients; returns the (device) loss."""

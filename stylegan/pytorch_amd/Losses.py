@@ -11,10 +11,21 @@ from . import functional as F
 
 
 class GANLoss:
-    """Base class -- reference models/Losses.py:20-51."""
+    """Base class -- reference models/Losses.py:20-51.
 
-    def __init__(self, dis):
+    ``mean_scale`` / ``batch_mean`` exist for data parallelism (the reference is single-device).  Every head
+    below is a MEAN over the batch, so under a gradient all-reduce(SUM) over N ranks holding B/N samples each, the local
+    mean carries ``mean_scale`` = 1/N and the sum of the rank losses is the loss of the global batch.  ``batch_mean`` is
+    the mean of a [B,1] prediction over the GLOBAL batch where a head uses one as a term (the relativistic loss):
+    ``torch.mean`` on one device, ``DataParallelGroup.global_mean`` (a differentiable all-reduce) on several."""
+
+    def __init__(self, dis, mean_scale=1.0, batch_mean=None):
         self.dis = dis
+        self.mean_scale = float(mean_scale)
+        self.batch_mean = batch_mean if batch_mean is not None else torch.mean
+
+    def _scaled(self, loss):
+        return loss if self.mean_scale == 1.0 else loss * self.mean_scale
 
     def dis_loss(self, real_samps, fake_samps, height, alpha):
         raise NotImplementedError("dis_loss method has not been implemented")
@@ -25,21 +36,25 @@ class GANLoss:
 
 class ConditionalGANLoss:
     """Binary cross entropy on the logits of the label-conditioned discriminator -- reference models/Losses.py:54-93
-    (``dis(samples, height, alpha, labels_in=labels)``)."""
+    (``dis(samples, height, alpha, labels_in=labels)``).  ``mean_scale``: see GANLoss (the labels are sharded with the
+    images)."""
 
-    def __init__(self, dis):
+    def __init__(self, dis, mean_scale=1.0):
         self.dis = dis
+        self.mean_scale = float(mean_scale)
+
+    _scaled = GANLoss._scaled
 
     def dis_loss(self, real_samps, fake_samps, labels, height, alpha):
         r_preds = torch.squeeze(self.dis(real_samps, height, alpha, labels_in=labels))
         f_preds = torch.squeeze(self.dis(fake_samps, height, alpha, labels_in=labels))
         real_loss = TF.binary_cross_entropy_with_logits(r_preds, torch.ones_like(r_preds))
         fake_loss = TF.binary_cross_entropy_with_logits(f_preds, torch.zeros_like(f_preds))
-        return (real_loss + fake_loss) / 2
+        return self._scaled((real_loss + fake_loss) / 2)
 
     def gen_loss(self, _, fake_samps, labels, height, alpha):
         preds = torch.squeeze(self.dis(fake_samps, height, alpha, labels_in=labels))
-        return TF.binary_cross_entropy_with_logits(preds, torch.ones_like(preds))
+        return self._scaled(TF.binary_cross_entropy_with_logits(preds, torch.ones_like(preds)))
 
 
 class StandardGAN(GANLoss):
@@ -53,11 +68,11 @@ class StandardGAN(GANLoss):
         f_preds = torch.squeeze(self.dis(fake_samps, height, alpha))
         real_loss = TF.binary_cross_entropy_with_logits(r_preds, torch.ones_like(r_preds))
         fake_loss = TF.binary_cross_entropy_with_logits(f_preds, torch.zeros_like(f_preds))
-        return (real_loss + fake_loss) / 2
+        return self._scaled((real_loss + fake_loss) / 2)
 
     def gen_loss(self, _, fake_samps, height, alpha):
         preds = torch.squeeze(self.dis(fake_samps, height, alpha))
-        return TF.binary_cross_entropy_with_logits(preds, torch.ones_like(preds))
+        return self._scaled(TF.binary_cross_entropy_with_logits(preds, torch.ones_like(preds)))
 
 
 class HingeGAN(GANLoss):
@@ -66,40 +81,40 @@ class HingeGAN(GANLoss):
     def dis_loss(self, real_samps, fake_samps, height, alpha):
         r_preds = self.dis(real_samps, height, alpha)
         f_preds = self.dis(fake_samps, height, alpha)
-        return torch.mean(TF.relu(1 - r_preds)) + torch.mean(TF.relu(1 + f_preds))
+        return self._scaled(torch.mean(TF.relu(1 - r_preds)) + torch.mean(TF.relu(1 + f_preds)))
 
     def gen_loss(self, _, fake_samps, height, alpha):
-        return -torch.mean(self.dis(fake_samps, height, alpha))
+        return self._scaled(-torch.mean(self.dis(fake_samps, height, alpha)))
 
 
 class RelativisticAverageHingeGAN(GANLoss):
-    """reference models/Losses.py:154-189."""
+    """reference models/Losses.py:154-189.  The two "average" terms are means over the whole batch (:166-167,183-184):
+    ``batch_mean`` (the global mean under data parallelism, see GANLoss)."""
 
     def dis_loss(self, real_samps, fake_samps, height, alpha):
         r_preds = self.dis(real_samps, height, alpha)
         f_preds = self.dis(fake_samps, height, alpha)
-        r_f_diff = r_preds - torch.mean(f_preds)
-        f_r_diff = f_preds - torch.mean(r_preds)
-        return torch.mean(TF.relu(1 - r_f_diff)) + torch.mean(TF.relu(1 + f_r_diff))
+        r_f_diff = r_preds - self.batch_mean(f_preds)
+        f_r_diff = f_preds - self.batch_mean(r_preds)
+        return self._scaled(torch.mean(TF.relu(1 - r_f_diff)) + torch.mean(TF.relu(1 + f_r_diff)))
 
     def gen_loss(self, real_samps, fake_samps, height, alpha):
         r_preds = self.dis(real_samps, height, alpha)
         f_preds = self.dis(fake_samps, height, alpha)
-        r_f_diff = r_preds - torch.mean(f_preds)
-        f_r_diff = f_preds - torch.mean(r_preds)
-        return torch.mean(TF.relu(1 + r_f_diff)) + torch.mean(TF.relu(1 - f_r_diff))
+        r_f_diff = r_preds - self.batch_mean(f_preds)
+        f_r_diff = f_preds - self.batch_mean(r_preds)
+        return self._scaled(torch.mean(TF.relu(1 + r_f_diff)) + torch.mean(TF.relu(1 - f_r_diff)))
 
 
 class LogisticGAN(GANLoss):
     """Non-saturating logistic loss with the R1 gradient penalty -- reference models/Losses.py:192-229.
 
-    ``r1_scale`` / ``mean_scale`` exist for data parallelism: the softplus terms are batch MEANS,
-    the R1 term is a batch SUM (:210), so under a gradient all-reduce(SUM) over N ranks the mean terms carry 1/N.
+    ``mean_scale`` (data parallelism, see GANLoss): the softplus terms are batch MEANS and carry it; the R1 term is a
+    batch SUM (:210) and does not.
     """
 
     def __init__(self, dis, mean_scale=1.0):
-        super().__init__(dis)
-        self.mean_scale = float(mean_scale)
+        super().__init__(dis, mean_scale=mean_scale)
 
     def _r1_from_logit(self, real_logit, real_img):
         with F.data_grad_only():                      # only d(logit)/d(image) is needed here, not the parameter grads

@@ -81,6 +81,26 @@ class GradBuckets:
         return all(p.grad is v for _, views in self.buckets for p, v in views)
 
 
+class _GlobalMeanFn(torch.autograd.Function):
+    """mean over the GLOBAL batch of a per-rank tensor holding B/N samples: m = (1/N) sum_k mean(x_k).
+
+    With L = sum_r L_r (every rank's loss already carries 1/N, Losses.GANLoss.mean_scale) and every L_r a function of m,
+    dL/dmean(x_k) = (1/N) sum_r dL_r/dm: the backward is the same all-reduce of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group, ctx.shape = group, x.shape
+        return group._mean_over_ranks(x.mean())
+
+    @staticmethod
+    def backward(ctx, g):
+        gm = ctx.group._mean_over_ranks(g)
+        n = 1
+        for d in ctx.shape:
+            n *= d
+        return (gm / n).expand(ctx.shape), None
+
+
 class DataParallelGroup:
     """Bucketed gradient all-reduce(SUM) + buffer broadcast over a torch.distributed process group
     (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests)."""
@@ -132,6 +152,19 @@ class DataParallelGroup:
         if self.world_size > 1 or self.force_collectives:
             self._all_reduce(out)
         return out
+
+    def _mean_over_ranks(self, t):
+        out = t.detach().clone()
+        if self.world_size > 1 or self.force_collectives:
+            self._all_reduce(out)
+            out = out / self.world_size
+        return out
+
+    def global_mean(self, x):
+        """Differentiable mean of ``x`` (this rank's B/N samples) over the global batch -- what ``torch.mean`` of the
+        single-device batch is to the reference's relativistic loss (models/Losses.py:166-167,183-184).  Equal shard sizes
+        (stddev_preserving_shard) make it the mean of the rank means."""
+        return _GlobalMeanFn.apply(x, self)
 
     def _side_stream(self, device):
         if device.type != "cuda":
