@@ -4,6 +4,7 @@ The kernels need the GPU, so the per-rank arithmetic here is the CPU oracle; wha
 itself: the stddev-preserving shard, the SUM all-reduce with bucketing, the mean-vs-sum loss scaling
 (softplus terms are batch means, R1 is a batch sum -- reference models/Losses.py:210,218), and the W-average
 broadcast.  Target: N-rank gradients == single-process gradients at the GLOBAL batch."""
+import datetime
 import os
 import socket
 
@@ -24,6 +25,13 @@ RES, DEPTH_TOTAL, DEPTH, ALPHA, B = 16, 3, 2, 0.5, 16      # tiny D: 16x16, 8 ch
 def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
+
+
+def _reap(procs):
+    """A rank that died leaves its peer waiting in a collective: never leave a child behind."""
+    for p in procs:
+        if p.is_alive():
+            p.terminate(); p.join(timeout=10)
 
 
 def tiny_d_params():
@@ -63,7 +71,7 @@ def test_bucketize():
 
 def _worker(rank, port, out_q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD, timeout=datetime.timedelta(seconds=120))
     torch.set_num_threads(2)
     try:
         group = DataParallelGroup(bucket_mb=0.001)          # tiny buckets: exercise the multi-bucket path
@@ -109,13 +117,16 @@ def test_two_rank_gradients_equal_global_batch():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, port, q), daemon=True) for r in range(WORLD)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(WORLD)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        got = [q.get(timeout=120) for _ in range(WORLD)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        _reap(procs)
     grads = next(g for g in got if isinstance(g, tuple))[0]
     for g in got:
         avg = g[1] if isinstance(g, tuple) else g
@@ -188,7 +199,7 @@ def _head_inputs():
 
 def _head_worker(rank, port, out_q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD, timeout=datetime.timedelta(seconds=120))
     torch.set_num_threads(2)
     try:
         group = DataParallelGroup()
@@ -214,13 +225,16 @@ def test_every_loss_head_two_ranks_equal_global_batch():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=_head_worker, args=(r, port, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_head_worker, args=(r, port, q), daemon=True) for r in range(WORLD)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        got = q.get(timeout=120)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        _reap(procs)
     real, fake, labels = _head_inputs()
     for name in LOSS_HEADS:
         for which in (0, 1):
@@ -242,9 +256,9 @@ def test_relativistic_mean_must_be_global():
     """The same comparison with the LOCAL mean in the relativistic head is off: the test above is sensitive to the wiring."""
     real, fake, labels = _head_inputs()
     dis = _TinyD()
-    want = float(_head_losses("relativistic-hinge", dis, real, fake, labels, 1.0, None)[0])
+    want = _head_losses("relativistic-hinge", dis, real, fake, labels, 1.0, None)[0].item()
     part = 0.0
     for rank in range(WORLD):
         idx = stddev_preserving_shard(B, WORLD, rank)
-        part += float(_head_losses("relativistic-hinge", dis, real[idx], fake[idx], labels[idx], 1.0 / WORLD, None)[0])
+        part += _head_losses("relativistic-hinge", dis, real[idx], fake[idx], labels[idx], 1.0 / WORLD, None)[0].item()
     assert abs(part - want) > 1e-6

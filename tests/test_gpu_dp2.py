@@ -77,7 +77,9 @@ def _worker(rank, port, q):
             sys.path.insert(0, p)
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    import datetime
+    # (a rank that dies leaves its peer in a collective: bound that wait, the parent reaps whatever is left)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD, timeout=datetime.timedelta(seconds=300))
     try:
         torch.cuda.set_device(0)
         from stylegan.pytorch_amd.dist import DataParallelGroup, stddev_preserving_shard
@@ -92,13 +94,18 @@ def test_two_ranks_equal_the_global_batch_run():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, port, q), daemon=True) for r in range(WORLD)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=600) for _ in range(WORLD))
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        got = dict(q.get(timeout=600) for _ in range(WORLD))
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:                                              # never leave a rank behind (it would hold the GPU)
+            if p.is_alive():
+                p.terminate(); p.join(timeout=10)
     ref = run_steps(build(None), list(range(GLOBAL_B)))              # single process, global batch
 
     def rel(a, b):
