@@ -105,8 +105,8 @@ struct ConvArgs {
     const void* x; const void* w; const float* bias; void* y;
     int B, H, W, OH, OW, OHc, OWc, Cin, Cout, act, tiles_x, tiles_y, ntiles;
     const void* mask;   // 3x3 only: y *= slope(mask) in the store (mask: a tensor shaped like y; the activation-backward of the layer below)
-    int bands;          // XCD-aware tile order (grid x a multiple of 8): see conv_kernel
     int dbg;   // ablation switches (SGX_CONV_DBG, profiling only): 1 no MFMA, 2 no global loads, 4 no LDS stores, 8 no output stores
+    int bands;          // XCD-aware tile order (grid x a multiple of 8): see conv_kernel
 };
 
 template <int GEO> struct Geo;
@@ -130,6 +130,15 @@ constexpr int conv_min_waves(int tsize, int CT, int BP, int GEO, int KC) {
     if (CT * BP >= 1024 || GEO == GDOWN) return 1;
     if (tsize == 2 && CT * BP <= 256) return SGX_CONV_OCC_SMALL;
     return 2;
+}
+// XCD-band tile order (see conv_kernel) is compiled only into the instantiations whose launches have enough tiles for it to
+// matter: the 16x16-pixel tiles of the bf16 3x3 / all-class transposed layers (>= 256^2).  Everywhere else its index registers
+// cost a wave of occupancy or spill (compiler resource remarks, tools/kernel_resources.py: 40 instantiations lost a wave per
+// SIMD, 8 gained scratch; the 1024^2 stride-2 layer went from 64 to 89 us, the 64^2 one from 33 to 51), so those keep the
+// plain walk and its single live tile index.
+template <typename T>
+constexpr bool conv_bands_ok(int GEO, int TH, int TW, int BP) {
+    return sizeof(T) == 2 && (GEO == G3X3 || GEO == GUPA) && TH == 16 && TW == 16 && BP == 256;
 }
 template <typename T, int KC, int GEO, int TH, int TW, int BP, int CT>
 // Register budget: two waves per SIMD (<= 256 VGPR+AGPR) except for the 64-channel x 256-pixel tile, whose prefetch
@@ -265,14 +274,22 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
     // hardware's round-robin, used as an affinity for speed only -- any placement is correct) walk ONE contiguous eighth of
     // the tile raster, so raster neighbours run on the same L2 close in time and the halo a tile shares with them is an L2
     // hit instead of a second HBM fetch (PMC: 336 MB fetched per launch against 268 MB algorithmic on the 1024^2 layer).
-    const int band = (a.ntiles + 7) >> 3, xcd = blockIdx.x & 7, nb8 = gridDim.x >> 3, bslot = blockIdx.x >> 3;
+    constexpr bool BANDS = conv_bands_ok<T>(GEO, TH, TW, BP);
+    int band, xcd, nb8, bslot;                         // band walk only: never read in the other instantiations
+    if constexpr (BANDS) { band = (a.ntiles + 7) >> 3; xcd = blockIdx.x & 7; nb8 = gridDim.x >> 3; bslot = blockIdx.x >> 3; }
     auto tile_of = [&](int it) {
         if (!a.bands) { const int t = blockIdx.x + it * (int)gridDim.x; return t < a.ntiles ? t : -1; }
         const int j = bslot + it * nb8, t = xcd * band + j;
         return (j < band && t < a.ntiles) ? t : -1;
     };
-    int iter = 0, tile = tile_of(0), next_tile = tile_of(1);
-    if (tile < 0) return;
+    int iter = 0, tile, next_tile = -1;
+    if constexpr (BANDS) {
+        tile = tile_of(0); next_tile = tile_of(1);
+        if (tile < 0) return;
+    } else {
+        tile = blockIdx.x;
+        if (tile >= a.ntiles) return;
+    }
     set_tile(tile);
     gload(0, true);
     bool first = true;
@@ -284,9 +301,15 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
         if (!(a.dbg & 4) || first) lstore(ww);
         first = false;
         __syncthreads();
+        if constexpr (BANDS) {
         if (a.dbg & 2) { if (k0 + KC >= a.Cin && next_tile >= 0) set_tile(next_tile); }
         else if (k0 + KC < a.Cin) gload(k0 + KC, true);    // in flight during the MFMAs below
         else if (next_tile >= 0) { set_tile(next_tile); gload(0, !w_static); }
+        } else {
+        if (a.dbg & 2) { if (k0 + KC >= a.Cin && tile + (int)gridDim.x < a.ntiles) set_tile(tile + gridDim.x); }
+        else if (k0 + KC < a.Cin) gload(k0 + KC, true);    // in flight during the MFMAs below
+        else if (tile + (int)gridDim.x < a.ntiles) { set_tile(tile + gridDim.x); gload(0, !w_static); }
+        }
         if constexpr (UPA) {
             // position-major: each of the 9 patch positions (dy, dx) is read once and feeds every class that has a tap
             // there -- class (py, px) uses tap (a, b) = (dy - py, dx - px) when both are 0 or 1, with the weight tap
@@ -445,8 +468,13 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
             }
         }
     }
-    tile = next_tile; next_tile = tile_of(++iter + 1);
-    if (tile < 0) break;
+    if constexpr (BANDS) {
+        tile = next_tile; next_tile = tile_of(++iter + 1);
+        if (tile < 0) break;
+    } else {
+        tile += gridDim.x;
+        if (tile >= a.ntiles) break;
+    }
 #pragma unroll
     for (int ct = 0; ct < NCL * CT; ++ct)
 #pragma unroll
@@ -495,7 +523,7 @@ static int launch_conv(ConvArgs& a, int ngroups, hipStream_t st) {
     if (gx < 1) gx = 1;
     static const int bands_on = [] { const char* e = getenv("SGX_TILE_BANDS"); return e ? atoi(e) : 1; }();   // measured (tools/gpu_r2u.sh): halo over-fetch gone (PMC), 80.8 vs 81.2 ms at batch 32, nothing at batch 4
     a.bands = 0;
-    if (bands_on && gx >= 64 && a.ntiles >= 8 * gx) {         // enough tiles per band for the order to matter
+    if (conv_bands_ok<T>(GEO, TH, TW, BP) && bands_on && gx >= 64 && a.ntiles >= 8 * gx) {   // enough tiles per band for the order to matter
         gx = gx / 8 * 8;
         a.bands = 1;
     }

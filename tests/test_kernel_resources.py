@@ -1,0 +1,60 @@
+"""Register / scratch budget of the compiled kernels, from the compiler's own resource remarks (no GPU).
+
+``make -C stylegan/pytorch_amd/csrc`` keeps them in ``csrc/build/*.res`` (tools/kernel_resources.py prints the table).  The first-
+generation convolution sits at its launch-bounds register cap in many instantiations: an innocent-looking edit (round 2: four
+index registers of the XCD-band tile walk, compiled into every instantiation) cost 40 of them a wave per SIMD and put scratch
+spills into the 1024x1024 stride-2 layer (64 -> 89 us) without any test noticing.  This pins what the hot kernels are allowed to
+use."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+kr = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(kr)
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    ks = kr.collect()
+    if not ks:
+        pytest.skip("no csrc/build/*.res (library not built by make in this tree)")
+    return {k["name"]: k for k in ks}
+
+
+def test_second_generation_and_streaming_kernels_never_spill(kernels):
+    checked = 0
+    for name, k in kernels.items():
+        if k["file"] in ("conv2.hip", "wgrad2.hip", "gepi.hip", "pointwise.hip", "small.hip", "optim.hip"):
+            assert k["scratch"] == 0 and k["vgpr_spill"] == 0, (name, k)
+            checked += 1
+    assert checked > 50
+
+
+# (instantiation, least waves per SIMD the register allocation must leave): the launches of the headline step that are
+# HBM- or latency-bound on resident blocks (profiles/r02_f_step_bf16_b4_layer_table.tsv)
+HOT = [
+    ("conv_kernel<unsigned short, 16, 0, 16, 16, 256, 1>(ConvArgs)", 3),     # 3x3 1024^2 16->16
+    ("conv_kernel<unsigned short, 16, 1, 8, 16, 128, 2>(ConvArgs)", 3),      # stride-2 1024^2 16->32
+    ("conv_kernel<unsigned short, 32, 1, 8, 16, 128, 2>(ConvArgs)", 2),      # stride-2 64^2 256->512 (batch 4), 32^2 (batch 32)
+    ("conv_kernel<unsigned short, 32, 0, 16, 16, 256, 1>(ConvArgs)", 3),     # 3x3 32^2 512->512
+    ("conv_kernel<unsigned short, 32, 3, 16, 16, 256, 1>(ConvArgs)", 2),     # transposed 512^2 -> 1024^2, all classes
+    ("conv_kernel<unsigned short, 128, 0, 4, 16, 64, 1>(ConvArgs)", 2),      # 3x3 16^2 512->512, deep K stages
+]
+
+
+@pytest.mark.parametrize("name,waves", HOT)
+def test_hot_convolutions_keep_their_occupancy_without_scratch(kernels, name, waves):
+    k = kernels[name]
+    assert k["scratch"] == 0 and k["vgpr_spill"] == 0, k
+    assert k["occupancy"] >= waves, k
+
+
+def test_scratch_is_confined_to_the_small_tile_fallbacks(kernels):
+    spilling = sorted(n for n, k in kernels.items() if k["scratch"])
+    # 4x4 / 8x8-pixel tiles at the register cap (layers of <= 8x8 pixels, microseconds per step): known, bounded
+    assert len(spilling) <= 7, spilling
+    for n in spilling:
+        assert n.startswith("conv_kernel<unsigned short") and (", 4, 4, " in n or ", 8, 8, " in n), n
