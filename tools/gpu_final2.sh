@@ -11,6 +11,7 @@ if [ "$2" != "notest" ]; then
 fi
 echo "== bench default"; timeout 600 python bench.py --layer-table $O/layers_b4.tsv 2>$O/bench_b4.err | tail -1 | tee $O/bench_b4.json | cut -c1-300
 echo "== bench b32"; timeout 400 python bench.py --batch-per-gpu 32 --steps 3 --warmup 1 --no-cpu-baseline --layer-table $O/layers_b32.tsv 2>$O/bench_b32.err | tail -1 | tee $O/bench_b32.json | cut -c1-300
+echo "== bench b32, single stream (per-layer times without the side stream's weight gradients sharing the GPU)"; timeout 400 python bench.py --batch-per-gpu 32 --steps 3 --warmup 1 --no-cpu-baseline --graphs off --streams 00 --layer-table $O/layers_b32_single_stream.tsv 2>/dev/null | tail -1 | tee $O/bench_b32_single_stream.json | cut -c1-200
 echo "== bench ffhq128 fp32 b64"; timeout 300 python bench.py --config ffhq128 --dtype fp32 --batch-per-gpu 64 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_ffhq128_fp32_b64.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprofv3 stats"
