@@ -846,6 +846,7 @@ class StyleGAN:
                         os.makedirs(os.path.join(output, 'samples'), exist_ok=True)
                         gen_img_file = os.path.join(output, 'samples', "gen_" + str(current_depth) + "_" + str(epoch) + "_"
                                                     + str(i) + ".png")
+                        self._wait_update("d"); self._wait_update("g")     # data parallel: G's Adam + EMA may still be in flight
                         with torch.no_grad():
                             sampler = self.gen_shadow if self.use_ema else self.gen
                             self.create_grid(
@@ -857,6 +858,9 @@ class StyleGAN:
                 elapsed = str(datetime.timedelta(seconds=timeit.default_timer() - t_epoch)).split('.')[0]
                 logger.info("Time taken for epoch: %s\n" % elapsed)
                 if self.is_checkpoint_epoch(epoch, n_epochs, checkpoint_factor):
+                    # data parallel: the last batch's all-reduce + Adam (+ EMA) run on the update stream; the state_dict copies
+                    # below are ordered on the current stream, so it joins the update stream first (no torn / stale state)
+                    self._wait_update("d"); self._wait_update("g")
                     save_dir = os.path.join(output, 'models')
                     os.makedirs(save_dir, exist_ok=True)
                     tag = str(current_depth) + "_" + str(epoch) + ".pth"
@@ -950,8 +954,11 @@ class _StepGraph:
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             self._stage(noise, real_batch, alpha)
+            loss_stream = None
             if self.graph is None and self.calls < self.WARMUP:
                 loss = self._body()                                                # eager, on the capture stream
+                # data parallel: the eager body hands back a loss produced on the update stream (all-reduced there)
+                loss_stream = sg.__dict__.pop("_loss_stream", None)
             else:
                 if self.graph is None:
                     try:
@@ -965,7 +972,8 @@ class _StepGraph:
                         torch.cuda.synchronize()
                         native.lib().sgx_clear_error()                             # the failed capture leaves a sticky error
                         self._undo_failed_capture()
-                        out = DeferredLoss(self._body())
+                        loss = self._body()
+                        out = DeferredLoss(loss, stream=sg.__dict__.pop("_loss_stream", None))
                         self.done.record()
                         self.calls += 1
                         cur.wait_stream(self.stream)
@@ -985,7 +993,7 @@ class _StepGraph:
                     if p.grad is not g:
                         p.grad = g
                 loss = self.loss_global if self.graph_update is not None else self.loss
-            out = DeferredLoss(loss)
+            out = DeferredLoss(loss, stream=loss_stream)
             self.done.record()
         self.calls += 1
         cur.wait_stream(self.stream)

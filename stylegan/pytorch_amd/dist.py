@@ -52,8 +52,9 @@ class GradBuckets:
 
     def __init__(self, params, bucket_elems):
         self.params = list(params)
+        assert self.params, "GradBuckets needs at least one parameter"
         dtype = self.params[0].dtype                        # fp32 in the product (parameters and their gradients are fp32)
-        assert self.params and all(p.dtype == dtype for p in self.params)
+        assert all(p.dtype == dtype for p in self.params)
         dev = self.params[0].device
         pad = lambda n: (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.buckets = []

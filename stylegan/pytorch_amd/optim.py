@@ -5,6 +5,7 @@ Replaces ``torch.optim.Adam`` / ``clip_grad_norm_`` / ``update_average`` of the 
 ``state_dict`` layout (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter), so optimizer checkpoints interchange.
 """
 import math
+from collections import OrderedDict
 
 import torch
 
@@ -15,19 +16,30 @@ from .functional import bump_weight_generation
 # Host -> device tables of the multi-tensor kernels.  Pinned staging + non_blocking so that the copy is stream ordered
 # and the host does not wait for the GPU queue to drain; pointer tables are cached (parameter / state / gradient
 # addresses are stable from step to step).
-_TABLES = {}
+_TABLES = OrderedDict()             # LRU: key -> device table
+_TABLES_MAX = 64
+_GRAPH_TABLES = []                  # tables a captured step graph baked the DEVICE ADDRESS of into its kernel arguments: kept for good
 _capturing = N.capturing
 _to_dev = N.upload
 
 
 def _dev_i64(vals, device):
+    """Cached device copy of an int64 table.  Keys contain gradient addresses, which change in eager mode whenever the
+    allocator hands ``zero_grad(set_to_none)``'s successors other blocks, so the cache is a small LRU; an evicted table
+    that a kernel in flight still reads stays alive through ``record_stream`` (callers do that), and every table used while
+    a step graph is being captured is pinned in ``_GRAPH_TABLES`` (the graph replays with its address)."""
     key = (tuple(vals), str(device))
     got = _TABLES.get(key)
     if got is None:
-        # never evicted: captured step graphs bake the DEVICE ADDRESS of these tables into their kernel arguments, so an
-        # entry must outlive every graph that was captured while it existed (an entry is a few hundred bytes; one per
-        # distinct parameter/gradient address set, i.e. a handful per progressive depth)
         got = _TABLES[key] = _to_dev(torch.tensor(vals, dtype=torch.int64), device)[0]
+        while len(_TABLES) > _TABLES_MAX:
+            _TABLES.popitem(last=False)
+    else:
+        _TABLES.move_to_end(key)
+    if _capturing():
+        _GRAPH_TABLES.append(got)
+    elif got.is_cuda:
+        got.record_stream(torch.cuda.current_stream())       # a consumer on another stream than the one that uploaded it
     return got
 
 
@@ -121,7 +133,7 @@ class FusedAdam(torch.optim.Optimizer):
                                      sb, sb + 4 * n, None if grad_scale is None else N.ptr(grad_scale), N.stream()),
                     "sgx_adam_multi")
             if not _capturing():
-                table.record_stream(torch.cuda.current_stream()); scal.record_stream(torch.cuda.current_stream())
+                scal.record_stream(torch.cuda.current_stream())
         bump_weight_generation(changed)              # parameters changed behind torch's version counters
         return None
 
