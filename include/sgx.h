@@ -192,9 +192,19 @@ int sgx_rgb_wgrad(const float* img, const void* f, float* dw, int sj, int sc, fl
  * terms).  use_noise=False is nw = 0, use_styles=False is style = 0 (both exact).  The default is ACT|NORM.           */
 enum { SGX_EPI_ACT = 1, SGX_EPI_NORM = 2 };
 size_t sgx_gepi_ws_bytes(int B, int HW, int C);
+/* pre_part (may be NULL): the instance-norm statistics pass was already done by the kernel that PRODUCED x -- pre_npart
+ * partial (sum a, sum a^2) pairs per (image, channel), double [B][pre_npart][C][2] (sgx_blur3x3_stats, sgx_conv3x3_stats):
+ * the epilogue then reads the tensor once (apply pass) instead of twice. */
 int sgx_gepi_fwd(const void* x, const float* bias, const float* noise, const float* nw, const float* style, void* y,
-                 float* mean, float* rstd, void* ws, size_t ws_bytes, int B, int HW, int C, int flags, int dtype,
-                 void* stream);
+                 float* mean, float* rstd, void* ws, size_t ws_bytes, const double* pre_part, int pre_npart, int B, int HW,
+                 int C, int flags, int dtype, void* stream);
+/* y = blur3x3(x) (the generator's upscale-conv -> blur, models/CustomLayers.py:176-177, Blocks.py:63-65) with the statistics
+ * pass of the LayerEpilogue that follows (:232-233 after :224-229) folded into the store: part receives the per-block partial
+ * sums of a = act(y + bias[c] + nw[c]*noise[b,p]) and a^2 (y as stored), sgx_blur3x3_stats_nparts(...) blocks per image.
+ * bias may be NULL; act: SGX_ACT_NONE | SGX_ACT_LRELU. */
+int sgx_blur3x3_stats_nparts(int B, int H, int W, int C, int dtype);
+int sgx_blur3x3_stats(const void* x, void* y, const float* bias, const float* noise, const float* nw, double* part,
+                      size_t part_bytes, int B, int H, int W, int C, int act, int dtype, void* stream);
 int sgx_gepi_bwd(const void* dy, const void* x, const float* bias, const float* noise, const float* nw,
                  const float* style, const float* mean, const float* rstd, void* dx, float* dstyle, float* dnw,
                  float* dbias, void* ws, size_t ws_bytes, int B, int HW, int C, int flags, int dtype, void* stream);

@@ -3,12 +3,19 @@
 ``forward`` keeps the reference contract (logical NCHW fp32); the networks call ``forward_nhwc`` and stay in the
 kernels' NHWC layout / compute dtype from the first layer to the last.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import functional as F
 from .CustomLayers import (BlurLayer, EqualizedConv2d, EqualizedLinear, LayerEpilogue, StddevLayer, View, act_code, apply_act)
 from .native import ACT_LRELU, ACT_NONE
+
+
+# Instance-norm statistics of a generator layer epilogue out of the kernel that PRODUCES its input (A/B switch, default on):
+# bit 0: the blur after conv0_up (epi1), bit 1: the 3x3 convolution conv1 (epi2).
+FUSE_EPI_STATS = int(os.environ.get("SGX_FUSE_EPI_STATS", "3"))
 
 
 def _lat(d, k):
@@ -70,8 +77,16 @@ class GSynthesisBlock(nn.Module):
                                   use_instance_norm, use_styles, activation_layer)
 
     def forward_nhwc(self, x, dlatents_in_range):
-        x = self.conv0_up.forward_nhwc(x, skip_bias=True)                 # transposed conv + blur; bias folded below
-        x = self.epi1.forward_nhwc(x, _lat(dlatents_in_range, 0), conv_bias=self.conv0_up.scaled_bias())
+        up = self.conv0_up
+        if (FUSE_EPI_STATS & 1) and self.epi1._fusable and up.intermediate is not None and up.intermediate._is_121:
+            # the blur after the upscale-conv also emits the epilogue's instance-norm statistics (one pass less over the tensor)
+            b, h, w, _ = x.shape
+            nin = self.epi1.noise_inputs((b, 2 * h, 2 * w, up.weight.shape[0]), x.device)
+            x, part = up.forward_nhwc(x, skip_bias=True, epi_stats=(up.scaled_bias(),) + nin)
+            x = self.epi1.forward_nhwc(x, _lat(dlatents_in_range, 0), conv_bias=up.scaled_bias(), noise_in=nin, pre_stats=part)
+        else:
+            x = up.forward_nhwc(x, skip_bias=True)                        # transposed conv + blur; bias folded below
+            x = self.epi1.forward_nhwc(x, _lat(dlatents_in_range, 0), conv_bias=up.scaled_bias())
         x = self.conv1.forward_nhwc(x, skip_bias=True)
         return self.epi2.forward_nhwc(x, _lat(dlatents_in_range, 1), conv_bias=self.conv1.scaled_bias())
 

@@ -210,7 +210,8 @@ class EqualizedConv2d(nn.Module):
             return None
         return self.bias * self.b_mul if self.b_mul != 1 else self.bias
 
-    def forward_nhwc(self, x, act=ACT_NONE, skip_bias=False, out_dtype=None, defer_act=False, x_masked=False, out_scale=1.0):
+    def forward_nhwc(self, x, act=ACT_NONE, skip_bias=False, out_dtype=None, defer_act=False, x_masked=False, out_scale=1.0,
+                     epi_stats=None):
         """x: NHWC.  ``skip_bias``: the caller folds the bias into the next kernel (generator epilogue).
         ``defer_act`` / ``x_masked``: the LeakyReLU backward of this layer is applied by its consumer / this layer's input is
         such an output and its data gradient leaves the kernel already masked (functional.ConvFn; discriminator chain only).
@@ -242,6 +243,18 @@ class EqualizedConv2d(nn.Module):
                 raise NotImplementedError("1x1 EqualizedConv2d is built for the to_rgb / from_rgb layers (3 channels on one side)")
             return F.call(F.BiasActFn, y, None, 1.0, act) if act else y
         assert self.kernel_size == 3
+        if epi_stats is not None:
+            # generator layers (Blocks.GSynthesisBlock / InputBlock): ``epi_stats`` = (epilogue bias, noise, noise weight) of
+            # the LayerEpilogue that follows; the kernel that writes this layer's output also emits the partial instance-norm
+            # statistics -> returns (y, partials)
+            assert skip_bias and act == ACT_NONE and self.downscale is None
+            ebias, noise, nw = epi_stats
+            if self.upscale is not None:
+                fused = min(x.shape[1], x.shape[2]) * 2 >= 128            # reference :143
+                y = F.conv(x, self.weight, None, "U" if fused else "UF", self.w_mul)
+                assert self.intermediate is not None and self.intermediate._is_121
+                return F.call(F.BlurStatsFn, y, ebias, noise, nw)         # blur + statistics in one pass
+            raise NotImplementedError("epi_stats: producer not built for this layer")
         if self.upscale is not None:
             fused = min(x.shape[1], x.shape[2]) * 2 >= 128                # reference :143
             y = F.conv(x, self.weight, None, "U" if fused else "UF", self.w_mul)
@@ -335,15 +348,25 @@ class LayerEpilogue(nn.Module):
             return dlatents_in_slice.style
         return self.style_mod.style(dlatents_in_slice)
 
-    def forward_nhwc(self, x, dlatents_in_slice, conv_bias=None):
+    def noise_inputs(self, x_shape, device):
+        """(noise [B,1,H,W], noise weight) of this layer for an NHWC activation of ``x_shape`` -- drawn here when the producer
+        of the activation folds the statistics pass into its store and needs them before the epilogue runs."""
+        noise_layer = self.top_epi.noise
+        return noise_layer.sample(x_shape, device), noise_layer.weight
+
+    def forward_nhwc(self, x, dlatents_in_slice, conv_bias=None, noise_in=None, pre_stats=None):
+        """``noise_in`` / ``pre_stats`` (default stack only): the (noise, weight) pair already drawn by ``noise_inputs`` and the
+        partial instance-norm statistics the producer of ``x`` computed with them (functional.BlurStatsFn / ConvFn)."""
         use_noise, use_pixel_norm, use_instance_norm, use_styles = self._use
         noise = nw = None
-        if use_noise:
-            noise_layer = self.top_epi.noise
-            noise, nw = noise_layer.sample(x.shape, x.device), noise_layer.weight
+        if noise_in is not None:
+            noise, nw = noise_in
+        elif use_noise:
+            noise, nw = self.noise_inputs(x.shape, x.device)
         style = self._style(dlatents_in_slice) if use_styles else None
         if self._fusable:
-            return F.call(F.GEpilogueFn, x, conv_bias, noise, nw, style)
+            return F.call(F.GEpilogueFn, x, conv_bias, noise, nw, style, EPI_ACT | EPI_NORM, pre_stats)
+        assert pre_stats is None
         # Non-default stacks (reference :224-246: noise -> activation -> [pixel norm] -> [instance norm] -> [style]), on the
         # same kernels: the fused op with its stages switched by flags, split in two around a ReLU / a pixel norm.
         lrelu = self._act == ACT_LRELU

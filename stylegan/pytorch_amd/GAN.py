@@ -35,7 +35,7 @@ class DeferredLoss:
     somebody actually reads it (``float(x)``, ``"%f" % x``, ``f"{x:.3f}"``, arithmetic, comparison).  The training loop
     can thus enqueue the next half-iteration while the GPU is still finishing this one."""
 
-    __slots__ = ("_host", "_event", "_scale", "_value")
+    __slots__ = ("_host", "_event", "_scale", "_value", "__weakref__")
 
     def __init__(self, dev_scalar, scale=1.0, stream=None):
         """``stream``: the stream the scalar is produced on, if not the current one (data parallel: the update stream)."""
@@ -43,10 +43,10 @@ class DeferredLoss:
         if dev_scalar.is_cuda:
             with torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext():
                 t = dev_scalar.detach().reshape(1).float()
-                self._host = torch.empty(1, dtype=torch.float32).pin_memory()
+                view, slot = native.RING.take(4)                    # a pinned slot allocated once (no hipHostMalloc per loss)
+                self._host = view.view(torch.float32)
                 self._host.copy_(t, non_blocking=True)
-                self._event = torch.cuda.Event()
-                self._event.record()
+                self._event = native.RING.mark(slot, owner=self)
         else:
             self._host, self._event = dev_scalar.detach().reshape(1).float().clone(), None
 

@@ -51,6 +51,24 @@ __device__ __forceinline__ void load_coef(const float* __restrict__ p, float (&k
     }
 }
 
+// raw 16-byte vector <-> VE floats (bf16: the pack is v_cvt_pk_bf16_f32, round to nearest even, as every store of the library)
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& q, float (&v)[VecTraits<T>::VE]);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& q, float (&v)[4]) {
+    v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y); v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& q, float (&v)[8]) {
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float (&v)[VecTraits<T>::VE]);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float (&v)[4]) {
+    return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float (&v)[8]) {
+    return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+
 // mode 0: (sum a, sum a^2)                       [forward statistics]
 // mode 1: (sum dy, sum dy*xh)                    [backward reduction]
 // mode 2: writes dx, (sum dp*noise, sum dp)      [backward apply]
@@ -273,12 +291,24 @@ __global__ __launch_bounds__(256) void gepi_apply(const T* __restrict__ x, const
 
 template <typename T>
 static int gepi_fwd_t(const void* x, const float* bias, const float* noise, const float* nw, const float* style, void* y,
-                      float* mean, float* rstd, void* ws, int B, int HW, int C, int flags, hipStream_t st) {
+                      float* mean, float* rstd, void* ws, const double* pre_part, int pre_npart, int B, int HW, int C, int flags,
+                      hipStream_t st) {
     const int act = (flags & SGX_EPI_ACT) ? SGX_ACT_LRELU : SGX_ACT_NONE, norm = (flags & SGX_EPI_NORM) ? 1 : 0;
     constexpr int VE = VecTraits<T>::VE;
     GepiGeom g = gepi_geom(B, HW, C, VE);
     double* part = static_cast<double*>(ws);
     const double nb = (double)sizeof(T) * B * HW * C;
+    if (norm && pre_part) {
+        // the statistics pass already happened in the kernel that PRODUCED x (sgx_blur3x3_stats / the convolution's store
+        // epilogue): pre_npart partial (sum a, sum a^2) pairs per (image, channel), same layout as gepi_pass<T, 0> writes
+        hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 15) / 16), dim3(256), 0, st, pre_part, mean, rstd, B, C, pre_npart, HW, norm);
+        SGX_LAUNCH_CHECK("gepi_fin_stats");
+        SGX_NOTE(0.0, 2.0 * nb, "gepi_apply B%d HW%d C%d", B, HW, C);
+        hipLaunchKernelGGL(gepi_apply<T>, dim3(g.nchunk, B), dim3(256), 0, st, (const T*)x, bias, noise, nw, style, mean, rstd,
+                           (T*)y, HW, C, g.cvt, g.rows, g.chunk, act);
+        SGX_LAUNCH_CHECK("gepi_apply");
+        return 0;
+    }
     if (norm) {
         SGX_NOTE(0.0, nb, "gepi_stats B%d HW%d C%d", B, HW, C);
         hipLaunchKernelGGL((gepi_pass<T, 0>), dim3(g.nchunk, B), dim3(256), 256 * 2 * VE * sizeof(double), st, (const T*)x,
@@ -334,12 +364,171 @@ static int gepi_check(int B, int HW, int C, int dtype, size_t ws_bytes) {
 }
 
 extern "C" int sgx_gepi_fwd(const void* x, const float* bias, const float* noise, const float* nw, const float* style, void* y,
-                            float* mean, float* rstd, void* ws, size_t ws_bytes, int B, int HW, int C, int flags, int dtype,
-                            void* stream) {
+                            float* mean, float* rstd, void* ws, size_t ws_bytes, const double* pre_part, int pre_npart, int B, int HW,
+                            int C, int flags, int dtype, void* stream) {
     int rc = gepi_check(B, HW, C, dtype, ws_bytes);
     if (rc) return rc;
-    if (dtype == SGX_F32) return gepi_fwd_t<float>(x, bias, noise, nw, style, y, mean, rstd, ws, B, HW, C, flags, (hipStream_t)stream);
-    return gepi_fwd_t<bf16_t>(x, bias, noise, nw, style, y, mean, rstd, ws, B, HW, C, flags, (hipStream_t)stream);
+    SGX_REQUIRE(!pre_part || pre_npart > 0, SGX_EINVAL, "gepi_fwd: %d producer partials", pre_npart);
+    if (dtype == SGX_F32)
+        return gepi_fwd_t<float>(x, bias, noise, nw, style, y, mean, rstd, ws, pre_part, pre_npart, B, HW, C, flags, (hipStream_t)stream);
+    return gepi_fwd_t<bf16_t>(x, bias, noise, nw, style, y, mean, rstd, ws, pre_part, pre_npart, B, HW, C, flags, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Blur with the epilogue's statistics pass folded into its store: y = blur3x3(x) (the generator's conv0_up -> blur,
+// models/CustomLayers.py:176-177) and, from the values just written (rounded to the storage type, exactly what gepi_apply
+// will read back), the per-(image, channel) partial sums of a = act(y + bias[c] + nw[c]*noise[b,p]) and a^2 that
+// gepi_pass<T, 0> would otherwise re-read the tensor for.  Block = image b, strip of rt (<= 64) output rows, 256/cvt columns;
+// thread = (column, channel vector) walking the strip with the separable sliding window of blur3x3_kernel (pointwise.hip).
+// Partials: part[((b * npart + blk) * C + c) * 2 + {0, 1}], npart = strips * column chunks (sgx_blur3x3_stats_nparts).
+template <typename T>
+__global__ __launch_bounds__(256, BS_WAVES) void blur_stats_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ bias,
+                                                         const float* __restrict__ noise, const float* __restrict__ nw,
+                                                         double* __restrict__ part, int H, int W, int C, int cvt, int wchunks, int act,
+                                                         int rt) {
+    constexpr int VE = VecTraits<T>::VE;
+    extern __shared__ double sh[];                                 // [256][2*VE]
+    const int b = blockIdx.y, blk = blockIdx.x, sidx = blk / wchunks, wc = blk % wchunks;
+    const int cols = 256 / cvt;                                    // columns per block
+    const int tc = threadIdx.x % cvt, tr = threadIdx.x / cvt;
+    const int cv = C / VE;
+    const int w = wc * cols + tr, h0 = sidx * rt;
+    const int h1 = h0 + rt < H ? h0 + rt : H;                      // output rows [h0, h1)
+    const bool live = w < W;
+    const bool hasl = w > 0, hasr = w + 1 < W;
+    const size_t rstride = (size_t)W * cv * VE;
+    for (int vb = 0; vb < cv; vb += cvt) {                         // uniform trip count (cv is a multiple of cvt)
+        const int v = vb + tc, c0 = v * VE;
+        float s0[VE], s1[VE], kb[VE], kw[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) { s0[j] = 0.f; s1[j] = 0.f; kb[j] = 0.f; }
+        if (bias) load_coef<VE>(bias + c0, kb);
+        load_coef<VE>(nw + c0, kw);
+        if (live) {
+            const size_t col = (((size_t)b * H * W + w) * cv + v) * VE;      // (b, row 0, w, v)
+            const float* nzp = noise + (size_t)b * H * W + w;
+            const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+            // raw 16-byte loads of input row r: left / centre / right pixel (zero outside the image)
+            auto ldrow = [&](int r, uint4 (&q)[3]) {
+                const bool ok = (unsigned)r < (unsigned)H;
+                const T* src = x + col + (size_t)(ok ? r : 0) * rstride;
+                q[1] = ok ? *reinterpret_cast<const uint4*>(src) : zero4;
+                q[0] = (ok && hasl) ? *reinterpret_cast<const uint4*>(src - cv * VE) : zero4;
+                q[2] = (ok && hasr) ? *reinterpret_cast<const uint4*>(src + cv * VE) : zero4;
+            };
+            auto hsum = [&](const uint4 (&q)[3], float (&h)[VE]) {           // horizontal [1,2,1]
+                float l[VE], m[VE], rr[VE];
+                unpack16<T>(q[0], l); unpack16<T>(q[1], m); unpack16<T>(q[2], rr);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) h[j] = l[j] + 2.f * m[j] + rr[j];
+            };
+            float ha[VE], hb[VE], hc[VE];                                     // horizontal sums of rows ro-1, ro, ro+1
+            {
+                uint4 q[3];
+                ldrow(h0 - 1, q); hsum(q, ha);
+                ldrow(h0, q); hsum(q, hb);
+            }
+            constexpr int G = BS_GROUP;                                       // rows per group: all 3*G loads (+G noise) issued, then the math
+            for (int rg = h0; rg < h1; rg += G) {
+                uint4 q[G][3];
+                float nz[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    ldrow(rg + g + 1 < h1 + 1 ? rg + g + 1 : -1, q[g]);
+                    nz[g] = rg + g < h1 ? nzp[(size_t)(rg + g) * W] : 0.f;
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int ro = rg + g;                                    // output row ro from input rows ro-1, ro, ro+1
+                    if (ro < h1) {
+                        hsum(q[g], hc);
+                        float o[VE];
+#pragma unroll
+                        for (int j = 0; j < VE; ++j) o[j] = (ha[j] + 2.f * hb[j] + hc[j]) * (1.f / 16.f);
+                        const uint4 packed = pack16<T>(o);
+                        *reinterpret_cast<uint4*>(y + col + (size_t)ro * rstride) = packed;
+                        float st[VE];
+                        unpack16<T>(packed, st);                              // the stored (rounded) values: what the apply pass reads back
+#pragma unroll
+                        for (int j = 0; j < VE; ++j) {
+                            const float a = act_apply(st[j] + kb[j] + kw[j] * nz[g], act);
+                            s0[j] += a; s1[j] += a * a;
+                            ha[j] = hb[j]; hb[j] = hc[j];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VE; ++j) { sh[threadIdx.x * 2 * VE + j] = (double)s0[j]; sh[threadIdx.x * 2 * VE + VE + j] = (double)s1[j]; }
+        __syncthreads();
+        // fixed-order sum over the block's columns (same two schemes as gepi_pass)
+        const int NO = cvt * 2 * VE;
+        double* outp = part + ((size_t)b * gridDim.x + blk) * C * 2;
+        if (NO < 256 && cols > 1) {
+            const int o = threadIdx.x % NO, slice = threadIdx.x / NO, otc = o / (2 * VE), oj = o % (2 * VE);
+            double acc = 0.0;
+#pragma unroll
+            for (int r = 0; r < 2 * VE; ++r) acc += sh[((slice * 2 * VE + r) * cvt + otc) * 2 * VE + oj];
+            __syncthreads();
+            sh[threadIdx.x] = acc;
+            __syncthreads();
+            if ((int)threadIdx.x < NO) {
+                double a = 0.0;
+                for (int sl = 0; sl < 256 / NO; ++sl) a += sh[sl * NO + threadIdx.x];
+                outp[((size_t)(vb + otc) * VE + (oj % VE)) * 2 + (oj / VE)] = a;
+            }
+        } else if (tr == 0) {
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {
+                double a0 = 0.0, a1 = 0.0;
+                for (int r = 0; r < cols; ++r) {
+                    a0 += sh[(r * cvt + tc) * 2 * VE + j];
+                    a1 += sh[(r * cvt + tc) * 2 * VE + VE + j];
+                }
+                outp[(size_t)(c0 + j) * 2] = a0; outp[(size_t)(c0 + j) * 2 + 1] = a1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// rows per thread: 64 (fp32 per-lane partials over <= 64 values, as in gepi_pass; the block reduction is amortised over a
+// 64-row strip and the vertical halo is 2 rows in 66), halved while the launch would have fewer than 1024 blocks
+struct BlurStatsGeom { int cvt, wchunks, rt, npart; };
+static BlurStatsGeom blur_stats_geom(int B, int H, int W, int C, int ve) {
+    BlurStatsGeom g;
+    const int cv = C / ve;
+    g.cvt = cv < 256 ? cv : 256;
+    const int cols = 256 / g.cvt;
+    g.wchunks = (W + cols - 1) / cols;
+    g.rt = 64;
+    while (g.rt > 8 && (long)B * ((H + g.rt - 1) / g.rt) * g.wchunks < 1024) g.rt >>= 1;
+    g.npart = ((H + g.rt - 1) / g.rt) * g.wchunks;
+    return g;
+}
+extern "C" int sgx_blur3x3_stats_nparts(int B, int H, int W, int C, int dtype) {
+    return blur_stats_geom(B, H, W, C, dtype == SGX_F32 ? 4 : 8).npart;
+}
+extern "C" int sgx_blur3x3_stats(const void* x, void* y, const float* bias, const float* noise, const float* nw, double* part,
+                                 size_t part_bytes, int B, int H, int W, int C, int act, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SGX_REQUIRE(dtype == SGX_F32 || dtype == SGX_BF16, SGX_EINVAL, "blur3x3_stats: bad dtype");
+    const int ve = dtype == SGX_F32 ? 4 : 8;
+    SGX_REQUIRE(C % ve == 0 && ((C / ve) <= 256 ? 256 % (C / ve) == 0 : (C / ve) % 256 == 0), SGX_EUNSUPPORTED, "blur3x3_stats: C=%d", C);
+    SGX_REQUIRE(x && y && noise && nw && part, SGX_EINVAL, "blur3x3_stats: null argument");
+    SGX_REQUIRE(act == SGX_ACT_NONE || act == SGX_ACT_LRELU, SGX_EINVAL, "blur3x3_stats: activation %d", act);
+    const BlurStatsGeom g = blur_stats_geom(B, H, W, C, ve);
+    SGX_REQUIRE(part_bytes >= (size_t)B * g.npart * C * 2 * sizeof(double), SGX_EWORKSPACE, "blur3x3_stats: partials buffer %zu < %zu",
+                part_bytes, (size_t)B * g.npart * C * 2 * sizeof(double));
+    SGX_NOTE(0.0, 2.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * C, "blur_stats B%d %dx%d C%d", B, H, W, C);
+    const size_t shb = 256 * 2 * ve * sizeof(double);
+    if (dtype == SGX_F32)
+        hipLaunchKernelGGL(blur_stats_kernel<float>, dim3(g.npart, B), dim3(256), shb, st, (const float*)x, (float*)y, bias, noise, nw, part, H, W, C, g.cvt, g.wchunks, act, g.rt);
+    else
+        hipLaunchKernelGGL(blur_stats_kernel<bf16_t>, dim3(g.npart, B), dim3(256), shb, st, (const bf16_t*)x, (bf16_t*)y, bias, noise, nw, part, H, W, C, g.cvt, g.wchunks, act, g.rt);
+    SGX_LAUNCH_CHECK("blur_stats_kernel");
+    return 0;
 }
 
 extern "C" int sgx_gepi_bwd(const void* dy, const void* x, const float* bias, const float* noise, const float* nw,

@@ -577,6 +577,34 @@ class BlurFn(Function):
         return _bcall(BlurFn, g)
 
 
+class BlurStatsFn(Function):
+    """y = blur(x) plus the statistics pass of the LayerEpilogue that consumes y, out of the same kernel: ``part`` holds the
+    per-block partial (sum a, sum a^2) of a = lrelu(y + bias + nw*noise) per (image, channel) -- handed to ``GEpilogueFn``
+    (``pre``), which then reads y once instead of twice.  ``part`` is not differentiable: the epilogue's own backward carries
+    the dependence of the statistics on y."""
+
+    @staticmethod
+    def forward(ctx, x, bias, noise, nw):
+        x = _c(x)
+        B, H, W, C = x.shape
+        y = torch.empty_like(x)
+        L = N.lib()
+        npart = L.sgx_blur3x3_stats_nparts(B, H, W, C, N.dt(x))
+        part = torch.empty((B, npart, C, 2), dtype=torch.float64, device=x.device)
+        noise_c = _c(noise.detach().reshape(B, H * W))
+        if noise_c.dtype != torch.float32:
+            noise_c = noise_c.float()
+        N.check(L.sgx_blur3x3_stats(N.ptr(x), N.ptr(y), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(noise_c),
+                                    N.ptr(_c(nw.detach())), N.ptr(part), part.numel() * 8, B, H, W, C, N.ACT_LRELU, N.dt(x), N.stream()),
+                "sgx_blur3x3_stats")
+        ctx.mark_non_differentiable(part)
+        return y, part
+
+    @staticmethod
+    def backward(ctx, g, _gpart):
+        return _bcall(BlurFn, g), None, None, None
+
+
 class BlurGenFn(Function):
     """Depthwise K x K correlation with zero padding for blur filters other than [1,2,1] (reference BlurLayer,
     models/CustomLayers.py:251-276): ``taps`` = the K*K kernel as a tuple of floats (row major), ``pad`` the zero padding,
@@ -790,7 +818,9 @@ class GEpilogueFn(Function):
     noise stage, ``style`` None = no style stage (exactly: zero noise weight / zero style)."""
 
     @staticmethod
-    def forward(ctx, x, bias, noise, nw, style, flags=N.EPI_ACT | N.EPI_NORM):
+    def forward(ctx, x, bias, noise, nw, style, flags=N.EPI_ACT | N.EPI_NORM, pre=None):
+        """``pre``: [B, npart, C, 2] float64 partial statistics already produced by the kernel that wrote x (``BlurStatsFn``,
+        ``ConvFn`` with ``stats``): the statistics pass over x is skipped."""
         x = _c(x)
         B, H, W, C = x.shape
         ctx.has_noise, ctx.has_style = nw is not None, style is not None
@@ -809,8 +839,11 @@ class GEpilogueFn(Function):
         rstd = torch.empty_like(mean)
         L = N.lib()
         ws = N.workspace(L.sgx_gepi_ws_bytes(B, H * W, C), x.device)
+        if pre is not None and (pre.dtype != torch.float64 or pre.dim() != 4 or pre.shape[0] != B or pre.shape[2] != C):
+            raise N.SgxError("GEpilogueFn: producer statistics must be float64 [B, npart, C, 2]")
         N.check(L.sgx_gepi_fwd(N.ptr(x), N.ptr(bias_c), N.ptr(noise), N.ptr(nw_c), N.ptr(style_c), N.ptr(y), N.ptr(mean), N.ptr(rstd),
-                               N.ptr(ws), ws.numel(), B, H * W, C, int(flags), N.dt(x), N.stream()), "sgx_gepi_fwd")
+                               N.ptr(ws), ws.numel(), N.ptr(pre), 0 if pre is None else pre.shape[1], B, H * W, C, int(flags), N.dt(x),
+                               N.stream()), "sgx_gepi_fwd")
         ctx.has_bias, ctx.flags = bias is not None, int(flags)
         ctx.save_for_backward(x, bias_c, noise, nw_c, style_c, mean, rstd)
         return y
@@ -830,7 +863,7 @@ class GEpilogueFn(Function):
         N.check(L.sgx_gepi_bwd(N.ptr(gy), N.ptr(x), N.ptr(bias_c), N.ptr(noise), N.ptr(nw_c), N.ptr(style_c), N.ptr(mean), N.ptr(rstd),
                                N.ptr(dx), N.ptr(dstyle), N.ptr(dnw), N.ptr(dbias), N.ptr(ws), ws.numel(), B, H * W, C, ctx.flags,
                                N.dt(x), N.stream()), "sgx_gepi_bwd")
-        return dx, dbias, None, dnw if ctx.has_noise else None, dstyle if ctx.has_style else None, None
+        return dx, dbias, None, dnw if ctx.has_noise else None, dstyle if ctx.has_style else None, None, None
 
 
 class PixelNormFn(Function):

@@ -1,0 +1,84 @@
+"""-m gpu: the pass fusions of round 3, each against (a) the unfused path of the library (fp32: tight, the algebra is
+exact up to summation order; bf16: identical stored bits where the fused kernel performs the same roundings) and (b) the
+CPU oracle in fp64.  Reference compositions: LayerEpilogue models/CustomLayers.py:219-248, BlurLayer :251-276,
+GSynthesisBlock / DiscriminatorBlock models/Blocks.py:63-88,137-146, fade-in / to_rgb / from_rgb models/GAN.py:199-202,
+425-427."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+import golden_util as gu
+from gpu_util import DEV, assert_close, rel_err
+from oracle import stylegan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    from stylegan.pytorch_amd import native
+    assert torch.cuda.is_available()
+    native.lib()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H", [(2, 16, 64), (3, 32, 16), (1, 64, 8), (2, 512, 4), (1, 16, 256), (2, 128, 12)])
+def test_blur_with_epilogue_statistics(B, C, H, dt):
+    """sgx_blur3x3_stats: y bit-identical to the plain blur; the partial sums reproduce the statistics of
+    lrelu(y + bias + nw*noise) computed in fp64 from the stored y."""
+    from stylegan.pytorch_amd import functional as F
+    x = gu.seeded((B, H, H, C), 70).to(DEV).to(dt)
+    bias = (0.1 * gu.seeded((C,), 71)).to(DEV)
+    nw = (0.3 * gu.seeded((C,), 72)).to(DEV)
+    noise = gu.seeded((B, 1, H, H), 73).to(DEV)
+    y, part = F.BlurStatsFn.apply(x, bias, noise, nw)
+    y_ref = F.BlurFn.apply(x)
+    assert torch.equal(y, y_ref)
+    a = TF.leaky_relu(y.double() + bias.double() + nw.double() * noise.double().reshape(B, H, H, 1), 0.2)
+    s = part.sum(dim=1)                                              # [B, C, 2]
+    assert_close(s[..., 0], a.sum(dim=(1, 2)), 1e-6, "sum a", floor=1e-6 * H * H)
+    assert_close(s[..., 1], (a * a).sum(dim=(1, 2)), 1e-6, "sum a^2")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,B,H", [(32, 16, 2, 16), (64, 64, 1, 64), (32, 32, 3, 8)])
+def test_generator_block_with_fused_statistics(cin, cout, B, H, dt):
+    """GSynthesisBlock with the instance-norm statistics produced by the blur / the 3x3 convolution (SGX_FUSE_EPI_STATS)
+    against the same block with the separate statistics passes, forward and every gradient; fp32 also against the oracle."""
+    from stylegan.pytorch_amd import Blocks
+    from stylegan.pytorch_amd import functional as F
+    blk = Blocks.GSynthesisBlock(cin, cout, [1, 2, 1], 512, 2 ** 0.5, True, True, False, True, True, torch.nn.LeakyReLU(0.2)).to(DEV)
+    names = dict(blk.named_parameters())
+    with torch.no_grad():
+        for k, p in names.items():
+            p.copy_(gu.fill_value("blk." + k, p.shape))
+    n1 = gu.seeded((B, 1, 2 * H, 2 * H), 80).to(DEV); n2 = gu.seeded((B, 1, 2 * H, 2 * H), 81).to(DEV)
+    blk.epi1.top_epi.noise.noise = n1; blk.epi2.top_epi.noise.noise = n2
+    x = gu.seeded((B, H, H, cin), 82); dl = gu.seeded((B, 2, 512), 83); gy = gu.seeded((B, 2 * H, 2 * H, cout), 84)
+
+    def run(fuse):
+        keep, Blocks.FUSE_EPI_STATS = Blocks.FUSE_EPI_STATS, fuse
+        try:
+            for p in names.values():
+                p.grad = None
+            xg = x.to(DEV).to(dt).requires_grad_(True); dg = dl.to(DEV).requires_grad_(True)
+            y = blk.forward_nhwc(xg, dg)
+            y.backward(gy.to(DEV).to(dt))
+            return y.detach(), xg.grad, dg.grad, {k: p.grad.clone() for k, p in names.items()}
+        finally:
+            Blocks.FUSE_EPI_STATS = keep
+    y0, gx0, gd0, gp0 = run(0)
+    y1, gx1, gd1, gp1 = run(3)
+    tol = 2e-6 if dt == torch.float32 else 4e-3                      # bf16: a statistic moving by 1e-7 flips roundings of y
+    assert_close(y1, y0, tol, "y fused vs unfused")
+    assert_close(gx1, gx0, 10 * tol, "dx")
+    assert_close(gd1, gd0, 10 * tol, "d dlatents")
+    for k in gp0:
+        assert_close(gp1[k], gp0[k], 10 * tol, k, floor=1e-7)
+    if dt == torch.float32:                                          # and against the oracle
+        p64 = {k: v.detach().double().cpu() for k, v in names.items()}
+        r = O.eq_conv2d(x.permute(0, 3, 1, 2).double(), p64["conv0_up.weight"], p64["conv0_up.bias"], up=True, blur_after=True)
+        r = O._epi(p64, "epi1.", r, n1.double().cpu(), dl[:, 0].double())
+        r = O.eq_conv2d(r, p64["conv1.weight"], p64["conv1.bias"])
+        r = O._epi(p64, "epi2.", r, n2.double().cpu(), dl[:, 1].double())
+        assert_close(F.nchw_view(y1), r, 2e-5, "y vs oracle")
