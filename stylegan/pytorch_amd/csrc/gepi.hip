@@ -381,6 +381,10 @@ extern "C" int sgx_gepi_fwd(const void* x, const float* bias, const float* noise
 // gepi_pass<T, 0> would otherwise re-read the tensor for.  Block = image b, strip of rt (<= 64) output rows, 256/cvt columns;
 // thread = (column, channel vector) walking the strip with the separable sliding window of blur3x3_kernel (pointwise.hip).
 // Partials: part[((b * npart + blk) * C + c) * 2 + {0, 1}], npart = strips * column chunks (sgx_blur3x3_stats_nparts).
+#ifndef BS_WAVES
+#define BS_WAVES 2        // waves per SIMD the register allocation is asked for (175 VGPRs without spills; 128 spills 23)
+#define BS_GROUP 4        // rows whose loads are issued together
+#endif
 template <typename T>
 __global__ __launch_bounds__(256, BS_WAVES) void blur_stats_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ bias,
                                                          const float* __restrict__ noise, const float* __restrict__ nw,
