@@ -27,6 +27,13 @@
 //   weight row (tap, n): swz = (n >> 2) & 3   -- 32 consecutive n
 // which makes every ds_read_b128 conflict-free (16-lane service groups {0-3,12-15,20-27}/{4-11,16-19,28-31} hit 16
 // distinct 16-byte bank groups for any starting column).  Halo / out-of-image lanes read a 64-byte page of zeros.
+//
+// 16-channel layers (round 3; the 1024x1024 layers of both networks: 3x3 16->16, stride-2 16->32, transposed 32->16):
+//   KC = 16: a K-step is 16 input channels = ONE 32x32x16 MFMA per tap; rows are 32 bytes = two 16-byte slots, stored
+//            PLANAR (slot = chunk * rows + row): a fragment's 32 lanes read 32 consecutive slots of one plane, conflict-free
+//            for any column shift without a swizzle.
+//   CO16:    16 output channels in a 32-channel block: weight rows 16..31 are DMA'd from the page of zeros (half of each
+//            MFMA is padding -- these layers are HBM-bound by a factor of 3), the store writes 32 bytes per pixel.
 #include "common.h"
 #include <stdlib.h>
 
@@ -55,29 +62,36 @@ template <> struct G2<C2_S> { static constexpr int NPH = 1, HALO = 2, IS = 1, NT
 template <> struct G2<C2_D> { static constexpr int NPH = 4, HALO = 1, IS = 2, NTW = 4, NDX = 2, NDY = 2, NCLS = 1; };
 template <> struct G2<C2_U> { static constexpr int NPH = 1, HALO = 2, IS = 1, NTW = 16, NDX = 3, NDY = 3, NCLS = 4; };
 
-template <int GEO, int NW, int MF> struct C2Lds {
+template <int GEO, int NW, int MF, int KC = 32> struct C2Lds {
     static constexpr int TH = 2 * NW, PH = TH + G2<GEO>::HALO, PW = 32 + G2<GEO>::HALO, BCO = MF * 32;
     static constexpr int PROWS = PH * PW;
+    static constexpr int SPR = KC / 8;                                              // 16-byte slots per row
+    static constexpr int WROWS = G2<GEO>::NTW * BCO;
     static constexpr int OROW = BCO * 2 + 16;
     static constexpr int SCRATCH = NW * (GEO == C2_U ? 64 : 32) * OROW;            // epilogue: per-wave pixel-major rows
-    static constexpr int P_RAW = ((PROWS * 4 + 63) / 64) * 1024;
-    static constexpr int P_INSTR = (PROWS * 4 + 63) / 64;
+    static constexpr int P_INSTR = (PROWS * SPR + 63) / 64;
+    static constexpr int P_RAW = P_INSTR * 1024;
     static constexpr int P_BYTES = ((P_RAW > SCRATCH ? P_RAW : SCRATCH) + 1023) / 1024 * 1024;
-    static constexpr int W_INSTR = G2<GEO>::NTW * BCO * 4 / 64, W_BYTES = W_INSTR * 1024;
+    static constexpr int W_INSTR = WROWS * SPR / 64, W_BYTES = W_INSTR * 1024;
+    static_assert(WROWS * SPR % 64 == 0, "weight stage: whole DMA instructions");
     static constexpr int STAGE = P_BYTES + W_BYTES;
     static constexpr int TOTAL = 2 * STAGE;
 };
 
 // NW waves per block, each owning 2 rows x 32 pixels of the tile grid; MF 32-channel accumulator rows per wave.
-template <int GEO, int NW, int MF>
+// KC: input channels per K-step (32; 16 = the planar half-width stage).  CO16: 16 real output channels in the 32-channel block.
+template <int GEO, int NW, int MF, int KC = 32, bool CO16 = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
     using G = G2<GEO>;
-    using L = C2Lds<GEO, NW, MF>;
-    constexpr int TH = L::TH, PW = L::PW, BCO = L::BCO, PROWS = L::PROWS;
+    using L = C2Lds<GEO, NW, MF, KC>;
+    constexpr int TH = L::TH, PW = L::PW, BCO = L::BCO, PROWS = L::PROWS, WROWS = L::WROWS;
     constexpr int P_INSTR = L::P_INSTR, P_BYTES = L::P_BYTES, W_INSTR = L::W_INSTR, STAGE = L::STAGE;
     constexpr int NPI = (P_INSTR + NW - 1) / NW, NWI = (W_INSTR + NW - 1) / NW;
-    constexpr int OROW = L::OROW, VPR = BCO * 2 / 16;
+    constexpr int OROW = L::OROW, VPR = CO16 ? 2 : BCO * 2 / 16;        // 16-byte vectors per stored pixel
     constexpr int NPH = G::NPH, IS = G::IS, NDX = G::NDX, NDY = G::NDY, NCLS = G::NCLS;
+    constexpr int KS = KC / 16;                                          // 32x32x16 MFMAs per tap and K-step
+    static_assert(KC == 32 || KC == 16, "K-step width");
+    static_assert(!CO16 || MF == 1, "16 output channels: one (half used) 32-channel block");
     static_assert(GEO != C2_U || MF == 1, "four parity classes of accumulators: one 32-channel row per wave");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -96,7 +110,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
     const int my_tiles = a.bands ? (lslot < band_len ? (band_len - lslot + per - 1) / per : 0)
                                  : (slot < a.ntiles ? (a.ntiles - slot + a.nslots - 1) / a.nslots : 0);
     if (my_tiles <= 0) return;
-    const int nchunks = a.Cin >> 5;
+    const int nchunks = a.Cin / KC;
     const int spt = nchunks * NPH;                        // K-steps per tile
     const int nsteps = my_tiles * spt;
 
@@ -104,29 +118,36 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
     int prel[NPI], ppos[NPI], wrel[NWI];
 #pragma unroll
     for (int jj = 0; jj < NPI; ++jj) {
-        const int s = (jj * NW + wave) * 64 + lane, row = s >> 2, c = s & 3;
+        const int s = (jj * NW + wave) * 64 + lane;
+        // KC = 32: slot s = (row, chunk c) row-major, XOR-swizzled source; KC = 16: planar, slot = chunk * PROWS + row
+        const int row = KC == 32 ? (s >> 2) : (s % PROWS), c = KC == 32 ? (s & 3) : (s / PROWS);
         const int pr = row / PW, pc = row % PW;
-        prel[jj] = (IS * pr * a.W + IS * pc) * a.Cin + ((c ^ ((pc >> 2) & 3)) << 3);
-        ppos[jj] = (row < PROWS) ? ((pr << 8) | pc) : -1;
+        prel[jj] = (IS * pr * a.W + IS * pc) * a.Cin + (KC == 32 ? ((c ^ ((pc >> 2) & 3)) << 3) : (c << 3));
+        ppos[jj] = (KC == 32 ? (row < PROWS) : (c < 2)) ? ((pr << 8) | pc) : -1;
     }
 #pragma unroll
     for (int jj = 0; jj < NWI; ++jj) {
-        const int s = (jj * NW + wave) * 64 + lane, row = s >> 2, c = s & 3;
+        const int s = (jj * NW + wave) * 64 + lane;
+        const int row = KC == 32 ? (s >> 2) : (s % WROWS), c = KC == 32 ? (s & 3) : (s / WROWS);
         const int t = row / BCO, n = row % BCO;
         const int tg0 = GEO == C2_D ? (2 * (t >> 1) + 1) * 4 + 2 * (t & 1) + 1 : t;      // phase (0,0) tap; phase shifts it
-        wrel[jj] = ((tg0 * a.Cout + co0 + n) * a.Cin) + ((c ^ ((n >> 2) & 3)) << 3);
+        wrel[jj] = ((tg0 * a.Cout + co0 + n) * a.Cin) + (KC == 32 ? ((c ^ ((n >> 2) & 3)) << 3) : (c << 3));
+        if (CO16 && n >= 16) wrel[jj] = -1;                                            // padding rows: the page of zeros
     }
     // ---- per-lane fragment read offsets inside a stage
-    int poff[NDX][2], woff[2];
+    int poff[NDX][KS], woff[KS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        woff[ks] = P_BYTES + l31 * 64 + (((hi + 2 * ks) ^ ((l31 >> 2) & 3)) << 4);
+    for (int ks = 0; ks < KS; ++ks) {
+        if constexpr (KC == 32) woff[ks] = P_BYTES + l31 * 64 + (((hi + 2 * ks) ^ ((l31 >> 2) & 3)) << 4);
+        else woff[ks] = P_BYTES + (hi * WROWS + l31) * 16;
 #pragma unroll
         for (int dx = 0; dx < NDX; ++dx) {
             const int pc = l31 + dx;
-            poff[dx][ks] = (2 * wave * PW + pc) * 64 + (((hi + 2 * ks) ^ ((pc >> 2) & 3)) << 4);
+            if constexpr (KC == 32) poff[dx][ks] = (2 * wave * PW + pc) * 64 + (((hi + 2 * ks) ^ ((pc >> 2) & 3)) << 4);
+            else poff[dx][ks] = (hi * PROWS + 2 * wave * PW + pc) * 16;
         }
     }
+    constexpr int PROWB = KC == 32 ? 64 : 16;             // byte distance of consecutive patch / weight rows in a fragment read
 
     const bf16_t* __restrict__ xg = a.x;
     const bf16_t* __restrict__ wg = a.w;
@@ -145,7 +166,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
         tile_coords(tile0 + it * tstride, b, ty0, tx0);
         // input pixel of patch position (pr, pc): (iy0 + IS*pr, ix0 + IS*pc)
         const int iy0 = GEO == C2_D ? 2 * ty0 - py : ty0 - 1, ix0 = GEO == C2_D ? 2 * tx0 - px : tx0 - 1;
-        const bf16_t* base = xg + (((long)b * a.H + iy0) * a.W + ix0) * a.Cin + kc * 32;
+        const bf16_t* base = xg + (((long)b * a.H + iy0) * a.W + ix0) * a.Cin + kc * KC;
 #pragma unroll
         for (int jj = 0; jj < NPI; ++jj) {
             const int ii = jj * NW + wave;
@@ -160,11 +181,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
             }
         }
         if (spt > 2 || step < 2) {                   // <= 2 K-steps per tile: step q's weights live in stage q for the whole launch
-            const bf16_t* w0 = wg + kc * 32 - (GEO == C2_D ? (long)(4 * py + px) * a.Cout * a.Cin : 0);
+            const bf16_t* w0 = wg + kc * KC - (GEO == C2_D ? (long)(4 * py + px) * a.Cout * a.Cin : 0);
 #pragma unroll
             for (int jj = 0; jj < NWI; ++jj) {
                 const int ii = jj * NW + wave;
-                if (ii < W_INSTR) glds16(w0 + wrel[jj], buf + P_BYTES + ii * 1024);
+                if (ii < W_INSTR) {
+                    if constexpr (CO16) {
+                        const unsigned long long ok = wrel[jj] >= 0 ? ~0ull : 0ull;
+                        const unsigned long long wa = reinterpret_cast<unsigned long long>(w0 + wrel[jj]);
+                        glds16(reinterpret_cast<const void*>(zaddr + ((wa - zaddr) & ok)), buf + P_BYTES + ii * 1024);
+                    } else {
+                        glds16(w0 + wrel[jj], buf + P_BYTES + ii * 1024);
+                    }
+                }
             }
         }
     };
@@ -190,10 +219,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < KS; ++ks) {
                     bf16x8 brow[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) brow[r] = *reinterpret_cast<const bf16x8*>(cur + poff[dx][ks] + r * PW * 64);
+                    for (int r = 0; r < 4; ++r) brow[r] = *reinterpret_cast<const bf16x8*>(cur + poff[dx][ks] + r * PW * PROWB);
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
@@ -201,7 +230,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                             const int py = cls >> 1, px = cls & 1, ta = dy - py, tb = dx - px;
                             if (ta >= 0 && ta <= 1 && tb >= 0 && tb <= 1) {
                                 const int tg = (3 - py - 2 * ta) * 4 + (3 - px - 2 * tb);
-                                const bf16x8 af = *reinterpret_cast<const bf16x8*>(cur + woff[ks] + (tg * BCO) * 64);
+                                const bf16x8 af = *reinterpret_cast<const bf16x8*>(cur + woff[ks] + (tg * BCO) * PROWB);
 #pragma unroll
                                 for (int f = 0; f < 2; ++f)
                                     acc[cls][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, brow[f + dy], acc[cls][f], 0, 0, 0);
@@ -213,18 +242,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
         } else {
             // NDX*2 groups (column shift dx, k-step ks) x NDY row shifts.  Per group the NDY+1 patch rows this wave touches
             // are read once; fragments are software-pipelined one sub-step (weights) / one group (patch rows) ahead.
-            constexpr int NG = NDX * 2, NSUB = NG * NDY;
+            constexpr int NG = NDX * KS, NSUB = NG * NDY;
             bf16x8 brow[2][NDY + 1], af[2][MF];
             auto ld_brow = [&](int g, bf16x8 (&dst)[NDY + 1]) {
-                const int dx = g >> 1, ks = g & 1;
+                const int dx = g / KS, ks = g % KS;
 #pragma unroll
-                for (int r = 0; r < NDY + 1; ++r) dst[r] = *reinterpret_cast<const bf16x8*>(cur + poff[dx][ks] + r * PW * 64);
+                for (int r = 0; r < NDY + 1; ++r) dst[r] = *reinterpret_cast<const bf16x8*>(cur + poff[dx][ks] + r * PW * PROWB);
             };
             auto ld_af = [&](int sub, bf16x8 (&dst)[MF]) {
-                const int g = sub / NDY, dy = sub % NDY, dx = g >> 1, ks = g & 1;
+                const int g = sub / NDY, dy = sub % NDY, dx = g / KS, ks = g % KS;
 #pragma unroll
                 for (int m = 0; m < MF; ++m)
-                    dst[m] = *reinterpret_cast<const bf16x8*>(cur + woff[ks] + ((dy * NDX + dx) * BCO + m * 32) * 64);
+                    dst[m] = *reinterpret_cast<const bf16x8*>(cur + woff[ks] + ((dy * NDX + dx) * BCO + m * 32) * PROWB);
             };
             ld_brow(0, brow[0]);
             ld_af(0, af[0]);
@@ -281,7 +310,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                 for (int m = 0; m < MF; ++m)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        bv[m][g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + co0 + m * 32 + 8 * g + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        bv[m][g] = (a.bias && !(CO16 && g >= 2)) ? *reinterpret_cast<const float4*>(a.bias + co0 + m * 32 + 8 * g + 4 * hi)
+                                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
                 __syncthreads();                 // every wave is done reading this stage's patch
                 char* scr = cur + wave * (32 * OROW);
 #pragma unroll
@@ -331,18 +361,35 @@ static int conv2_ncu() {
     return ncu;
 }
 
-template <int GEO, int NW, int MF>
+template <int GEO, int NW, int MF, int KC = 32, bool CO16 = false>
 static int launch_conv2(Conv2Args& a, hipStream_t st) {
-    using L = C2Lds<GEO, NW, MF>;
+    using L = C2Lds<GEO, NW, MF, KC>;
     static_assert(L::TOTAL <= 160 * 1024, "LDS budget");
-    auto kern = conv2_kernel<GEO, NW, MF>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
-    (void)attr;
+    auto kern = conv2_kernel<GEO, NW, MF, KC, CO16>;
+    // the > 64 KB dynamic-LDS opt-in is per device: applied once for every device a launch is made on
+    static bool attr_done[32] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+    if (!attr_done[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
+        attr_done[dev] = true;
+    }
     const int gh = GEO == C2_D ? a.OH : a.H, gw = GEO == C2_D ? a.OW : a.W;       // the tile grid
     a.tiles_x = (gw + 31) / 32; a.tiles_y = (gh + L::TH - 1) / L::TH;
     a.ntiles = a.B * a.tiles_y * a.tiles_x;
-    a.ncb = a.Cout / L::BCO;
-    int per = conv2_ncu() / (8 * a.ncb);                 // tile slots per XCD (one block per CU)
+    a.ncb = CO16 ? 1 : a.Cout / L::BCO;
+    // resident blocks per CU: one for the round-2 instantiations (their LDS stages fill the CU); the half-width stages of the
+    // 16-channel layers leave room for two (LDS <= 80 KB per block, <= 128 registers), so that one block's store epilogue
+    // overlaps the other's loads
+    int bpc = 1;
+    if constexpr (KC == 16) {
+        static const int bpc_max = [] { const char* e = getenv("SGX_CONV2_BPC"); return e ? atoi(e) : 2; }();   // A/B
+        bpc = (160 * 1024) / L::TOTAL;
+        if (bpc > 32 / NW) bpc = 32 / NW;
+        if (bpc > bpc_max) bpc = bpc_max;
+        if (bpc < 1) bpc = 1;
+    }
+    int per = conv2_ncu() * bpc / (8 * a.ncb);           // tile slots per XCD
     const int need = (a.ntiles + 7) / 8;
     if (per > need) per = need;
     if (per < 1) per = 1;
@@ -360,11 +407,33 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
 int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
                   const void* mask, int variant, hipStream_t st, int* launched) {
     // bit 0: S, 1: D, 2: U.  All three on: profiles/r02_conv2_probe.txt (S) and r02_conv2_probe_DU.txt (D, U) -- the shape
-    // heuristics below reproduce the per-shape winner of those tables
-    static const int on = [] { const char* e = getenv("SGX_CONV2"); return e ? atoi(e) : 7; }();
+    // heuristics below reproduce the per-shape winner of those tables.  bit 3: the 16-channel variants (round 3).
+    static const int on = [] { const char* e = getenv("SGX_CONV2"); return e ? atoi(e) : 15; }();
     *launched = 0;
     if (variant < 0 && !((on >> geo) & 1)) return 0;
     const int gw = geo == C2_D ? W / 2 : W, gh = geo == C2_D ? H / 2 : H;
+    const bool kc16 = Cin == 16, co16 = Cout == 16;
+    if (kc16 || co16) {
+        // the 16-channel layers: 3x3 16->16, stride-2 16->32, transposed 32->16 (and nothing else: the networks have no others)
+        const bool shape_ok = (geo == C2_S && kc16 && co16) || (geo == C2_D && kc16 && Cout == 32) || (geo == C2_U && Cin == 32 && co16);
+        if (!shape_ok || gw % 32 != 0 || gh < 1 || (geo == C2_D && ((H | W) & 1))) return 0;
+        if (variant < 0 && !(on & 8)) return 0;
+        // measured alone at batch 32 / 4 (tools/conv16_probe.py, profiles/r03_conv16_probe.txt): 3x3 16->16 @1024^2 first
+        // generation 619 / 78 us, this kernel 498 / 59 us (4.3-4.5 TB/s); stride-2 16->32 478 / 65 -> 369 / 43 us; the
+        // transposed 32->16 @512^2 stays with the first generation (338 vs 384 us: half of every MFMA is padding AND the
+        // full-width stage leaves one block per CU) unless bit 4 of SGX_CONV2 asks for it
+        if (variant < 0 && geo == C2_U && !(on & 16)) return 0;
+        const long blocks4 = (long)B * ((gh + 7) / 8) * (gw / 32), blocks8 = (long)B * ((gh + 15) / 16) * (gw / 32);
+        if (variant < 0 && blocks4 < conv2_ncu()) return 0;
+        static const int force16 = [] { const char* e = getenv("SGX_CONV2_NW16"); return e ? atoi(e) : 0; }();
+        const int nw = variant > 0 ? variant : (force16 ? force16 : (blocks8 >= 2 * conv2_ncu() ? 8 : 4));
+        Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
+                    geo == C2_D ? H / 2 : (geo == C2_U ? 2 * H : H), geo == C2_D ? W / 2 : (geo == C2_U ? 2 * W : W), Cin, Cout, act, 0, 0, 0, 0, 0};
+        *launched = 1;
+        if (geo == C2_S) return nw == 8 ? launch_conv2<C2_S, 8, 1, 16, true>(a, st) : launch_conv2<C2_S, 4, 1, 16, true>(a, st);
+        if (geo == C2_D) return nw == 8 ? launch_conv2<C2_D, 8, 1, 16, false>(a, st) : launch_conv2<C2_D, 4, 1, 16, false>(a, st);
+        return nw == 8 ? launch_conv2<C2_U, 8, 1, 32, true>(a, st) : launch_conv2<C2_U, 4, 1, 32, true>(a, st);
+    }
     const int bco = (geo == C2_S && Cout % 64 == 0) ? 64 : 32;       // (3x3 with 32 output channels: the MF = 1 block)
     if (Cin % 32 != 0 || Cout % bco != 0 || gw % 32 != 0 || Cout / bco > 32 || gh < 1 || (geo == C2_D && ((H | W) & 1))) return 0;
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,

@@ -586,6 +586,11 @@ CONV2_CASES = [
     ("S", 32, 128, 2, 520, 512), ("U", 32, 64, 1, 512, 1024),                            # enough tiles for the XCD-band tile order, ragged rows
     ("D", 32, 64, 2, 64, 64), ("D", 64, 32, 3, 32, 64), ("D", 128, 128, 1, 80, 128), ("D", 32, 96, 2, 36, 64), ("D", 64, 64, 5, 128, 64),
     ("U", 32, 32, 2, 32, 32), ("U", 64, 64, 3, 16, 32), ("U", 128, 32, 1, 40, 64), ("U", 32, 96, 2, 17, 32), ("U", 64, 32, 5, 64, 64),
+    # the 16-channel layers (round 3: half-width planar stages / 16 real output channels in a 32-channel block): the three shapes
+    # of the 1024x1024 level -- small, ragged rows, and enough tiles for the XCD-band tile order and two blocks per CU
+    ("S", 16, 16, 2, 32, 32), ("S", 16, 16, 3, 40, 64), ("S", 16, 16, 1, 520, 512), ("S", 16, 16, 5, 17, 96),
+    ("D", 16, 32, 2, 64, 64), ("D", 16, 32, 3, 36, 128), ("D", 16, 32, 1, 512, 1024),
+    ("U", 32, 16, 2, 32, 32), ("U", 32, 16, 3, 17, 64), ("U", 32, 16, 1, 256, 512),
 ]
 
 
