@@ -203,6 +203,12 @@ int sgx_gepi_fwd(const void* x, const float* bias, const float* noise, const flo
  * sums of a = act(y + bias[c] + nw[c]*noise[b,p]) and a^2 (y as stored), sgx_blur3x3_stats_nparts(...) blocks per image.
  * bias may be NULL; act: SGX_ACT_NONE | SGX_ACT_LRELU. */
 int sgx_blur3x3_stats_nparts(int B, int H, int W, int C, int dtype);
+/* y = conv3x3(x, pack) (no bias, no activation: the generator's conv1, models/Blocks.py:86, whose bias the epilogue adds) with
+ * the same statistics out of the convolution's store epilogue: one partial per (image, pixel tile).  sgx_conv3x3_stats_nparts:
+ * tiles per image, or 0 when the shape has no fused variant (then: sgx_conv3x3 + the plain sgx_gepi_fwd).  bf16 only. */
+int sgx_conv3x3_stats_nparts(int B, int H, int W, int Cin, int Cout, int dtype);
+int sgx_conv3x3_stats(const void* x, const void* w, void* y, const float* ebias, const float* noise, const float* nw, double* part,
+                      size_t part_bytes, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
 int sgx_blur3x3_stats(const void* x, void* y, const float* bias, const float* noise, const float* nw, double* part,
                       size_t part_bytes, int B, int H, int W, int C, int act, int dtype, void* stream);
 int sgx_gepi_bwd(const void* dy, const void* x, const float* bias, const float* noise, const float* nw,

@@ -13,9 +13,14 @@ from .CustomLayers import (BlurLayer, EqualizedConv2d, EqualizedLinear, LayerEpi
 from .native import ACT_LRELU, ACT_NONE
 
 
-# Instance-norm statistics of a generator layer epilogue out of the kernel that PRODUCES its input (A/B switch, default on):
-# bit 0: the blur after conv0_up (epi1), bit 1: the 3x3 convolution conv1 (epi2).
-FUSE_EPI_STATS = int(os.environ.get("SGX_FUSE_EPI_STATS", "3"))
+# Instance-norm statistics of a generator layer epilogue out of the kernel that PRODUCES its input (A/B switch):
+# bit 0: the blur after conv0_up (epi1), bit 1: the 3x3 convolution conv1 (epi2).  Measured alone on the GPU
+# (tools/convstats_probe.py, profiles/r03_convstats_probe.txt): the convolution's statistics epilogue costs it 60-80 us at
+# batch 32 and saves a 1-tensor read pass -- +136 us per layer at 1024^2, +27 at 512^2 and 256^2, a loss below 2^27 elements
+# (the finalize over one partial per tile slot is latency-bound: -45 us at batch 4, 1024^2) -> on from FUSE_EPI_STATS_MIN elements.
+# The blur variant is slower than blur + statistics pass at every size (175 registers: two waves per SIMD) -> off by default.
+FUSE_EPI_STATS = int(os.environ.get("SGX_FUSE_EPI_STATS", "2"))
+FUSE_EPI_STATS_MIN = int(os.environ.get("SGX_FUSE_EPI_STATS_MIN", str(1 << 27)))
 
 
 def _lat(d, k):
@@ -87,6 +92,10 @@ class GSynthesisBlock(nn.Module):
         else:
             x = up.forward_nhwc(x, skip_bias=True)                        # transposed conv + blur; bias folded below
             x = self.epi1.forward_nhwc(x, _lat(dlatents_in_range, 0), conv_bias=up.scaled_bias())
+        if (FUSE_EPI_STATS & 2) and self.epi2._fusable and x.numel() >= FUSE_EPI_STATS_MIN:
+            nin = self.epi2.noise_inputs(x.shape, x.device)               # conv1 keeps the shape
+            x, part = self.conv1.forward_nhwc(x, skip_bias=True, epi_stats=(self.conv1.scaled_bias(),) + nin)
+            return self.epi2.forward_nhwc(x, _lat(dlatents_in_range, 1), conv_bias=self.conv1.scaled_bias(), noise_in=nin, pre_stats=part)
         x = self.conv1.forward_nhwc(x, skip_bias=True)
         return self.epi2.forward_nhwc(x, _lat(dlatents_in_range, 1), conv_bias=self.conv1.scaled_bias())
 

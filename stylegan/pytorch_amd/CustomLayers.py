@@ -254,7 +254,10 @@ class EqualizedConv2d(nn.Module):
                 y = F.conv(x, self.weight, None, "U" if fused else "UF", self.w_mul)
                 assert self.intermediate is not None and self.intermediate._is_121
                 return F.call(F.BlurStatsFn, y, ebias, noise, nw)         # blur + statistics in one pass
-            raise NotImplementedError("epi_stats: producer not built for this layer")
+            assert self.intermediate is None
+            if F.conv_stats_nparts(x, self.weight.shape[0]) > 0:          # 3x3: statistics out of the convolution's store epilogue
+                return F.conv(x, self.weight, None, "S", self.w_mul, ipad=x.shape[3], stats=(ebias, noise, nw))
+            return F.conv(x, self.weight, None, "S", self.w_mul, ipad=x.shape[3]), None   # no fused kernel: separate pass
         if self.upscale is not None:
             fused = min(x.shape[1], x.shape[2]) * 2 >= 128                # reference :143
             y = F.conv(x, self.weight, None, "U" if fused else "UF", self.w_mul)

@@ -716,6 +716,17 @@ class StyleGAN:
     # sets it -- enqueues the next half-iteration while the GPU still runs this one.
     deferred_losses = False
 
+    # True: the eager step takes the fade-in alpha from DEVICE memory, exactly as the hipGraph-replayed step must (a captured
+    # graph cannot bake a per-iteration scalar into kernel arguments): the fade-in lerp reads [alpha, 1-alpha] from a device
+    # tensor and from_rgb's (1-alpha) is not folded into its weights.  Same arithmetic as the replay, launch by launch -- what
+    # the graph-vs-eager parity tests compare against (host alpha rounds the residual branch once instead of twice in bf16).
+    alpha_on_device = False
+
+    def _alpha_arg(self, alpha):
+        if not self.alpha_on_device or isinstance(alpha, torch.Tensor):
+            return alpha
+        return native.upload(torch.tensor([float(alpha), 1.0 - float(alpha)], dtype=torch.float32), self.device)[0]
+
     def _loss_out(self, deferred):
         return deferred if self.deferred_losses else deferred.item()
 
@@ -724,6 +735,7 @@ class StyleGAN:
         if self._graphable(labels):
             return self._loss_out(self._graphed("d", noise, real_batch, depth, alpha))
         loss_val = None
+        alpha = self._alpha_arg(alpha)
         for _ in range(self.d_repeats):
             loss = self._d_body(noise, real_batch, depth, alpha, labels)
             if loss_val is not None and self.__dict__.get("_loss_stream") is not None:   # data parallel and d_repeats > 1
@@ -735,7 +747,7 @@ class StyleGAN:
         """One generator update incl. gradient clipping and EMA -- reference models/GAN.py:624-659."""
         if self._graphable(labels):
             return self._loss_out(self._graphed("g", noise, real_batch, depth, alpha))
-        loss = self._g_body(noise, real_batch, depth, alpha, labels)
+        loss = self._g_body(noise, real_batch, depth, self._alpha_arg(alpha), labels)
         return self._loss_out(DeferredLoss(loss, stream=self.__dict__.pop("_loss_stream", None)))
 
     # ------------------------------------------------------------------------------------------------------------

@@ -55,7 +55,12 @@ struct Conv2Args {
     int tiles_x, tiles_y, ntiles;             // tiles of the tile grid (S: the image, D: the output, U: the coarse input)
     int ncb, nslots;                          // channel blocks; persistent stride over tiles
     int bands;                                // tile order: 0 = slot, slot + nslots, ...; 1 = each XCD walks one contiguous eighth of the raster
+    // EPI_STATS (C2_S): the LayerEpilogue that consumes y takes its instance-norm statistics from this store: per (image, tile
+    // slot of the persistent grid) the sums of a = lrelu(y + ebias[c] + enw[c] * enoise[b, pixel]) and a^2 over the pixels of the
+    // image that the slot's blocks stored, y as stored (bf16)
+    const float* ebias; const float* enoise; const float* enw; double* part;   // part[((b * nslots + slot) * Cout + c) * 2 + {0, 1}]
 };
+enum { EPI_NONE = 0, EPI_STATS = 1 };
 
 template <int GEO> struct G2;
 template <> struct G2<C2_S> { static constexpr int NPH = 1, HALO = 2, IS = 1, NTW = 9, NDX = 3, NDY = 3, NCLS = 1; };
@@ -80,7 +85,7 @@ template <int GEO, int NW, int MF, int KC = 32> struct C2Lds {
 
 // NW waves per block, each owning 2 rows x 32 pixels of the tile grid; MF 32-channel accumulator rows per wave.
 // KC: input channels per K-step (32; 16 = the planar half-width stage).  CO16: 16 real output channels in the 32-channel block.
-template <int GEO, int NW, int MF, int KC = 32, bool CO16 = false>
+template <int GEO, int NW, int MF, int KC = 32, bool CO16 = false, int EPI = EPI_NONE>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
     using G = G2<GEO>;
     using L = C2Lds<GEO, NW, MF, KC>;
@@ -93,7 +98,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
     static_assert(KC == 32 || KC == 16, "K-step width");
     static_assert(!CO16 || MF == 1, "16 output channels: one (half used) 32-channel block");
     static_assert(GEO != C2_U || MF == 1, "four parity classes of accumulators: one 32-channel row per wave");
+    static_assert(EPI == EPI_NONE || GEO == C2_S, "the statistics epilogue is built for the 3x3 geometry");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
+    float* const ecoef = reinterpret_cast<float*>(smem + L::TOTAL);     // EPI_STATS: [2][BCO] epilogue bias / noise weight of this channel block
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,6 +116,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
     const int tile0 = a.bands ? xcd * band + lslot : slot, tstride = a.bands ? per : a.nslots;
     const int my_tiles = a.bands ? (lslot < band_len ? (band_len - lslot + per - 1) / per : 0)
                                  : (slot < a.ntiles ? (a.ntiles - slot + a.nslots - 1) / a.nslots : 0);
+    constexpr int REAL = CO16 ? 16 : BCO;                 // real output channels of the block
+    if constexpr (EPI == EPI_STATS) {
+        // this slot's partial statistics of every image start at zero -- also for slots that get no tile (the same threads write
+        // the real sums later: program order)
+        if (tid < 2 * REAL) {
+            const int c = tid % REAL, k = tid / REAL;
+            for (int bb = 0; bb < a.B; ++bb) a.part[(((size_t)bb * a.nslots + slot) * a.Cout + co0 + c) * 2 + k] = 0.0;
+        }
+    }
     if (my_tiles <= 0) return;
     const int nchunks = a.Cin / KC;
     const int spt = nchunks * NPH;                        // K-steps per tile
@@ -208,12 +224,74 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                 for (int r = 0; r < 16; ++r) acc[m][f][r] = 0.f;
     };
     zero_acc();
+    // EPI_STATS: this lane's channel vector (lane % VPR) -- sums over the pixels it stored for image st_b, kept across the tiles
+    // of the persistent loop and written out when the image changes (and at the end): no per-tile reduction
+    float st0[8], st1[8];
+    int st_b = -1;
+    if constexpr (EPI == EPI_STATS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { st0[j] = 0.f; st1[j] = 0.f; }
+        if (tid < 2 * BCO) {
+            const int c = tid % BCO;
+            const float* src = tid < BCO ? a.ebias : a.enw;
+            ecoef[tid] = (src && c < REAL) ? src[co0 + c] : 0.f;
+        }
+    }
+    // lanes with the same channel vector -> lane % VPR; waves -> the block, in a fixed order; one partial per (image, slot,
+    // channel): deterministic, no atomics.  Called by the whole block (two barriers); scratch = the free patch region of a stage.
+    auto stats_flush = [&](char* stage) {
+        if constexpr (EPI == EPI_STATS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int o = 32; o >= VPR; o >>= 1) {
+                    st0[j] += __shfl_xor(st0[j], o, 64);
+                    st1[j] += __shfl_xor(st1[j], o, 64);
+                }
+            }
+            float* wtot = reinterpret_cast<float*>(stage + wave * (32 * OROW));    // [VPR][16] floats at the start of this wave's scratch
+            if (lane < VPR) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { wtot[lane * 16 + j] = st0[j]; wtot[lane * 16 + 8 + j] = st1[j]; }
+            }
+            __syncthreads();
+            if (tid < 2 * REAL) {
+                const int c = tid % REAL, k = tid / REAL;
+                double sum = 0.0;
+#pragma unroll
+                for (int w8 = 0; w8 < NW; ++w8)
+                    sum += (double)reinterpret_cast<const float*>(stage + w8 * (32 * OROW))[(c >> 3) * 16 + k * 8 + (c & 7)];
+                a.part[(((size_t)st_b * a.nslots + slot) * a.Cout + co0 + c) * 2 + k] = sum;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { st0[j] = 0.f; st1[j] = 0.f; }
+        }
+    };
 
     issue(0, smem);
     for (int step = 0; step < nsteps; ++step) {
         char* cur = smem + (step & 1) * STAGE;
         __syncthreads();                         // (vmcnt(0) first) stage `step` landed; everyone is done with step-1
         if (step + 1 < nsteps) issue(step + 1, smem + ((step + 1) & 1) * STAGE);
+        // EPI_STATS: the noise values of the pixels this lane stores in the tile's epilogue, requested before the MFMAs of the
+        // tile's last K-step so that they have landed when the epilogue needs them
+        constexpr int NSI = (GEO == C2_U ? 64 : 32) * VPR / 64;       // store iterations per row
+        float nzv[2][NSI];
+        if constexpr (EPI == EPI_STATS) {
+            const int it_ = step / spt;
+            if (step - it_ * spt == spt - 1) {
+                int b_, ty_, tx_;
+                tile_coords(tile0 + it_ * tstride, b_, ty_, tx_);
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int i = 0; i < NSI; ++i) {
+                        const int px = (i * 64 + lane) / VPR, oy = ty_ + 2 * wave + f, ox = tx_ + px;
+                        nzv[f][i] = (oy < a.OH && ox < a.OW) ? a.enoise[((size_t)b_ * a.OH + oy) * a.OW + ox] : 0.f;
+                    }
+            }
+        }
         if constexpr (GEO == C2_U) {
             // position-major: each of the 9 patch offsets is read once and feeds every class that has a tap there
 #pragma unroll
@@ -313,6 +391,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                         bv[m][g] = (a.bias && !(CO16 && g >= 2)) ? *reinterpret_cast<const float4*>(a.bias + co0 + m * 32 + 8 * g + 4 * hi)
                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
                 __syncthreads();                 // every wave is done reading this stage's patch
+                if constexpr (EPI == EPI_STATS) {
+                    if (b != st_b) {             // the loop moved on to another image (block-uniform)
+                        if (st_b >= 0) stats_flush(cur);
+                        st_b = b;
+                    }
+                }
                 char* scr = cur + wave * (32 * OROW);
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
@@ -343,12 +427,29 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                             const size_t doff = (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8;
                             if (GEO == C2_S && a.mask) val = lrelu_mask_bf16x8(val, *reinterpret_cast<const uint4*>(a.mask + doff));
                             *reinterpret_cast<uint4*>(a.y + doff) = val;
+                            if constexpr (EPI == EPI_STATS) {
+                                // (64 % VPR == 0: v = lane % VPR is the same channel vector in every iteration)
+                                const float nz = nzv[f][i];
+                                const unsigned wv[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float x0 = __uint_as_float(wv[q] << 16), x1 = __uint_as_float(wv[q] & 0xffff0000u);
+                                    const float a0 = lrelu(x0 + ecoef[v * 8 + 2 * q] + ecoef[BCO + v * 8 + 2 * q] * nz);
+                                    const float a1 = lrelu(x1 + ecoef[v * 8 + 2 * q + 1] + ecoef[BCO + v * 8 + 2 * q + 1] * nz);
+                                    st0[2 * q] += a0; st1[2 * q] += a0 * a0;
+                                    st0[2 * q + 1] += a1; st1[2 * q + 1] += a1 * a1;
+                                }
+                            }
                         }
                     }
                 }
             }
             zero_acc();
         }
+    }
+    if constexpr (EPI == EPI_STATS) {
+        __syncthreads();                         // (every wave is past its last scratch read)
+        if (st_b >= 0) stats_flush(smem);
     }
 }
 
@@ -361,17 +462,18 @@ static int conv2_ncu() {
     return ncu;
 }
 
-template <int GEO, int NW, int MF, int KC = 32, bool CO16 = false>
+template <int GEO, int NW, int MF, int KC = 32, bool CO16 = false, int EPI = EPI_NONE>
 static int launch_conv2(Conv2Args& a, hipStream_t st) {
     using L = C2Lds<GEO, NW, MF, KC>;
-    static_assert(L::TOTAL <= 160 * 1024, "LDS budget");
-    auto kern = conv2_kernel<GEO, NW, MF, KC, CO16>;
+    constexpr int LDS = L::TOTAL + (EPI != EPI_NONE ? 1024 : 0);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto kern = conv2_kernel<GEO, NW, MF, KC, CO16, EPI>;
     // the > 64 KB dynamic-LDS opt-in is per device: applied once for every device a launch is made on
     static bool attr_done[32] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
     if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done[dev] = true;
     }
     const int gh = GEO == C2_D ? a.OH : a.H, gw = GEO == C2_D ? a.OW : a.W;       // the tile grid
@@ -384,7 +486,7 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
     int bpc = 1;
     if constexpr (KC == 16) {
         static const int bpc_max = [] { const char* e = getenv("SGX_CONV2_BPC"); return e ? atoi(e) : 2; }();   // A/B
-        bpc = (160 * 1024) / L::TOTAL;
+        bpc = (160 * 1024) / LDS;
         if (bpc > 32 / NW) bpc = 32 / NW;
         if (bpc > bpc_max) bpc = bpc_max;
         if (bpc < 1) bpc = 1;
@@ -396,65 +498,122 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
     a.nslots = per * 8;
     static const int bands_on = [] { const char* e = getenv("SGX_TILE_BANDS"); return e ? atoi(e) : 1; }();   // measured (tools/gpu_r2u.sh): halo over-fetch gone (PMC), 80.8 vs 81.2 ms at batch 32, nothing at batch 4
     a.bands = (bands_on && a.ntiles >= 8 * a.nslots) ? 1 : 0;      // enough tiles per slot for the order to matter
-    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.ncb * per)), dim3(NW * 64), L::TOTAL, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.ncb * per)), dim3(NW * 64), LDS, st, a);
     SGX_LAUNCH_CHECK("conv2_kernel");
     return 0;
 }
 
-// Which layers take this kernel (SGX_CONV2=0 switches it off: A/B against conv.hip).  geo: 0 = 3x3, 1 = 4x4 stride-2 down,
-// 2 = 4x4 stride-2 up (H, W = input size).  *launched = 1 if it ran; 0 leaves the shape to the first-generation kernel.
-// ``variant``: -1 = choose (environment switch + heuristics), 4 / 8 = force the 4- / 8-wave block (A/B probes, tests).
-int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
-                  const void* mask, int variant, hipStream_t st, int* launched) {
+// Which layers take this kernel, and with which block shape (SGX_CONV2=0 switches it off: A/B against conv.hip).
+// geo: 0 = 3x3, 1 = 4x4 stride-2 down, 2 = 4x4 stride-2 up (H, W = input size).  ``variant``: -1 = choose (environment switch +
+// heuristics), 4 / 8 = force the 4- / 8-wave block (A/B probes, tests).  nw == 0: the shape stays with the first generation.
+struct Conv2Pick { int nw; bool mf2, k16; };
+static Conv2Pick conv2_pick(int geo, int B, int H, int W, int Cin, int Cout, int variant) {
     // bit 0: S, 1: D, 2: U.  All three on: profiles/r02_conv2_probe.txt (S) and r02_conv2_probe_DU.txt (D, U) -- the shape
-    // heuristics below reproduce the per-shape winner of those tables.  bit 3: the 16-channel variants (round 3).
+    // heuristics below reproduce the per-shape winner of those tables.  bit 3: the 16-channel variants (round 3); bit 4: also the
+    // transposed 32->16 one.
     static const int on = [] { const char* e = getenv("SGX_CONV2"); return e ? atoi(e) : 15; }();
-    *launched = 0;
-    if (variant < 0 && !((on >> geo) & 1)) return 0;
+    const Conv2Pick none{0, false, false};
+    if (variant < 0 && !((on >> geo) & 1)) return none;
     const int gw = geo == C2_D ? W / 2 : W, gh = geo == C2_D ? H / 2 : H;
     const bool kc16 = Cin == 16, co16 = Cout == 16;
     if (kc16 || co16) {
         // the 16-channel layers: 3x3 16->16, stride-2 16->32, transposed 32->16 (and nothing else: the networks have no others)
         const bool shape_ok = (geo == C2_S && kc16 && co16) || (geo == C2_D && kc16 && Cout == 32) || (geo == C2_U && Cin == 32 && co16);
-        if (!shape_ok || gw % 32 != 0 || gh < 1 || (geo == C2_D && ((H | W) & 1))) return 0;
-        if (variant < 0 && !(on & 8)) return 0;
+        if (!shape_ok || gw % 32 != 0 || gh < 1 || (geo == C2_D && ((H | W) & 1))) return none;
+        if (variant < 0 && !(on & 8)) return none;
         // measured alone at batch 32 / 4 (tools/conv16_probe.py, profiles/r03_conv16_probe.txt): 3x3 16->16 @1024^2 first
         // generation 619 / 78 us, this kernel 498 / 59 us (4.3-4.5 TB/s); stride-2 16->32 478 / 65 -> 369 / 43 us; the
         // transposed 32->16 @512^2 stays with the first generation (338 vs 384 us: half of every MFMA is padding AND the
         // full-width stage leaves one block per CU) unless bit 4 of SGX_CONV2 asks for it
-        if (variant < 0 && geo == C2_U && !(on & 16)) return 0;
+        if (variant < 0 && geo == C2_U && !(on & 16)) return none;
         const long blocks4 = (long)B * ((gh + 7) / 8) * (gw / 32), blocks8 = (long)B * ((gh + 15) / 16) * (gw / 32);
-        if (variant < 0 && blocks4 < conv2_ncu()) return 0;
+        if (variant < 0 && blocks4 < conv2_ncu()) return none;
         static const int force16 = [] { const char* e = getenv("SGX_CONV2_NW16"); return e ? atoi(e) : 0; }();
-        const int nw = variant > 0 ? variant : (force16 ? force16 : (blocks8 >= 2 * conv2_ncu() ? 8 : 4));
-        Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
-                    geo == C2_D ? H / 2 : (geo == C2_U ? 2 * H : H), geo == C2_D ? W / 2 : (geo == C2_U ? 2 * W : W), Cin, Cout, act, 0, 0, 0, 0, 0};
-        *launched = 1;
-        if (geo == C2_S) return nw == 8 ? launch_conv2<C2_S, 8, 1, 16, true>(a, st) : launch_conv2<C2_S, 4, 1, 16, true>(a, st);
-        if (geo == C2_D) return nw == 8 ? launch_conv2<C2_D, 8, 1, 16, false>(a, st) : launch_conv2<C2_D, 4, 1, 16, false>(a, st);
-        return nw == 8 ? launch_conv2<C2_U, 8, 1, 32, true>(a, st) : launch_conv2<C2_U, 4, 1, 32, true>(a, st);
+        return Conv2Pick{variant > 0 ? variant : (force16 ? force16 : (blocks8 >= 2 * conv2_ncu() ? 8 : 4)), false, true};
     }
     const int bco = (geo == C2_S && Cout % 64 == 0) ? 64 : 32;       // (3x3 with 32 output channels: the MF = 1 block)
-    if (Cin % 32 != 0 || Cout % bco != 0 || gw % 32 != 0 || Cout / bco > 32 || gh < 1 || (geo == C2_D && ((H | W) & 1))) return 0;
-    Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
-                geo == C2_D ? H / 2 : (geo == C2_U ? 2 * H : H), geo == C2_D ? W / 2 : (geo == C2_U ? 2 * W : W), Cin, Cout, act, 0, 0, 0, 0, 0};
+    if (Cin % 32 != 0 || Cout % bco != 0 || gw % 32 != 0 || Cout / bco > 32 || gh < 1 || (geo == C2_D && ((H | W) & 1))) return none;
     const bool mf2 = geo != C2_U && Cout % 64 == 0;
-    if (variant < 0 && geo == C2_D && !mf2) return 0;      // 32-channel stride-2 blocks: measured no better than the first generation
+    if (variant < 0 && geo == C2_D && !mf2) return none;   // 32-channel stride-2 blocks: measured no better than the first generation
     const int cbs = Cout / (mf2 ? 64 : 32);
     const long blocks8 = (long)B * ((gh + 15) / 16) * (gw / 32) * cbs, blocks4 = (long)B * ((gh + 7) / 8) * (gw / 32) * cbs;
     static const int force_nw = [] { const char* e = getenv("SGX_CONV2_NW"); return e ? atoi(e) : 0; }();
     // measured (profiles/r02_conv2_probe.txt): the 8-wave block wins once its 512-pixel tiles fill the chip, the 4-wave
     // block (256-pixel tiles) down to one block per CU, below that the first-generation kernel's 64-pixel tiles do
-    if (variant < 0 && !force_nw && blocks4 < conv2_ncu()) return 0;
-    const int nw = variant > 0 ? variant : (force_nw ? force_nw : (blocks8 >= conv2_ncu() ? 8 : 4));
+    if (variant < 0 && !force_nw && blocks4 < conv2_ncu()) return none;
+    return Conv2Pick{variant > 0 ? variant : (force_nw ? force_nw : (blocks8 >= conv2_ncu() ? 8 : 4)), mf2, false};
+}
+
+// *launched = 1 if the second-generation kernel ran; 0 leaves the shape to the first-generation kernel.
+int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
+                  const void* mask, int variant, hipStream_t st, int* launched) {
+    *launched = 0;
+    const Conv2Pick p = conv2_pick(geo, B, H, W, Cin, Cout, variant);
+    if (!p.nw) return 0;
+    Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
+                geo == C2_D ? H / 2 : (geo == C2_U ? 2 * H : H), geo == C2_D ? W / 2 : (geo == C2_U ? 2 * W : W), Cin, Cout, act, 0, 0, 0, 0, 0, 0,
+                nullptr, nullptr, nullptr, nullptr};
     *launched = 1;
+    const int nw = p.nw;
+    if (p.k16) {
+        if (geo == C2_S) return nw == 8 ? launch_conv2<C2_S, 8, 1, 16, true>(a, st) : launch_conv2<C2_S, 4, 1, 16, true>(a, st);
+        if (geo == C2_D) return nw == 8 ? launch_conv2<C2_D, 8, 1, 16, false>(a, st) : launch_conv2<C2_D, 4, 1, 16, false>(a, st);
+        return nw == 8 ? launch_conv2<C2_U, 8, 1, 32, true>(a, st) : launch_conv2<C2_U, 4, 1, 32, true>(a, st);
+    }
     if (geo == C2_S) {
-        if (mf2) return nw == 8 ? launch_conv2<C2_S, 8, 2>(a, st) : launch_conv2<C2_S, 4, 2>(a, st);
+        if (p.mf2) return nw == 8 ? launch_conv2<C2_S, 8, 2>(a, st) : launch_conv2<C2_S, 4, 2>(a, st);
         return nw == 8 ? launch_conv2<C2_S, 8, 1>(a, st) : launch_conv2<C2_S, 4, 1>(a, st);
     }
     if (geo == C2_D) {
-        if (mf2) return nw == 8 ? launch_conv2<C2_D, 8, 2>(a, st) : launch_conv2<C2_D, 4, 2>(a, st);
+        if (p.mf2) return nw == 8 ? launch_conv2<C2_D, 8, 2>(a, st) : launch_conv2<C2_D, 4, 2>(a, st);
         return nw == 8 ? launch_conv2<C2_D, 8, 1>(a, st) : launch_conv2<C2_D, 4, 1>(a, st);
     }
     return nw == 8 ? launch_conv2<C2_U, 8, 1>(a, st) : launch_conv2<C2_U, 4, 1>(a, st);
+}
+
+// ---- 3x3 convolution whose store also produces the instance-norm statistics of the LayerEpilogue that follows (generator
+// conv1 -> epi2, models/Blocks.py:86-87 over models/CustomLayers.py:224-233): tiles per image covered by the second-generation
+// kernel, 0 = this shape has no fused variant (the caller runs the plain convolution and the separate statistics pass).
+// tile slots of the persistent grid for a plan (== Conv2Args::nslots as launch_conv2 sets it)
+static int conv2_stats_slots(const Conv2Pick& p, int B, int H, int W, int Cout) {
+    const int th = 2 * p.nw, ntiles = B * ((H + th - 1) / th) * ((W + 31) / 32);
+    const int ncb = p.k16 ? 1 : Cout / (p.mf2 ? 64 : 32);
+    int bpc = 1;
+    if (p.k16) {
+        static const int bpc_max = [] { const char* e = getenv("SGX_CONV2_BPC"); return e ? atoi(e) : 2; }();
+        const int lds = (p.nw == 8 ? C2Lds<C2_S, 8, 1, 16>::TOTAL : C2Lds<C2_S, 4, 1, 16>::TOTAL) + 1024;
+        bpc = (160 * 1024) / lds;
+        if (bpc > 32 / p.nw) bpc = 32 / p.nw;
+        if (bpc > bpc_max) bpc = bpc_max;
+        if (bpc < 1) bpc = 1;
+    }
+    int per = conv2_ncu() * bpc / (8 * ncb);
+    const int need = (ntiles + 7) / 8;
+    if (per > need) per = need;
+    if (per < 1) per = 1;
+    return per * 8;
+}
+extern "C" int sgx_conv3x3_stats_nparts(int B, int H, int W, int Cin, int Cout, int dtype) {
+    if (dtype != SGX_BF16) return 0;
+    const Conv2Pick p = conv2_pick(C2_S, B, H, W, Cin, Cout, -1);
+    if (!p.nw) return 0;
+    return conv2_stats_slots(p, B, H, W, Cout);
+}
+extern "C" int sgx_conv3x3_stats(const void* x, const void* w, void* y, const float* ebias, const float* noise, const float* nw_,
+                                 double* part, size_t part_bytes, int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    SGX_REQUIRE(dtype == SGX_BF16, SGX_EUNSUPPORTED, "conv3x3_stats: bf16 only");
+    SGX_REQUIRE(x && w && y && noise && nw_ && part, SGX_EINVAL, "conv3x3_stats: null argument");
+    const Conv2Pick p = conv2_pick(C2_S, B, H, W, Cin, Cout, -1);
+    SGX_REQUIRE(p.nw, SGX_EUNSUPPORTED, "conv3x3_stats: shape B%d %dx%d %d->%d has no fused variant (sgx_conv3x3_stats_nparts == 0)", B, H, W, Cin, Cout);
+    const int npart = conv2_stats_slots(p, B, H, W, Cout);
+    SGX_REQUIRE(part_bytes >= (size_t)B * npart * Cout * 2 * sizeof(double), SGX_EWORKSPACE, "conv3x3_stats: partials buffer %zu < %zu", part_bytes,
+                (size_t)B * npart * Cout * 2 * sizeof(double));
+    SGX_NOTE(2.0 * 9 * Cin * Cout * B * H * W, 2.0 * ((double)B * H * W * (Cin + Cout) + 9.0 * Cin * Cout), "convS+stats B%d %dx%d %d->%d", B, H, W, Cin, Cout);
+    Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), nullptr, static_cast<bf16_t*>(y), nullptr, B, H, W, H, W, Cin, Cout,
+                SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, ebias, noise, nw_, part};
+    hipStream_t st = (hipStream_t)stream;
+    const int nw = p.nw;
+    if (p.k16) return nw == 8 ? launch_conv2<C2_S, 8, 1, 16, true, EPI_STATS>(a, st) : launch_conv2<C2_S, 4, 1, 16, true, EPI_STATS>(a, st);
+    if (p.mf2) return nw == 8 ? launch_conv2<C2_S, 8, 2, 32, false, EPI_STATS>(a, st) : launch_conv2<C2_S, 4, 2, 32, false, EPI_STATS>(a, st);
+    return nw == 8 ? launch_conv2<C2_S, 8, 1, 32, false, EPI_STATS>(a, st) : launch_conv2<C2_S, 4, 1, 32, false, EPI_STATS>(a, st);
 }

@@ -338,18 +338,27 @@ class ConvFn(Function):
     (``mask`` argument of the adjoint launch, fused in its store; bit-identical to the separate pass)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, mode, scale, ipad, adjoint, act, mask=None, defer_act=False, x_masked=False):
+    def forward(ctx, x, weight, bias, mode, scale, ipad, adjoint, act, mask=None, defer_act=False, x_masked=False, stats=None):
+        """``stats`` = (epilogue bias or None, noise [B,1,H,W], noise weight) of the generator LayerEpilogue that consumes y: the
+        store of the convolution also emits the epilogue's partial instance-norm statistics -> returns (y, partials); only where
+        ``conv_stats_nparts`` says the shape has such a kernel (plain 3x3, bf16)."""
         x = _c(x)
         fwd, adj = packs(weight, mode, scale, ipad, x.dtype)
         geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
-        y = _conv_launch(geo, x, adj if adjoint else fwd, None if bias is None else _c(bias.detach()), act, mask)
         ctx.cfg = (mode, scale, ipad, adjoint, act, bias is not None, bool(defer_act), bool(x_masked))
         ctx.bias_ref = weakref.ref(bias) if bias is not None else (lambda: None)
+        if stats is not None:
+            assert geo == "S" and not adjoint and bias is None and act == 0 and mask is None
+            y, part = _conv_stats_launch(x, fwd, *stats)
+            ctx.mark_non_differentiable(part)
+            ctx.save_for_backward(x, weight, None, None)
+            return y, part
+        y = _conv_launch(geo, x, adj if adjoint else fwd, None if bias is None else _c(bias.detach()), act, mask)
         ctx.save_for_backward(x, weight, y if (act and not defer_act) else None, mask)
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gpart=None):
         x, weight, y, mask = ctx.saved_tensors
         mode, scale, ipad, adjoint, act, has_bias, defer_act, x_masked = ctx.cfg
         gy = _c(gy)
@@ -380,7 +389,7 @@ class ConvFn(Function):
                 gw, gb = _bcall(WgradFn, x, gy, weight, mode, scale, adjoint, fuse_b)
             if want_b and not fuse_b:
                 gb = _bcall(ColSumFn, gy, 1.0)
-        return gx, gw, gb, None, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None
 
 
 class WgradFn(Function):
@@ -396,9 +405,38 @@ class WgradFn(Function):
         raise NotImplementedError("second derivative through a weight gradient is not part of the training path")
 
 
-def conv(x, weight, bias, mode, scale, act=N.ACT_NONE, ipad=None, defer_act=False, x_masked=False):
+def conv(x, weight, bias, mode, scale, act=N.ACT_NONE, ipad=None, defer_act=False, x_masked=False, stats=None):
     return call(ConvFn, x, weight, bias, mode, float(scale), int(ipad if ipad is not None else weight.shape[1]), False, act, None,
-                bool(defer_act), bool(x_masked))
+                bool(defer_act), bool(x_masked), stats)
+
+
+def conv_stats_nparts(x, cout):
+    """Tiles per image of the 3x3 convolution kernel that also emits the following epilogue's statistics for NHWC input ``x``
+    and ``cout`` output channels; 0 = no such kernel for this shape / dtype."""
+    if x.dtype != torch.bfloat16:
+        return 0
+    B, H, W, Cin = x.shape
+    return N.lib().sgx_conv3x3_stats_nparts(B, H, W, Cin, int(cout), N.BF16)
+
+
+def _conv_stats_launch(x, wq, ebias, noise, nw):
+    B, H, W, Cin = x.shape
+    taps, Cout, K = wq.shape
+    if K != Cin or taps != 9:
+        raise N.SgxError("conv+stats: 3x3 pack with the activation's channel count expected")
+    L = N.lib()
+    npart = L.sgx_conv3x3_stats_nparts(B, H, W, Cin, Cout, N.dt(x))
+    if npart <= 0:
+        raise N.SgxError("conv+stats: no fused kernel for this shape (ask conv_stats_nparts first)")
+    y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
+    part = torch.empty((B, npart, Cout, 2), dtype=torch.float64, device=x.device)
+    noise_c = _c(noise.detach().reshape(B, H * W))
+    if noise_c.dtype != torch.float32:
+        noise_c = noise_c.float()
+    N.check(L.sgx_conv3x3_stats(N.ptr(x), N.ptr(wq), N.ptr(y), N.ptr(None if ebias is None else _c(ebias.detach())), N.ptr(noise_c),
+                                N.ptr(_c(nw.detach())), N.ptr(part), part.numel() * 8, B, H, W, Cin, Cout, N.dt(x), N.stream()),
+            "sgx_conv3x3_stats")
+    return y, part
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -40,8 +40,35 @@ def test_blur_with_epilogue_statistics(B, C, H, dt):
     assert_close(s[..., 1], (a * a).sum(dim=(1, 2)), 1e-6, "sum a^2")
 
 
+# (C, B, H): the six instantiations of the statistics epilogue -- 16-channel 8 / 4 waves, 32-channel blocks 8 / 4, 64-channel 8 / 4 --
+# plus ragged rows and several channel blocks
+CONV_STATS_CASES = [(16, 2, 512), (16, 1, 256), (32, 2, 256), (32, 1, 256), (64, 4, 256), (64, 1, 256), (128, 3, 136), (16, 3, 520)]
+
+
+@pytest.mark.parametrize("C,B,H", CONV_STATS_CASES)
+def test_conv3x3_with_epilogue_statistics(C, B, H):
+    """sgx_conv3x3_stats: y bit-identical to the plain convolution; the per-tile partials add up to the statistics of
+    lrelu(y + bias + nw*noise) computed in fp64 from the stored y."""
+    from stylegan.pytorch_amd import functional as F
+    W = 256 if H != 520 else 512
+    x = gu.seeded((B, H, W, C), 90).to(DEV).bfloat16()
+    w = gu.seeded((C, C, 3, 3), 91).to(DEV)
+    bias = (0.1 * gu.seeded((C,), 92)).to(DEV)
+    nw = (0.3 * gu.seeded((C,), 93)).to(DEV)
+    noise = gu.seeded((B, 1, H, W), 94).to(DEV)
+    scale = O.he_w_mul(C * 9, 2 ** 0.5)
+    assert F.conv_stats_nparts(x, C) > 0, "shape expected to have a fused kernel"
+    y, part = F.ConvFn.apply(x, w, None, "S", scale, C, False, 0, None, False, False, (bias, noise, nw))
+    y_ref = F.ConvFn.apply(x, w, None, "S", scale, C, False, 0)
+    assert torch.equal(y, y_ref)
+    a = TF.leaky_relu(y.double() + bias.double() + nw.double() * noise.double().reshape(B, H, W, 1), 0.2)
+    s = part.sum(dim=1)                                              # [B, C, 2]
+    assert_close(s[..., 0], a.sum(dim=(1, 2)), 2e-6, "sum a", floor=2e-6 * H * W)
+    assert_close(s[..., 1], (a * a).sum(dim=(1, 2)), 2e-6, "sum a^2")
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cin,cout,B,H", [(32, 16, 2, 16), (64, 64, 1, 64), (32, 32, 3, 8)])
+@pytest.mark.parametrize("cin,cout,B,H", [(32, 16, 2, 16), (64, 64, 1, 64), (32, 32, 3, 8), (32, 16, 2, 256), (64, 32, 1, 128), (128, 64, 4, 128)])
 def test_generator_block_with_fused_statistics(cin, cout, B, H, dt):
     """GSynthesisBlock with the instance-norm statistics produced by the blur / the 3x3 convolution (SGX_FUSE_EPI_STATS)
     against the same block with the separate statistics passes, forward and every gradient; fp32 also against the oracle."""
@@ -58,6 +85,7 @@ def test_generator_block_with_fused_statistics(cin, cout, B, H, dt):
 
     def run(fuse):
         keep, Blocks.FUSE_EPI_STATS = Blocks.FUSE_EPI_STATS, fuse
+        keep_min, Blocks.FUSE_EPI_STATS_MIN = Blocks.FUSE_EPI_STATS_MIN, 0
         try:
             for p in names.values():
                 p.grad = None
@@ -66,7 +94,7 @@ def test_generator_block_with_fused_statistics(cin, cout, B, H, dt):
             y.backward(gy.to(DEV).to(dt))
             return y.detach(), xg.grad, dg.grad, {k: p.grad.clone() for k, p in names.items()}
         finally:
-            Blocks.FUSE_EPI_STATS = keep
+            Blocks.FUSE_EPI_STATS, Blocks.FUSE_EPI_STATS_MIN = keep, keep_min
     y0, gx0, gd0, gp0 = run(0)
     y1, gx1, gd1, gp1 = run(3)
     tol = 2e-6 if dt == torch.float32 else 4e-3                      # bf16: a statistic moving by 1e-7 flips roundings of y

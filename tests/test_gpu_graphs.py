@@ -37,8 +37,10 @@ def make(use_graphs, act_dtype, psi=0.7, dp=None):
     return sg
 
 
-def run(use_graphs, act_dtype, iters, depth=5, **kw):
+def run(use_graphs, act_dtype, iters, depth=5, dev_alpha=False, **kw):
     sg = make(use_graphs, act_dtype, **kw)
+    if dev_alpha:
+        sg.alpha_on_device = True
     torch.manual_seed(5); random.seed(5)
     losses = []
     for i in range(iters):
@@ -90,12 +92,17 @@ def close(a, b, tol):
 # 4 iterations = 2 eager warm-up calls + the capture + one pure replay: tight.  6 iterations: the sign-like Adam update
 # (beta1 = 0) amplifies the ulp-level summation-order differences by ~10x per iteration, so the bound is loose there.
 @pytest.mark.parametrize("act_dtype,iters,lscale,ptol", [(torch.float32, 4, 1.0, 3e-2), (torch.float32, 6, 1.0, 5e-2),
-                                                         # bf16: eager folds the residual branch's (1-alpha) into from_rgb's weights,
-                                                         # replay (alpha in device memory) scales the bf16 activation: two roundings
-                                                         # of the same quantity, 5e-3 on the first G loss (measured)
+                                                         # bf16, eager with alpha_on_device (the arithmetic of the replay: the
+                                                         # fade-in coefficient read from device memory, nothing folded into
+                                                         # from_rgb): sharp.  x10: bf16 re-rounds ulp-level gradient-sum differences
+                                                         (torch.bfloat16, 4, 10.0, 5e-2),
+                                                         # bf16, eager with the HOST alpha: it folds the residual branch's (1-alpha)
+                                                         # into from_rgb's weights where the replay scales the stored bf16
+                                                         # activation -- two roundings of the same quantity, 5e-3 on the first G
+                                                         # loss (measured): the documented difference between the two eager forms
                                                          (torch.bfloat16, 4, 5e3, 5e-2)])
 def test_graph_replay_matches_eager(act_dtype, iters, lscale, ptol):
-    le, se, _ = run(False, act_dtype, iters)                         # 2 eager warm-up calls, the capture, pure replays
+    le, se, _ = run(False, act_dtype, iters, dev_alpha=(act_dtype == torch.bfloat16 and lscale <= 10.0))   # 2 eager warm-up calls, the capture, pure replays
     lg, sgr, sg = run(True, act_dtype, iters)
     assert all(g.graph is not None and g.calls == iters for g in sg._step_graphs.values()) and len(sg._step_graphs) == 2
     losses_agree(le, lg, lscale)
@@ -160,13 +167,7 @@ def test_data_parallel_graphs_split_around_the_all_reduce():
         la, sa, sga = run(False, torch.float32, 5, psi=-1.0, dp=DataParallelGroup(force_collectives=True, bucket_mb=1.0))
         assert "_update_stream" in sga.__dict__
         for other_l, other_s in ((lg, sgr), (la, sa)):
-            # x10: the data-parallel runs accumulate every gradient into zero-filled flat buckets where the plain run writes the
-            # first contribution, and the bias-correction scalars travel separately: ulp-level differences in iteration 0 that
-            # Adam with beta1 = 0 turns into +-lr steps of near-zero-gradient elements.  Measured (deterministic) 3.0e-5 on the
-            # D loss of iteration 1 with the instance-norm statistics taken from the producing kernel, < 5e-7 without
-            # (tools/gpu_ab_env.sh, SGX_FUSE_EPI_STATS=0|3): which elements sit near zero changes with every change of the
-            # summation order.  Errors of the kind this test is for (stale scalars, races, a wrong all-reduce) are >= 1e-2.
-            losses_agree(le, other_l, scale=10.0)
+            losses_agree(le, other_l)
             for part in ("gen", "dis", "shadow"):
                 for k, v in se[part].items():
                     assert k in SKIP or close(other_s[part][k], v, 3e-2), (part, k)
