@@ -207,6 +207,15 @@ int sgx_blur3x3_stats_nparts(int B, int H, int W, int C, int dtype);
  * the same statistics out of the convolution's store epilogue: one partial per (image, pixel tile).  sgx_conv3x3_stats_nparts:
  * tiles per image, or 0 when the shape has no fused variant (then: sgx_conv3x3 + the plain sgx_gepi_fwd).  bf16 only. */
 int sgx_conv3x3_stats_nparts(int B, int H, int W, int Cin, int Cout, int dtype);
+/* y = blur3x3(conv_transpose4x4s2(x, pack)) [* slope(mask)] in one kernel: the transposed convolution and the BlurLayer that
+ * follows it -- generator conv0_up -> blur (models/CustomLayers.py:143-152,176-177) and, with mask = the pre-activation z, the
+ * discriminator's backward through "LeakyReLU -> blur -> conv1_down" (models/Blocks.py:140-145: the adjoint of the stride-2
+ * convolution is this transposed one, the blur is self-adjoint, slope(z) = z > 0 ? 1 : 0.2).  mask: [B][2H][2W][Cout] or NULL.
+ * The kernel applies the UNNORMALISED [1,2,1]x[1,2,1] filter: the caller packs the weights with scale / 16.
+ * sgx_conv4x4s2_up_blur_ok: 1 if the shape has the fused kernel (bf16), else run sgx_conv4x4s2_up + sgx_blur3x3(_act). */
+int sgx_conv4x4s2_up_blur_ok(int B, int H, int W, int Cin, int Cout, int dtype);
+int sgx_conv4x4s2_up_blur(const void* x, const void* w, void* y, const void* mask, int B, int H, int W, int Cin, int Cout,
+                          int dtype, void* stream);
 int sgx_conv3x3_stats(const void* x, const void* w, void* y, const float* ebias, const float* noise, const float* nw, double* part,
                       size_t part_bytes, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
 int sgx_blur3x3_stats(const void* x, void* y, const float* bias, const float* noise, const float* nw, double* part,

@@ -23,6 +23,12 @@ FUSE_EPI_STATS = int(os.environ.get("SGX_FUSE_EPI_STATS", "2"))
 FUSE_EPI_STATS_MIN = int(os.environ.get("SGX_FUSE_EPI_STATS_MIN", str(1 << 27)))
 
 
+# Discriminator block backward: the blur (and the LeakyReLU mask) between conv0 and conv1_down folded into conv1_down's data
+# gradient (functional.ConvFn x_pre / ConvBlurFn).  0: the separate blur-and-mask pass (A/B; the kernel-level switch is
+# SGX_CONV_UP_BLUR, which also covers the generator's conv0_up -> blur).
+FUSE_BLUR_BWD = os.environ.get("SGX_FUSE_BLUR_BWD", "1") != "0"
+
+
 def _lat(d, k):
     """Layer k of a block's pair of dlatents: a [B, 2, D] tensor (reference signature) or a pair of [B, D] tensors."""
     return d[k] if isinstance(d, (tuple, list)) else d[:, k]
@@ -163,6 +169,11 @@ class DiscriminatorBlock(nn.Module):
         x_masked = x_masked and self._act == ACT_LRELU
         defer_out = defer_out and self._act == ACT_LRELU
         z = self.conv0.forward_nhwc(x, act=ACT_NONE, x_masked=x_masked)   # bias fused in the conv store; pre-activation
+        if self.blur._is_121 and self._act == ACT_LRELU and FUSE_BLUR_BWD:
+            # LeakyReLU folded into the blur pass; backward: the blur and the activation's mask ride in the data-gradient
+            # kernel of conv1_down (ConvFn x_pre), so the chain has no blur pass of its own on the way back
+            x = F.call(F.ActBlurPassFn, z)
+            return self.conv1_down.forward_nhwc(x, act=ACT_LRELU, defer_act=defer_out, x_pre=z)
         if self.blur._is_121 and self._act == ACT_LRELU:
             x = F.call(F.ActBlurFn, z)                                      # LeakyReLU folded into the blur pass (both ways)
         else:                                                               # ReLU / another blur filter: stage by stage

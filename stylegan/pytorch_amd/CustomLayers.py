@@ -211,7 +211,7 @@ class EqualizedConv2d(nn.Module):
         return self.bias * self.b_mul if self.b_mul != 1 else self.bias
 
     def forward_nhwc(self, x, act=ACT_NONE, skip_bias=False, out_dtype=None, defer_act=False, x_masked=False, out_scale=1.0,
-                     epi_stats=None):
+                     epi_stats=None, x_pre=None):
         """x: NHWC.  ``skip_bias``: the caller folds the bias into the next kernel (generator epilogue).
         ``defer_act`` / ``x_masked``: the LeakyReLU backward of this layer is applied by its consumer / this layer's input is
         such an output and its data gradient leaves the kernel already masked (functional.ConvFn; discriminator chain only).
@@ -260,15 +260,22 @@ class EqualizedConv2d(nn.Module):
             return F.conv(x, self.weight, None, "S", self.w_mul, ipad=x.shape[3]), None   # no fused kernel: separate pass
         if self.upscale is not None:
             fused = min(x.shape[1], x.shape[2]) * 2 >= 128                # reference :143
-            y = F.conv(x, self.weight, None, "U" if fused else "UF", self.w_mul)
-            if self.intermediate is not None:
-                y = self.intermediate.forward_nhwc(y)
+            mode = "U" if fused else "UF"
+            if (self.intermediate is not None and self.intermediate._is_121
+                    and F.conv_blur_ok(x, self.weight.shape[0], mode, False)):
+                # transposed convolution and the blur after it in one kernel (the blur in the store epilogue)
+                y = F.call(F.ConvBlurFn, x, self.weight, mode, float(self.w_mul), int(self.weight.shape[1]), False, None)
+            else:
+                y = F.conv(x, self.weight, None, mode, self.w_mul)
+                if self.intermediate is not None:
+                    y = self.intermediate.forward_nhwc(y)
             if bias is not None or act:
                 y = F.call(F.BiasActFn, y, bias, 1.0, act)                  # bias after the blur (:178-179)
             return y
         if self.downscale is not None:
             assert self.intermediate is None                              # reference :167
-            return F.conv(x, self.weight, bias, "D", self.w_mul, act, defer_act=defer_act and act == ACT_LRELU)   # bias after the 2x2 mean == bias in the fused store
+            return F.conv(x, self.weight, bias, "D", self.w_mul, act, defer_act=defer_act and act == ACT_LRELU,
+                          x_pre=x_pre)                                    # bias after the 2x2 mean == bias in the fused store
         if self.intermediate is None:
             return F.conv(x, self.weight, bias, "S", self.w_mul, act, ipad=x.shape[3], x_masked=x_masked)
         y = self.intermediate.forward_nhwc(F.conv(x, self.weight, None, "S", self.w_mul))

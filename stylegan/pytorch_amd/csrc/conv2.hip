@@ -60,7 +60,7 @@ struct Conv2Args {
     // image that the slot's blocks stored, y as stored (bf16)
     const float* ebias; const float* enoise; const float* enw; double* part;   // part[((b * nslots + slot) * Cout + c) * 2 + {0, 1}]
 };
-enum { EPI_NONE = 0, EPI_STATS = 1 };
+enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BLUR = 2 };
 
 template <int GEO> struct G2;
 template <> struct G2<C2_S> { static constexpr int NPH = 1, HALO = 2, IS = 1, NTW = 9, NDX = 3, NDY = 3, NCLS = 1; };
@@ -98,7 +98,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
     static_assert(KC == 32 || KC == 16, "K-step width");
     static_assert(!CO16 || MF == 1, "16 output channels: one (half used) 32-channel block");
     static_assert(GEO != C2_U || MF == 1, "four parity classes of accumulators: one 32-channel row per wave");
-    static_assert(EPI == EPI_NONE || GEO == C2_S, "the statistics epilogue is built for the 3x3 geometry");
+    static_assert(EPI != EPI_STATS || GEO == C2_S, "the statistics epilogue is built for the 3x3 geometry");
+    static_assert(EPI != EPI_BLUR || GEO == C2_U, "the blur epilogue is built for the transposed geometry");
+    // EPI_BLUR: y = blur3x3(conv(x)) [* slope(mask)] -- the [1,2,1]x[1,2,1]/16 blur that follows the transposed convolution in
+    // both networks (generator: conv0_up -> blur, models/CustomLayers.py:176-177; discriminator backward: the adjoint of
+    // "LeakyReLU -> blur -> conv1_down", models/Blocks.py:140-145) applied to the accumulators before they are stored: the
+    // vertical [1,2,1] in registers (a lane holds a 2x2 fine block of both of its wave's coarse rows; the fine rows above and
+    // below come from the neighbouring waves through LDS), the horizontal [1,2,1] in the transposed store's read-back.  Tiles
+    // overlap by one coarse row / column (steps TH-1, 31): the first / last fine row and column of a tile lack a neighbour and
+    // are stored by the adjacent tile instead -- except at the image border, where the neighbour is the blur's zero padding.
+    constexpr int TSY = EPI == EPI_BLUR ? TH - 1 : TH, TSX = EPI == EPI_BLUR ? 31 : 32;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     float* const ecoef = reinterpret_cast<float*>(smem + L::TOTAL);     // EPI_STATS: [2][BCO] epilogue bias / noise weight of this channel block
 
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
     auto tile_coords = [&](int t, int& b, int& ty0, int& tx0) {
         const int tx_i = t % a.tiles_x; t /= a.tiles_x;
         const int ty_i = t % a.tiles_y;
-        b = t / a.tiles_y; ty0 = ty_i * TH; tx0 = tx_i * 32;
+        b = t / a.tiles_y; ty0 = ty_i * TSY; tx0 = tx_i * TSX;
     };
     // stage K-step `step` (tile it, channel chunk kc, phase ph) into LDS stage buffer `buf`
     auto issue = [&](int step, char* buf) {
@@ -196,7 +205,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                 glds16(reinterpret_cast<const void*>(zaddr + ((pa - zaddr) & ok)), buf + ii * 1024);
             }
         }
-        if (spt > 2 || step < 2) {                   // <= 2 K-steps per tile: step q's weights live in stage q for the whole launch
+        // <= 2 K-steps per tile: step q's weights live in stage q for the whole launch (not with the blur epilogue: its row
+        // exchange takes the whole stage of a tile's last K-step)
+        if (EPI == EPI_BLUR || spt > 2 || step < 2) {
             const bf16_t* w0 = wg + kc * KC - (GEO == C2_D ? (long)(4 * py + px) * a.Cout * a.Cin : 0);
 #pragma unroll
             for (int jj = 0; jj < NWI; ++jj) {
@@ -353,7 +364,135 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
             // the stage just consumed) so that every lane stores 16 bytes and neighbouring lanes cover whole channel rows
             int b, ty0, tx0;
             tile_coords(tile0 + it * tstride, b, ty0, tx0);
-            if constexpr (GEO == C2_U) {
+            if constexpr (GEO == C2_U && EPI == EPI_BLUR) {
+                __syncthreads();                 // every wave is done reading this stage (patch AND weights)
+                const int r0 = ty0 + 2 * wave;   // this wave's coarse rows r0 (f = 0), r0 + 1 (f = 1)
+                // the blur pads with zeros OUTSIDE the image: fine pixels of coarse positions beyond it are not conv outputs
+                // (only tiles that reach over the right / bottom border have any)
+                if (tx0 + 32 > a.W || ty0 + TH > a.H) {
+                    const bool colok = tx0 + l31 < a.W;
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const float keep = (colok && r0 + f < a.H) ? 1.f : 0.f;
+#pragma unroll
+                        for (int cls = 0; cls < 4; ++cls)
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) acc[cls][f][j] *= keep;
+                    }
+                }
+                // publish this wave's first (f 0, py 0) and last (f 1, py 1) fine row, both px, 16 channels per lane as bf16
+                auto ex_at = [&](int w8, int side, int px) { return cur + ((((w8 * 2 + side) * 2 + px) * 64) + lane) * 32; };
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+#pragma unroll
+                    for (int side = 0; side < 2; ++side) {
+                        const f32x16& v = side ? acc[2 + px][1] : acc[px][0];
+                        uint4 lo, hi4;
+                        lo.x = pack_bf16x2(v[0], v[1]); lo.y = pack_bf16x2(v[2], v[3]); lo.z = pack_bf16x2(v[4], v[5]); lo.w = pack_bf16x2(v[6], v[7]);
+                        hi4.x = pack_bf16x2(v[8], v[9]); hi4.y = pack_bf16x2(v[10], v[11]); hi4.z = pack_bf16x2(v[12], v[13]); hi4.w = pack_bf16x2(v[14], v[15]);
+                        char* e = ex_at(wave, side, px);
+                        *reinterpret_cast<uint4*>(e) = lo;
+                        *reinterpret_cast<uint4*>(e + 16) = hi4;
+                    }
+                }
+                __syncthreads();
+                // vertical [1,2,1] over the wave's four fine rows R0..R3 = (f0,py0) (f0,py1) (f1,py0) (f1,py1); the neighbour waves'
+                // rows 8 channels at a time (register budget: 128 accumulators live).  The 1/16 of the filter is in the weights.
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        uint4 uq = make_uint4(0u, 0u, 0u, 0u), dq = make_uint4(0u, 0u, 0u, 0u);
+                        if (wave > 0) uq = *reinterpret_cast<const uint4*>(ex_at(wave - 1, 1, px) + hf * 16);   // (wave-uniform branches)
+                        if (wave < NW - 1) dq = *reinterpret_cast<const uint4*>(ex_at(wave + 1, 0, px) + hf * 16);
+                        const unsigned uw[4] = {uq.x, uq.y, uq.z, uq.w}, dw[4] = {dq.x, dq.y, dq.z, dq.w};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int j = hf * 8 + q;
+                            const float up = (q & 1) ? __uint_as_float(uw[q >> 1] & 0xffff0000u) : __uint_as_float(uw[q >> 1] << 16);
+                            const float dn = (q & 1) ? __uint_as_float(dw[q >> 1] & 0xffff0000u) : __uint_as_float(dw[q >> 1] << 16);
+                            const float t0 = acc[px][0][j], t1 = acc[2 + px][0][j], t2 = acc[px][1][j], t3 = acc[2 + px][1][j];
+                            acc[px][0][j] = up + 2.f * t0 + t1;
+                            acc[2 + px][0][j] = t0 + 2.f * t1 + t2;
+                            acc[px][1][j] = t1 + 2.f * t2 + t3;
+                            acc[2 + px][1][j] = t2 + 2.f * t3 + dn;
+                        }
+                        asm volatile("" ::: "memory");       // keep the next group's LDS loads from being hoisted over this one
+                    }
+                }
+                __syncthreads();                 // the exchange area is read: the wave-private store scratch may overwrite it
+                char* scr = cur + wave * (64 * OROW);
+                // the horizontal [1,2,1] in the read-back of the transposed store (three 16-byte reads of the wave's row instead of
+                // one; measured faster than DPP wave shifts on the accumulators: 817 vs 962 us on the 1024^2 layer at batch 32).
+                // The mask of row r + 1 is requested while row r is processed (its latency is not hidden by anything else here).
+                constexpr int NSU = 64 * VPR / 64;
+                auto row_of = [&](int r, int& oy, bool& ok) {        // r = 2 * f + py
+                    const int f = r >> 1, py = r & 1;
+                    oy = 2 * (r0 + f) + py;
+                    // a tile's first / last fine row has no neighbour row in this block unless that neighbour is outside the image
+                    ok = oy < a.OH && !(wave == 0 && r == 0 && ty0 > 0) && !(wave == NW - 1 && r == 3 && ty0 + TH < a.H);
+                };
+                auto col_of = [&](int i, int& fpx, int& v, int& ox, bool& ok) {
+                    const int idx = i * 64 + lane;
+                    fpx = idx / VPR; v = idx % VPR; ox = 2 * tx0 + fpx;
+                    ok = ox < a.OW && (fpx >= 1 || tx0 == 0) && (fpx <= 62 || tx0 + 32 >= a.W);
+                };
+                const uint4 ones4 = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);     // bf16 1.0 pairs: slope 1
+                uint4 mk[2][NSU];
+                auto load_mask = [&](int r, uint4 (&m)[NSU]) {
+                    int oy; bool rok;
+                    row_of(r, oy, rok);
+#pragma unroll
+                    for (int i = 0; i < NSU; ++i) {
+                        int fpx, v, ox; bool cok;
+                        col_of(i, fpx, v, ox, cok);
+                        m[i] = (a.mask && rok && cok) ? *reinterpret_cast<const uint4*>(a.mask + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8) : ones4;
+                    }
+                };
+                load_mask(0, mk[0]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = r >> 1, py = r & 1;
+                    if (r + 1 < 4) load_mask(r + 1, mk[(r + 1) & 1]);
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x16& v = acc[py * 2 + px][f];
+                            uint2 o;
+                            o.x = pack_bf16x2(v[4 * g], v[4 * g + 1]);
+                            o.y = pack_bf16x2(v[4 * g + 2], v[4 * g + 3]);
+                            *reinterpret_cast<uint2*>(scr + (2 * l31 + px) * OROW + (8 * g + 4 * hi) * 2) = o;
+                        }
+                    }
+                    int oy; bool rowok;
+                    row_of(r, oy, rowok);
+#pragma unroll
+                    for (int i = 0; i < NSU; ++i) {
+                        int fpx, v, ox; bool colv;
+                        col_of(i, fpx, v, ox, colv);
+                        const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+                        const uint4 cc = *reinterpret_cast<const uint4*>(scr + fpx * OROW + v * 16);
+                        const uint4 ll = fpx > 0 ? *reinterpret_cast<const uint4*>(scr + (fpx - 1) * OROW + v * 16) : zero4;
+                        const uint4 rr = fpx < 63 ? *reinterpret_cast<const uint4*>(scr + (fpx + 1) * OROW + v * 16) : zero4;
+                        if (rowok && colv) {
+                            const size_t doff = (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8;
+                            const unsigned cw[4] = {cc.x, cc.y, cc.z, cc.w}, lw[4] = {ll.x, ll.y, ll.z, ll.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
+                            const uint4 mm = mk[r & 1][i];
+                            const unsigned mw[4] = {mm.x, mm.y, mm.z, mm.w};
+                            unsigned ow[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float h0 = __uint_as_float(lw[q] << 16) + 2.f * __uint_as_float(cw[q] << 16) + __uint_as_float(rw[q] << 16);
+                                const float h1 = __uint_as_float(lw[q] & 0xffff0000u) + 2.f * __uint_as_float(cw[q] & 0xffff0000u) +
+                                                 __uint_as_float(rw[q] & 0xffff0000u);
+                                ow[q] = pack_bf16x2(h0 * lrelu_slope(__uint_as_float(mw[q] << 16)), h1 * lrelu_slope(__uint_as_float(mw[q] & 0xffff0000u)));
+                            }
+                            *reinterpret_cast<uint4*>(a.y + doff) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                        }
+                    }
+                }
+            } else if constexpr (GEO == C2_U) {
                 __syncthreads();                 // every wave is done reading this stage's patch
                 char* scr = cur + wave * (64 * OROW);
 #pragma unroll
@@ -478,6 +617,10 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
     }
     const int gh = GEO == C2_D ? a.OH : a.H, gw = GEO == C2_D ? a.OW : a.W;       // the tile grid
     a.tiles_x = (gw + 31) / 32; a.tiles_y = (gh + L::TH - 1) / L::TH;
+    if constexpr (EPI == EPI_BLUR) {              // tiles overlap by one coarse row / column: steps TH - 1 and 31
+        a.tiles_y = gh <= L::TH ? 1 : (gh - L::TH + L::TH - 2) / (L::TH - 1) + 1;
+        a.tiles_x = gw <= 32 ? 1 : (gw - 32 + 30) / 31 + 1;
+    }
     a.ntiles = a.B * a.tiles_y * a.tiles_x;
     a.ncb = CO16 ? 1 : a.Cout / L::BCO;
     // resident blocks per CU: one for the round-2 instantiations (their LDS stages fill the CU); the half-width stages of the
@@ -507,7 +650,7 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
 // geo: 0 = 3x3, 1 = 4x4 stride-2 down, 2 = 4x4 stride-2 up (H, W = input size).  ``variant``: -1 = choose (environment switch +
 // heuristics), 4 / 8 = force the 4- / 8-wave block (A/B probes, tests).  nw == 0: the shape stays with the first generation.
 struct Conv2Pick { int nw; bool mf2, k16; };
-static Conv2Pick conv2_pick(int geo, int B, int H, int W, int Cin, int Cout, int variant) {
+static Conv2Pick conv2_pick(int geo, int B, int H, int W, int Cin, int Cout, int variant, bool allow_u16 = false) {
     // bit 0: S, 1: D, 2: U.  All three on: profiles/r02_conv2_probe.txt (S) and r02_conv2_probe_DU.txt (D, U) -- the shape
     // heuristics below reproduce the per-shape winner of those tables.  bit 3: the 16-channel variants (round 3); bit 4: also the
     // transposed 32->16 one.
@@ -525,7 +668,7 @@ static Conv2Pick conv2_pick(int geo, int B, int H, int W, int Cin, int Cout, int
         // generation 619 / 78 us, this kernel 498 / 59 us (4.3-4.5 TB/s); stride-2 16->32 478 / 65 -> 369 / 43 us; the
         // transposed 32->16 @512^2 stays with the first generation (338 vs 384 us: half of every MFMA is padding AND the
         // full-width stage leaves one block per CU) unless bit 4 of SGX_CONV2 asks for it
-        if (variant < 0 && geo == C2_U && !(on & 16)) return none;
+        if (variant < 0 && geo == C2_U && !(on & 16) && !allow_u16) return none;
         const long blocks4 = (long)B * ((gh + 7) / 8) * (gw / 32), blocks8 = (long)B * ((gh + 15) / 16) * (gw / 32);
         if (variant < 0 && blocks4 < conv2_ncu()) return none;
         static const int force16 = [] { const char* e = getenv("SGX_CONV2_NW16"); return e ? atoi(e) : 0; }();
@@ -616,4 +759,27 @@ extern "C" int sgx_conv3x3_stats(const void* x, const void* w, void* y, const fl
     if (p.k16) return nw == 8 ? launch_conv2<C2_S, 8, 1, 16, true, EPI_STATS>(a, st) : launch_conv2<C2_S, 4, 1, 16, true, EPI_STATS>(a, st);
     if (p.mf2) return nw == 8 ? launch_conv2<C2_S, 8, 2, 32, false, EPI_STATS>(a, st) : launch_conv2<C2_S, 4, 2, 32, false, EPI_STATS>(a, st);
     return nw == 8 ? launch_conv2<C2_S, 8, 1, 32, false, EPI_STATS>(a, st) : launch_conv2<C2_S, 4, 1, 32, false, EPI_STATS>(a, st);
+}
+
+// ---- transposed convolution + the blur that follows it (+ the LeakyReLU-backward mask of the discriminator's backward chain)
+// in one kernel: 1 if this shape has the fused variant, 0 = the caller runs sgx_conv4x4s2_up and sgx_blur3x3(_act).
+extern "C" int sgx_conv4x4s2_up_blur_ok(int B, int H, int W, int Cin, int Cout, int dtype) {
+    if (dtype != SGX_BF16) return 0;
+    static const int on = [] { const char* e = getenv("SGX_CONV_UP_BLUR"); return e ? atoi(e) : 1; }();   // A/B switch
+    if (!on) return 0;
+    return conv2_pick(C2_U, B, H, W, Cin, Cout, -1, true).nw ? 1 : 0;
+}
+extern "C" int sgx_conv4x4s2_up_blur(const void* x, const void* w, void* y, const void* mask, int B, int H, int W, int Cin, int Cout,
+                                     int dtype, void* stream) {
+    SGX_REQUIRE(dtype == SGX_BF16, SGX_EUNSUPPORTED, "conv4x4s2_up_blur: bf16 only");
+    SGX_REQUIRE(x && w && y, SGX_EINVAL, "conv4x4s2_up_blur: null argument");
+    const Conv2Pick p = conv2_pick(C2_U, B, H, W, Cin, Cout, -1, true);
+    SGX_REQUIRE(p.nw, SGX_EUNSUPPORTED, "conv4x4s2_up_blur: shape B%d %dx%d %d->%d has no fused variant (sgx_conv4x4s2_up_blur_ok == 0)", B, H, W, Cin, Cout);
+    SGX_NOTE(2.0 * 16 * Cin * Cout * B * H * W, 2.0 * ((double)B * H * W * (Cin + 4.0 * Cout * (mask ? 2 : 1)) + 16.0 * Cin * Cout),
+             "convU+blur%s B%d %dx%d %d->%d", mask ? "*mask" : "", B, H, W, Cin, Cout);
+    Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), nullptr, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
+                2 * H, 2 * W, Cin, Cout, SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t st = (hipStream_t)stream;
+    if (p.k16) return p.nw == 8 ? launch_conv2<C2_U, 8, 1, 32, true, EPI_BLUR>(a, st) : launch_conv2<C2_U, 4, 1, 32, true, EPI_BLUR>(a, st);
+    return p.nw == 8 ? launch_conv2<C2_U, 8, 1, 32, false, EPI_BLUR>(a, st) : launch_conv2<C2_U, 4, 1, 32, false, EPI_BLUR>(a, st);
 }

@@ -338,15 +338,20 @@ class ConvFn(Function):
     (``mask`` argument of the adjoint launch, fused in its store; bit-identical to the separate pass)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, mode, scale, ipad, adjoint, act, mask=None, defer_act=False, x_masked=False, stats=None):
+    def forward(ctx, x, weight, bias, mode, scale, ipad, adjoint, act, mask=None, defer_act=False, x_masked=False, stats=None,
+                x_pre=None):
         """``stats`` = (epilogue bias or None, noise [B,1,H,W], noise weight) of the generator LayerEpilogue that consumes y: the
         store of the convolution also emits the epilogue's partial instance-norm statistics -> returns (y, partials); only where
-        ``conv_stats_nparts`` says the shape has such a kernel (plain 3x3, bf16)."""
+        ``conv_stats_nparts`` says the shape has such a kernel (plain 3x3, bf16).
+        ``x_pre`` (stride-2 layers of the discriminator): x = blur(lrelu(x_pre)), made by ``ActBlurPassFn`` whose own backward is
+        the identity -- THIS op's backward then returns the gradient w.r.t. x_pre, blur(conv_adjoint(gy)) * slope(x_pre), from
+        one kernel where the shape has it (``ConvBlurFn``), else from the adjoint convolution and the blur-and-mask pass."""
         x = _c(x)
         fwd, adj = packs(weight, mode, scale, ipad, x.dtype)
         geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
         ctx.cfg = (mode, scale, ipad, adjoint, act, bias is not None, bool(defer_act), bool(x_masked))
         ctx.bias_ref = weakref.ref(bias) if bias is not None else (lambda: None)
+        ctx.x_pre = x_pre
         if stats is not None:
             assert geo == "S" and not adjoint and bias is None and act == 0 and mask is None
             y, part = _conv_stats_launch(x, fwd, *stats)
@@ -367,8 +372,16 @@ class ConvFn(Function):
         if act and not defer_act:
             gy = _bcall(LReluBwdFn, gy, y, 0.2, 1.0)
         gx = gw = gb = None
+        x_pre = getattr(ctx, "x_pre", None)
         if ctx.needs_input_grad[0]:
-            gx = _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0, x if x_masked else None, False, False)
+            if x_pre is not None:
+                assert not x_masked
+                if conv_blur_ok(gy, weight.shape[1] if not adjoint else weight.shape[0], mode, not adjoint):
+                    gx = _bcall(ConvBlurFn, gy, weight, mode, scale, ipad, not adjoint, x_pre)      # one kernel
+                else:
+                    gx = _bcall(BlurMaskFn, _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0), x_pre)
+            else:
+                gx = _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0, x if x_masked else None, False, False)
         if not _DATA_GRAD_ONLY:
             want_b = has_bias and ctx.needs_input_grad[2]
             # the bias gradient rides along in the weight-gradient pass when gy is its O-channel side
@@ -389,7 +402,80 @@ class ConvFn(Function):
                 gw, gb = _bcall(WgradFn, x, gy, weight, mode, scale, adjoint, fuse_b)
             if want_b and not fuse_b:
                 gb = _bcall(ColSumFn, gy, 1.0)
-        return gx, gw, gb, None, None, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
+
+
+# Where the transposed convolution and the blur after it run as ONE kernel.  "auto": where it was measured to win alone on the
+# GPU (tools/upblur_probe.py, profiles/r03_upblur_probe.txt) -- the 16-channel 1024x1024 output at a large batch: 872 -> 740 us
+# (plain blur) and 1026 -> 846 us (blur * activation mask) at batch 32; at 512x512 (64 -> 32) it is a wash (430 vs 450 / 507 vs
+# 482 us), below that and at batch 4 a loss: the blur epilogue is ~1000 VALU instructions per wave and tile, executed by all
+# eight waves of the CU's single block at once, where the separate blur pass streams at 4.6-5.2 TB/s.  "all": every shape that
+# has the kernel (the parity tests); "off": never (process-wide A/B without a rebuild: SGX_CONV_UP_BLUR=0).
+CONV_BLUR_POLICY = os.environ.get("SGX_CONV_UP_BLUR_POLICY", "auto")
+CONV_BLUR_MIN_PIXELS = 1 << 22          # coarse input pixels B*H*W from which "auto" fuses the 16-channel layer
+
+
+def conv_blur_ok(x, cout, mode, adjoint):
+    """True if ``ConvBlurFn`` has a kernel for the convolution (mode, adjoint) applied to NHWC ``x`` with ``cout`` outputs AND the
+    policy wants it used."""
+    geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
+    if CONV_BLUR_POLICY == "off" or geo != "U" or x.dtype != torch.bfloat16:
+        return False
+    B, H, W, Cin = x.shape
+    if CONV_BLUR_POLICY == "auto" and not (int(cout) == 16 and B * H * W >= CONV_BLUR_MIN_PIXELS):
+        return False
+    return bool(N.lib().sgx_conv4x4s2_up_blur_ok(B, H, W, Cin, int(cout), N.BF16))
+
+
+class ConvBlurFn(Function):
+    """blur3x3(conv(x)) [* slope(z)] for a transposed (4x4 stride-2 up) convolution in ONE kernel: the blur is applied to the
+    accumulators in the store epilogue (sgx_conv4x4s2_up_blur).  (mode, adjoint) as in ``ConvFn``: the layer's own up-convolution
+    (generator conv0_up -> blur) or the data gradient of a stride-2 layer (discriminator: ``z`` = the pre-activation whose
+    LeakyReLU and blur precede that layer; the result is the gradient w.r.t. z).  Backward: the blur (and mask) adjoint as their
+    own pass, then exactly ``ConvFn``'s backward -- so the op composes under ``create_graph`` like the separate ops did."""
+
+    @staticmethod
+    def forward(ctx, x, weight, mode, scale, ipad, adjoint, z=None):
+        x = _c(x)
+        geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
+        assert geo == "U"
+        fwd, adj = packs(weight, mode, scale / 16.0, ipad, x.dtype)    # the blur's 1/16 rides in the weight scale (a power of two: exact)
+        wq = adj if adjoint else fwd
+        B, H, W, Cin = x.shape
+        taps, Cout, K = wq.shape
+        if K != Cin:
+            raise N.SgxError(f"conv+blur: weight pack expects {K} input channels, activation has {Cin}")
+        y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
+        if z is not None and (z.shape != y.shape or z.dtype != y.dtype):
+            raise N.SgxError("conv+blur: the mask must have the output's shape and dtype")
+        N.check(N.lib().sgx_conv4x4s2_up_blur(N.ptr(x), N.ptr(wq), N.ptr(y), N.ptr(None if z is None else _c(z)), B, H, W, Cin, Cout,
+                                              N.dt(x), N.stream()), "sgx_conv4x4s2_up_blur")
+        ctx.cfg = (mode, scale, ipad, adjoint, 0, False, False, False)
+        ctx.bias_ref = lambda: None
+        ctx.x_pre = None
+        ctx.save_for_backward(x, weight, None, None)
+        ctx.z = z
+        return y
+
+    @staticmethod
+    def backward(ctx, gg):
+        gg = _c(gg)
+        m = _bcall(MaskBlurFn, gg, ctx.z) if ctx.z is not None else _bcall(BlurFn, gg)
+        out = ConvFn.backward(ctx, m)                      # (gx, gw, gb, ...): same saved tensors / cfg layout
+        return out[0], out[1], None, None, None, None, None
+
+
+class ActBlurPassFn(Function):
+    """blur(lrelu(z)) whose backward is the IDENTITY: its only consumer is a ``ConvFn`` called with ``x_pre=z``, whose backward
+    already returns the gradient w.r.t. z (the blur and the activation's mask folded into the data-gradient kernel)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        return _blur_act(_c(z), None, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
 class WgradFn(Function):
@@ -405,9 +491,9 @@ class WgradFn(Function):
         raise NotImplementedError("second derivative through a weight gradient is not part of the training path")
 
 
-def conv(x, weight, bias, mode, scale, act=N.ACT_NONE, ipad=None, defer_act=False, x_masked=False, stats=None):
+def conv(x, weight, bias, mode, scale, act=N.ACT_NONE, ipad=None, defer_act=False, x_masked=False, stats=None, x_pre=None):
     return call(ConvFn, x, weight, bias, mode, float(scale), int(ipad if ipad is not None else weight.shape[1]), False, act, None,
-                bool(defer_act), bool(x_masked), stats)
+                bool(defer_act), bool(x_masked), stats, x_pre)
 
 
 def conv_stats_nparts(x, cout):

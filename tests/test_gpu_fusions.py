@@ -110,3 +110,124 @@ def test_generator_block_with_fused_statistics(cin, cout, B, H, dt):
         r = O.eq_conv2d(r, p64["conv1.weight"], p64["conv1.bias"])
         r = O._epi(p64, "epi2.", r, n2.double().cpu(), dl[:, 1].double())
         assert_close(F.nchw_view(y1), r, 2e-5, "y vs oracle")
+
+
+# transposed convolution + blur (+ mask) in one kernel: 8- and 4-wave blocks, 32- and 16-channel output blocks, several input
+# chunks, ragged heights (tiles overlap by one coarse row / column: every seam position and the image borders are exercised)
+UPBLUR_CASES = [
+    # (cin, cout, B, H, W)
+    (64, 32, 2, 256, 256), (64, 32, 1, 256, 256), (32, 16, 4, 256, 256), (32, 16, 2, 256, 256), (128, 64, 2, 128, 128),
+    (64, 32, 8, 40, 256), (32, 32, 48, 17, 64), (64, 64, 3, 250, 96), (32, 16, 3, 120, 512), (96, 32, 64, 16, 64), (32, 32, 64, 15, 64),
+]
+
+
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("cin,cout,B,H,W", UPBLUR_CASES)
+def test_conv_up_blur_fused_vs_separate_and_oracle(cin, cout, B, H, W, masked):
+    """sgx_conv4x4s2_up_blur against conv -> blur (-> mask) run as separate kernels, and both against fp64 on the bf16-rounded
+    operands: both round twice to bf16 (separate: the convolution's output and the blur's; fused: the vertically blurred rows in
+    the store scratch and the result), measured 2.1e-3 vs 1.9e-3 rel-L2 from fp64."""
+    from stylegan.pytorch_amd import functional as F
+    w = gu.seeded((cout, cin, 3, 3), 5).to(DEV)
+    scale = O.he_w_mul(cin * 9, 2 ** 0.5)
+    x = gu.seeded((B, H, W, cin), 7).to(DEV).bfloat16()
+    z = gu.seeded((B, 2 * H, 2 * W, cout), 8).to(DEV).bfloat16() if masked else None
+    keep, F.CONV_BLUR_POLICY = F.CONV_BLUR_POLICY, "all"
+    try:
+        assert F.conv_blur_ok(x, cout, "U", False), "shape expected to have the fused kernel"
+    finally:
+        F.CONV_BLUR_POLICY = keep
+    with torch.no_grad():
+        y1 = F.ConvBlurFn.apply(x, w, "U", scale, cin, False, z)
+        t = F.ConvFn.apply(x, w, None, "U", scale, cin, False, 0)
+        y0 = F.BlurMaskFn.apply(t, z) if masked else F.BlurFn.apply(t)
+        wq, _ = F.packs(w, "U", scale, cin, torch.bfloat16)
+    wr = wq.float().view(4, 4, cout, cin).permute(2, 3, 0, 1).double().cpu()
+    ref = TF.conv_transpose2d(x.float().permute(0, 3, 1, 2).double().cpu(), wr.permute(1, 0, 2, 3), stride=2, padding=1)
+    k = torch.tensor([1.0, 2.0, 1.0], dtype=torch.float64); k = (k[:, None] * k[None, :] / 16.0).expand(cout, 1, 3, 3)
+    ref = TF.conv2d(ref, k, padding=1, groups=cout)
+    if masked:
+        ref = ref * torch.where(z.float().permute(0, 3, 1, 2).double().cpu() > 0, 1.0, 0.2)
+    assert torch.isfinite(y1.float()).all()
+    e1, e0 = rel_err(F.nchw_view(y1), ref), rel_err(F.nchw_view(y0), ref)
+    assert e1 <= 3e-3 and e1 <= 1.25 * e0 + 1e-4, (e1, e0)
+    assert_close(y1, y0, 6e-3, "fused vs separate passes")
+    # every position, borders and tile seams included: the worst element is a rounding error, as in the separate passes (a wrong
+    # seam row / column or border would be off by the size of the values)
+    d1 = (F.nchw_view(y1).double().cpu() - ref).abs().max().item()
+    d0 = (F.nchw_view(y0).double().cpu() - ref).abs().max().item()
+    assert d1 <= 2.0 * d0 + 1e-3 and d1 < 0.05 * ref.abs().max().item(), (d1, d0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,cout,B,H", [(32, 64, 2, 256), (16, 32, 4, 512), (64, 128, 2, 128)])
+def test_discriminator_block_backward_with_fused_blur(cin, cout, B, H):
+    """DiscriminatorBlock in bf16: first-order gradients and the R1-style double backward with the blur + mask folded into
+    conv1_down's data-gradient kernel, against the separate passes (same kernels otherwise)."""
+    from stylegan.pytorch_amd import Blocks
+    from stylegan.pytorch_amd import functional as F
+    blk = Blocks.DiscriminatorBlock(cin, cout, 2 ** 0.5, True, torch.nn.LeakyReLU(0.2), [1, 2, 1]).to(DEV)
+    names = dict(blk.named_parameters())
+    with torch.no_grad():
+        for k, p in names.items():
+            p.copy_(gu.fill_value("blk." + k, p.shape))
+    x = gu.seeded((B, H, H, cin), 60); gy = gu.seeded((B, H // 2, H // 2, cout), 61)
+
+    def run(on):
+        keep, F.CONV_BLUR_POLICY = F.CONV_BLUR_POLICY, "all" if on else "off"
+        try:
+            for p in names.values():
+                p.grad = None
+            xg = x.to(DEV).bfloat16().requires_grad_(True)
+            y = blk.forward_nhwc(xg)
+            (g1,) = torch.autograd.grad((y.float() * gy.to(DEV)).sum(), xg, create_graph=True)
+            pen = (g1.float() ** 2).sum()
+            pen.backward()                                            # second order: d pen / d params, d pen / d x
+            return y.detach(), g1.detach(), xg.grad, {k: p.grad.clone() for k, p in names.items()}
+        finally:
+            F.CONV_BLUR_POLICY = keep
+    y0, g0, gx0, gp0 = run(False)
+    y1, g1, gx1, gp1 = run(True)
+    assert torch.equal(y0, y1)
+    assert_close(g1, g0, 6e-3, "first-order data gradient")
+    assert_close(gx1, gx0, 2e-2, "second-order data gradient")
+    for k in gp0:
+        assert_close(gp1[k], gp0[k], 2e-2, "second-order " + k)
+
+
+@pytest.mark.parametrize("cin,cout,B,H", [(64, 32, 2, 128), (32, 16, 2, 256), (128, 64, 4, 64)])
+def test_generator_block_with_fused_up_blur(cin, cout, B, H):
+    """GSynthesisBlock in bf16 with conv0_up -> blur as one kernel against the separate passes: output and every gradient."""
+    from stylegan.pytorch_amd import Blocks
+    from stylegan.pytorch_amd import functional as F
+    blk = Blocks.GSynthesisBlock(cin, cout, [1, 2, 1], 512, 2 ** 0.5, True, True, False, True, True, torch.nn.LeakyReLU(0.2)).to(DEV)
+    names = dict(blk.named_parameters())
+    with torch.no_grad():
+        for k, p in names.items():
+            p.copy_(gu.fill_value("blk." + k, p.shape))
+    blk.epi1.top_epi.noise.noise = gu.seeded((B, 1, 2 * H, 2 * H), 80).to(DEV)
+    blk.epi2.top_epi.noise.noise = gu.seeded((B, 1, 2 * H, 2 * H), 81).to(DEV)
+    x = gu.seeded((B, H, H, cin), 82); dl = gu.seeded((B, 2, 512), 83); gy = gu.seeded((B, 2 * H, 2 * H, cout), 84)
+
+    def run(on):
+        keep, F.CONV_BLUR_POLICY = F.CONV_BLUR_POLICY, "all" if on else "off"
+        try:
+            for p in names.values():
+                p.grad = None
+            xg = x.to(DEV).bfloat16().requires_grad_(True); dg = dl.to(DEV).requires_grad_(True)
+            y = blk.forward_nhwc(xg, dg)
+            y.backward(gy.to(DEV).bfloat16())
+            return y.detach(), xg.grad, dg.grad, {k: p.grad.clone() for k, p in names.items()}
+        finally:
+            F.CONV_BLUR_POLICY = keep
+    y0, gx0, gd0, gp0 = run(False)
+    y1, gx1, gd1, gp1 = run(True)
+    # the two forwards differ by bf16 rounding noise (2e-3 per element, kernel test above); the gradients see it through two
+    # instance norms and every LeakyReLU whose argument it flips: measured up to 3.8e-2 on dx / 6.5e-2 on a bias with 16 channels
+    assert_close(y1, y0, 1e-2, "y fused vs separate")
+    assert_close(gx1, gx0, 8e-2, "dx")
+    assert_close(gd1, gd0, 8e-2, "d dlatents")
+    gmax = max(float(v.norm()) for v in gp0.values())
+    for k in gp0:
+        # (a convolution bias in front of an instance norm has a nearly cancelling gradient: noise relative to itself, judged
+        # against the block's largest gradient tensor instead)
+        assert_close(gp1[k], gp0[k], 8e-2, k, floor=(2e-2 * gmax if k.endswith(".bias") else 1e-6))
