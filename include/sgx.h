@@ -177,6 +177,14 @@ int sgx_rgb_in(const float* img, const float* w, int sj, int sc, float wscale, c
 int sgx_rgb_out(const void* x, const float* w, int sj, int sc, float wscale, const float* bias, float* img, size_t npix,
                 int C, int dtype, void* stream);
 size_t sgx_rgb_wgrad_ws_bytes(size_t npix, int C);
+/* real images at the current depth with the fade-in blend (models/GAN.py:575-586): out = alpha * x + beta *
+ * nearest_up2(avgpool2(x)) on fp32 [B][H][W][3] in one pass; ab_dev as in sgx_rgb_out_fade. */
+int sgx_downsample_fade_rgb(const float* x, float* out, int B, int H, int W, float alpha, float beta, const float* ab_dev, void* stream);
+/* the generator's output in one pass: img = alpha * to_rgb(x) + beta * nearest_up2(low) (models/GAN.py:199-202 with the 1x1
+ * convolution commuted in front of the upsample): low = [B][H/2][W/2][3] fp32.  ab_dev != NULL: alpha, beta = ab_dev[0], ab_dev[1]
+ * read on the device (fade-in coefficient of a captured step graph). */
+int sgx_rgb_out_fade(const void* x, const float* w, int sj, int sc, float wscale, const float* bias, const float* low, float alpha,
+                     float beta, const float* ab_dev, float* img, int B, int H, int W, int C, int dtype, void* stream);
 int sgx_rgb_wgrad(const float* img, const void* f, float* dw, int sj, int sc, float wscale, void* ws, size_t ws_bytes,
                   size_t npix, int C, int dtype, void* stream);
 

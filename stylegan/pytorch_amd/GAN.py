@@ -76,6 +76,11 @@ class DeferredLoss:
     def __hash__(self): return hash(self.item())
 
 
+# Generator output: to_rgb, the nearest upsample of the previous resolution's RGB image and the fade-in lerp as one kernel
+# (functional.RgbOutFadeFn); 0 = the three separate passes (A/B).
+FUSE_RGB_FADE = os.environ.get("SGX_FUSE_RGB_FADE", "1") != "0"
+
+
 def _nonlinearity(name):
     """(activation module, gain) of the reference's ``nonlinearity`` argument (models/GAN.py:67-68,150-151,346-347).  The
     reference maps 'relu' to the FUNCTION ``torch.relu`` and then puts it into ``nn.Sequential`` / module attributes, which
@@ -232,10 +237,14 @@ class GSynthesis(nn.Module):
                     x = block.forward_nhwc(x, dl[2 * (i + 1):2 * (i + 2)])
                 # reference GAN.py:199 applies to_rgb AFTER the nearest upsample; a 1x1 conv commutes with
                 # replication, so convert at the low resolution (4x fewer bytes) and upsample the RGB image.
-                residual = F.call(F.Up2Fn, self.to_rgb[depth - 1].forward_nhwc(x), 1.0)
-                straight = self.to_rgb[depth].forward_nhwc(
-                    self.blocks[depth - 1].forward_nhwc(x, dl[2 * depth:2 * (depth + 1)]))
-                images = F.fade(straight, residual, alpha)                                        # GAN.py:202
+                low = self.to_rgb[depth - 1].forward_nhwc(x)                                      # RGB at the previous resolution
+                xs = self.blocks[depth - 1].forward_nhwc(x, dl[2 * depth:2 * (depth + 1)])
+                rgb = self.to_rgb[depth]
+                if FUSE_RGB_FADE and rgb.weight.shape[0] == 3 and low.dtype == torch.float32:
+                    # to_rgb + upsample of ``low`` + fade-in lerp in one pass over xs (GAN.py:199-202)
+                    images = F.call(F.RgbOutFadeFn, xs, rgb.weight, rgb.scaled_bias(), float(rgb.w_mul), low, alpha)
+                else:
+                    images = F.fade(rgb.forward_nhwc(xs), F.call(F.Up2Fn, low, 1.0), alpha)       # GAN.py:202
             else:
                 images = self.to_rgb[0].forward_nhwc(x)
         else:
@@ -489,8 +498,11 @@ class StyleGAN:
         for _ in range(levels):
             x = F.call(F.Pool2Fn, x, 0.25)
         if depth > 0:
-            prior = F.call(F.Up2Fn, F.call(F.Pool2Fn, x, 0.25), 1.0)
-            x = F.fade(x, prior, alpha)
+            if FUSE_RGB_FADE and x.shape[3] == 3 and x.dtype == torch.float32 and not x.requires_grad:
+                x = F.downsample_fade_rgb(x, alpha)                    # pool, upsample and lerp in one pass (:575-586)
+            else:
+                prior = F.call(F.Up2Fn, F.call(F.Pool2Fn, x, 0.25), 1.0)
+                x = F.fade(x, prior, alpha)
         else:
             x = F.fade(x, x, alpha)                                       # prior == current at depth 0 (:583-584)
         return F.nchw_view(x)

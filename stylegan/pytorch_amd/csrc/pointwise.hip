@@ -354,6 +354,44 @@ extern "C" int sgx_pool2(const void* x, void* y, int B, int H, int W, int C, flo
     return 0;
 }
 
+// ---------------------------------------------------------------- real images at the current depth with the fade-in blend
+// out = alpha * x + beta * nearest_up2(avgpool2(x)) on fp32 RGB images (models/GAN.py:575-586: ds_real_samples and its
+// down-then-up-sampled "prior" blended by alpha) in one pass: a lane owns one 2x2 pixel block (two runs of 6 floats).
+__global__ void downsample_fade_rgb_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W, float alpha, float beta,
+                                           const float* __restrict__ ab_dev) {
+    if (ab_dev) { alpha = ab_dev[0]; beta = ab_dev[1]; }
+    const int hw = W >> 1, hh = H >> 1;
+    const size_t n = (size_t)B * hh * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int bx = (int)(i % hw);
+        const size_t r = i / hw;                                  // b * hh + by
+        const int by = (int)(r % hh);
+        const size_t b = r / hh;
+        const size_t o0 = ((b * H + 2 * by) * W + 2 * bx) * 3, o1 = o0 + (size_t)W * 3;
+        float v0[6], v1[6];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float2 a2 = *reinterpret_cast<const float2*>(x + o0 + 2 * k), b2 = *reinterpret_cast<const float2*>(x + o1 + 2 * k);
+            v0[2 * k] = a2.x; v0[2 * k + 1] = a2.y; v1[2 * k] = b2.x; v1[2 * k + 1] = b2.y;
+        }
+        float m[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m[c] = beta * (0.25f * ((v0[c] + v0[3 + c]) + (v1[c] + v1[3 + c])));   // (the 2x2 mean as sgx_pool2 sums it)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            *reinterpret_cast<float2*>(out + o0 + 2 * k) = make_float2(alpha * v0[2 * k] + m[(2 * k) % 3], alpha * v0[2 * k + 1] + m[(2 * k + 1) % 3]);
+            *reinterpret_cast<float2*>(out + o1 + 2 * k) = make_float2(alpha * v1[2 * k] + m[(2 * k) % 3], alpha * v1[2 * k + 1] + m[(2 * k + 1) % 3]);
+        }
+    }
+}
+extern "C" int sgx_downsample_fade_rgb(const float* x, float* out, int B, int H, int W, float alpha, float beta, const float* ab_dev, void* stream) {
+    SGX_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, SGX_EINVAL, "downsample_fade_rgb: bad arguments (%dx%d)", H, W);
+    SGX_NOTE(0.0, 2.0 * 4.0 * 3.0 * B * H * W, "downsample_fade B%d %dx%d", B, H, W);
+    hipLaunchKernelGGL(downsample_fade_rgb_kernel, dim3(grid_for((size_t)B * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, x, out, B, H, W, alpha, beta, ab_dev);
+    SGX_LAUNCH_CHECK("downsample_fade_rgb");
+    return 0;
+}
+
 // ---------------------------------------------------------------- uint8 images -> normalised NHWC activations
 // ToTensor + Normalize(0.5, 0.5) (+ RandomHorizontalFlip with host-drawn decisions) of the reference's input pipeline,
 // on the device: the batch crosses PCIe as bytes (12.6 MB at B=4, 1024^2 instead of 50 MB of fp32).  HBM-bound: 3 B in,
@@ -658,14 +696,19 @@ extern "C" int sgx_rgb_in(const float* img, const float* w, int sj, int sc, floa
 
 // one pixel per group of LPP lanes (LPP = C/VE capped at 16); partial dot products reduced with shuffles.
 // The 3 x C weights are staged once per block in LDS, pre-multiplied by wscale.
+// ``low`` (optional): the fade-in lerp of the generator's output folded in (models/GAN.py:199-202) -- img = alpha * to_rgb(x) +
+// beta * nearest_up2(low), low = the previous resolution's RGB image [B][H/2][W/2][3]; alpha / beta from the launch or, for a
+// captured step graph, from device memory (ab_dev[0], ab_dev[1]).
 template <typename T>
 __global__ void rgb_out_kernel(const T* __restrict__ x, const float* __restrict__ w, int sj, int sc, float wscale,
-                               const float* __restrict__ bias, float* __restrict__ img, size_t npix, int C, int lpp) {
+                               const float* __restrict__ bias, float* __restrict__ img, size_t npix, int C, int lpp,
+                               const float* __restrict__ low, int Himg, int Wimg, float alpha, float beta, const float* __restrict__ ab_dev) {
     constexpr int VE = VecTraits<T>::VE;
     extern __shared__ float sw[];                            // [3][C]
-    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) sw[i] = wscale * w[(i / C) * sj + (i % C) * sc];
+    if (ab_dev) { alpha = ab_dev[0]; beta = ab_dev[1]; }
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) sw[i] = (alpha * wscale) * w[(i / C) * sj + (i % C) * sc];
     __syncthreads();
-    const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f, b2 = bias ? bias[2] : 0.f;
+    const float b0 = bias ? alpha * bias[0] : 0.f, b1 = bias ? alpha * bias[1] : 0.f, b2 = bias ? alpha * bias[2] : 0.f;
     const int cv = C / VE;
     const int sub = threadIdx.x % lpp;
     const size_t gid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / lpp;
@@ -694,15 +737,23 @@ __global__ void rgb_out_kernel(const T* __restrict__ x, const float* __restrict_
             s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64);
         }
         if (p < npix && sub == 0) {
-            img[p * 3] = s0 + b0;
-            img[p * 3 + 1] = s1 + b1;
-            img[p * 3 + 2] = s2 + b2;
+            float o0 = s0 + b0, o1 = s1 + b1, o2 = s2 + b2;
+            if (low) {
+                const int xw = (int)(p % Wimg);
+                const size_t row = p / Wimg;                       // b * Himg + y
+                const int y = (int)(row % Himg);
+                const size_t bimg = row / Himg;
+                const float* l = low + ((bimg * (Himg >> 1) + (y >> 1)) * (Wimg >> 1) + (xw >> 1)) * 3;
+                o0 += beta * l[0]; o1 += beta * l[1]; o2 += beta * l[2];
+            }
+            img[p * 3] = o0;
+            img[p * 3 + 1] = o1;
+            img[p * 3 + 2] = o2;
         }
     }
 }
-extern "C" int sgx_rgb_out(const void* x, const float* w, int sj, int sc, float wscale, const float* bias, float* img, size_t npix, int C, int dtype, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    SGX_NOTE(6.0 * npix * C, npix * (12.0 + (dtype == SGX_F32 ? 4.0 : 2.0) * C), "rgb_out %zux%d", npix, C);
+static int rgb_out_launch(const void* x, const float* w, int sj, int sc, float wscale, const float* bias, float* img, size_t npix, int C, int dtype,
+                          const float* low, int H, int W, float alpha, float beta, const float* ab_dev, hipStream_t st) {
     const int ve = dtype == SGX_F32 ? 4 : 8;
     SGX_REQUIRE(C % ve == 0 && C <= 4096, SGX_EUNSUPPORTED, "rgb_out: C=%d", C);
     int lpp = C / ve;
@@ -710,10 +761,21 @@ extern "C" int sgx_rgb_out(const void* x, const float* w, int sj, int sc, float 
     SGX_REQUIRE((lpp & (lpp - 1)) == 0, SGX_EUNSUPPORTED, "rgb_out: C=%d", C);
     const unsigned g = grid_for(npix * lpp);
     const size_t sh = (size_t)3 * C * sizeof(float);
-    if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_out_kernel<float>, dim3(g), dim3(256), sh, st, (const float*)x, w, sj, sc, wscale, bias, img, npix, C, lpp);
-    else hipLaunchKernelGGL(rgb_out_kernel<bf16_t>, dim3(g), dim3(256), sh, st, (const bf16_t*)x, w, sj, sc, wscale, bias, img, npix, C, lpp);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_out_kernel<float>, dim3(g), dim3(256), sh, st, (const float*)x, w, sj, sc, wscale, bias, img, npix, C, lpp, low, H, W, alpha, beta, ab_dev);
+    else hipLaunchKernelGGL(rgb_out_kernel<bf16_t>, dim3(g), dim3(256), sh, st, (const bf16_t*)x, w, sj, sc, wscale, bias, img, npix, C, lpp, low, H, W, alpha, beta, ab_dev);
     SGX_LAUNCH_CHECK("rgb_out");
     return 0;
+}
+extern "C" int sgx_rgb_out(const void* x, const float* w, int sj, int sc, float wscale, const float* bias, float* img, size_t npix, int C, int dtype, void* stream) {
+    SGX_NOTE(6.0 * npix * C, npix * (12.0 + (dtype == SGX_F32 ? 4.0 : 2.0) * C), "rgb_out %zux%d", npix, C);
+    return rgb_out_launch(x, w, sj, sc, wscale, bias, img, npix, C, dtype, nullptr, 1, 1, 1.f, 0.f, nullptr, (hipStream_t)stream);
+}
+extern "C" int sgx_rgb_out_fade(const void* x, const float* w, int sj, int sc, float wscale, const float* bias, const float* low, float alpha,
+                                float beta, const float* ab_dev, float* img, int B, int H, int W, int C, int dtype, void* stream) {
+    SGX_REQUIRE(x && w && low && img && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, SGX_EINVAL, "rgb_out_fade: bad arguments (%dx%d)", H, W);
+    const size_t npix = (size_t)B * H * W;
+    SGX_NOTE(6.0 * npix * C, npix * (12.0 + 3.0 + (dtype == SGX_F32 ? 4.0 : 2.0) * C), "rgb_out+fade %zux%d", npix, C);
+    return rgb_out_launch(x, w, sj, sc, wscale, bias, img, npix, C, dtype, low, H, W, alpha, beta, ab_dev, (hipStream_t)stream);
 }
 
 // dw[j][c] = sum_p img[p][j] * f[p][c]: stage 1 partials per block in double, stage 2 sums them.

@@ -685,6 +685,19 @@ def fade(a, b, alpha, a_act=False, b_prescaled=False):
     return call(AxpbyFn, a, b, float(alpha), 1.0 if b_prescaled else float(1 - alpha), bool(a_act))
 
 
+def downsample_fade_rgb(x, alpha):
+    """alpha * x + (1 - alpha) * nearest_up2(avgpool2(x)) for an fp32 NHWC RGB batch that needs no gradient (the real images
+    of a training step, reference models/GAN.py:575-586), one pass.  ``alpha`` as in ``fade``."""
+    x = _c(x)
+    B, H, W, C = x.shape
+    assert C == 3 and x.dtype == torch.float32 and not x.requires_grad
+    out = torch.empty_like(x)
+    dev = isinstance(alpha, torch.Tensor)
+    N.check(N.lib().sgx_downsample_fade_rgb(N.ptr(x), N.ptr(out), B, H, W, 0.0 if dev else float(alpha), 0.0 if dev else float(1 - alpha),
+                                            alpha.data_ptr() if dev else None, N.stream()), "sgx_downsample_fade_rgb")
+    return out
+
+
 class BlurFn(Function):
     """Depthwise [1,2,1]x[1,2,1]/16 blur with zero padding; self-adjoint."""
 
@@ -912,6 +925,50 @@ class RgbOutFn(Function):
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 gb = _bcall(ColSumFn, g, 1.0)                   # 3 numbers
         return gx, gw, gb, None
+
+
+class RgbOutFadeFn(Function):
+    """img = alpha * to_rgb(x) + (1 - alpha) * nearest_up2(low): the generator's output (1x1 convolution, upsample of the
+    previous resolution's RGB image and fade-in lerp, reference models/GAN.py:199-202) in ONE pass over x.  ``alpha``: python
+    float, or a device fp32 tensor [alpha, 1 - alpha] (graph replay).  Backward: the lerp coefficients ride in the scales of the
+    1x1 convolution's own gradient kernels (python-float alpha), so no scaling pass touches the image-sized gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, wscale, low, alpha):
+        x, w, low = _c(x), _c(weight.detach()), _c(low)
+        sj, sc, C = rgb_layout(w)
+        B, H, W, Cx = x.shape
+        assert Cx == C and low.shape == (B, H // 2, W // 2, 3) and low.dtype == torch.float32
+        img = torch.empty((B, H, W, 3), dtype=torch.float32, device=x.device)
+        dev = isinstance(alpha, torch.Tensor)
+        N.check(N.lib().sgx_rgb_out_fade(N.ptr(x), N.ptr(w), sj, sc, float(wscale), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(low),
+                                         0.0 if dev else float(alpha), 0.0 if dev else float(1 - alpha), alpha.data_ptr() if dev else None,
+                                         N.ptr(img), B, H, W, C, N.dt(x), N.stream()), "sgx_rgb_out_fade")
+        ctx.has_bias, ctx.wscale, ctx.alpha = bias is not None, float(wscale), alpha
+        ctx.save_for_backward(x, weight)
+        return img
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = _c(g)
+        al = ctx.alpha
+        gx = gw = gb = glow = None
+        if isinstance(al, torch.Tensor):                              # coefficients on the device: two scaling passes, then as below
+            ga, a_s = _bcall(ScaleDevFn, g, al[0:1]), 1.0
+            gl, b_s = (_bcall(ScaleDevFn, g, al[1:2]) if ctx.needs_input_grad[4] else None), 1.0
+        else:
+            ga, a_s, gl, b_s = g, float(al), g, float(1 - al)
+        if ctx.needs_input_grad[0]:
+            gx = _bcall(RgbInFn, ga, weight, None, ctx.wscale * a_s, x.dtype)
+        if not _DATA_GRAD_ONLY:
+            if ctx.needs_input_grad[1]:
+                gw = _bcall(RgbWgradFn, ga, x, weight, ctx.wscale * a_s)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = _bcall(ColSumFn, ga, a_s)                         # 3 numbers
+        if ctx.needs_input_grad[4]:
+            glow = _bcall(Pool2Fn, gl, b_s)                            # adjoint of the nearest upsample, times (1 - alpha)
+        return gx, gw, gb, None, glow, None
 
 
 class RgbWgradFn(Function):

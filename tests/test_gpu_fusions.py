@@ -231,3 +231,50 @@ def test_generator_block_with_fused_up_blur(cin, cout, B, H):
         # (a convolution bias in front of an instance norm has a nearly cancelling gradient: noise relative to itself, judged
         # against the block's largest gradient tensor instead)
         assert_close(gp1[k], gp0[k], 8e-2, k, floor=(2e-2 * gmax if k.endswith(".bias") else 1e-6))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,B,H", [(16, 2, 64), (32, 3, 16), (128, 1, 8), (16, 4, 256)])
+@pytest.mark.parametrize("dev_alpha", [False, True])
+def test_generator_output_in_one_pass(C, B, H, dt, dev_alpha):
+    """to_rgb + nearest upsample of the previous resolution's RGB + fade-in lerp (models/GAN.py:199-202) as one kernel against
+    the three separate ops: image and every gradient; fp32 also against the formula in fp64."""
+    from stylegan.pytorch_amd import functional as F
+    w = (0.2 * gu.seeded((3, C, 1, 1), 40)).to(DEV).requires_grad_(True)
+    bias = (0.1 * gu.seeded((3,), 41)).to(DEV).requires_grad_(True)
+    x = gu.seeded((B, H, H, C), 42); low = gu.seeded((B, H // 2, H // 2, 3), 43); g = gu.seeded((B, H, H, 3), 44)
+    alpha = 0.3
+    al = torch.tensor([alpha, 1 - alpha], dtype=torch.float32, device=DEV) if dev_alpha else alpha
+
+    def run(fused):
+        w.grad = bias.grad = None
+        xg = x.to(DEV).to(dt).requires_grad_(True); lg = low.to(DEV).requires_grad_(True)
+        if fused:
+            img = F.RgbOutFadeFn.apply(xg, w, bias, 0.25, lg, al)
+        else:
+            img = F.fade(F.RgbOutFn.apply(xg, w, bias, 0.25), F.Up2Fn.apply(lg, 1.0), al)
+        img.backward(g.to(DEV))
+        return img.detach(), xg.grad, lg.grad, w.grad.clone(), bias.grad.clone()
+    a, b = run(False), run(True)
+    tol = 2e-6 if dt == torch.float32 else 4e-3
+    for u, v, what in zip(b, a, ("image", "dx", "d low", "d weight", "d bias")):
+        assert_close(u, v, tol, what)
+    if dt == torch.float32:
+        ref = alpha * (torch.einsum("bhwc,jc->bhwj", x.double(), w.detach().double().cpu().view(3, C)) * 0.25 + bias.detach().double().cpu()) \
+            + (1 - alpha) * low.double().repeat_interleave(2, 1).repeat_interleave(2, 2)
+        assert_close(b[0], ref, 2e-6, "image vs fp64")
+
+
+@pytest.mark.parametrize("dev_alpha", [False, True])
+@pytest.mark.parametrize("B,H", [(2, 8), (3, 64), (4, 1024)])
+def test_real_batch_downsample_fade_in_one_pass(B, H, dev_alpha):
+    """alpha * x + (1 - alpha) * up2(avgpool2(x)) in one kernel: bit-identical to pool -> upsample -> lerp."""
+    from stylegan.pytorch_amd import functional as F
+    x = gu.seeded((B, H, H, 3), 50).to(DEV)
+    alpha = 0.4
+    al = torch.tensor([alpha, 1 - alpha], dtype=torch.float32, device=DEV) if dev_alpha else alpha
+    fused = F.downsample_fade_rgb(x, al)
+    ref = F.fade(x, F.Up2Fn.apply(F.Pool2Fn.apply(x, 0.25), 1.0), al)
+    assert_close(fused, ref, 1e-7, "fused vs separate")
+    r64 = alpha * x.double() + (1 - alpha) * torch.nn.functional.avg_pool2d(x.double().permute(0, 3, 1, 2), 2).repeat_interleave(2, 2).repeat_interleave(2, 3).permute(0, 2, 3, 1)
+    assert_close(fused, r64, 1e-6, "vs fp64")
