@@ -347,6 +347,153 @@ __global__ __launch_bounds__(512, 2) void wgrad2_d_kernel(Wg2Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------- W2_S16
+// The 16 x 16-channel weights of the 1024x1024 level (3x3, both networks; round 3): dW[tap][n][k] over ALL pixels is one
+// 16 x 16 tile per tap, so the whole problem is bandwidth -- both activations exactly once.  v_mfma_f32_16x16x32_bf16: M = the 16
+// dy channels, N = the 16 x channels, K = the 32 pixels of one tile row: ONE MFMA per (row, tap).  Tile 16 rows x 32 pixels, k-side
+// patch 18 x 34; a wave owns two tile rows (four patch rows, read once: 12 K-major fragments via ds_read_b64_tr_b16) and keeps
+// all nine taps' 16 x 16 accumulators (+ the bias column sums) in 40 registers; the eight waves are summed through LDS once, at
+// the end.  Operands pixel-major with a 32-byte pixel pitch (16 channels): a 16-lane group's transpose read touches 4 pixels =
+// 128 contiguous bytes, and the K index <-> pixel mapping (group g: pixels 4g..4g+3 and 16+4g..16+4g+3 of the row) makes the two
+// groups of a half-wave read adjacent 128-byte runs: all 64 banks once.  36 KB per stage, two stages, two blocks per CU; each XCD
+// walks one contiguous eighth of the tile raster (halo rows / columns shared through its L2).
+typedef __attribute__((ext_vector_type(4))) float f32x4w;
+__device__ __forceinline__ bf16x8 wg16_frag(const char* p) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x4 lo = wg2_tr16(p), hi = wg2_tr16(p + 512);               // pixels +0..3 and +16..19 of the lane's group
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__global__ __launch_bounds__(512, 2) void wgrad16_s_kernel(Wg2Args a) {
+    constexpr int TH = 16, TW = 32, PH = TH + 2, PW = TW + 2;
+    constexpr int A_BYTES = TH * TW * 32, A_INSTR = A_BYTES / 1024;                         // 16 KB
+    constexpr int B_PIX = PH * PW, B_INSTR = (B_PIX * 32 + 1023) / 1024, B_BYTES = B_INSTR * 1024;   // 612 pixels -> 20 KB
+    constexpr int STAGE = A_BYTES + B_BYTES, NINSTR = A_INSTR + B_INSTR, NPI = (NINSTR + 7) / 8;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x, xcd = bid & 7, lslot = bid >> 3, per = a.nsplit >> 3;
+    const int split = lslot * 8 + xcd;
+    if (split >= a.nsplit) return;
+    // XCD `xcd` owns tiles [xcd*band, (xcd+1)*band) of the raster; its `per` blocks walk them in order
+    const int band = (a.ntiles + 7) >> 3;
+    const int band_len = a.ntiles - xcd * band < band ? a.ntiles - xcd * band : band;
+    const int nsteps = lslot < band_len ? (band_len - lslot + per - 1) / per : 0;
+    const int tile0 = xcd * band + lslot;
+
+    // per-lane DMA descriptors: instruction ii fills LDS bytes [ii*1024, +1024) = 32 pixels x 32 bytes; lane -> pixel lane/2, chunk lane%2
+    int rel[NPI], pos[NPI];
+#pragma unroll
+    for (int jj = 0; jj < NPI; ++jj) {
+        const int ii = jj * 8 + wave, c8 = (lane & 1) * 8;
+        rel[jj] = 0; pos[jj] = -1;
+        if (ii < A_INSTR) {
+            const int r = ii, c = lane >> 1;
+            rel[jj] = (r * a.Wn + c) * 16 + c8;
+            pos[jj] = (r << 8) | c;
+        } else if (ii < NINSTR) {
+            const int pix = (ii - A_INSTR) * 32 + (lane >> 1);
+            if (pix < B_PIX) {
+                const int pr = pix / PW, pc = pix % PW;
+                rel[jj] = (pr * a.Wk + pc) * 16 + c8;
+                pos[jj] = (pr << 8) | pc;
+            }
+        }
+    }
+    const unsigned long long zaddr = reinterpret_cast<unsigned long long>(wg2_zero_page) + (lane & 3) * 16;
+    auto issue = [&](int step, char* buf) {
+        int t = tile0 + step * per;
+        const int tx_i = t % a.tiles_x; t /= a.tiles_x;
+        const int ty_i = t % a.tiles_y, b = t / a.tiles_y;
+        const int ty0 = ty_i * TH, tx0 = tx_i * TW;
+        const bf16_t* abase = a.nside + (((long)b * a.Hn + ty0) * a.Wn + tx0) * 16;
+        const bf16_t* bbase = a.kside + (((long)b * a.Hk + ty0 - 1) * a.Wk + tx0 - 1) * 16;
+#pragma unroll
+        for (int jj = 0; jj < NPI; ++jj) {
+            const int ii = jj * 8 + wave;
+            if (ii < NINSTR) {
+                const bool isb = ii >= A_INSTR;                              // wave uniform
+                const int pp = pos[jj];
+                const int gy = (isb ? ty0 - 1 : ty0) + (pp >> 8), gx = (isb ? tx0 - 1 : tx0) + (pp & 255);
+                const unsigned long long ok = ((pp >= 0) & ((unsigned)gy < (unsigned)a.Hn) & ((unsigned)gx < (unsigned)a.Wn)) ? ~0ull : 0ull;
+                const unsigned long long pa = reinterpret_cast<unsigned long long>((isb ? bbase : abase) + rel[jj]);
+                wg2_glds16(reinterpret_cast<const void*>(zaddr + ((pa - zaddr) & ok)), buf + ii * 1024);
+            }
+        }
+    };
+
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int lane_off = (g16 * 4 + (i16 >> 2)) * 32 + (i16 & 3) * 8;
+    const int r0 = 2 * wave;
+    f32x4w acc[9], bacc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bacc[q] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t][q] = 0.f;
+    }
+    const bf16x8 ones = wg2_ones();
+
+    if (nsteps > 0) issue(0, smem);
+    for (int step = 0; step < nsteps; ++step) {
+        const char* cur = smem + (step & 1) * STAGE;
+        __syncthreads();                         // stage `step` landed (vmcnt(0) precedes the barrier); step-1 is consumed
+        if (step + 1 < nsteps) issue(step + 1, smem + ((step + 1) & 1) * STAGE);
+        bf16x8 bf[4][3];
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) bf[pr][dx] = wg16_frag(cur + A_BYTES + ((r0 + pr) * PW + dx) * 32 + lane_off);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const bf16x8 af = wg16_frag(cur + (r0 + rr) * TW * 32 + lane_off);
+            if (a.want_bias) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, bacc, 0, 0, 0);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[rr + dy][dx], acc[dy * 3 + dx], 0, 0, 0);
+        }
+    }
+
+    // ---- sum the eight waves through LDS (the stages are dead): 4 -> 2 -> 1, fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int half = 4; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+            float* dst = red + ((wave - half) * 64 + lane) * 40;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) *reinterpret_cast<float4*>(dst + 4 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+            *reinterpret_cast<float4*>(dst + 36) = make_float4(bacc[0], bacc[1], bacc[2], bacc[3]);
+        }
+        __syncthreads();
+        if (wave < half) {
+            const float* src = red + (wave * 64 + lane) * 40;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float4 o = *reinterpret_cast<const float4*>(src + 4 * t);
+                acc[t][0] += o.x; acc[t][1] += o.y; acc[t][2] += o.z; acc[t][3] += o.w;
+            }
+            const float4 o = *reinterpret_cast<const float4*>(src + 36);
+            bacc[0] += o.x; bacc[1] += o.y; bacc[2] += o.z; bacc[3] += o.w;
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    // C/D layout of the 16x16 MFMA: column (x channel k) = lane & 15, row (dy channel n) = 4 * (lane >> 4) + register
+    float* out = a.out + (size_t)split * a.split_stride;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[(size_t)t * 256 + (size_t)(4 * g16 + q) * 16 + i16] = acc[t][q];
+    if (a.want_bias && i16 == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[(size_t)9 * 256 + 4 * g16 + q] = bacc[q];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------- host side
 static int wg2_ncu() {
     static const int ncu = [] {
@@ -356,8 +503,8 @@ static int wg2_ncu() {
     }();
     return ncu;
 }
-static int wg2_switch() {                        // SGX_WGRAD2: bit 0 = the 3x3 geometry, bit 1 = the 4x4 stride-2 geometry (A/B)
-    static const int on = [] { const char* e = getenv("SGX_WGRAD2"); return e ? atoi(e) : 3; }();
+static int wg2_switch() {                        // SGX_WGRAD2: bit 0 = the 3x3 geometry, bit 1 = the 4x4 stride-2 geometry, bit 2 = 3x3 16x16 channels (A/B)
+    static const int on = [] { const char* e = getenv("SGX_WGRAD2"); return e ? atoi(e) : 7; }();
     return on;
 }
 static int wg2_max_ct() { static const int v = [] { const char* e = getenv("SGX_WGRAD2_MAXCT"); return e && atoi(e) > 0 ? atoi(e) : 32; }(); return v; }
@@ -367,6 +514,14 @@ static int wg2_max_ct() { static const int v = [] { const char* e = getenv("SGX_
 int sgx_wgrad2_plan(int geo, int B, int H, int W, int Ck, int Cn, int* nct_n, int* nct_k, int* kbw, int* ntiles) {
     if (!((wg2_switch() >> geo) & 1)) return 0;
     int th, tw, kt;
+    if (geo == 0 && Ck == 16 && Cn == 16) {           // the 16 x 16-channel weights: wgrad16_s_kernel (bit 2 of SGX_WGRAD2)
+        if (!(wg2_switch() & 4) || W % 32) return 0;
+        *nct_n = 1; *nct_k = 1; *kbw = 16;
+        *ntiles = B * ((H + 15) / 16) * (W / 32);
+        int ns = 2 * wg2_ncu() / 8 * 8;                // two blocks per CU
+        if (*ntiles < 2 * ns) ns = *ntiles / 2 / 8 * 8;
+        return ns >= 8 ? ns : 0;
+    }
     if (geo == 0) {
         if (Ck % 64 || Cn % 64 || W % 32 || H % 8) return 0;
         th = 8; tw = 32; kt = 64; *kbw = 2;
@@ -400,7 +555,19 @@ int sgx_wgrad2_launch(int geo, const void* kside, const void* nside, float* ws, 
     Wg2Args a{static_cast<const bf16_t*>(kside), static_cast<const bf16_t*>(nside), ws, B, geo == 0 ? H : 2 * H, geo == 0 ? W : 2 * W, H, W, Ck, Cn,
               W / (geo == 0 ? 32 : 16), H / (geo == 0 ? 8 : 4), ntiles, ns, nct_n, nct_k, want_bias, (long)total};
     const dim3 grid((unsigned)(nct_n * nct_k * ns)), block(512);
-    if (geo == 0) {
+    if (geo == 0 && kbw == 16) {
+        a.tiles_y = (H + 15) / 16;
+        constexpr int LDS = 2 * (16 * 32 * 32 + ((18 * 34 * 32 + 1023) / 1024) * 1024);
+        static_assert(LDS >= 4 * 64 * 40 * 4, "the final reduction's scratch fits the stages");
+        static bool attr_done[32] = {};                              // the > 64 KB dynamic-LDS opt-in is per device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+        if (!attr_done[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            attr_done[dev] = true;
+        }
+        hipLaunchKernelGGL(wgrad16_s_kernel, grid, block, LDS, st, a);
+    } else if (geo == 0) {
         constexpr int LDS = 2 * (2 * 8 * 32 * 64 + 2 * ((10 * 34 * 64 + 1023) / 1024) * 1024);
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad2_s_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)attr;

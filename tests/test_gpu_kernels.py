@@ -99,6 +99,8 @@ WGRAD2_CASES = [
     ("down", 32, 64, 2, 64), ("down", 64, 64, 2, 64), ("down", 64, 128, 2, 128), ("down", 128, 256, 1, 64),
     ("up", 64, 64, 2, 32), ("up", 128, 32, 2, 32), ("up", 64, 64, 4, 16), ("up", 128, 64, 1, 64),
     ("plain", 320, 512, 16, 32), ("down", 512, 512, 16, 32),        # > 32 channel tiles: taken when a block walks >= 8 pixel tiles
+    # the 16 x 16-channel weights (wgrad16_s_kernel, 16x16x32 MFMA): few tiles, many tiles, ragged height, several images
+    ("plain", 16, 16, 2, 64), ("plain", 16, 16, 1, 512), ("plain", 16, 16, 3, 96), ("plain", 16, 16, 5, 128),
 ]
 
 
@@ -121,7 +123,7 @@ def test_wgrad2_vs_oracle(mode, cin, cout, B, H):
     torch.cuda.synchronize()
     native.prof_start(0)
     names = [r[0] for r in native.prof_records()]
-    assert any("wgrad2_" in n for n in names), names
+    assert any(("wgrad16_" if cin == 16 else "wgrad2_") in n for n in names), names
     y64.backward(gy.double())
     assert_close(m.weight.grad, w64.grad, 1e-4, "dW")
     assert_close(m.bias.grad, b64.grad, 1e-4, "db")
