@@ -44,7 +44,12 @@ def gate(section, measured):
         return
     want = json.load(open(GATES_PATH))[section]
     assert sorted(want) == sorted(measured), (section, sorted(set(want) ^ set(measured)))
-    bad = {k: (measured[k], want[k]) for k in want if measured[k] > 2.0 * want[k] + 1e-4}
+
+    def floor(k):
+        # quantities that are small differences of large ones move by more than 2x under ANY change of the summation / rounding
+        # order (a fused kernel, another tile size): gradients of a tensor to 2e-2 of its norm, directions to 1e-3, scalars 1e-4
+        return 2e-2 if k.endswith(":rel") else (1e-3 if k.endswith(":1-cos") else 1e-4)
+    bad = {k: (measured[k], want[k]) for k in want if measured[k] > 2.0 * want[k] + floor(k)}
     assert not bad, f"{section}: beyond 2x the measured error: {bad}"
 
 

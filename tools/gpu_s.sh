@@ -5,7 +5,7 @@ tag=$1; sel=$2; shift 2
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R
 if [ -n "$sel" ]; then
-  timeout 1500 python -m pytest $sel -q -m gpu -x --durations=5 > $O/pytest.log 2>&1; echo "pytest rc=$?"
+  timeout 1500 python -m pytest $sel -q -m gpu $PYTEST_EXTRA --durations=5 > $O/pytest.log 2>&1; echo "pytest rc=$?"
   grep -E "passed|failed|Error|FAILED|assert|rel-L2" $O/pytest.log | tail -30
 fi
 i=0
