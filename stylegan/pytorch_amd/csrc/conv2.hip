@@ -521,6 +521,51 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                         }
                     }
                 }
+            } else if constexpr (EPI == EPI_NONE) {
+                // ---- register epilogue (round 3): a lane holds its pixel's channels 8g+4hi .. +3 (g = 0..3 per 32-channel row), the
+                // other half-wave the 4 channels in between.  One v_permlane32_swap per dword and pair of groups hands every lane 8
+                // CONSECUTIVE channels (lanes 0-31: 16k..16k+7, lanes 32-63: 16k+8..16k+15), i.e. one 16-byte store per lane and
+                // pair, the two half-waves filling each pixel's 32-byte sectors together -- no LDS transposition, no barrier
+                float4 bv[MF][4];
+#pragma unroll
+                for (int m = 0; m < MF; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        bv[m][g] = (a.bias && !(CO16 && g >= 2)) ? *reinterpret_cast<const float4*>(a.bias + co0 + m * 32 + 8 * g + 4 * hi)
+                                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const int oy = ty0 + 2 * wave + f, ox = tx0 + l31;
+                    const bool inimg = oy < a.OH && ox < a.OW;
+                    const size_t pix = (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + 8 * hi;
+#pragma unroll
+                    for (int m = 0; m < MF; ++m) {
+                        uint2 o2[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float v[4] = {acc[m][f][4 * g], acc[m][f][4 * g + 1], acc[m][f][4 * g + 2], acc[m][f][4 * g + 3]};
+                            v[0] += bv[m][g].x; v[1] += bv[m][g].y; v[2] += bv[m][g].z; v[3] += bv[m][g].w;
+                            if (a.act == SGX_ACT_LRELU) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i]);
+                            }
+                            o2[g].x = pack_bf16x2(v[0], v[1]);
+                            o2[g].y = pack_bf16x2(v[2], v[3]);
+                        }
+#pragma unroll
+                        for (int k = 0; k < (CO16 ? 1 : 2); ++k) {
+                            uint2 lo = o2[2 * k], up = o2[2 * k + 1];
+                            auto rx = __builtin_amdgcn_permlane32_swap(lo.x, up.x, false, false);
+                            auto ry = __builtin_amdgcn_permlane32_swap(lo.y, up.y, false, false);
+                            uint4 val = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                            if (inimg) {
+                                const size_t doff = pix + m * 32 + 16 * k;
+                                if (GEO == C2_S && a.mask) val = lrelu_mask_bf16x8(val, *reinterpret_cast<const uint4*>(a.mask + doff));
+                                *reinterpret_cast<uint4*>(a.y + doff) = val;
+                            }
+                        }
+                    }
+                }
             } else {
                 float4 bv[MF][4];
 #pragma unroll
