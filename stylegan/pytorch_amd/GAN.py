@@ -520,19 +520,56 @@ class StyleGAN:
         if gb is not None:
             gb.attach()
 
+    def _sched_begin(self, kind, depth, param_stream):
+        """Data parallel, eager: bucket-level overlap of the gradient all-reduce with this backward (dist.BucketScheduler).  The
+        first backward at a depth RECORDS how often and in which order the parameters' gradients are written; later ones fire
+        a bucket's all-reduce as soon as its last gradient is final."""
+        from . import dist as D
+        self.__dict__["_sched_active"] = None
+        if self.dp is None or not self.dp.overlap_buckets or torch.cuda.is_current_stream_capturing():
+            return
+        if F.GRAD_NOTE is None:
+            F.GRAD_NOTE = D.note_grad_write
+        net = self.dis if kind == "d" else self.gen
+        if not net.__dict__.get("_sgx_grad_hooks"):
+            D.install_grad_hooks(net.parameters())
+            net.__dict__["_sgx_grad_hooks"] = True
+        scheds = self.__dict__.setdefault("_bucket_scheds", {})
+        key = (kind, int(depth))
+        sched = scheds.get(key)
+        gb = self._grad_buckets.get(key)
+        if sched is None or (not sched.recording and (gb is None or sched.gb is not gb or not gb.attached())):
+            sched = scheds[key] = D.BucketScheduler(self.dp)   # (re-)record
+        if not sched.recording:
+            sched.begin(param_stream)
+        self.__dict__["_sched_active"] = sched
+        D.set_active_scheduler(sched)
+
     def _note_active_grads(self, kind, depth):
-        """After a backward: remember the active set of this (network, depth) as a flat bucket layout for the next iteration."""
+        """After a backward: remember the active set of this (network, depth) as a flat bucket layout for the next iteration
+        (in gradient-ready order when the backward was recorded by a BucketScheduler)."""
         if self.dp is None:
             return
+        from . import dist as D
+        D.set_active_scheduler(None)
+        sched = self.__dict__.get("_sched_active")
         net = self.dis if kind == "d" else self.gen
         active = [p for p in net.parameters() if p.grad is not None]
         gb = self._grad_buckets.get((kind, int(depth)))
-        if active and (gb is None or not gb.matches(active)) and not torch.cuda.is_current_stream_capturing():
-            from .dist import GradBuckets
+        recorded = sched is not None and sched.recording
+        if active and (gb is None or not gb.matches(active) or recorded) and not torch.cuda.is_current_stream_capturing():
             for key in [k for k in self._grad_buckets if k[0] == kind and k[1] != int(depth)
                         and not any(g.depth == k[1] and g.graph is not None for g in self._step_graphs.values())]:
                 del self._grad_buckets[key]                    # progressive growing moves on: drop the previous depth's ~100 MB
-            self._grad_buckets[(kind, int(depth))] = GradBuckets(active, self.dp.bucket_elems)
+                self.__dict__.get("_bucket_scheds", {}).pop(key, None)
+            new = None
+            if sched is not None and sched.recording:
+                new = sched.layout(self.dp.bucket_elems, only=active)
+                if new is None or not new.matches(active):     # a parameter got its gradient without a note: no early firing
+                    new = None
+                    self.__dict__.get("_bucket_scheds", {}).pop((kind, int(depth)), None)
+            self._grad_buckets[(kind, int(depth))] = new if new is not None else D.GradBuckets(active, self.dp.bucket_elems)
+            self.__dict__["_sched_active"] = None              # this iteration's gradients are not in the new buckets yet
 
     def _aux_stream(self):
         """Second compute stream for work that is independent of the main chain (the D-step generator forward)."""
@@ -606,6 +643,7 @@ class StyleGAN:
             loss = self.loss.dis_loss(real_samples, make_fakes if lazy else make_fakes(), depth, alpha)
         self._zero_grads("d", depth)
         side = self._param_stream(two_branches=aux is not None and lazy)
+        self._sched_begin("d", depth, side)
         # conv weight / bias gradients accumulate inside the finishing kernel, on a side stream next to the backward chain
         with F.accumulate_param_grads(), F.param_grad_stream(side):
             loss.backward()
@@ -616,6 +654,11 @@ class StyleGAN:
 
     def _reduce(self, kind):
         if self.dp is None:
+            return
+        sched = self.__dict__.pop("_sched_active", None)
+        if sched is not None and not sched.recording and sched.gb is not None and sched.gb.attached():
+            sched.finish()                                           # most buckets were all-reduced during the backward
+            self.__dict__["_last_sched"] = sched
             return
         gb = next((g for (k, _), g in self._grad_buckets.items() if k == kind and g.attached()), None)
         if gb is not None:
@@ -651,6 +694,7 @@ class StyleGAN:
                 loss = self.loss.gen_loss(real_samples, fake_samples, depth, alpha)
             self._zero_grads("g", depth)
             side = self._param_stream()
+            self._sched_begin("g", depth, side)
             with F.accumulate_param_grads(), F.param_grad_stream(side):
                 loss.backward()
             if side is not None:

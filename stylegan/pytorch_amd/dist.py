@@ -68,9 +68,10 @@ class GradBuckets:
             self.buckets.append((flat, views))
 
     def matches(self, params):
-        """True if ``params`` (the parameters that received a gradient) are exactly this layout's parameters."""
+        """True if ``params`` (the parameters that received a gradient) are exactly this layout's parameters (in any order: a
+        layout built by ``BucketScheduler`` is in gradient-ready order, not in parameter order)."""
         params = list(params)
-        return len(params) == len(self.params) and all(a is b for a, b in zip(params, self.params))
+        return len(params) == len(self.params) and {id(p) for p in params} == {id(p) for p in self.params}
 
     def attach(self):
         for flat, views in self.buckets:
@@ -80,6 +81,140 @@ class GradBuckets:
 
     def attached(self):
         return all(p.grad is v for _, views in self.buckets for p, v in views)
+
+
+class BucketScheduler:
+    """Bucket-level overlap of the gradient all-reduce with the backward that produces the gradients (the reference's
+    multi-GPU TODO, models/GAN.py:509-510).
+
+    The backward of a half-iteration writes every active parameter's gradient a FIXED number of times in a FIXED order (one
+    graph per (network, depth): the discriminator's parameters get up to three contributions -- fake pass, real pass, R1 double
+    backward).  ``record`` mode (first iteration at a depth) counts the contributions per parameter and notes the order in which
+    the parameters become FINAL; ``GradBuckets`` is then laid out in that order, so a bucket fills up early, and from the next
+    iteration on ``note(p)`` -- called by the autograd post-accumulate hook of ``p`` or, for convolution parameters whose
+    gradient is accumulated inside the weight-gradient kernel, by functional.ConvFn.backward -- fires the bucket's all-reduce the
+    moment its last parameter is final: on the collective side stream, after the stream(s) that wrote the gradients, while the
+    backward carries on with the higher-resolution layers.  ``finish`` fires what is left and joins.  A parameter that is
+    written MORE often than recorded would be reduced too early: ``finish`` checks every count and raises (the step's
+    gradients are then unusable; the layout is re-recorded by the caller)."""
+
+    def __init__(self, group, params=None):
+        self.group = group
+        self.lock = __import__("threading").Lock()
+        self.recording = params is None
+        self.count, self.order = {}, []                       # recording: id(p) -> contributions, ids in order of LAST write
+        self.gb = None
+        self._params = {}
+
+    # ---- recording (first iteration at a depth)
+    def note(self, p):
+        with self.lock:
+            k = id(p)
+            if self.recording:
+                self._params[k] = p
+                self.count[k] = self.count.get(k, 0) + 1
+                if k in self.order:
+                    self.order.remove(k)
+                self.order.append(k)
+                return
+            c = self.seen.get(k)
+            if c is None:
+                self.unknown += 1                              # a parameter outside the recorded set received a gradient
+                return
+            self.seen[k] = c + 1
+            if c + 1 == self.count[k]:
+                b = self.bucket_of[k]
+                self.left[b] -= 1
+                if self.left[b] == 0:
+                    self._fire(b)
+
+    def layout(self, bucket_elems, only=None):
+        """After a recording backward: GradBuckets of the recorded parameters (``only``: restrict to these, e.g. the ones that
+        really hold a gradient) in gradient-ready order, and this object switched to firing mode for the next backward."""
+        keep = None if only is None else {id(p) for p in only}
+        ids = [k for k in self.order if keep is None or k in keep]
+        if not ids:
+            return None
+        self.gb = GradBuckets([self._params[k] for k in ids], bucket_elems)
+        self.bucket_of = {}
+        for bi, (_, views) in enumerate(self.gb.buckets):
+            for p, _ in views:
+                self.bucket_of[id(p)] = bi
+        self.count = {k: self.count[k] for k in ids}
+        self.recording = False
+        self._params = {}
+        return self.gb
+
+    # ---- firing (later iterations)
+    def begin(self, param_stream=None):
+        """Before the backward.  ``param_stream``: the side stream the convolution weight gradients are written on (the bucket's
+        all-reduce must be ordered after it as well as after the stream of the backward chain)."""
+        self.seen = {k: 0 for k in self.count}
+        self.left = [len(views) for _, views in self.gb.buckets]
+        self.fired = [False] * len(self.gb.buckets)
+        self.unknown = 0
+        self.handles = []
+        self.param_stream = param_stream
+        self.fired_early = 0
+
+    def _fire(self, b):
+        flat = self.gb.buckets[b][0]
+        self.fired[b] = True
+        g = self.group
+        if g.world_size == 1 and not g.force_collectives:
+            return
+        if flat.is_cuda:
+            side = g._side_stream(flat.device)
+            side.wait_stream(torch.cuda.current_stream(flat.device))
+            if self.param_stream is not None:
+                side.wait_stream(self.param_stream)
+            with torch.cuda.stream(side):
+                g._all_reduce(flat)
+            flat.record_stream(side)
+        else:
+            self.handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=g.group, async_op=True))
+
+    def finish(self):
+        """After the backward: all-reduce the buckets that did not complete early (none, if the recording still holds), join
+        the collective stream / the pending handles, and verify that every parameter was written exactly as often as recorded."""
+        with self.lock:
+            self.fired_early = sum(self.fired)
+            bad = [k for k, c in self.seen.items() if c != self.count[k]]
+            late = [b for b, f in enumerate(self.fired) if not f]
+            if self.unknown or any(self.seen[k] > self.count[k] for k in bad):
+                raise RuntimeError("BucketScheduler: the backward wrote gradients that the recorded schedule does not know "
+                                   f"({self.unknown} unknown parameters, {len(bad)} with another count): a bucket may have been reduced early")
+            for b in late:                                     # parameters that got FEWER writes this time (or none): reduce now
+                self._fire(b)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        flat0 = self.gb.buckets[0][0]
+        if flat0.is_cuda and (self.group.world_size > 1 or self.group.force_collectives):
+            torch.cuda.current_stream(flat0.device).wait_stream(self.group._side_stream(flat0.device))
+
+
+_ACTIVE_SCHEDULER = None            # the scheduler of the backward in flight (one process drives one GPU)
+
+
+def set_active_scheduler(s):
+    global _ACTIVE_SCHEDULER
+    _ACTIVE_SCHEDULER = s
+
+
+def note_grad_write(p):
+    """A gradient contribution to ``p`` has been enqueued (on the current stream, or on the weight-gradient side stream)."""
+    s = _ACTIVE_SCHEDULER
+    if s is not None:
+        s.note(p)
+
+
+def install_grad_hooks(params):
+    """Post-accumulate hooks (autograd's AccumulateGrad) for parameters whose gradient travels through autograd; convolution
+    parameters accumulated in-kernel are noted by functional.ConvFn.backward.  Idempotent."""
+    for p in params:
+        if getattr(p, "_sgx_grad_hook", None) is None and p.requires_grad:
+            p._sgx_grad_hook = p.register_post_accumulate_grad_hook(note_grad_write)
 
 
 class _GlobalMeanFn(torch.autograd.Function):
@@ -106,10 +241,11 @@ class DataParallelGroup:
     """Bucketed gradient all-reduce(SUM) + buffer broadcast over a torch.distributed process group
     (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests)."""
 
-    def __init__(self, group=None, bucket_mb: float = 32.0, force_collectives: bool = False):
+    def __init__(self, group=None, bucket_mb: float = 32.0, force_collectives: bool = False, overlap_buckets: bool = True):
         assert dist.is_initialized()
         self.group = group
         self.force_collectives = force_collectives          # tests: issue the collectives even in a group of one rank
+        self.overlap_buckets = overlap_buckets               # BucketScheduler: all-reduce a bucket as soon as its gradients are final
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)

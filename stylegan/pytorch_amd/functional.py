@@ -81,6 +81,7 @@ MODES = {"S": N.PACK_S, "D": N.PACK_D, "U": N.PACK_U, "UF": N.PACK_UF}
 FWD_GEO = {"S": "S", "D": "D", "U": "U", "UF": "U"}
 ADJ_GEO = {"S": "S", "D": "U", "U": "D", "UF": "D"}
 _PACKS = {}
+GRAD_NOTE = None                    # callable(parameter) told of every in-kernel accumulation into .grad (set by dist.py users)
 _WEIGHT_GEN = 0
 _ACCUM_PARAM_GRADS = False
 _PARAM_GRAD_STREAM = None
@@ -398,6 +399,10 @@ class ConvFn(Function):
                     if bias.grad is None:
                         bias.grad = db
                     want_b = False
+                if GRAD_NOTE is not None:                      # data parallel: bucket-level all-reduce overlap (dist.BucketScheduler)
+                    GRAD_NOTE(weight)
+                    if fuse_b:
+                        GRAD_NOTE(bias)
             elif ctx.needs_input_grad[1]:
                 gw, gb = _bcall(WgradFn, x, gy, weight, mode, scale, adjoint, fuse_b)
             if want_b and not fuse_b:

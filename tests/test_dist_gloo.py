@@ -16,7 +16,8 @@ import torch.nn.functional as TF
 
 import golden_util as gu
 from oracle import stylegan_oracle as O
-from stylegan.pytorch_amd.dist import DataParallelGroup, GradBuckets, bucketize, stddev_preserving_shard
+from stylegan.pytorch_amd.dist import (BucketScheduler, DataParallelGroup, GradBuckets, bucketize, install_grad_hooks, note_grad_write,
+                                       set_active_scheduler, stddev_preserving_shard)
 
 WORLD = 2
 RES, DEPTH_TOTAL, DEPTH, ALPHA, B = 16, 3, 2, 0.5, 16      # tiny D: 16x16, 8 channels
@@ -262,3 +263,101 @@ def test_relativistic_mean_must_be_global():
         idx = stddev_preserving_shard(B, WORLD, rank)
         part += _head_losses("relativistic-hinge", dis, real[idx], fake[idx], labels[idx], 1.0 / WORLD, None)[0].item()
     assert abs(part - want) > 1e-6
+
+
+# ---- bucket-level overlap: a bucket is all-reduced as soon as its last gradient of the backward is final ----
+def _overlap_worker(rank, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD, timeout=datetime.timedelta(seconds=120))
+    torch.set_num_threads(2)
+    try:
+        group = DataParallelGroup(bucket_mb=0.001)          # tiny buckets: several per network
+        # (1) autograd path: the oracle's D step on this rank's shard, gradients through AccumulateGrad + post-accumulate hooks
+        dp = tiny_d_params()
+        real = gu.seeded((B, 3, RES, RES), 1, torch.float64); fake = gu.seeded((B, 3, RES, RES), 2, torch.float64)
+        idx = stddev_preserving_shard(B, WORLD, rank)
+        leaves = list(dp.values())
+        install_grad_hooks(leaves)
+        sched = BucketScheduler(group)                      # iteration 1: record
+        set_active_scheduler(sched)
+        local_d_loss(dp, real[idx], fake[idx], mean_scale=1.0 / WORLD).backward()
+        set_active_scheduler(None)
+        active = [p for p in leaves if p.grad is not None]
+        assert len(active) < len(leaves)                    # the inactive resolutions never got a note
+        gb = sched.layout(group.bucket_elems, only=active)
+        assert gb is not None and gb.matches(active) and len(gb.buckets) > 2
+        first_iter = {k: v.grad.clone() for k, v in dp.items() if v.grad is not None}
+        gb.attach()                                         # iteration 2: the gradients live in the buckets, zeroed
+        sched.begin()
+        set_active_scheduler(sched)
+        fired_during = []
+        orig_fire = sched._fire
+        sched._fire = lambda b: (fired_during.append(b), orig_fire(b))[1]
+        local_d_loss(dp, real[idx], fake[idx], mean_scale=1.0 / WORLD).backward()
+        set_active_scheduler(None)
+        n_early = len(fired_during)
+        sched.finish()
+        assert n_early == len(gb.buckets) == sched.fired_early      # every bucket left during the backward, none at the join
+        assert fired_during == sorted(fired_during)          # ... in layout (= gradient-ready) order
+        for k, g in first_iter.items():                      # same local gradients both times; now summed over the ranks
+            assert dp[k].grad.shape == g.shape
+        # (2) several contributions per parameter, noted by hand (what ConvFn.backward does for in-kernel accumulation)
+        ps = [torch.nn.Parameter(torch.zeros(n, dtype=torch.float64)) for n in (300, 7, 1200, 64, 500)]
+        contrib = {0: 3, 1: 1, 2: 2, 3: 3, 4: 1}
+        seq = [0, 2, 3, 0, 1, 3, 2, 0, 4, 3]                 # write order: parameter 1 is final first, then 2, 0, 4, 3
+        def val(i, j): return torch.full_like(ps[i], float((rank + 1) * (10 * i + j + 1)))
+        def backward(sch):
+            seen = {i: 0 for i in contrib}
+            for i in seq:
+                g = val(i, seen[i]); seen[i] += 1
+                ps[i].grad = g.clone() if ps[i].grad is None else ps[i].grad.add_(g)
+                sch.note(ps[i])
+        s2 = BucketScheduler(group)
+        backward(s2)
+        gb2 = s2.layout(group.bucket_elems)
+        assert [id(p) for p in gb2.params] == [id(ps[i]) for i in (1, 2, 0, 4, 3)]      # gradient-ready order
+        gb2.attach(); s2.begin(); backward(s2)
+        assert sum(s2.fired) == len(gb2.buckets)
+        s2.finish()
+        for i in contrib:
+            want = sum(float((r + 1) * (10 * i + j + 1)) for r in range(WORLD) for j in range(contrib[i]))
+            assert torch.allclose(ps[i].grad, torch.full_like(ps[i], want)), (i, float(ps[i].grad[0]), want)
+        # a write beyond the recorded count means a bucket left too early: refused loudly
+        gb2.attach(); s2.begin(); backward(s2); s2.note(ps[1])
+        try:
+            s2.finish(); raised = False
+        except RuntimeError:
+            raised = True
+        assert raised
+        if rank == 0:
+            out_q.put({k: v.grad.numpy() for k, v in dp.items() if v.grad is not None})
+        else:
+            out_q.put(None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_buckets_are_reduced_as_soon_as_their_gradients_are_final():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, port, q), daemon=True) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    try:
+        got = [q.get(timeout=120) for _ in range(WORLD)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        _reap(procs)
+    grads = next(g for g in got if g is not None)
+    dp = tiny_d_params()
+    real = gu.seeded((B, 3, RES, RES), 1, torch.float64); fake = gu.seeded((B, 3, RES, RES), 2, torch.float64)
+    loss = local_d_loss(dp, real, fake, mean_scale=1.0)
+    names = sorted(dp)
+    ref = dict(zip(names, torch.autograd.grad(loss, [dp[k] for k in names], allow_unused=True)))
+    assert sorted(grads) == sorted(k for k in names if ref[k] is not None)
+    for k, g in grads.items():
+        err = (torch.as_tensor(g) - ref[k]).abs().max().item()
+        assert err <= 1e-10 * (ref[k].abs().max().item() + 1e-30) + 1e-14, (k, err)
