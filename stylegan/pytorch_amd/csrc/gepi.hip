@@ -6,6 +6,7 @@
 //           of d(noise weight) and d(bias).
 // Layout per block: image b, pixel chunk; thread = (pixel row tr, channel vector tc); channel vectors are 16 bytes.
 #include "common.h"
+#include <stdlib.h>
 
 #define GEPI_EPS 1e-5f
 #define GEPI_ROWS_PER_THREAD 64
@@ -69,6 +70,42 @@ template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float (&v)[8])
     return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
 }
 
+// Block-wide, fixed-order sum of the per-chunk partial pairs of image b: part_b[k][C][2], k < npart -> for every channel the two
+// totals, handed to ``fin(c, total0, total1)`` by ONE thread per channel.  256 threads; red: 512 doubles of LDS scratch.  This is
+// the work of the former gepi_fin_stats / gepi_fin_bwd1 launches, done by every block of the pass that consumes the result
+// (a few KB of L2 reads per block) instead of a 7 us launch of its own between the two passes.
+template <typename Fin>
+__device__ __forceinline__ void gepi_block_totals(const double* __restrict__ part_b, int npart, int C, double* red, Fin fin) {
+    const int Cc = C < 256 ? C : 256, L = 256 / Cc;               // L lanes per channel stride over the chunks
+    const int cl = threadIdx.x % Cc, ln = threadIdx.x / Cc;
+    for (int cb = 0; cb < C; cb += Cc) {                          // uniform trip count
+        const int c = cb + cl;
+        double t0 = 0.0, t1 = 0.0;
+        if (ln < L) {
+            // eight independent 16-byte loads in flight per lane (a dependent chain of L2 misses here sits on the critical path of
+            // every block of the pass: measured +10 us per launch with a rolled loop)
+            for (int k0 = ln; k0 < npart; k0 += 8 * L) {
+                double2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * L;
+                    v[u] = k < npart ? *reinterpret_cast<const double2*>(part_b + ((size_t)k * C + c) * 2) : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { t0 += v[u].x; t1 += v[u].y; }
+            }
+        }
+        red[threadIdx.x * 2] = t0; red[threadIdx.x * 2 + 1] = t1;
+        __syncthreads();
+        if (ln == 0) {
+            double a0 = 0.0, a1 = 0.0;
+            for (int l = 0; l < L; ++l) { a0 += red[(l * Cc + cl) * 2]; a1 += red[(l * Cc + cl) * 2 + 1]; }
+            fin(c, a0, a1);
+        }
+        __syncthreads();
+    }
+}
+
 // mode 0: (sum a, sum a^2)                       [forward statistics]
 // mode 1: (sum dy, sum dy*xh)                    [backward reduction]
 // mode 2: writes dx, (sum dp*noise, sum dp)      [backward apply]
@@ -78,10 +115,24 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
                                                  const float* __restrict__ nw, const float* __restrict__ style,
                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                  const float* __restrict__ coef, double* __restrict__ part, int HW, int C,
-                                                 int cvt, int rows, int chunk, int act) {
+                                                 int cvt, int rows, int chunk, int act,
+                                                 const double* __restrict__ fpart, int fnpart, int fnorm, float* __restrict__ dstyle) {
     constexpr int VE = VecTraits<T>::VE;
-    extern __shared__ double sh[];                                 // [256][2*VE]
+    extern __shared__ double sh[];                                 // [256][2*VE]  (+ MODE 2 with fpart: float [2][C] after it)
     const int b = blockIdx.y, ch = blockIdx.x;
+    float* const scoef = reinterpret_cast<float*>(sh + 256 * 2 * VE);   // [C] k1, [C] k2 of image b
+    if (MODE == 2 && fpart) {
+        // what gepi_fin_bwd1 computed: dstyle (written by the image's first block) and the two statistics-gradient coefficients
+        gepi_block_totals(fpart + (size_t)b * fnpart * C * 2, fnpart, C, sh, [&](int c, double s1, double s0) {
+            if (ch == 0 && dstyle) {
+                dstyle[(size_t)b * 2 * C + c] = (float)s0;         // d/d style[:,0] = sum dy*xh
+                dstyle[(size_t)b * 2 * C + C + c] = (float)s1;     // d/d style[:,1] = sum dy
+            }
+            const double sc = (double)style[(size_t)b * 2 * C + c] + 1.0;
+            scoef[c] = fnorm ? (float)(sc * s1 / HW) : 0.f;
+            scoef[C + c] = fnorm ? (float)(sc * s0 / HW) : 0.f;
+        });
+    }
     const int tc = threadIdx.x % cvt, tr = threadIdx.x / cvt;
     const int cv = C / VE;
     const int p0 = ch * chunk, p1 = (p0 + chunk < HW) ? p0 + chunk : HW;
@@ -100,10 +151,15 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
             for (int j = 0; j < VE; ++j) ks[j] += 1.f;
         }
         if (MODE == 2) {
-            float kk[2 * VE];
-            load_coef<2 * VE>(coef + ((size_t)b * C + c0) * 2, kk);
+            if (fpart) {
 #pragma unroll
-            for (int j = 0; j < VE; ++j) { k1[j] = kk[2 * j]; k2[j] = kk[2 * j + 1]; }
+                for (int j = 0; j < VE; ++j) { k1[j] = scoef[c0 + j]; k2[j] = scoef[C + c0 + j]; }
+            } else {
+                float kk[2 * VE];
+                load_coef<2 * VE>(coef + ((size_t)b * C + c0) * 2, kk);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) { k1[j] = kk[2 * j]; k2[j] = kk[2 * j + 1]; }
+            }
         }
         if (tr < rows) {
             // loads in flight per lane: 8 rows for the read-only statistics pass (2 blocks per CU: it is latency-bound, 2.6 ->
@@ -252,12 +308,31 @@ template <typename T>
 __global__ __launch_bounds__(256) void gepi_apply(const T* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ noise,
                                                   const float* __restrict__ nw, const float* __restrict__ style,
                                                   const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ y,
-                                                  int HW, int C, int cvt, int rows, int chunk, int act) {
+                                                  int HW, int C, int cvt, int rows, int chunk, int act,
+                                                  const double* __restrict__ spart, int snpart, int snorm,
+                                                  float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     constexpr int VE = VecTraits<T>::VE;
+    extern __shared__ double sha[];                                // spart: 512 doubles of scratch, then float [2][C] mean / rstd
     const int b = blockIdx.y, ch = blockIdx.x;
     const int tc = threadIdx.x % cvt, tr = threadIdx.x / cvt;
     const int cv = C / VE;
     const int p0 = ch * chunk, p1 = (p0 + chunk < HW) ? p0 + chunk : HW;
+    float* const sstat = reinterpret_cast<float*>(sha + 512);
+    if (spart) {
+        // what gepi_fin_stats computed (mean / rstd per channel of image b), by every block for itself; the image's first block
+        // also writes them out (the backward reads them)
+        gepi_block_totals(spart + (size_t)b * snpart * C * 2, snpart, C, sha, [&](int c, double sum, double sq) {
+            float m = 0.f, r = 1.f;
+            if (snorm) {
+                const double mm = sum / HW;
+                double var = sq / HW - mm * mm;
+                if (var < 0.0) var = 0.0;
+                m = (float)mm; r = (float)(1.0 / sqrt(var + (double)GEPI_EPS));
+            }
+            sstat[c] = m; sstat[C + c] = r;
+            if (ch == 0) { mean_out[(size_t)b * C + c] = m; rstd_out[(size_t)b * C + c] = r; }
+        });
+    }
     if (tr >= rows) return;
     for (int vb = 0; vb < cv; vb += cvt) {
         const int v = vb + tc, c0 = v * VE;
@@ -266,8 +341,13 @@ __global__ __launch_bounds__(256) void gepi_apply(const T* __restrict__ x, const
         for (int j = 0; j < VE; ++j) kb[j] = 0.f;
         if (bias) load_coef<VE>(bias + c0, kb);
         load_coef<VE>(nw + c0, kw);
-        load_coef<VE>(mean + (size_t)b * C + c0, km);
-        load_coef<VE>(rstd + (size_t)b * C + c0, kr);
+        if (spart) {
+#pragma unroll
+            for (int j = 0; j < VE; ++j) { km[j] = sstat[c0 + j]; kr[j] = sstat[C + c0 + j]; }
+        } else {
+            load_coef<VE>(mean + (size_t)b * C + c0, km);
+            load_coef<VE>(rstd + (size_t)b * C + c0, kr);
+        }
         load_coef<VE>(style + (size_t)b * 2 * C + c0, ks);
         load_coef<VE>(style + (size_t)b * 2 * C + C + c0, k1);
 #pragma unroll
@@ -305,7 +385,7 @@ static int gepi_fwd_t(const void* x, const float* bias, const float* noise, cons
         SGX_LAUNCH_CHECK("gepi_fin_stats");
         SGX_NOTE(0.0, 2.0 * nb, "gepi_apply B%d HW%d C%d", B, HW, C);
         hipLaunchKernelGGL(gepi_apply<T>, dim3(g.nchunk, B), dim3(256), 0, st, (const T*)x, bias, noise, nw, style, mean, rstd,
-                           (T*)y, HW, C, g.cvt, g.rows, g.chunk, act);
+                           (T*)y, HW, C, g.cvt, g.rows, g.chunk, act, (const double*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr);
         SGX_LAUNCH_CHECK("gepi_apply");
         return 0;
     }
@@ -313,14 +393,24 @@ static int gepi_fwd_t(const void* x, const float* bias, const float* noise, cons
         SGX_NOTE(0.0, nb, "gepi_stats B%d HW%d C%d", B, HW, C);
         hipLaunchKernelGGL((gepi_pass<T, 0>), dim3(g.nchunk, B), dim3(256), 256 * 2 * VE * sizeof(double), st, (const T*)x,
                            (const T*)nullptr, (T*)nullptr, bias, noise, nw, style, mean, rstd, (const float*)nullptr, part, HW, C,
-                           g.cvt, g.rows, g.chunk, act);
+                           g.cvt, g.rows, g.chunk, act, (const double*)nullptr, 0, 0, (float*)nullptr);
         SGX_LAUNCH_CHECK("gepi_stats");
+    }
+    // the statistics' finalize (mean / rstd from the per-chunk partials) rides in the apply pass: every block sums the partials of
+    // its image itself (SGX_GEPI_FOLD=0: the separate gepi_fin_stats launch, A/B)
+    static const int fold = [] { const char* e = getenv("SGX_GEPI_FOLD"); return e ? atoi(e) : 1; }();
+    if (fold) {
+        SGX_NOTE(0.0, 2.0 * nb, "gepi_apply B%d HW%d C%d", B, HW, C);
+        hipLaunchKernelGGL(gepi_apply<T>, dim3(g.nchunk, B), dim3(256), 512 * sizeof(double) + 2 * C * sizeof(float), st, (const T*)x, bias, noise,
+                           nw, style, mean, rstd, (T*)y, HW, C, g.cvt, g.rows, g.chunk, act, (const double*)part, norm ? g.nchunk : 0, norm, mean, rstd);
+        SGX_LAUNCH_CHECK("gepi_apply");
+        return 0;
     }
     hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 15) / 16), dim3(256), 0, st, part, mean, rstd, B, C, g.nchunk, HW, norm);
     SGX_LAUNCH_CHECK("gepi_fin_stats");
     SGX_NOTE(0.0, 2.0 * nb, "gepi_apply B%d HW%d C%d", B, HW, C);
     hipLaunchKernelGGL(gepi_apply<T>, dim3(g.nchunk, B), dim3(256), 0, st, (const T*)x, bias, noise, nw, style, mean, rstd,
-                       (T*)y, HW, C, g.cvt, g.rows, g.chunk, act);
+                       (T*)y, HW, C, g.cvt, g.rows, g.chunk, act, (const double*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr);
     SGX_LAUNCH_CHECK("gepi_apply");
     return 0;
 }
@@ -339,14 +429,25 @@ static int gepi_bwd_t(const void* dy, const void* x, const float* bias, const fl
     const double nb = (double)sizeof(T) * B * HW * C;
     SGX_NOTE(0.0, 2.0 * nb, "gepi_bwd1 B%d HW%d C%d", B, HW, C);
     hipLaunchKernelGGL((gepi_pass<T, 1>), dim3(g.nchunk, B), dim3(256), shb, st, (const T*)x, (const T*)dy, (T*)nullptr, bias,
-                       noise, nw, style, mean, rstd, (const float*)nullptr, partA, HW, C, g.cvt, g.rows, g.chunk, act);
+                       noise, nw, style, mean, rstd, (const float*)nullptr, partA, HW, C, g.cvt, g.rows, g.chunk, act,
+                       (const double*)nullptr, 0, 0, (float*)nullptr);
     SGX_LAUNCH_CHECK("gepi_bwd1");
-    hipLaunchKernelGGL(gepi_fin_bwd1, dim3((B * C + 15) / 16), dim3(256), 0, st, partA, style, dstyle, coef, B, C, g.nchunk, HW, norm);
-    SGX_LAUNCH_CHECK("gepi_fin_bwd1");
-    SGX_NOTE(0.0, 3.0 * nb, "gepi_bwd2 B%d HW%d C%d", B, HW, C);
-    hipLaunchKernelGGL((gepi_pass<T, 2>), dim3(g.nchunk, B), dim3(256), shb, st, (const T*)x, (const T*)dy, (T*)dx, bias, noise,
-                       nw, style, mean, rstd, (const float*)coef, partB, HW, C, g.cvt, g.rows, g.chunk, act);
-    SGX_LAUNCH_CHECK("gepi_bwd2");
+    static const int fold = [] { const char* e = getenv("SGX_GEPI_FOLD"); return e ? atoi(e) : 1; }();
+    if (fold) {          // gepi_fin_bwd1's work (dstyle, the statistics-gradient coefficients) in the prologue of the apply pass
+        SGX_NOTE(0.0, 3.0 * nb, "gepi_bwd2 B%d HW%d C%d", B, HW, C);
+        hipLaunchKernelGGL((gepi_pass<T, 2>), dim3(g.nchunk, B), dim3(256), shb + 2 * C * sizeof(float), st, (const T*)x, (const T*)dy, (T*)dx, bias,
+                           noise, nw, style, mean, rstd, (const float*)nullptr, partB, HW, C, g.cvt, g.rows, g.chunk, act,
+                           (const double*)partA, g.nchunk, norm, dstyle);
+        SGX_LAUNCH_CHECK("gepi_bwd2");
+    } else {
+        hipLaunchKernelGGL(gepi_fin_bwd1, dim3((B * C + 15) / 16), dim3(256), 0, st, partA, style, dstyle, coef, B, C, g.nchunk, HW, norm);
+        SGX_LAUNCH_CHECK("gepi_fin_bwd1");
+        SGX_NOTE(0.0, 3.0 * nb, "gepi_bwd2 B%d HW%d C%d", B, HW, C);
+        hipLaunchKernelGGL((gepi_pass<T, 2>), dim3(g.nchunk, B), dim3(256), shb, st, (const T*)x, (const T*)dy, (T*)dx, bias, noise,
+                           nw, style, mean, rstd, (const float*)coef, partB, HW, C, g.cvt, g.rows, g.chunk, act,
+                           (const double*)nullptr, 0, 0, (float*)nullptr);
+        SGX_LAUNCH_CHECK("gepi_bwd2");
+    }
     hipLaunchKernelGGL(gepi_fin_bwd2, dim3((C + 15) / 16), dim3(256), 0, st, partB, dnw, dbias, B, C, g.nchunk);
     SGX_LAUNCH_CHECK("gepi_fin_bwd2");
     return 0;
