@@ -146,6 +146,9 @@ int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, v
  * mode 0: y = blur(x);  1: y = blur(lrelu(x))  [forward];  2: y = blur(x) * slope(z)  [backward: z = the pre-activation];
  * 3: y = blur(x * slope(z))  [backward of mode 2 w.r.t. x: the R1 double backward].  slope(z) = z > 0 ? 1 : 0.2 */
 int sgx_blur3x3_act(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, int dtype, void* stream);
+/* modes 2 / 3 with z as SIGN BITS: bits[pixel][C/8] bytes, bit j of byte v = (z[8v + j] > 0), as sgx_conv3x3_signbits writes them:
+ * the backward passes of the block read 1 bit per mask element instead of 16 (bf16 only). */
+int sgx_blur3x3_bits(const void* x, const void* bits, void* y, int B, int H, int W, int C, int mode, int dtype, void* stream);
 /* BlurLayer with any other filter (models/CustomLayers.py:251-276: kernel = outer(f,f) [/sum] [flipped], F.conv2d with
  * groups=C, padding (K-1)//2):  y[oy][ox] = sum_{i,j} taps[i*K+j] * x[oy+i-pad][ox+j-pad], zero outside, K <= 7.
  * taps_host: K*K floats in HOST memory (copied into the launch).  x: [B][IH][IW][C], y: [B][OH][OW][C] with
@@ -215,6 +218,11 @@ int sgx_blur3x3_stats_nparts(int B, int H, int W, int C, int dtype);
  * the same statistics out of the convolution's store epilogue: one partial per (image, pixel tile).  sgx_conv3x3_stats_nparts:
  * tiles per image, or 0 when the shape has no fused variant (then: sgx_conv3x3 + the plain sgx_gepi_fwd).  bf16 only. */
 int sgx_conv3x3_stats_nparts(int B, int H, int W, int Cin, int Cout, int dtype);
+/* sgx_conv3x3 that also writes the sign bits of its output (the discriminator block's conv0, models/Blocks.py:139-140, whose
+ * pre-activation is the LeakyReLU-backward mask): bits = [B][H][W][Cout/8] bytes.  _ok: 1 if the shape has the variant (bf16). */
+int sgx_conv3x3_signbits_ok(int B, int H, int W, int Cin, int Cout, int dtype);
+int sgx_conv3x3_signbits(const void* x, const void* w, const float* bias, void* y, void* bits, int B, int H, int W, int Cin, int Cout,
+                         int act, const void* mask, int dtype, void* stream);
 /* y = blur3x3(conv_transpose4x4s2(x, pack)) [* slope(mask)] in one kernel: the transposed convolution and the BlurLayer that
  * follows it -- generator conv0_up -> blur (models/CustomLayers.py:143-152,176-177) and, with mask = the pre-activation z, the
  * discriminator's backward through "LeakyReLU -> blur -> conv1_down" (models/Blocks.py:140-145: the adjoint of the stride-2

@@ -168,12 +168,14 @@ class DiscriminatorBlock(nn.Module):
         LeakyReLU networks: one elementwise pass less per block and backward."""
         x_masked = x_masked and self._act == ACT_LRELU
         defer_out = defer_out and self._act == ACT_LRELU
-        z = self.conv0.forward_nhwc(x, act=ACT_NONE, x_masked=x_masked)   # bias fused in the conv store; pre-activation
         if self.blur._is_121 and self._act == ACT_LRELU and FUSE_BLUR_BWD:
-            # LeakyReLU folded into the blur pass; backward: the blur and the activation's mask ride in the data-gradient
-            # kernel of conv1_down (ConvFn x_pre), so the chain has no blur pass of its own on the way back
+            # LeakyReLU folded into the blur pass; backward: the blur and the activation's mask belong to conv1_down's data
+            # gradient (ConvFn x_pre): one kernel where that wins, else the blur-and-mask pass -- which reads the mask as the
+            # SIGN BITS that conv0's store wrote next to z (1 bit per element instead of 16) where conv0 has that variant
+            z, zbits = self.conv0.forward_nhwc(x, act=ACT_NONE, x_masked=x_masked, sign_bits=True)
             x = F.call(F.ActBlurPassFn, z)
-            return self.conv1_down.forward_nhwc(x, act=ACT_LRELU, defer_act=defer_out, x_pre=z)
+            return self.conv1_down.forward_nhwc(x, act=ACT_LRELU, defer_act=defer_out, x_pre=z, x_pre_bits=zbits)
+        z = self.conv0.forward_nhwc(x, act=ACT_NONE, x_masked=x_masked)   # bias fused in the conv store; pre-activation
         if self.blur._is_121 and self._act == ACT_LRELU:
             x = F.call(F.ActBlurFn, z)                                      # LeakyReLU folded into the blur pass (both ways)
         else:                                                               # ReLU / another blur filter: stage by stage

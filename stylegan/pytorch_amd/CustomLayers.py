@@ -211,7 +211,7 @@ class EqualizedConv2d(nn.Module):
         return self.bias * self.b_mul if self.b_mul != 1 else self.bias
 
     def forward_nhwc(self, x, act=ACT_NONE, skip_bias=False, out_dtype=None, defer_act=False, x_masked=False, out_scale=1.0,
-                     epi_stats=None, x_pre=None):
+                     epi_stats=None, x_pre=None, sign_bits=False, x_pre_bits=None):
         """x: NHWC.  ``skip_bias``: the caller folds the bias into the next kernel (generator epilogue).
         ``defer_act`` / ``x_masked``: the LeakyReLU backward of this layer is applied by its consumer / this layer's input is
         such an output and its data gradient leaves the kernel already masked (functional.ConvFn; discriminator chain only).
@@ -275,8 +275,13 @@ class EqualizedConv2d(nn.Module):
         if self.downscale is not None:
             assert self.intermediate is None                              # reference :167
             return F.conv(x, self.weight, bias, "D", self.w_mul, act, defer_act=defer_act and act == ACT_LRELU,
-                          x_pre=x_pre)                                    # bias after the 2x2 mean == bias in the fused store
+                          x_pre=x_pre, x_pre_bits=x_pre_bits)             # bias after the 2x2 mean == bias in the fused store
         if self.intermediate is None:
+            if sign_bits:
+                # -> (y, sign bits of y or None): the discriminator block's conv0, whose output is the LeakyReLU-backward mask
+                if F.conv_signbits_ok(x, self.weight.shape[0]):
+                    return F.conv(x, self.weight, bias, "S", self.w_mul, act, ipad=x.shape[3], x_masked=x_masked, bits_out=True)
+                return F.conv(x, self.weight, bias, "S", self.w_mul, act, ipad=x.shape[3], x_masked=x_masked), None
             return F.conv(x, self.weight, bias, "S", self.w_mul, act, ipad=x.shape[3], x_masked=x_masked)
         y = self.intermediate.forward_nhwc(F.conv(x, self.weight, None, "S", self.w_mul))
         return F.call(F.BiasActFn, y, bias, 1.0, act) if (bias is not None or act) else y

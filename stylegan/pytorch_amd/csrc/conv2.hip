@@ -59,6 +59,9 @@ struct Conv2Args {
     // slot of the persistent grid) the sums of a = lrelu(y + ebias[c] + enw[c] * enoise[b, pixel]) and a^2 over the pixels of the
     // image that the slot's blocks stored, y as stored (bf16)
     const float* ebias; const float* enoise; const float* enw; double* part;   // part[((b * nslots + slot) * Cout + c) * 2 + {0, 1}]
+    // C2_S, register epilogue: one SIGN bit per stored element (1 = value > 0), [pixel][Cout / 8] bytes, bit j = channel 8v + j --
+    // what the LeakyReLU backward of the discriminator block needs of the pre-activation (1/16 of re-reading it)
+    unsigned char* signbits;
 };
 enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BLUR = 2 };
 
@@ -562,6 +565,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                                 const size_t doff = pix + m * 32 + 16 * k;
                                 if (GEO == C2_S && a.mask) val = lrelu_mask_bf16x8(val, *reinterpret_cast<const uint4*>(a.mask + doff));
                                 *reinterpret_cast<uint4*>(a.y + doff) = val;
+                                if (GEO == C2_S && a.signbits) {
+                                    const unsigned wv[4] = {val.x, val.y, val.z, val.w};
+                                    unsigned bits = 0;
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        bits |= ((short)(wv[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q);
+                                        bits |= ((short)(wv[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
+                                    }
+                                    a.signbits[doff >> 3] = (unsigned char)bits;
+                                }
                             }
                         }
                     }
@@ -740,7 +753,7 @@ int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void
     if (!p.nw) return 0;
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
                 geo == C2_D ? H / 2 : (geo == C2_U ? 2 * H : H), geo == C2_D ? W / 2 : (geo == C2_U ? 2 * W : W), Cin, Cout, act, 0, 0, 0, 0, 0, 0,
-                nullptr, nullptr, nullptr, nullptr};
+                nullptr, nullptr, nullptr, nullptr, nullptr};
     *launched = 1;
     const int nw = p.nw;
     if (p.k16) {
@@ -798,7 +811,7 @@ extern "C" int sgx_conv3x3_stats(const void* x, const void* w, void* y, const fl
                 (size_t)B * npart * Cout * 2 * sizeof(double));
     SGX_NOTE(2.0 * 9 * Cin * Cout * B * H * W, 2.0 * ((double)B * H * W * (Cin + Cout) + 9.0 * Cin * Cout), "convS+stats B%d %dx%d %d->%d", B, H, W, Cin, Cout);
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), nullptr, static_cast<bf16_t*>(y), nullptr, B, H, W, H, W, Cin, Cout,
-                SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, ebias, noise, nw_, part};
+                SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, ebias, noise, nw_, part, nullptr};
     hipStream_t st = (hipStream_t)stream;
     const int nw = p.nw;
     if (p.k16) return nw == 8 ? launch_conv2<C2_S, 8, 1, 16, true, EPI_STATS>(a, st) : launch_conv2<C2_S, 4, 1, 16, true, EPI_STATS>(a, st);
@@ -823,8 +836,33 @@ extern "C" int sgx_conv4x4s2_up_blur(const void* x, const void* w, void* y, cons
     SGX_NOTE(2.0 * 16 * Cin * Cout * B * H * W, 2.0 * ((double)B * H * W * (Cin + 4.0 * Cout * (mask ? 2 : 1)) + 16.0 * Cin * Cout),
              "convU+blur%s B%d %dx%d %d->%d", mask ? "*mask" : "", B, H, W, Cin, Cout);
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), nullptr, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
-                2 * H, 2 * W, Cin, Cout, SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+                2 * H, 2 * W, Cin, Cout, SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     if (p.k16) return p.nw == 8 ? launch_conv2<C2_U, 8, 1, 32, true, EPI_BLUR>(a, st) : launch_conv2<C2_U, 4, 1, 32, true, EPI_BLUR>(a, st);
     return p.nw == 8 ? launch_conv2<C2_U, 8, 1, 32, false, EPI_BLUR>(a, st) : launch_conv2<C2_U, 4, 1, 32, false, EPI_BLUR>(a, st);
+}
+
+// ---- 3x3 convolution that also writes the SIGN bits of its (bias-added, activated) output: one byte per pixel and 8 channels.
+// The discriminator block's conv0 (models/Blocks.py:139-140): its pre-activation is the mask of the LeakyReLU backward, and the
+// backward passes then read 1 bit instead of 16 per element.  1 = available for this shape (bf16, second-generation kernel).
+extern "C" int sgx_conv3x3_signbits_ok(int B, int H, int W, int Cin, int Cout, int dtype) {
+    if (dtype != SGX_BF16 || Cout % 8) return 0;
+    static const int on = [] { const char* e = getenv("SGX_SIGNBITS"); return e ? atoi(e) : 1; }();   // A/B switch
+    return on && conv2_pick(C2_S, B, H, W, Cin, Cout, -1).nw ? 1 : 0;
+}
+extern "C" int sgx_conv3x3_signbits(const void* x, const void* w, const float* bias, void* y, void* bits, int B, int H, int W, int Cin,
+                                    int Cout, int act, const void* mask, int dtype, void* stream) {
+    SGX_REQUIRE(dtype == SGX_BF16, SGX_EUNSUPPORTED, "conv3x3_signbits: bf16 only");
+    SGX_REQUIRE(x && w && y && bits, SGX_EINVAL, "conv3x3_signbits: null argument");
+    const Conv2Pick p = conv2_pick(C2_S, B, H, W, Cin, Cout, -1);
+    SGX_REQUIRE(p.nw && Cout % 8 == 0, SGX_EUNSUPPORTED, "conv3x3_signbits: shape B%d %dx%d %d->%d has no variant (sgx_conv3x3_signbits_ok == 0)", B, H, W, Cin, Cout);
+    SGX_NOTE(2.0 * 9 * Cin * Cout * B * H * W, 2.0 * ((double)B * H * W * (Cin + Cout) + 9.0 * Cin * Cout) + (double)B * H * W * Cout / 8.0,
+             "convS+bits B%d %dx%d %d->%d", B, H, W, Cin, Cout);
+    Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W, H, W,
+                Cin, Cout, act, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, static_cast<unsigned char*>(bits)};
+    hipStream_t st = (hipStream_t)stream;
+    const int nw = p.nw;
+    if (p.k16) return nw == 8 ? launch_conv2<C2_S, 8, 1, 16, true>(a, st) : launch_conv2<C2_S, 4, 1, 16, true>(a, st);
+    if (p.mf2) return nw == 8 ? launch_conv2<C2_S, 8, 2>(a, st) : launch_conv2<C2_S, 4, 2>(a, st);
+    return nw == 8 ? launch_conv2<C2_S, 8, 1>(a, st) : launch_conv2<C2_S, 4, 1>(a, st);
 }

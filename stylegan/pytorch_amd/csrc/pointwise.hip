@@ -149,6 +149,8 @@ extern "C" int sgx_axpby_dev(const void* a, const void* b, void* out, const floa
 // MODE 0: y = blur(x)            1: y = blur(lrelu(x))            2: y = blur(x) * slope(z)            3: y = blur(x * slope(z))
 // 1..3 are the forward, backward and double-backward of "LeakyReLU then blur" (discriminator block: conv0 -> act -> blur)
 // with the activation folded into the blur pass: no separate activation-backward pass over the tensor.
+// MODE 4 / 5 (bf16): modes 2 / 3 with z given as SIGN BITS (one byte per 8-channel vector, bit j = z[8v + j] > 0; written by the
+// convolution that produced z, sgx_conv3x3_signbits): the backward passes read 1/16 of the mask bytes.
 template <typename T, int MODE, int ROWS = BLUR_ROWS>
 __global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, const T* __restrict__ z, T* __restrict__ y, int B, int H,
                                                       int W, int C) {
@@ -176,11 +178,23 @@ __global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, c
                 VecTraits<T>::load(z + off, m);
 #pragma unroll
                 for (int j = 0; j < VE; ++j) v[j] *= lrelu_slope(m[j]);
+            } else if (MODE == 5) {
+                const unsigned bits = reinterpret_cast<const unsigned char*>(z)[off / VE];
+#pragma unroll
+                for (int j = 0; j < VE; ++j) v[j] *= ((bits >> j) & 1u) ? 1.f : SGX_LRELU;
             }
         };
         float ha[VE], hb[VE], hc[VE];                                         // horizontal sums of rows r-2, r-1, r
 #pragma unroll
         for (int j = 0; j < VE; ++j) { ha[j] = 0.f; hb[j] = 0.f; }
+        // MODE 4: the strip's mask bytes are requested up front (a one-byte load issued when its output row is ready would put
+        // its latency on every row's critical path: 572 us instead of the 2-tensor streaming time at 1024^2, batch 32)
+        unsigned mbits[ROWS];
+        if (MODE == 4) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+                mbits[r] = h0 + r < H ? reinterpret_cast<const unsigned char*>(z)[((((size_t)b * H + h0 + r) * W + w) * cv * VE + c * VE) / VE] : 0u;
+        }
 #pragma unroll
         for (int k = 0; k < ROWS + 2; ++k) {
             const int r = h0 - 1 + k;                                         // input row
@@ -208,6 +222,10 @@ __global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, c
                         VecTraits<T>::load(z + dst, m);
 #pragma unroll
                         for (int j = 0; j < VE; ++j) o[j] *= lrelu_slope(m[j]);
+                    } else if (MODE == 4) {
+                        const unsigned bits = mbits[k - 2];
+#pragma unroll
+                        for (int j = 0; j < VE; ++j) o[j] *= ((bits >> j) & 1u) ? 1.f : SGX_LRELU;
                     }
                     VecTraits<T>::store(y + dst, o);
                 }
@@ -226,7 +244,9 @@ static void blur_launch_rows(const void* x, const void* z, void* y, int B, int H
         case 0: hipLaunchKernelGGL((blur3x3_kernel<T, 0, ROWS>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
         case 1: hipLaunchKernelGGL((blur3x3_kernel<T, 1, ROWS>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
         case 2: hipLaunchKernelGGL((blur3x3_kernel<T, 2, ROWS>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
-        default: hipLaunchKernelGGL((blur3x3_kernel<T, 3, ROWS>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        case 3: hipLaunchKernelGGL((blur3x3_kernel<T, 3, ROWS>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        case 4: hipLaunchKernelGGL((blur3x3_kernel<T, 4, ROWS>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        default: hipLaunchKernelGGL((blur3x3_kernel<T, 5, ROWS>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
     }
 }
 // 8-row strips amortise the vertical halo (3.75 loads per output vector) where the tensor streams from HBM; a small tensor
@@ -250,6 +270,16 @@ extern "C" int sgx_blur3x3_act(const void* x, const void* z, void* y, int B, int
 }
 extern "C" int sgx_blur3x3(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
     return sgx_blur3x3_act(x, nullptr, y, B, H, W, C, 0, dtype, stream);
+}
+// modes 2 / 3 of sgx_blur3x3_act with the pre-activation given as sign bits ([pixel][C / 8] bytes, sgx_conv3x3_signbits); bf16
+extern "C" int sgx_blur3x3_bits(const void* x, const void* bits, void* y, int B, int H, int W, int C, int mode, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SGX_REQUIRE((mode == 2 || mode == 3) && bits, SGX_EINVAL, "blur3x3_bits: mode %d", mode);
+    SGX_REQUIRE(dtype == SGX_BF16 && C % 8 == 0, SGX_EUNSUPPORTED, "blur3x3_bits: bf16 with C %% 8 == 0 (C=%d dtype=%d)", C, dtype);
+    SGX_NOTE(0.0, (2.0 * 2.0 + 1.0 / 8.0) * B * H * W * C, "blur%db B%d %dx%d C%d", mode, B, H, W, C);
+    blur_launch<bf16_t>(x, bits, y, B, H, W, C, mode + 2, st);
+    SGX_LAUNCH_CHECK("blur3x3_bits");
+    return 0;
 }
 
 // ---------------------------------------------------------------- depthwise K x K correlation, zero padded, any filter

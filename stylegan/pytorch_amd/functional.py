@@ -340,19 +340,27 @@ class ConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, mode, scale, ipad, adjoint, act, mask=None, defer_act=False, x_masked=False, stats=None,
-                x_pre=None):
+                x_pre=None, bits_out=False, x_pre_bits=None):
         """``stats`` = (epilogue bias or None, noise [B,1,H,W], noise weight) of the generator LayerEpilogue that consumes y: the
         store of the convolution also emits the epilogue's partial instance-norm statistics -> returns (y, partials); only where
         ``conv_stats_nparts`` says the shape has such a kernel (plain 3x3, bf16).
         ``x_pre`` (stride-2 layers of the discriminator): x = blur(lrelu(x_pre)), made by ``ActBlurPassFn`` whose own backward is
         the identity -- THIS op's backward then returns the gradient w.r.t. x_pre, blur(conv_adjoint(gy)) * slope(x_pre), from
-        one kernel where the shape has it (``ConvBlurFn``), else from the adjoint convolution and the blur-and-mask pass."""
+        one kernel where the shape has it (``ConvBlurFn``), else from the adjoint convolution and the blur-and-mask pass
+        (``x_pre_bits``: the sign bits of x_pre, which that pass then reads instead of x_pre).
+        ``bits_out`` (plain 3x3, bf16, where ``conv_signbits_ok``): also return the sign bits of y, [B,H,W,C/8] uint8."""
         x = _c(x)
         fwd, adj = packs(weight, mode, scale, ipad, x.dtype)
         geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
         ctx.cfg = (mode, scale, ipad, adjoint, act, bias is not None, bool(defer_act), bool(x_masked))
         ctx.bias_ref = weakref.ref(bias) if bias is not None else (lambda: None)
-        ctx.x_pre = x_pre
+        ctx.x_pre, ctx.x_pre_bits = x_pre, x_pre_bits
+        if bits_out:
+            assert geo == "S" and not adjoint and stats is None
+            y, bits = _conv_bits_launch(x, fwd, None if bias is None else _c(bias.detach()), act, mask)
+            ctx.mark_non_differentiable(bits)
+            ctx.save_for_backward(x, weight, y if (act and not defer_act) else None, mask)
+            return y, bits
         if stats is not None:
             assert geo == "S" and not adjoint and bias is None and act == 0 and mask is None
             y, part = _conv_stats_launch(x, fwd, *stats)
@@ -377,10 +385,11 @@ class ConvFn(Function):
         if ctx.needs_input_grad[0]:
             if x_pre is not None:
                 assert not x_masked
+                xb = getattr(ctx, "x_pre_bits", None)
                 if conv_blur_ok(gy, weight.shape[1] if not adjoint else weight.shape[0], mode, not adjoint):
                     gx = _bcall(ConvBlurFn, gy, weight, mode, scale, ipad, not adjoint, x_pre)      # one kernel
                 else:
-                    gx = _bcall(BlurMaskFn, _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0), x_pre)
+                    gx = _bcall(BlurMaskFn, _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0), x_pre, xb)
             else:
                 gx = _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0, x if x_masked else None, False, False)
         if not _DATA_GRAD_ONLY:
@@ -407,7 +416,7 @@ class ConvFn(Function):
                 gw, gb = _bcall(WgradFn, x, gy, weight, mode, scale, adjoint, fuse_b)
             if want_b and not fuse_b:
                 gb = _bcall(ColSumFn, gy, 1.0)
-        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 # Where the transposed convolution and the blur after it run as ONE kernel.  "auto": where it was measured to win alone on the
@@ -496,9 +505,33 @@ class WgradFn(Function):
         raise NotImplementedError("second derivative through a weight gradient is not part of the training path")
 
 
-def conv(x, weight, bias, mode, scale, act=N.ACT_NONE, ipad=None, defer_act=False, x_masked=False, stats=None, x_pre=None):
+def conv(x, weight, bias, mode, scale, act=N.ACT_NONE, ipad=None, defer_act=False, x_masked=False, stats=None, x_pre=None,
+         bits_out=False, x_pre_bits=None):
     return call(ConvFn, x, weight, bias, mode, float(scale), int(ipad if ipad is not None else weight.shape[1]), False, act, None,
-                bool(defer_act), bool(x_masked), stats, x_pre)
+                bool(defer_act), bool(x_masked), stats, x_pre, bool(bits_out), x_pre_bits)
+
+
+SIGNBITS_ON = True                  # tests flip this to compare against masks read from the pre-activation itself
+
+
+def conv_signbits_ok(x, cout):
+    """True if the plain 3x3 convolution of NHWC ``x`` to ``cout`` channels can also write the sign bits of its output."""
+    if not SIGNBITS_ON or x.dtype != torch.bfloat16:
+        return False
+    B, H, W, Cin = x.shape
+    return bool(N.lib().sgx_conv3x3_signbits_ok(B, H, W, Cin, int(cout), N.BF16))
+
+
+def _conv_bits_launch(x, wq, bias, act, mask):
+    B, H, W, Cin = x.shape
+    taps, Cout, K = wq.shape
+    if K != Cin or taps != 9:
+        raise N.SgxError("conv+bits: 3x3 pack with the activation's channel count expected")
+    y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
+    bits = torch.empty((B, H, W, Cout // 8), dtype=torch.uint8, device=x.device)
+    N.check(N.lib().sgx_conv3x3_signbits(N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), N.ptr(bits), B, H, W, Cin, Cout, act, N.ptr(mask),
+                                         N.dt(x), N.stream()), "sgx_conv3x3_signbits")
+    return y, bits
 
 
 def conv_stats_nparts(x, cout):
@@ -770,10 +803,14 @@ class BlurGenFn(Function):
         return _bcall(BlurGenFn, g, tuple(reversed(taps)), K, K - 1 - pad, IH, IW), None, None, None, None, None
 
 
-def _blur_act(x, z, mode):
+def _blur_act(x, z, mode, bits=None):
+    """``bits`` (modes 2, 3): the sign bits of z ([B,H,W,C/8] uint8, written by the convolution that produced z) instead of z."""
     x = _c(x)
     B, H, W, C = x.shape
     y = torch.empty_like(x)
+    if bits is not None:
+        N.check(N.lib().sgx_blur3x3_bits(N.ptr(x), N.ptr(bits), N.ptr(y), B, H, W, C, mode, N.dt(x), N.stream()), "sgx_blur3x3_bits")
+        return y
     N.check(N.lib().sgx_blur3x3_act(N.ptr(x), None if z is None else N.ptr(z), N.ptr(y), B, H, W, C, mode, N.dt(x), N.stream()), "sgx_blur3x3_act")
     return y
 
@@ -794,31 +831,32 @@ class ActBlurFn(Function):
 
 
 class BlurMaskFn(Function):
-    """blur(g) * slope(z): backward of ActBlurFn.  Linear in g; z only selects the slope."""
+    """blur(g) * slope(z): backward of ActBlurFn.  Linear in g; z only selects the slope (``bits``: its sign bits, read instead
+    of z where the producing convolution wrote them)."""
 
     @staticmethod
-    def forward(ctx, g, z):
-        ctx.save_for_backward(z)
-        return _blur_act(g, z, 2)
+    def forward(ctx, g, z, bits=None):
+        ctx.save_for_backward(z, bits)
+        return _blur_act(g, z, 2, bits)
 
     @staticmethod
     def backward(ctx, gg):
-        (z,) = ctx.saved_tensors
-        return _bcall(MaskBlurFn, gg, z), None
+        z, bits = ctx.saved_tensors
+        return _bcall(MaskBlurFn, gg, z, bits), None, None
 
 
 class MaskBlurFn(Function):
     """blur(g * slope(z)): adjoint of BlurMaskFn in g (the blur is self-adjoint)."""
 
     @staticmethod
-    def forward(ctx, g, z):
-        ctx.save_for_backward(z)
-        return _blur_act(g, z, 3)
+    def forward(ctx, g, z, bits=None):
+        ctx.save_for_backward(z, bits)
+        return _blur_act(g, z, 3, bits)
 
     @staticmethod
     def backward(ctx, gg):
-        (z,) = ctx.saved_tensors
-        return _bcall(BlurMaskFn, gg, z), None
+        z, bits = ctx.saved_tensors
+        return _bcall(BlurMaskFn, gg, z, bits), None, None
 
 
 class Pool2Fn(Function):

@@ -71,6 +71,9 @@ SIGNATURES = {
     "sgx_gepi_fwd": (I, [P, P, P, P, P, P, P, P, P, Z, P, I, I, I, I, I, I, P]),
     "sgx_blur3x3_stats_nparts": (I, [I, I, I, I, I]),
     "sgx_conv3x3_stats_nparts": (I, [I, I, I, I, I, I]),
+    "sgx_conv3x3_signbits_ok": (I, [I, I, I, I, I, I]),
+    "sgx_conv3x3_signbits": (I, [P, P, P, P, P, I, I, I, I, I, I, P, I, P]),
+    "sgx_blur3x3_bits": (I, [P, P, P, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_up_blur_ok": (I, [I, I, I, I, I, I]),
     "sgx_conv4x4s2_up_blur": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "sgx_conv3x3_stats": (I, [P, P, P, P, P, P, P, Z, I, I, I, I, I, I, P]),

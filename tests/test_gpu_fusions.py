@@ -278,3 +278,57 @@ def test_real_batch_downsample_fade_in_one_pass(B, H, dev_alpha):
     assert_close(fused, ref, 1e-7, "fused vs separate")
     r64 = alpha * x.double() + (1 - alpha) * torch.nn.functional.avg_pool2d(x.double().permute(0, 3, 1, 2), 2).repeat_interleave(2, 2).repeat_interleave(2, 3).permute(0, 2, 3, 1)
     assert_close(fused, r64, 1e-6, "vs fp64")
+
+
+@pytest.mark.parametrize("C,B,H", [(16, 2, 512), (16, 1, 256), (32, 2, 256), (64, 4, 256), (64, 1, 256), (128, 3, 136)])
+def test_sign_bits_of_the_block_preactivation(C, B, H):
+    """The discriminator block's conv0 writes one sign bit per element next to z; the backward passes (blur * slope, blur of
+    slope * g) read the bits instead of z: bit-identical results."""
+    from stylegan.pytorch_amd import functional as F
+    W = 256
+    x = gu.seeded((B, H, W, C), 90).to(DEV).bfloat16()
+    w = gu.seeded((C, C, 3, 3), 91).to(DEV); bias = (0.3 * gu.seeded((C,), 92)).to(DEV)
+    scale = O.he_w_mul(C * 9, 2 ** 0.5)
+    assert F.conv_signbits_ok(x, C)
+    with torch.no_grad():
+        z, bits = F.ConvFn.apply(x, w, bias, "S", scale, C, False, 0, None, False, False, None, None, True)
+        z_ref = F.ConvFn.apply(x, w, bias, "S", scale, C, False, 0)
+        assert torch.equal(z, z_ref)
+        want = (z.float() > 0).reshape(B, H, W, C // 8, 8)
+        got = ((bits.unsqueeze(-1).int() >> torch.arange(8, device=DEV)) & 1).bool()
+        assert torch.equal(got, want)
+        g = gu.seeded((B, H, W, C), 93).to(DEV).bfloat16()
+        assert torch.equal(F.BlurMaskFn.apply(g, z, bits), F.BlurMaskFn.apply(g, z))
+        assert torch.equal(F.MaskBlurFn.apply(g, z, bits), F.MaskBlurFn.apply(g, z))
+
+
+@pytest.mark.parametrize("cin,cout,B,H", [(32, 64, 2, 256), (16, 32, 2, 512)])
+def test_discriminator_block_with_sign_bits(cin, cout, B, H):
+    """DiscriminatorBlock in bf16, first and second order, with the mask read as sign bits against the mask read from z."""
+    from stylegan.pytorch_amd import Blocks
+    from stylegan.pytorch_amd import functional as F
+    blk = Blocks.DiscriminatorBlock(cin, cout, 2 ** 0.5, True, torch.nn.LeakyReLU(0.2), [1, 2, 1]).to(DEV)
+    names = dict(blk.named_parameters())
+    with torch.no_grad():
+        for k, p in names.items():
+            p.copy_(gu.fill_value("blk." + k, p.shape))
+    x = gu.seeded((B, H, H, cin), 60); gy = gu.seeded((B, H // 2, H // 2, cout), 61)
+
+    def run(on):
+        keep, F.SIGNBITS_ON = F.SIGNBITS_ON, on
+        keep_p, F.CONV_BLUR_POLICY = F.CONV_BLUR_POLICY, "off"
+        try:
+            for p in names.values():
+                p.grad = None
+            xg = x.to(DEV).bfloat16().requires_grad_(True)
+            y = blk.forward_nhwc(xg)
+            (g1,) = torch.autograd.grad((y.float() * gy.to(DEV)).sum(), xg, create_graph=True)
+            (g1.float() ** 2).sum().backward()
+            return y.detach(), g1.detach(), xg.grad, {k: p.grad.clone() for k, p in names.items()}
+        finally:
+            F.SIGNBITS_ON, F.CONV_BLUR_POLICY = keep, keep_p
+    y0, g0, gx0, gp0 = run(False)
+    y1, g1, gx1, gp1 = run(True)
+    assert torch.equal(y0, y1) and torch.equal(g0, g1) and torch.equal(gx0, gx1)      # the same arithmetic, the mask from another place
+    for k in gp0:
+        assert_close(gp1[k], gp0[k], 1e-6, k)

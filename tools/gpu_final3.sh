@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round-3 evidence in one GPU-box session.   usage: tools/gpu_final3.sh <tag> [notest]
+#   full parity suite + smoke; the default bench line (headline batch 4 + the batch-32 block + cpu_baseline) and its layer tables;
+#   single-stream bench lines (per-kernel times without stream overlap) at batch 4 and 32; BASELINE configs[1] (ffhq128 fp32 b64);
+#   the 2-ranks-on-one-GPU dry run of the N>1 control flow; rocprofv3 --kernel-trace --stats, one SQ counter pass, two HBM traffic
+#   passes of the single-stream headline step; the kernel probes.
+tag=${1:-final3}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
+cd $R
+if [ "$2" != "notest" ]; then
+  timeout 1500 python -m pytest tests -q -m gpu --durations=8 > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
+  grep -aE "passed|failed" $O/pytest.log | tail -2
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
+fi
+echo "== bench default (b4 + b32 blocks, cpu baseline)"; timeout 900 python bench.py --layer-table $O/layers_b4.tsv 2>$O/bench_default.err | tail -1 > $O/bench_default.json; cut -c1-260 $O/bench_default.json
+echo "== bench b4 single stream"; timeout 400 python bench.py --no-b32 --no-cpu-baseline --graphs off --streams 00 --layer-table $O/layers_b4_single.tsv 2>/dev/null | tail -1 > $O/bench_b4_single.json; cut -c1-200 $O/bench_b4_single.json
+echo "== bench b32 single stream"; timeout 400 python bench.py --batch-per-gpu 32 --steps 8 --warmup 2 --no-cpu-baseline --graphs off --streams 00 --layer-table $O/layers_b32_single.tsv 2>/dev/null | tail -1 > $O/bench_b32_single.json; cut -c1-200 $O/bench_b32_single.json
+echo "== bench ffhq128 fp32 b64"; timeout 300 python bench.py --config ffhq128 --dtype fp32 --batch-per-gpu 64 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_ffhq128_fp32_b64.json; cut -c1-200 $O/bench_ffhq128_fp32_b64.json
+echo "== dry run: 2 ranks on this GPU (gloo)"; timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --dry-run-ranks-on-one-gpu --steps 4 --warmup 1 --no-cpu-baseline --graphs off 2>/dev/null | grep '^{"metric"' | tail -1 > $O/bench_dry_run_2ranks_one_gpu.json; cut -c1-200 $O/bench_dry_run_2ranks_one_gpu.json
+for p in conv16_probe conv2_probe wgrad16_probe; do timeout 300 python tools/$p.py 2>&1 | grep -v amdgpu.ids > $O/$p.txt; done
+cd /tmp && export TMPDIR=/tmp
+echo "== rocprofv3 stats"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o st -- python $R/bench.py --steps 4 --warmup 1 --no-b32 --no-cpu-baseline --no-kernel-timing --graphs off --streams 00 > $O/prof_bench.log 2>&1
+tail -1 $O/prof_bench.log | cut -c1-200
+rm -f $O/prof/*kernel_trace.csv $O/prof/*agent_info.csv
+echo "== SQ counter pass"
+SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"
+timeout 600 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/sq -o p -- python $R/bench.py --steps 1 --warmup 1 --no-b32 --no-cpu-baseline --no-kernel-timing --graphs off --streams 00 > $O/sq.log 2>&1
+python $R/tools/pmc_mfma.py $O/sq/p_counter_collection.csv $O/pmc_mfma_b4.json | head -24
+rm -rf $O/sq
+echo "== HBM traffic passes"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/$c -o p -- python $R/bench.py --steps 2 --warmup 1 --no-b32 --no-cpu-baseline --no-kernel-timing --graphs off --streams 00 > $O/$c.log 2>&1
+done
+python $R/tools/pmc_traffic.py $O/FETCH_SIZE/p_counter_collection.csv $O/WRITE_SIZE/p_counter_collection.csv $O/pmc_traffic_b4.json 0.4 | head -24
+rm -rf $O/FETCH_SIZE $O/WRITE_SIZE
