@@ -49,12 +49,13 @@ def main():
     ap.add_argument("--variants", type=int, nargs="+", default=[0, 4, 8])
     ap.add_argument("--check", type=int, default=1)
     ap.add_argument("--geo", nargs="+", default=["S", "D", "U"])
+    ap.add_argument("--only-h", type=int, default=0, help="only the shapes of this input height (counter passes: one shape per kernel name)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     only = set(a.geo)
     for B in a.batch:
         for geo, H, ci, co in SHAPES:
-            if geo not in only:
+            if geo not in only or (a.only_h and H != a.only_h):
                 continue
             torch.manual_seed(H + ci)
             w = torch.randn(co, ci, 3, 3, device=dev)
