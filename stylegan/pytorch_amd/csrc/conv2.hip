@@ -62,7 +62,6 @@ struct Conv2Args {
     // C2_S, register epilogue: one SIGN bit per stored element (1 = value > 0), [pixel][Cout / 8] bytes, bit j = channel 8v + j --
     // what the LeakyReLU backward of the discriminator block needs of the pre-activation (1/16 of re-reading it)
     unsigned char* signbits;
-    int dbg;                                  // profiling ablations (SGX_CONV2_DBG; wrong results by design): 1 = no DMA after the first two stages
 };
 enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BLUR = 2 };
 
@@ -90,7 +89,7 @@ template <int GEO, int NW, int MF, int KC = 32> struct C2Lds {
 // NW waves per block, each owning 2 rows x 32 pixels of the tile grid; MF 32-channel accumulator rows per wave.
 // KC: input channels per K-step (32; 16 = the planar half-width stage).  CO16: 16 real output channels in the 32-channel block.
 template <int GEO, int NW, int MF, int KC = 32, bool CO16 = false, int EPI = EPI_NONE>
-__global__ __launch_bounds__(NW * 64, (KC == 16 && GEO == C2_S && EPI == EPI_NONE ? 2 : 1) * NW / 4) void conv2_kernel(Conv2Args a) {
+__global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
     using G = G2<GEO>;
     using L = C2Lds<GEO, NW, MF, KC>;
     constexpr int TH = L::TH, PW = L::PW, BCO = L::BCO, PROWS = L::PROWS, WROWS = L::WROWS;
@@ -288,7 +287,7 @@ __global__ __launch_bounds__(NW * 64, (KC == 16 && GEO == C2_S && EPI == EPI_NON
     for (int step = 0; step < nsteps; ++step) {
         char* cur = smem + (step & 1) * STAGE;
         __syncthreads();                         // (vmcnt(0) first) stage `step` landed; everyone is done with step-1
-        if (step + 1 < nsteps && !(a.dbg & 1)) issue(step + 1, smem + ((step + 1) & 1) * STAGE);
+        if (step + 1 < nsteps) issue(step + 1, smem + ((step + 1) & 1) * STAGE);
         // EPI_STATS: the noise values of the pixels this lane stores in the tile's epilogue, requested before the MFMAs of the
         // tile's last K-step so that they have landed when the epilogue needs them
         constexpr int NSI = (GEO == C2_U ? 64 : 32) * VPR / 64;       // store iterations per row
@@ -651,228 +650,6 @@ __global__ __launch_bounds__(NW * 64, (KC == 16 && GEO == C2_S && EPI == EPI_NON
     }
 }
 
-// ---- round 3: the MFMA-bound 3x3 layers with a DEEPER DMA pipeline.  Ablation (SGX_CONV2_DBG=1, profiles/r03_conv2_pipe.txt):
-// with the DMA of the steady state removed the two-stage kernel above runs 20-25 % faster on the 64..512-channel layers -- a K-step's
-// MFMAs (2.3 k cycles) do not cover an HBM/L2 round trip plus the issue arithmetic, and __syncthreads() drains vmcnt to 0 at every
-// step.  Here: NST stages of 16 input channels (the planar layout of the 16-channel variants; a stage of the 8-wave, 64-channel
-// block is 38 KB, four fill 152 KB), stage s + NST - 1 requested while stage s is consumed, and the barrier waits with
-// s_waitcnt vmcnt(N), N = the DMA instructions THIS wave issued for the NST - 2 younger stages (loads retire in order; stores of
-// an epilogue in between only make the wait conservative) -- a request has 3 K-steps (3.5 k cycles) to land instead of 1 (2.3 k).
-// The issue cursor (tile, chunk) advances incrementally: no integer division in the steady state.
-template <int NW, int MF, int NST> struct C2PLds {
-    static constexpr int TH = 2 * NW, PH = TH + 2, PW = 34, BCO = MF * 32, PROWS = PH * PW, WROWS = 9 * BCO;
-    static constexpr int P_INSTR = (PROWS * 2 + 63) / 64, P_BYTES = P_INSTR * 1024;
-    static constexpr int W_INSTR = WROWS * 2 / 64, W_BYTES = W_INSTR * 1024;
-    static constexpr int STAGE = P_BYTES + W_BYTES, TOTAL = NST * STAGE;
-    static_assert((NST & (NST - 1)) == 0 && NST >= 2, "stage ring: a power of two");
-};
-
-// s_waitcnt vmcnt(K * DMA instructions per stage of wave `wave`) + s_barrier
-template <int NW, int PI, int WI, int K, int w = 0> __device__ __forceinline__ void c2p_wait_barrier(int wave) {
-    constexpr int cnt = (PI - w + NW - 1) / NW + (WI - w + NW - 1) / NW;
-    static_assert(K * cnt <= 63, "vmcnt is a 6-bit counter");
-    if constexpr (w == NW - 1) {
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(K * cnt) : "memory");
-    } else {
-        if (wave == w) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(K * cnt) : "memory");
-        else c2p_wait_barrier<NW, PI, WI, K, w + 1>(wave);
-    }
-}
-
-template <int NW, int MF, int NST>
-__global__ __launch_bounds__(NW * 64, NW / 4) void conv2p_kernel(Conv2Args a) {
-    using L = C2PLds<NW, MF, NST>;
-    constexpr int TH = L::TH, PW = L::PW, BCO = L::BCO, PROWS = L::PROWS, WROWS = L::WROWS;
-    constexpr int P_INSTR = L::P_INSTR, P_BYTES = L::P_BYTES, W_INSTR = L::W_INSTR, STAGE = L::STAGE;
-    constexpr int NPI = (P_INSTR + NW - 1) / NW, NWI = (W_INSTR + NW - 1) / NW;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // block -> (channel block, tile slot), XCD bands: as in conv2_kernel
-    const int bid = blockIdx.x, xcd = bid & 7, j8 = bid >> 3;
-    const int cb = j8 % a.ncb, slot = (j8 / a.ncb) * 8 + xcd;
-    const int co0 = cb * BCO;
-    const int band = (a.ntiles + 7) >> 3, per = a.nslots >> 3, lslot = j8 / a.ncb;
-    const int band_len = a.ntiles - xcd * band < band ? a.ntiles - xcd * band : band;
-    const int tile0 = a.bands ? xcd * band + lslot : slot, tstride = a.bands ? per : a.nslots;
-    const int my_tiles = a.bands ? (lslot < band_len ? (band_len - lslot + per - 1) / per : 0)
-                                 : (slot < a.ntiles ? (a.ntiles - slot + a.nslots - 1) / a.nslots : 0);
-    if (my_tiles <= 0) return;
-    const int nchunks = a.Cin >> 4;
-    const int nsteps = my_tiles * nchunks;
-
-    // ---- per-lane DMA descriptors: slot s of a stage region = (chunk c, row) planar
-    int prel[NPI], ppos[NPI], wrel[NWI];
-#pragma unroll
-    for (int jj = 0; jj < NPI; ++jj) {
-        const int s = (jj * NW + wave) * 64 + lane;
-        const int row = s % PROWS, c = s / PROWS, pr = row / PW, pc = row % PW;
-        prel[jj] = (pr * a.W + pc) * a.Cin + (c << 3);
-        ppos[jj] = c < 2 ? ((pr << 8) | pc) : -1;
-    }
-#pragma unroll
-    for (int jj = 0; jj < NWI; ++jj) {
-        const int s = (jj * NW + wave) * 64 + lane;
-        const int row = s % WROWS, c = s / WROWS, t = row / BCO, n = row % BCO;
-        wrel[jj] = ((t * a.Cout + co0 + n) * a.Cin) + (c << 3);
-    }
-    int poff[3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) poff[dx] = (hi * PROWS + 2 * wave * PW + l31 + dx) * 16;
-    const int woff = P_BYTES + (hi * WROWS + l31) * 16;
-
-    const bf16_t* __restrict__ xg = a.x;
-    const bf16_t* __restrict__ wg = a.w;
-    const unsigned long long zaddr = reinterpret_cast<unsigned long long>(sgx_zero_page) + (lane & 3) * 16;
-    auto tile_coords = [&](int t, int& b, int& ty0, int& tx0) {
-        const int tx_i = t % a.tiles_x; t /= a.tiles_x;
-        const int ty_i = t % a.tiles_y;
-        b = t / a.tiles_y; ty0 = ty_i * TH; tx0 = tx_i * 32;
-    };
-    // ---- the issue cursor: K-step `issued` = (tile i_t, chunk i_kc) goes to stage issued % NST
-    int issued = 0, i_t = tile0, i_kc = 0, i_b, i_ty0, i_tx0;
-    tile_coords(i_t, i_b, i_ty0, i_tx0);
-    auto issue_next = [&]() {
-        char* buf = smem + (issued & (NST - 1)) * STAGE;
-        const int iy0 = i_ty0 - 1, ix0 = i_tx0 - 1;
-        const bf16_t* base = xg + (((long)i_b * a.H + iy0) * a.W + ix0) * a.Cin + i_kc * 16;
-#pragma unroll
-        for (int jj = 0; jj < NPI; ++jj) {
-            const int ii = jj * NW + wave;
-            if (ii < P_INSTR) {
-                const int pp = ppos[jj];
-                const int gy = iy0 + (pp >> 8), gx = ix0 + (pp & 255);
-                const unsigned long long ok = ((pp >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W)) ? ~0ull : 0ull;
-                const unsigned long long pa = reinterpret_cast<unsigned long long>(base + prel[jj]);
-                glds16(reinterpret_cast<const void*>(zaddr + ((pa - zaddr) & ok)), buf + ii * 1024);
-            }
-        }
-        const bf16_t* w0 = wg + i_kc * 16;
-#pragma unroll
-        for (int jj = 0; jj < NWI; ++jj) {
-            const int ii = jj * NW + wave;
-            if (ii < W_INSTR) glds16(w0 + wrel[jj], buf + P_BYTES + ii * 1024);
-        }
-        ++issued;
-        if (++i_kc == nchunks) {
-            i_kc = 0; i_t += tstride;
-            if (issued < nsteps) tile_coords(i_t, i_b, i_ty0, i_tx0);
-        }
-    };
-
-    f32x16 acc[MF][2];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int m = 0; m < MF; ++m)
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][f][r] = 0.f;
-    };
-    zero_acc();
-    // bias once, before the pipeline starts: a load in the steady state would make the compiler wait for every DMA issued before it
-    float4 bv[MF][4];
-#pragma unroll
-    for (int m = 0; m < MF; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            bv[m][g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + co0 + m * 32 + 8 * g + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
-    // (an empty use: the compiler places its wait for the bias HERE -- it cannot see the vmcnt waits of the loop, and would otherwise
-    // drain the DMA pipeline with vmcnt(0) at the first use in every tile's epilogue)
-#pragma unroll
-    for (int m = 0; m < MF; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(bv[m][g].x), "v"(bv[m][g].y), "v"(bv[m][g].z), "v"(bv[m][g].w));
-
-    for (int i = 0; i < NST - 1 && i < nsteps; ++i) issue_next();
-    int c_t = tile0, c_kc = 0, b, ty0, tx0;
-    tile_coords(c_t, b, ty0, tx0);
-    for (int step = 0; step < nsteps; ++step) {
-        char* cur = smem + (step & (NST - 1)) * STAGE;
-        // stage `step` has landed (this wave's share: vmcnt; everyone's: the barrier) and everyone is done with stage step - 1
-        if (issued - step == NST - 1) c2p_wait_barrier<NW, P_INSTR, W_INSTR, NST - 2>(wave);
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (issued < nsteps) issue_next();
-        {
-            // 3 column shifts x 3 row shifts; per column shift the 4 patch rows this wave touches are read once; fragments are
-            // software-pipelined one tap (weights) / one column shift (patch rows) ahead
-            bf16x8 brow[2][4], af[2][MF];
-            auto ld_brow = [&](int dx, bf16x8 (&dst)[4]) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[r] = *reinterpret_cast<const bf16x8*>(cur + poff[dx] + r * PW * 16);
-            };
-            auto ld_af = [&](int sub, bf16x8 (&dst)[MF]) {
-                const int dx = sub / 3, dy = sub % 3;
-#pragma unroll
-                for (int m = 0; m < MF; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(cur + woff + ((dy * 3 + dx) * BCO + m * 32) * 16);
-            };
-            ld_brow(0, brow[0]);
-            ld_af(0, af[0]);
-#pragma unroll
-            for (int sub = 0; sub < 9; ++sub) {
-                const int dx = sub / 3, dy = sub % 3;
-                if (sub + 1 < 9) ld_af(sub + 1, af[(sub + 1) & 1]);
-                if (dy == 0 && dx + 1 < 3) ld_brow(dx + 1, brow[(dx + 1) & 1]);
-#pragma unroll
-                for (int m = 0; m < MF; ++m)
-#pragma unroll
-                    for (int f = 0; f < 2; ++f)
-                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sub & 1][m], brow[dx & 1][f + dy], acc[m][f], 0, 0, 0);
-            }
-        }
-        if (++c_kc == nchunks) {
-            // ---- register epilogue (see conv2_kernel): permlane32_swap pairs the half-waves' 4-channel groups into 16-byte stores
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                const int oy = ty0 + 2 * wave + f, ox = tx0 + l31;
-                const bool inimg = oy < a.OH && ox < a.OW;
-                const size_t pix = (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + 8 * hi;
-#pragma unroll
-                for (int m = 0; m < MF; ++m) {
-                    uint2 o2[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float v[4] = {acc[m][f][4 * g], acc[m][f][4 * g + 1], acc[m][f][4 * g + 2], acc[m][f][4 * g + 3]};
-                        v[0] += bv[m][g].x; v[1] += bv[m][g].y; v[2] += bv[m][g].z; v[3] += bv[m][g].w;
-                        if (a.act == SGX_ACT_LRELU) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i]);
-                        }
-                        o2[g].x = pack_bf16x2(v[0], v[1]);
-                        o2[g].y = pack_bf16x2(v[2], v[3]);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        uint2 lo = o2[2 * k], up = o2[2 * k + 1];
-                        auto rx = __builtin_amdgcn_permlane32_swap(lo.x, up.x, false, false);
-                        auto ry = __builtin_amdgcn_permlane32_swap(lo.y, up.y, false, false);
-                        uint4 val = make_uint4(rx[0], ry[0], rx[1], ry[1]);
-                        if (inimg) {
-                            const size_t doff = pix + m * 32 + 16 * k;
-                            if (a.mask) val = lrelu_mask_bf16x8(val, *reinterpret_cast<const uint4*>(a.mask + doff));
-                            *reinterpret_cast<uint4*>(a.y + doff) = val;
-                            if (a.signbits) {
-                                const unsigned wv[4] = {val.x, val.y, val.z, val.w};
-                                unsigned bits = 0;
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    bits |= ((short)(wv[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q);
-                                    bits |= ((short)(wv[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
-                                }
-                                a.signbits[doff >> 3] = (unsigned char)bits;
-                            }
-                        }
-                    }
-                }
-            }
-            zero_acc();
-            c_kc = 0; c_t += tstride;
-            if (step + 1 < nsteps) tile_coords(c_t, b, ty0, tx0);
-        }
-    }
-}
-
 static int conv2_ncu() {
     static const int ncu = [] {
         int dev = 0, n = 0;
@@ -922,46 +699,9 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
     a.nslots = per * 8;
     static const int bands_on = [] { const char* e = getenv("SGX_TILE_BANDS"); return e ? atoi(e) : 1; }();   // measured (tools/gpu_r2u.sh): halo over-fetch gone (PMC), 80.8 vs 81.2 ms at batch 32, nothing at batch 4
     a.bands = (bands_on && a.ntiles >= 8 * a.nslots) ? 1 : 0;      // enough tiles per slot for the order to matter
-    static const int dbg = [] { const char* e = getenv("SGX_CONV2_DBG"); return e ? atoi(e) : 0; }();
-    a.dbg = dbg;
     hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.ncb * per)), dim3(NW * 64), LDS, st, a);
     SGX_LAUNCH_CHECK("conv2_kernel");
     return 0;
-}
-
-template <int NW, int MF, int NST>
-static int launch_conv2p(Conv2Args& a, hipStream_t st) {
-    using L = C2PLds<NW, MF, NST>;
-    static_assert(L::TOTAL <= 160 * 1024, "LDS budget");
-    auto kern = conv2p_kernel<NW, MF, NST>;
-    static bool attr_done[32] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
-    if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
-        attr_done[dev] = true;
-    }
-    a.tiles_x = (a.W + 31) / 32; a.tiles_y = (a.H + L::TH - 1) / L::TH;
-    a.ntiles = a.B * a.tiles_y * a.tiles_x;
-    a.ncb = a.Cout / L::BCO;
-    int per = conv2_ncu() / (8 * a.ncb);
-    const int need = (a.ntiles + 7) / 8;
-    if (per > need) per = need;
-    if (per < 1) per = 1;
-    a.nslots = per * 8;
-    static const int bands_on = [] { const char* e = getenv("SGX_TILE_BANDS"); return e ? atoi(e) : 1; }();
-    a.bands = (bands_on && a.ntiles >= 8 * a.nslots) ? 1 : 0;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.ncb * per)), dim3(NW * 64), L::TOTAL, st, a);
-    SGX_LAUNCH_CHECK("conv2p_kernel");
-    return 0;
-}
-// the 3x3 layers of >= 32 channels: the deep-pipeline kernel (SGX_CONV2_PIPE, default on) or the two-stage one
-template <int NW, int MF>
-static int launch_conv2_s(Conv2Args& a, hipStream_t st) {
-    static const int pipe = [] { const char* e = getenv("SGX_CONV2_PIPE"); return e ? atoi(e) : 1; }();   // A/B switch
-    if (pipe == 1 && a.Cin % 16 == 0 && a.Cin >= 32) return launch_conv2p<NW, MF, 4>(a, st);
-    if (pipe == 2 && a.Cin % 16 == 0 && a.Cin >= 32) return launch_conv2<C2_S, NW, MF, 16, false>(a, st);   // half-width stages, two blocks per CU
-    return launch_conv2<C2_S, NW, MF>(a, st);
 }
 
 // Which layers take this kernel, and with which block shape (SGX_CONV2=0 switches it off: A/B against conv.hip).
@@ -1013,7 +753,7 @@ int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void
     if (!p.nw) return 0;
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
                 geo == C2_D ? H / 2 : (geo == C2_U ? 2 * H : H), geo == C2_D ? W / 2 : (geo == C2_U ? 2 * W : W), Cin, Cout, act, 0, 0, 0, 0, 0, 0,
-                nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+                nullptr, nullptr, nullptr, nullptr, nullptr};
     *launched = 1;
     const int nw = p.nw;
     if (p.k16) {
@@ -1022,8 +762,8 @@ int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void
         return nw == 8 ? launch_conv2<C2_U, 8, 1, 32, true>(a, st) : launch_conv2<C2_U, 4, 1, 32, true>(a, st);
     }
     if (geo == C2_S) {
-        if (p.mf2) return nw == 8 ? launch_conv2_s<8, 2>(a, st) : launch_conv2_s<4, 2>(a, st);
-        return nw == 8 ? launch_conv2_s<8, 1>(a, st) : launch_conv2_s<4, 1>(a, st);
+        if (p.mf2) return nw == 8 ? launch_conv2<C2_S, 8, 2>(a, st) : launch_conv2<C2_S, 4, 2>(a, st);
+        return nw == 8 ? launch_conv2<C2_S, 8, 1>(a, st) : launch_conv2<C2_S, 4, 1>(a, st);
     }
     if (geo == C2_D) {
         if (p.mf2) return nw == 8 ? launch_conv2<C2_D, 8, 2>(a, st) : launch_conv2<C2_D, 4, 2>(a, st);
@@ -1071,7 +811,7 @@ extern "C" int sgx_conv3x3_stats(const void* x, const void* w, void* y, const fl
                 (size_t)B * npart * Cout * 2 * sizeof(double));
     SGX_NOTE(2.0 * 9 * Cin * Cout * B * H * W, 2.0 * ((double)B * H * W * (Cin + Cout) + 9.0 * Cin * Cout), "convS+stats B%d %dx%d %d->%d", B, H, W, Cin, Cout);
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), nullptr, static_cast<bf16_t*>(y), nullptr, B, H, W, H, W, Cin, Cout,
-                SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, ebias, noise, nw_, part, nullptr, 0};
+                SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, ebias, noise, nw_, part, nullptr};
     hipStream_t st = (hipStream_t)stream;
     const int nw = p.nw;
     if (p.k16) return nw == 8 ? launch_conv2<C2_S, 8, 1, 16, true, EPI_STATS>(a, st) : launch_conv2<C2_S, 4, 1, 16, true, EPI_STATS>(a, st);
@@ -1096,7 +836,7 @@ extern "C" int sgx_conv4x4s2_up_blur(const void* x, const void* w, void* y, cons
     SGX_NOTE(2.0 * 16 * Cin * Cout * B * H * W, 2.0 * ((double)B * H * W * (Cin + 4.0 * Cout * (mask ? 2 : 1)) + 16.0 * Cin * Cout),
              "convU+blur%s B%d %dx%d %d->%d", mask ? "*mask" : "", B, H, W, Cin, Cout);
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), nullptr, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
-                2 * H, 2 * W, Cin, Cout, SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+                2 * H, 2 * W, Cin, Cout, SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     if (p.k16) return p.nw == 8 ? launch_conv2<C2_U, 8, 1, 32, true, EPI_BLUR>(a, st) : launch_conv2<C2_U, 4, 1, 32, true, EPI_BLUR>(a, st);
     return p.nw == 8 ? launch_conv2<C2_U, 8, 1, 32, false, EPI_BLUR>(a, st) : launch_conv2<C2_U, 4, 1, 32, false, EPI_BLUR>(a, st);
@@ -1119,10 +859,10 @@ extern "C" int sgx_conv3x3_signbits(const void* x, const void* w, const float* b
     SGX_NOTE(2.0 * 9 * Cin * Cout * B * H * W, 2.0 * ((double)B * H * W * (Cin + Cout) + 9.0 * Cin * Cout) + (double)B * H * W * Cout / 8.0,
              "convS+bits B%d %dx%d %d->%d", B, H, W, Cin, Cout);
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W, H, W,
-                Cin, Cout, act, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, static_cast<unsigned char*>(bits), 0};
+                Cin, Cout, act, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, static_cast<unsigned char*>(bits)};
     hipStream_t st = (hipStream_t)stream;
     const int nw = p.nw;
     if (p.k16) return nw == 8 ? launch_conv2<C2_S, 8, 1, 16, true>(a, st) : launch_conv2<C2_S, 4, 1, 16, true>(a, st);
-    if (p.mf2) return nw == 8 ? launch_conv2_s<8, 2>(a, st) : launch_conv2_s<4, 2>(a, st);
-    return nw == 8 ? launch_conv2_s<8, 1>(a, st) : launch_conv2_s<4, 1>(a, st);
+    if (p.mf2) return nw == 8 ? launch_conv2<C2_S, 8, 2>(a, st) : launch_conv2<C2_S, 4, 2>(a, st);
+    return nw == 8 ? launch_conv2<C2_S, 8, 1>(a, st) : launch_conv2<C2_S, 4, 1>(a, st);
 }
