@@ -54,6 +54,9 @@ class _NoGradCtx:
     def mark_non_differentiable(self, *tensors):
         pass
 
+    def set_materialize_grads(self, value):
+        pass
+
 
 def call(fn, *args):
     """``fn.apply(*args)`` -- or, when no gradient can flow (``torch.no_grad()``: the D-step generator forward; or no
@@ -355,6 +358,9 @@ class ConvFn(Function):
         ctx.cfg = (mode, scale, ipad, adjoint, act, bias is not None, bool(defer_act), bool(x_masked))
         ctx.bias_ref = weakref.ref(bias) if bias is not None else (lambda: None)
         ctx.x_pre, ctx.x_pre_bits = x_pre, x_pre_bits
+        # (two outputs: without this the engine hands backward a freshly zero-filled "gradient" of the non-differentiable one --
+        # a fill kernel per call, 20 a step)
+        ctx.set_materialize_grads(False)
         if bits_out:
             assert geo == "S" and not adjoint and stats is None
             y, bits = _conv_bits_launch(x, fwd, None if bias is None else _c(bias.detach()), act, mask)
@@ -373,6 +379,8 @@ class ConvFn(Function):
 
     @staticmethod
     def backward(ctx, gy, _gpart=None):
+        if gy is None:                                        # (only a non-differentiable output was "used")
+            return (None,) * 15
         x, weight, y, mask = ctx.saved_tensors
         mode, scale, ipad, adjoint, act, has_bias, defer_act, x_masked = ctx.cfg
         gy = _c(gy)
@@ -773,11 +781,12 @@ class BlurStatsFn(Function):
                                     N.ptr(_c(nw.detach())), N.ptr(part), part.numel() * 8, B, H, W, C, N.ACT_LRELU, N.dt(x), N.stream()),
                 "sgx_blur3x3_stats")
         ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)
         return y, part
 
     @staticmethod
     def backward(ctx, g, _gpart):
-        return _bcall(BlurFn, g), None, None, None
+        return (_bcall(BlurFn, g) if g is not None else None), None, None, None
 
 
 class BlurGenFn(Function):

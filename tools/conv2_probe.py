@@ -22,22 +22,28 @@ SHAPES = [  # (geo, H (input), Cin, Cout)
 GEO = {"S": 0, "D": 1, "U": 2}
 
 
-def run(geo, variant, x, wq, bias, act, reps):
+def run(geo, variant, x, wq, bias, act, reps, cold=0):
     B, H, W, Cin = x.shape
     Cout = wq.shape[1]
     oh = H // 2 if geo == "D" else (2 * H if geo == "U" else H)
     y = torch.empty((B, oh, oh, Cout), dtype=x.dtype, device=x.device)
     L = N.lib()
+    # --cold N: rotate through N copies of every operand, so that a launch finds none of them in L2 / the memory-side cache (as in
+    # the training step, where the operands were last touched many launches ago); 0 = the same buffers every time (all cache hits)
+    xs = [x] + [x.clone() for _ in range(cold)]
+    ws = [wq] + [wq.clone() for _ in range(cold)]
+    ys = [y] + [torch.empty_like(y) for _ in range(cold)]
 
-    def go():
-        N.check(L.sgx_conv_variant(GEO[geo], N.ptr(x), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, Cin, Cout, act, N.BF16, variant, N.stream()),
+    def go(i=0):
+        k = i % len(xs)
+        N.check(L.sgx_conv_variant(GEO[geo], N.ptr(xs[k]), N.ptr(ws[k]), N.ptr(bias), N.ptr(ys[k]), B, H, W, Cin, Cout, act, N.BF16, variant, N.stream()),
                 "sgx_conv_variant")
     go(); go()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        go()
+    for i in range(reps):
+        go(i)
     e1.record(); torch.cuda.synchronize()
     return y, e0.elapsed_time(e1) * 1e3 / reps
 
@@ -49,6 +55,7 @@ def main():
     ap.add_argument("--variants", type=int, nargs="+", default=[0, 4, 8])
     ap.add_argument("--check", type=int, default=1)
     ap.add_argument("--geo", nargs="+", default=["S", "D", "U"])
+    ap.add_argument("--cold", type=int, default=0, help="rotate through this many extra copies of the operands (cache-cold launches)")
     ap.add_argument("--only-h", type=int, default=0, help="only the shapes of this input height (counter passes: one shape per kernel name)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -83,7 +90,7 @@ def main():
             line = f"conv{geo} B{B} {H}x{H} {ci}->{co}:"
             for v in a.variants:
                 try:
-                    y, us = run(geo, v, x, wq, bias, 0 if geo == "U" else 1, a.reps)
+                    y, us = run(geo, v, x, wq, bias, 0 if geo == "U" else 1, a.reps, a.cold)
                 except N.SgxError as e:
                     line += f"  v{v}: n/a"
                     continue
