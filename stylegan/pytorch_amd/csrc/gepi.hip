@@ -285,18 +285,19 @@ __global__ void gepi_fin_bwd1(const double* __restrict__ part, const float* __re
     coef[(size_t)i * 2 + 1] = norm ? (float)(sc * s0 / HW) : 0.f;
 }
 
-// backward finalize 2: d noise-weight and d bias per channel (sum over images and chunks); 16 lanes per channel
+// backward finalize 2: d noise-weight and d bias per channel (sum over images and chunks); one wave per channel (batch 32 at
+// 1024^2 has 8192 partials per channel: with 16 lanes per channel and one block for 16 channels this was a 32 us serial tail)
 __global__ void gepi_fin_bwd2(const double* __restrict__ part, float* __restrict__ dnw, float* __restrict__ dbias, int B, int C,
                               int nchunk) {
-    const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
     const bool ok = c < C;
     double a = 0.0, d = 0.0;
     if (ok)
-        for (int k = l; k < B * nchunk; k += 16) {
-            const double* p = part + ((size_t)k * C + c) * 2;
-            a += p[0]; d += p[1];
+        for (int k = l; k < B * nchunk; k += 64) {
+            const double2 p = *reinterpret_cast<const double2*>(part + ((size_t)k * C + c) * 2);
+            a += p.x; d += p.y;
         }
-    a = sum16(a); d = sum16(d);
+    a = wave_sum_d(a); d = wave_sum_d(d);
     if (!ok || l) return;
     dnw[c] = (float)a;
     if (dbias) dbias[c] = (float)d;
@@ -448,7 +449,7 @@ static int gepi_bwd_t(const void* dy, const void* x, const float* bias, const fl
                            (const double*)nullptr, 0, 0, (float*)nullptr);
         SGX_LAUNCH_CHECK("gepi_bwd2");
     }
-    hipLaunchKernelGGL(gepi_fin_bwd2, dim3((C + 15) / 16), dim3(256), 0, st, partB, dnw, dbias, B, C, g.nchunk);
+    hipLaunchKernelGGL(gepi_fin_bwd2, dim3((C + 3) / 4), dim3(256), 0, st, partB, dnw, dbias, B, C, g.nchunk);
     SGX_LAUNCH_CHECK("gepi_fin_bwd2");
     return 0;
 }

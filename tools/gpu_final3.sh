@@ -8,6 +8,10 @@ tag=${1:-final3}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R
 if [ "$2" != "notest" ]; then
+  # bf16 gates = 2 x the error measured for THIS code: recorded first, then the whole suite runs against them
+  rm -f $O/bf16_gates.json
+  SGX_RECORD_BF16_GATES=$O/bf16_gates.json timeout 900 python -m pytest tests/test_gpu_bf16.py -q -m gpu > $O/pytest_record_gates.log 2>&1; echo "record rc=$?"
+  [ -s $O/bf16_gates.json ] && cp $O/bf16_gates.json tests/golden/bf16_gates.json
   timeout 1500 python -m pytest tests -q -m gpu --durations=8 > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
   grep -aE "passed|failed" $O/pytest.log | tail -2
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
