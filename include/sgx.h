@@ -257,6 +257,12 @@ int sgx_mbstd_bwd2(const void* ggx, const void* dy, const void* x, void* ddy, vo
 size_t sgx_sumsq_ws_bytes(void);
 int sgx_sumsq_f32(const float* x, size_t n, void* ws, size_t ws_bytes, float* out, void* stream);
 int sgx_scale_dev_f32(const float* x, const float* s, float alpha, float* out, size_t n, void* stream);
+/* Logistic loss heads (models/Losses.py:213-229: mean softplus(fake) + mean softplus(-real); generator :227-229: mean softplus(-fake)),
+ * times `scale` (1 / world size under data parallelism): loss[0] and the derivative w.r.t. every logit (g_fake [n_fake], g_real
+ * [n_real]) from ONE launch instead of ~9 elementwise / reduction launches forward and as many backward.  generator != 0: real /
+ * g_real are ignored (n_real must be 0).  fp32 logits.                                                                           */
+int sgx_logistic_loss(const float* fake, int n_fake, const float* real, int n_real, float scale, int generator, float* loss,
+                      float* g_fake, float* g_real, void* stream);
 /* C[M][N] = alpha * op(A) * op(B) (+ beta*C), row-major fp32, MFMA f32 16x16x4.  EqualizedLinear
  * (models/CustomLayers.py:99-103: F.linear(x, W*w_mul)) and its gradients.  ta/tb: 0 = as stored, 1 = transposed:
  *   ta=0: A is [M][K], ta=1: A is [K][M];  tb=0: B is [K][N], tb=1: B is [N][K].                                      */

@@ -147,9 +147,14 @@ class LogisticGAN(GANLoss):
             if callable(fake_samps):                  # produced lazily, after D(real)
                 fake_samps = fake_samps()
             f_preds = self.dis(fake_samps, height, alpha)
-        loss = (torch.mean(TF.softplus(f_preds)) + torch.mean(TF.softplus(-r_preds))) * self.mean_scale
+        if f_preds.is_cuda:                          # one launch for both terms and their derivatives (sgx_logistic_loss)
+            loss = F.call(F.LogisticLossFn, f_preds, r_preds, self.mean_scale, False)
+        else:                                        # (host tensors: the data-parallel logic tests drive these classes on the CPU)
+            loss = (torch.mean(TF.softplus(f_preds)) + torch.mean(TF.softplus(-r_preds))) * self.mean_scale
         return loss if r1 is None else loss + r1
 
     def gen_loss(self, _, fake_samps, height, alpha):
         f_preds = self.dis(fake_samps, height, alpha)
+        if f_preds.is_cuda:
+            return F.call(F.LogisticLossFn, f_preds, None, self.mean_scale, True)
         return torch.mean(TF.softplus(-f_preds)) * self.mean_scale

@@ -560,6 +560,39 @@ extern "C" int sgx_sumsq_f32(const float* x, size_t n, void* ws, size_t ws_bytes
     SGX_LAUNCH_CHECK("sumsq_stage2");
     return 0;
 }
+// ---- logistic GAN loss heads (models/Losses.py:213-229) in one launch: the scalar loss AND its derivative w.r.t. every logit
+//   discriminator: loss = scale * (mean softplus(fake) + mean softplus(-real)),  d/dfake = scale * sigmoid(fake) / n_fake,
+//                                                                                   d/dreal = -scale * sigmoid(-real) / n_real
+//   generator:     loss = scale * mean softplus(-fake),                            d/dfake = -scale * sigmoid(-fake) / n_fake
+// softplus as torch computes it (threshold 20: beyond it the identity).  One wave: a batch is at most a few hundred logits.
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+__global__ void logistic_loss_kernel(const float* __restrict__ fake, int nf, const float* __restrict__ real, int nr, float scale, int gen,
+                                     float* __restrict__ loss, float* __restrict__ gfake, float* __restrict__ greal) {
+    const int l = threadIdx.x;
+    float sf = 0.f, sr = 0.f;
+    const float sgn = gen ? -1.f : 1.f;                     // the generator wants its fakes called real
+    for (int i = l; i < nf; i += 64) {
+        const float x = sgn * fake[i];
+        sf += softplus_f(x);
+        gfake[i] = sgn * scale * sigmoid_f(x) / (float)nf;
+    }
+    for (int i = l; i < nr; i += 64) {
+        const float x = -real[i];
+        sr += softplus_f(x);
+        greal[i] = -scale * sigmoid_f(x) / (float)nr;
+    }
+    sf = wave_sum(sf); sr = wave_sum(sr);
+    if (l == 0) loss[0] = scale * (sf / (float)(nf > 0 ? nf : 1) + (nr > 0 ? sr / (float)nr : 0.f));
+}
+extern "C" int sgx_logistic_loss(const float* fake, int n_fake, const float* real, int n_real, float scale, int generator, float* loss,
+                                 float* g_fake, float* g_real, void* stream) {
+    SGX_REQUIRE(fake && n_fake > 0 && loss && g_fake, SGX_EINVAL, "logistic_loss: fake logits, loss and g_fake are required");
+    SGX_REQUIRE(generator ? n_real == 0 : (real && g_real && n_real > 0), SGX_EINVAL, "logistic_loss: real logits %s", generator ? "are not part of the generator loss" : "are required");
+    hipLaunchKernelGGL(logistic_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, fake, n_fake, real, n_real, scale, generator, loss, g_fake, g_real);
+    SGX_LAUNCH_CHECK("logistic_loss");
+    return 0;
+}
 __global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ s, float alpha, float* __restrict__ out, size_t n) {
     const float k = alpha * s[0];
     const size_t nvec = n / 4;

@@ -1193,6 +1193,43 @@ class SumSqFn(Function):
         return gx if ctx.back is None else gx.permute(*ctx.back)
 
 
+class LogisticLossFn(Function):
+    """The logistic loss heads (reference models/Losses.py:213-229) as ONE launch forward -- the loss scalar and its derivative w.r.t.
+    every logit -- and one scaling launch per logit tensor backward, instead of ~9 elementwise / reduction kernels each way.
+    ``generator``: mean softplus(-fake) * scale; else (mean softplus(fake) + mean softplus(-real)) * scale.  First order only (the R1
+    penalty differentiates the discriminator, not this head)."""
+
+    @staticmethod
+    def forward(ctx, fake, real, scale, generator):
+        f = _c(fake.detach().reshape(-1))
+        r = None if real is None else _c(real.detach().reshape(-1))
+        if f.dtype != torch.float32 or (r is not None and r.dtype != torch.float32):
+            raise N.SgxError("LogisticLossFn: fp32 logits expected")
+        loss = torch.empty((), dtype=torch.float32, device=f.device)
+        gf = torch.empty_like(f)
+        gr = None if r is None else torch.empty_like(r)
+        N.check(N.lib().sgx_logistic_loss(N.ptr(f), f.numel(), N.ptr(r), 0 if r is None else r.numel(), float(scale), int(bool(generator)),
+                                          N.ptr(loss), N.ptr(gf), N.ptr(gr), N.stream()), "sgx_logistic_loss")
+        ctx.save_for_backward(gf, gr)
+        ctx.shapes = (fake.shape, None if real is None else real.shape)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        gf, gr = ctx.saved_tensors
+        g = _c(g.float())
+        out = []
+        for t, shape in zip((gf, gr), ctx.shapes):
+            if t is None:
+                out.append(None)
+                continue
+            o = torch.empty_like(t)
+            N.check(N.lib().sgx_scale_dev_f32(N.ptr(t), N.ptr(g), 1.0, N.ptr(o), t.numel(), N.stream()), "sgx_scale_dev_f32")
+            out.append(o.view(shape))
+        return out[0], out[1], None, None
+
+
 class MatMulFn(Function):
     """C = alpha * op(A) @ op(B), fp32 row-major.  ta/tb as in sgx_gemm_f32.  Closed under differentiation."""
 

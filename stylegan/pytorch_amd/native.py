@@ -87,6 +87,7 @@ SIGNATURES = {
     "sgx_sumsq_ws_bytes": (Z, []),
     "sgx_sumsq_f32": (I, [P, Z, P, Z, P, P]),
     "sgx_scale_dev_f32": (I, [P, P, F, P, Z, P]),
+    "sgx_logistic_loss": (I, [P, I, P, I, F, I, P, P, P, P]),
     "sgx_gemm_ws_bytes": (Z, [I, I, I]),
     "sgx_gemm_f32": (I, [P, P, P, I, I, I, I, I, F, P, Z, P]),
     "sgx_linear_fwd": (I, [P, P, P, P, I, I, I, F, F, I, P]),

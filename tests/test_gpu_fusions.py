@@ -182,7 +182,8 @@ def test_discriminator_block_backward_with_fused_blur(cin, cout, B, H):
             (g1,) = torch.autograd.grad((y.float() * gy.to(DEV)).sum(), xg, create_graph=True)
             pen = (g1.float() ** 2).sum()
             pen.backward()                                            # second order: d pen / d params, d pen / d x
-            return y.detach(), g1.detach(), xg.grad, {k: p.grad.clone() for k, p in names.items()}
+            # (a parameter the penalty does not depend on -- a bias acts through the LeakyReLU masks only -- has no gradient: zero)
+            return y.detach(), g1.detach(), xg.grad, {k: (torch.zeros_like(p) if p.grad is None else p.grad.clone()) for k, p in names.items()}
         finally:
             F.CONV_BLUR_POLICY = keep
     y0, g0, gx0, gp0 = run(False)
@@ -324,7 +325,8 @@ def test_discriminator_block_with_sign_bits(cin, cout, B, H):
             y = blk.forward_nhwc(xg)
             (g1,) = torch.autograd.grad((y.float() * gy.to(DEV)).sum(), xg, create_graph=True)
             (g1.float() ** 2).sum().backward()
-            return y.detach(), g1.detach(), xg.grad, {k: p.grad.clone() for k, p in names.items()}
+            # (a parameter the penalty does not depend on -- a bias acts through the LeakyReLU masks only -- has no gradient: zero)
+            return y.detach(), g1.detach(), xg.grad, {k: (torch.zeros_like(p) if p.grad is None else p.grad.clone()) for k, p in names.items()}
         finally:
             F.SIGNBITS_ON, F.CONV_BLUR_POLICY = keep, keep_p
     y0, g0, gx0, gp0 = run(False)
@@ -332,3 +334,29 @@ def test_discriminator_block_with_sign_bits(cin, cout, B, H):
     assert torch.equal(y0, y1) and torch.equal(g0, g1) and torch.equal(gx0, gx1)      # the same arithmetic, the mask from another place
     for k in gp0:
         assert_close(gp1[k], gp0[k], 1e-6, k)
+
+
+@pytest.mark.parametrize("B", [1, 4, 32, 100])
+@pytest.mark.parametrize("scale", [1.0, 0.125])
+def test_logistic_loss_heads_in_one_launch(B, scale):
+    """sgx_logistic_loss (reference models/Losses.py:213-229): loss and logit gradients of both heads against torch's own softplus /
+    mean in fp64, including logits beyond softplus' linear threshold; the upstream gradient arrives as a device scalar."""
+    from stylegan.pytorch_amd import functional as F
+    f = (6.0 * gu.seeded((B, 1), 90)).to(DEV)
+    r = (6.0 * gu.seeded((B, 1), 91)).to(DEV)
+    f[0, 0] = 31.0
+    r[0, 0] = -27.5
+    up = torch.tensor(1.7, device=DEV)
+    for gen in (False, True):
+        fa, ra = f.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        loss = F.LogisticLossFn.apply(fa, None if gen else ra, scale, gen)
+        (loss * up).backward()
+        fd, rd = f.double().requires_grad_(True), r.double().requires_grad_(True)
+        ref = (TF.softplus(-fd).mean() if gen else TF.softplus(fd).mean() + TF.softplus(-rd).mean()) * scale
+        (ref * up.double()).backward()
+        assert_close(loss, ref, 1e-6, f"loss gen={gen}")
+        assert_close(fa.grad, fd.grad, 2e-6, f"d/dfake gen={gen}", floor=1e-12)
+        if not gen:
+            assert_close(ra.grad, rd.grad, 2e-6, "d/dreal", floor=1e-12)
+        else:
+            assert ra.grad is None
