@@ -19,6 +19,8 @@ SHAPES = [  # (geo, H (input), Cin, Cout)
     ("D", 512, 32, 64), ("D", 256, 64, 128), ("D", 128, 128, 256), ("D", 64, 256, 512), ("D", 512, 32, 32),
     ("U", 256, 64, 32), ("U", 128, 128, 64), ("U", 64, 256, 128), ("U", 32, 512, 256), ("U", 256, 32, 32),
 ]
+LOWRES = [("S", 16, 512, 512), ("S", 8, 512, 512), ("S", 4, 512, 512), ("D", 64, 256, 512), ("D", 32, 512, 512), ("D", 16, 512, 512), ("D", 8, 512, 512),
+          ("U", 4, 512, 512), ("U", 8, 512, 512), ("U", 16, 512, 512)]          # the latency-bound layers (first generation: --variants 0)
 GEO = {"S": 0, "D": 1, "U": 2}
 
 
@@ -55,13 +57,14 @@ def main():
     ap.add_argument("--variants", type=int, nargs="+", default=[0, 4, 8])
     ap.add_argument("--check", type=int, default=1)
     ap.add_argument("--geo", nargs="+", default=["S", "D", "U"])
+    ap.add_argument("--lowres", action="store_true", help="the 512-channel layers at 4^2..32^2 instead of the default shapes")
     ap.add_argument("--cold", type=int, default=0, help="rotate through this many extra copies of the operands (cache-cold launches)")
     ap.add_argument("--only-h", type=int, default=0, help="only the shapes of this input height (counter passes: one shape per kernel name)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     only = set(a.geo)
     for B in a.batch:
-        for geo, H, ci, co in SHAPES:
+        for geo, H, ci, co in (LOWRES if a.lowres else SHAPES):
             if geo not in only or (a.only_h and H != a.only_h):
                 continue
             torch.manual_seed(H + ci)
