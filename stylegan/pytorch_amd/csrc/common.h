@@ -126,6 +126,18 @@ static inline void sgx_launch(K kern, dim3 grid, dim3 block, size_t lds, hipStre
     kern<<<grid, block, lds, st>>>(args...);
     if (slot >= 0) sgx_prof_end(slot, st);
 }
+// The > 64 KB dynamic-LDS opt-in of a kernel is per DEVICE: applied once for every device a launch of this kernel is made on (a
+// process that drives several GPUs would otherwise fail its first big-LDS launch on the second one).  Keyed by the kernel itself.
+template <auto Kern>
+static inline void sgx_lds_opt_in(int lds_bytes) {
+    static bool done[32] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+    if (!done[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        done[dev] = true;
+    }
+}
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kern, grid, block, lds, st, ...) sgx_launch(kern, grid, block, lds, st, __VA_ARGS__)
 #define SGX_NOTE(flops, bytes, ...)                                     \

@@ -496,9 +496,7 @@ static int launch_conv(ConvArgs& a, int ngroups, hipStream_t st) {
     constexpr int LDS = OPER > OUTB ? OPER : OUTB;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kern = conv_kernel<T, KC, GEO, TH, TW, BP, CT>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)attr;
+    sgx_lds_opt_in<conv_kernel<T, KC, GEO, TH, TW, BP, CT>>(LDS);
     a.ntiles = ngroups * a.tiles_y * a.tiles_x;
     static const int dbg = [] { const char* e = getenv("SGX_CONV_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
@@ -1108,9 +1106,7 @@ static int launch_wgrad(WgradArgs& a, void* ws, size_t ws_bytes, int* nsplit_out
     a.out = static_cast<float*>(ws);
     a.direct = (nsplit == 1 && a.dw != nullptr) ? 1 : 0;
     auto kern = wgrad_kernel<T, GEO, TH, TW, BP, NSUB, KSUB, TR>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)attr;
+    sgx_lds_opt_in<wgrad_kernel<T, GEO, TH, TW, BP, NSUB, KSUB, TR>>(LDS);
     hipLaunchKernelGGL(kern, dim3(pairs, nsplit), dim3(256), LDS, st, a);
     SGX_LAUNCH_CHECK("wgrad_kernel");
     *nsplit_out = nsplit;

@@ -665,14 +665,7 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
     constexpr int LDS = L::TOTAL + (EPI != EPI_NONE ? 1024 : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kern = conv2_kernel<GEO, NW, MF, KC, CO16, EPI>;
-    // the > 64 KB dynamic-LDS opt-in is per device: applied once for every device a launch is made on
-    static bool attr_done[32] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
-    if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_done[dev] = true;
-    }
+    sgx_lds_opt_in<conv2_kernel<GEO, NW, MF, KC, CO16, EPI>>(LDS);
     const int gh = GEO == C2_D ? a.OH : a.H, gw = GEO == C2_D ? a.OW : a.W;       // the tile grid
     a.tiles_x = (gw + 31) / 32; a.tiles_y = (gh + L::TH - 1) / L::TH;
     if constexpr (EPI == EPI_BLUR) {              // tiles overlap by one coarse row / column: steps TH - 1 and 31

@@ -559,28 +559,19 @@ int sgx_wgrad2_launch(int geo, const void* kside, const void* nside, float* ws, 
         a.tiles_y = (H + 15) / 16;
         constexpr int LDS = 2 * (16 * 32 * 32 + ((18 * 34 * 32 + 1023) / 1024) * 1024);
         static_assert(LDS >= 4 * 64 * 40 * 4, "the final reduction's scratch fits the stages");
-        static bool attr_done[32] = {};                              // the > 64 KB dynamic-LDS opt-in is per device
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
-        if (!attr_done[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            attr_done[dev] = true;
-        }
+        sgx_lds_opt_in<wgrad16_s_kernel>(LDS);
         hipLaunchKernelGGL(wgrad16_s_kernel, grid, block, LDS, st, a);
     } else if (geo == 0) {
         constexpr int LDS = 2 * (2 * 8 * 32 * 64 + 2 * ((10 * 34 * 64 + 1023) / 1024) * 1024);
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad2_s_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)attr;
+        sgx_lds_opt_in<wgrad2_s_kernel<8>>(LDS);
         hipLaunchKernelGGL(wgrad2_s_kernel<8>, grid, block, LDS, st, a);
     } else if (kbw == 2) {
         constexpr int LDS = 2 * (2 * 4096 + 8 * 6144);
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad2_d_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)attr;
+        sgx_lds_opt_in<wgrad2_d_kernel<2>>(LDS);
         hipLaunchKernelGGL(wgrad2_d_kernel<2>, grid, block, LDS, st, a);
     } else {
         constexpr int LDS = 2 * (2 * 4096 + 4 * 6144);
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad2_d_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)attr;
+        sgx_lds_opt_in<wgrad2_d_kernel<1>>(LDS);
         hipLaunchKernelGGL(wgrad2_d_kernel<1>, grid, block, LDS, st, a);
     }
     SGX_LAUNCH_CHECK("wgrad2_kernel");
