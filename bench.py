@@ -336,7 +336,7 @@ def measure(sg, a, cfg, dev, B, steps, warmup, rank, world, want_graphs, stream_
         traffic, traffic_src = None, None
         if traffic_ok:
             # HBM bytes per launch of this instantiation from the committed PMC passes of this same workload (rocprofv3
-            # cannot run inside the benchmark): tools/gpu_pmc.sh -> tools/pmc_traffic.py, corrected as the guide prescribes
+            # cannot run inside the benchmark): tools/gpu_final3.sh -> tools/pmc_traffic.py, corrected as the guide prescribes
             import glob
             for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_bf16_b4.json")), reverse=True):   # newest round first
                 ent = json.load(open(pmc))["kernels"].get(dom_name)

@@ -519,7 +519,7 @@ static int launch_conv(ConvArgs& a, int ngroups, hipStream_t st) {
     int gx = (ncu * per_cu + yz - 1) / yz;
     if (gx > a.ntiles) gx = a.ntiles;
     if (gx < 1) gx = 1;
-    static const int bands_on = [] { const char* e = getenv("SGX_TILE_BANDS"); return e ? atoi(e) : 1; }();   // measured (tools/gpu_r2u.sh): halo over-fetch gone (PMC), 80.8 vs 81.2 ms at batch 32, nothing at batch 4
+    static const int bands_on = [] { const char* e = getenv("SGX_TILE_BANDS"); return e ? atoi(e) : 1; }();   // measured (round 2): halo over-fetch gone (PMC), 80.8 vs 81.2 ms at batch 32, nothing at batch 4
     a.bands = 0;
     if (conv_bands_ok<T>(GEO, TH, TW, BP) && bands_on && gx >= 64 && a.ntiles >= 8 * gx) {   // enough tiles per band for the order to matter
         gx = gx / 8 * 8;

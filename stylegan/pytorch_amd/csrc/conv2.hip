@@ -690,7 +690,7 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
     if (per > need) per = need;
     if (per < 1) per = 1;
     a.nslots = per * 8;
-    static const int bands_on = [] { const char* e = getenv("SGX_TILE_BANDS"); return e ? atoi(e) : 1; }();   // measured (tools/gpu_r2u.sh): halo over-fetch gone (PMC), 80.8 vs 81.2 ms at batch 32, nothing at batch 4
+    static const int bands_on = [] { const char* e = getenv("SGX_TILE_BANDS"); return e ? atoi(e) : 1; }();   // measured (round 2): halo over-fetch gone (PMC), 80.8 vs 81.2 ms at batch 32, nothing at batch 4
     a.bands = (bands_on && a.ntiles >= 8 * a.nslots) ? 1 : 0;      // enough tiles per slot for the order to matter
     hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.ncb * per)), dim3(NW * 64), LDS, st, a);
     SGX_LAUNCH_CHECK("conv2_kernel");
