@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Host-side profile of the training iteration (cProfile over a few steps, GPU running asynchronously): shows where the
-Python/ctypes/autograd launch path spends its time when the step becomes launch-bound.   python tools/host_profile.py [steps]"""
+Python/ctypes/autograd launch path spends its time when the step becomes launch-bound.
+    python tools/host_profile.py [steps] [single]        ("single": one stream, deferred losses -- the mode bench.py times at batch 4)"""
 import cProfile
 import os
 import pstats
@@ -21,6 +22,9 @@ def main():
     sg = StyleGAN("linear", 1024, 3, 512, g_args=dict(latent_size=512, mapping_layers=8, blur_filter=[1, 2, 1], truncation_psi=-1.0, truncation_cutoff=8),
                   d_args=dict(use_wscale=True, blur_filter=[1, 2, 1]), g_opt_args=opt, d_opt_args=opt, loss="logistic", use_ema=True,
                   device=dev, act_dtype=torch.bfloat16)
+    if "single" in sys.argv[2:]:
+        sg.aux_stream = sg.param_stream = False
+        sg.deferred_losses = True
     z = torch.randn(4, 512, device=dev)
     x = torch.randn(4, 1024, 1024, 3, device=dev).permute(0, 3, 1, 2)
 
