@@ -47,6 +47,12 @@ HOT = [
     ("conv_kernel<unsigned short, 32, 0, 16, 16, 256, 1>(ConvArgs)", 3),     # 3x3 32^2 512->512
     ("conv_kernel<unsigned short, 32, 3, 16, 16, 256, 1>(ConvArgs)", 2),     # transposed 512^2 -> 1024^2, all classes
     ("conv_kernel<unsigned short, 128, 0, 4, 16, 64, 1>(ConvArgs)", 2),      # 3x3 16^2 512->512, deep K stages
+    # round 3: the 16-channel layers at 1024^2 run TWO 8-wave blocks per CU (4 waves per SIMD, <= 128 registers) so that one block's
+    # store epilogue overlaps the other's loads; the 64..512-channel 3x3 kernel needs its two waves per SIMD
+    ("conv2_kernel<0, 8, 1, 16, true, 0>(Conv2Args)", 4),                    # 3x3 1024^2 16->16
+    ("conv2_kernel<1, 8, 1, 16, false, 0>(Conv2Args)", 4),                   # stride-2 1024^2 16->32
+    ("wgrad16_s_kernel(Wg2Args)", 4),                                        # its 16x16-channel weight gradient
+    ("conv2_kernel<0, 8, 2, 32, false, 0>(Conv2Args)", 2),                   # 3x3, 64..512 channels (the batch-32 dominant kernel)
 ]
 
 
