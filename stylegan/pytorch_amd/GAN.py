@@ -545,6 +545,13 @@ class StyleGAN:
         self.__dict__["_sched_active"] = sched
         D.set_active_scheduler(sched)
 
+    def _sched_abort(self):
+        """The backward raised: no scheduler may stay installed (a later, unrelated backward would feed it)."""
+        if self.dp is not None:
+            from . import dist as D
+            D.set_active_scheduler(None)
+            self.__dict__["_sched_active"] = None
+
     def _note_active_grads(self, kind, depth):
         """After a backward: remember the active set of this (network, depth) as a flat bucket layout for the next iteration
         (in gradient-ready order when the backward was recorded by a BucketScheduler)."""
@@ -564,7 +571,7 @@ class StyleGAN:
                 self.__dict__.get("_bucket_scheds", {}).pop(key, None)
             new = None
             if sched is not None and sched.recording:
-                new = sched.layout(self.dp.bucket_elems, only=active)
+                new = sched.layout(self.dp.bucket_elems, only=active, canonical=list(net.parameters()))
                 if new is None or not new.matches(active):     # a parameter got its gradient without a note: no early firing
                     new = None
                     self.__dict__.get("_bucket_scheds", {}).pop((kind, int(depth)), None)
@@ -645,8 +652,12 @@ class StyleGAN:
         side = self._param_stream(two_branches=aux is not None and lazy)
         self._sched_begin("d", depth, side)
         # conv weight / bias gradients accumulate inside the finishing kernel, on a side stream next to the backward chain
-        with F.accumulate_param_grads(), F.param_grad_stream(side):
-            loss.backward()
+        try:
+            with F.accumulate_param_grads(), F.param_grad_stream(side):
+                loss.backward()
+        except BaseException:
+            self._sched_abort()
+            raise
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         self._note_active_grads("d", depth)
@@ -657,7 +668,16 @@ class StyleGAN:
             return
         sched = self.__dict__.pop("_sched_active", None)
         if sched is not None and not sched.recording and sched.gb is not None and sched.gb.attached():
-            sched.finish()                                           # most buckets were all-reduced during the backward
+            try:
+                sched.finish()                                       # most buckets were all-reduced during the backward
+            except RuntimeError:
+                # a gradient was written more often than recorded: this step's gradients are unusable (a bucket may have left
+                # early).  Drop the schedule AND the layout of this (network, depth) so the next backward records afresh, then
+                # let the caller see the error.
+                for key in [k for k, v in self.__dict__.get("_bucket_scheds", {}).items() if v is sched]:
+                    self._bucket_scheds.pop(key, None)
+                    self._grad_buckets.pop(key, None)
+                raise
             self.__dict__["_last_sched"] = sched
             return
         gb = next((g for (k, _), g in self._grad_buckets.items() if k == kind and g.attached()), None)
@@ -695,8 +715,12 @@ class StyleGAN:
             self._zero_grads("g", depth)
             side = self._param_stream()
             self._sched_begin("g", depth, side)
-            with F.accumulate_param_grads(), F.param_grad_stream(side):
-                loss.backward()
+            try:
+                with F.accumulate_param_grads(), F.param_grad_stream(side):
+                    loss.backward()
+            except BaseException:
+                self._sched_abort()
+                raise
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
             self._note_active_grads("g", depth)

@@ -96,7 +96,18 @@ class BucketScheduler:
     moment its last parameter is final: on the collective side stream, after the stream(s) that wrote the gradients, while the
     backward carries on with the higher-resolution layers.  ``finish`` fires what is left and joins.  A parameter that is
     written MORE often than recorded would be reduced too early: ``finish`` checks every count and raises (the step's
-    gradients are then unusable; the layout is re-recorded by the caller)."""
+    gradients are then unusable; ``StyleGAN._reduce`` drops the schedule and the layout so that the next backward records again).
+
+    Cross-rank agreement (round 4).  The order in which THIS rank saw gradients become final is not a safe basis for a layout:
+    autograd sums the contributions of a parameter that is used several times in an order that depends on thread-local
+    sequence numbers, so two ranks can record different last-write orders -- and buckets with different contents or sizes mean
+    mismatched collectives (a hang or silent corruption under RCCL).  So (i) ``layout`` takes RANK 0's recorded order: rank 0
+    broadcasts (canonical parameter index, contribution count) pairs, every rank lays its buckets out from that list and checks
+    its own recorded set and counts against it (a mismatch raises on ALL ranks together: the verdict is all-reduced); (ii) buckets
+    are FIRED IN BUCKET ORDER -- a bucket that completes before an earlier one waits for it (as torch DDP does) -- so every rank
+    issues the same sequence of collectives whatever its local completion order; (iii) collectives are issued under the
+    scheduler's lock, during the backward only from autograd's hook calls and after it only from the caller's thread (the
+    backward call blocks that thread), so the per-process issue order is a total order."""
 
     def __init__(self, group, params=None):
         self.group = group
@@ -105,6 +116,7 @@ class BucketScheduler:
         self.count, self.order = {}, []                       # recording: id(p) -> contributions, ids in order of LAST write
         self.gb = None
         self._params = {}
+        self.order_source = "local"                           # "rank0" once the layout came from rank 0's broadcast
 
     # ---- recording (first iteration at a depth)
     def note(self, p):
@@ -122,17 +134,62 @@ class BucketScheduler:
                 self.unknown += 1                              # a parameter outside the recorded set received a gradient
                 return
             self.seen[k] = c + 1
+            b = self.bucket_of[k]
+            if p.is_cuda:
+                # the stream this contribution was enqueued on (AccumulateGrad runs on the stream of the parameter's forward
+                # use: with the fake branch of the D step on the auxiliary stream a bucket can hold gradients written on two
+                # streams); the bucket's all-reduce is ordered behind every one of them
+                st = torch.cuda.current_stream(p.device)
+                self.streams[b][st.cuda_stream] = st
             if c + 1 == self.count[k]:
-                b = self.bucket_of[k]
                 self.left[b] -= 1
                 if self.left[b] == 0:
-                    self._fire(b)
+                    self.ready[b] = True
+                    self._fire_ready()
 
-    def layout(self, bucket_elems, only=None):
+    def _fire_ready(self):
+        """Fire, in BUCKET ORDER, every complete bucket whose predecessors have all been fired (lock held)."""
+        while self.next_fire < len(self.ready) and self.ready[self.next_fire]:
+            self._fire(self.next_fire)
+            self.next_fire += 1
+
+    def _agree_on_order(self, ids, canonical):
+        """Rank 0's gradient-ready order for everybody.  ``ids``: this rank's recorded order; ``canonical``: the parameters in an
+        order every rank shares (``net.parameters()``).  Returns the ids in rank 0's order; raises on ALL ranks if any rank's
+        recorded set or contribution counts differ from rank 0's."""
+        g = self.group
+        index_of = {id(p): i for i, p in enumerate(canonical)}
+        if any(k not in index_of for k in ids):
+            raise RuntimeError("BucketScheduler.layout: a recorded parameter is not in the canonical parameter list")
+        mine = [(index_of[k], self.count[k]) for k in ids]
+        dev = canonical[0].device if (canonical and dist.get_backend(g.group) == "nccl") else torch.device("cpu")
+        n = torch.tensor([len(mine)], dtype=torch.int64, device=dev)
+        dist.broadcast(n, src=0, group=g.group)
+        table = torch.tensor(mine if g.rank == 0 else [[0, 0]] * int(n.item()), dtype=torch.int64, device=dev).reshape(-1, 2)
+        dist.broadcast(table, src=0, group=g.group)
+        theirs = [(int(i), int(c)) for i, c in table.cpu().tolist()]
+        ok = sorted(mine) == sorted(theirs)
+        verdict = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=g.group)
+        if int(verdict.item()) != 1:
+            raise RuntimeError("BucketScheduler.layout: the ranks recorded different gradient sets or contribution counts "
+                               f"(rank {g.rank}: {'matches' if ok else 'differs from'} rank 0); no bucket layout was built")
+        self.order_source = "rank0"
+        return [id(canonical[i]) for i, _ in theirs]
+
+    def layout(self, bucket_elems, only=None, canonical=None):
         """After a recording backward: GradBuckets of the recorded parameters (``only``: restrict to these, e.g. the ones that
-        really hold a gradient) in gradient-ready order, and this object switched to firing mode for the next backward."""
+        really hold a gradient) in gradient-ready order, and this object switched to firing mode for the next backward.
+        ``canonical`` (data parallel: REQUIRED for more than one rank): the network's parameters in an order all ranks share;
+        the layout then follows rank 0's gradient-ready order (class docstring)."""
         keep = None if only is None else {id(p) for p in only}
         ids = [k for k in self.order if keep is None or k in keep]
+        g = self.group
+        multi = g is not None and (g.world_size > 1 or g.force_collectives)
+        if multi:
+            if canonical is None:
+                raise RuntimeError("BucketScheduler.layout: more than one rank needs the canonical parameter list")
+            ids = self._agree_on_order(ids, list(canonical))      # (also with an empty list: the collectives must match)
         if not ids:
             return None
         self.gb = GradBuckets([self._params[k] for k in ids], bucket_elems)
@@ -152,6 +209,9 @@ class BucketScheduler:
         self.seen = {k: 0 for k in self.count}
         self.left = [len(views) for _, views in self.gb.buckets]
         self.fired = [False] * len(self.gb.buckets)
+        self.ready = [False] * len(self.gb.buckets)
+        self.next_fire = 0
+        self.streams = [dict() for _ in self.gb.buckets]      # per bucket: raw handle -> stream its gradients were written on
         self.unknown = 0
         self.handles = []
         self.param_stream = param_stream
@@ -165,9 +225,13 @@ class BucketScheduler:
             return
         if flat.is_cuda:
             side = g._side_stream(flat.device)
-            side.wait_stream(torch.cuda.current_stream(flat.device))
+            cur = torch.cuda.current_stream(flat.device)
+            side.wait_stream(cur)
             if self.param_stream is not None:
                 side.wait_stream(self.param_stream)
+            for raw, st in self.streams[b].items():            # every stream a gradient of this bucket was written on
+                if raw != cur.cuda_stream and (self.param_stream is None or raw != self.param_stream.cuda_stream):
+                    side.wait_stream(st)
             with torch.cuda.stream(side):
                 g._all_reduce(flat)
             flat.record_stream(side)
@@ -184,8 +248,9 @@ class BucketScheduler:
             if self.unknown or any(self.seen[k] > self.count[k] for k in bad):
                 raise RuntimeError("BucketScheduler: the backward wrote gradients that the recorded schedule does not know "
                                    f"({self.unknown} unknown parameters, {len(bad)} with another count): a bucket may have been reduced early")
-            for b in late:                                     # parameters that got FEWER writes this time (or none): reduce now
-                self._fire(b)
+            for b in late:                                     # parameters that got FEWER writes this time (or none): reduce
+                self.ready[b] = True                           # now -- still in bucket order
+            self._fire_ready()
         for h in self.handles:
             h.wait()
         self.handles = []

@@ -284,7 +284,8 @@ def _overlap_worker(rank, port, out_q):
         set_active_scheduler(None)
         active = [p for p in leaves if p.grad is not None]
         assert len(active) < len(leaves)                    # the inactive resolutions never got a note
-        gb = sched.layout(group.bucket_elems, only=active)
+        gb = sched.layout(group.bucket_elems, only=active, canonical=leaves)
+        assert sched.order_source == "rank0"
         assert gb is not None and gb.matches(active) and len(gb.buckets) > 2
         first_iter = {k: v.grad.clone() for k, v in dp.items() if v.grad is not None}
         gb.attach()                                         # iteration 2: the gradients live in the buckets, zeroed
@@ -304,7 +305,10 @@ def _overlap_worker(rank, port, out_q):
         # (2) several contributions per parameter, noted by hand (what ConvFn.backward does for in-kernel accumulation)
         ps = [torch.nn.Parameter(torch.zeros(n, dtype=torch.float64)) for n in (300, 7, 1200, 64, 500)]
         contrib = {0: 3, 1: 1, 2: 2, 3: 3, 4: 1}
-        seq = [0, 2, 3, 0, 1, 3, 2, 0, 4, 3]                 # write order: parameter 1 is final first, then 2, 0, 4, 3
+        # write order: on rank 0 parameter 1 is final first, then 2, 0, 4, 3.  Rank 1 is deliberately PERTURBED (same counts,
+        # another order: final 4, 3, 1, 0, 2) -- what autograd's thread-local sequence numbers can do to the order in which a
+        # parameter's contributions are summed.  The layout must still be rank 0's on both ranks and the collectives must match.
+        seq = [0, 2, 3, 0, 1, 3, 2, 0, 4, 3] if rank == 0 else [3, 3, 0, 4, 2, 0, 3, 1, 0, 2]
         def val(i, j): return torch.full_like(ps[i], float((rank + 1) * (10 * i + j + 1)))
         def backward(sch):
             seen = {i: 0 for i in contrib}
@@ -314,10 +318,17 @@ def _overlap_worker(rank, port, out_q):
                 sch.note(ps[i])
         s2 = BucketScheduler(group)
         backward(s2)
-        gb2 = s2.layout(group.bucket_elems)
-        assert [id(p) for p in gb2.params] == [id(ps[i]) for i in (1, 2, 0, 4, 3)]      # gradient-ready order
+        local_order = [next(i for i in contrib if id(ps[i]) == k) for k in s2.order]
+        assert local_order == ([1, 2, 0, 4, 3] if rank == 0 else [4, 3, 1, 0, 2])
+        gb2 = s2.layout(group.bucket_elems, canonical=ps)
+        assert [id(p) for p in gb2.params] == [id(ps[i]) for i in (1, 2, 0, 4, 3)]      # RANK 0's gradient-ready order, on every rank
+        assert s2.order_source == "rank0" and len(gb2.buckets) == 5                       # five buckets of five different sizes
+        fired2 = []
+        fire2 = s2._fire
+        s2._fire = lambda b: (fired2.append(b), fire2(b))[1]
         gb2.attach(); s2.begin(); backward(s2)
         assert sum(s2.fired) == len(gb2.buckets)
+        assert fired2 == list(range(len(gb2.buckets)))       # fired in BUCKET order on both ranks, whatever the local completion order
         s2.finish()
         for i in contrib:
             want = sum(float((r + 1) * (10 * i + j + 1)) for r in range(WORLD) for j in range(contrib[i]))
@@ -329,6 +340,15 @@ def _overlap_worker(rank, port, out_q):
         except RuntimeError:
             raised = True
         assert raised
+        # ranks that recorded different contribution COUNTS (or sets) must not build a layout: refused on every rank together
+        s3 = BucketScheduler(group)
+        for i in ([0, 1, 0, 2] if rank == 0 else [0, 1, 2, 2]):
+            s3.note(ps[i])
+        try:
+            s3.layout(group.bucket_elems, canonical=ps); raised = False
+        except RuntimeError:
+            raised = True
+        assert raised and s3.recording
         if rank == 0:
             out_q.put({k: v.grad.numpy() for k, v in dp.items() if v.grad is not None})
         else:
