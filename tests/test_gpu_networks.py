@@ -183,6 +183,9 @@ def test_bf16_activations_track_fp32(nets):
         # bf16 cast is at 6.7e-2 / 1.6e-1 at this depth
         assert_close(img, ref, 2 * BF16_MID[0], "bf16 G image")
         assert_close(score, ref_s, 2 * BF16_MID[1], "bf16 D score")
+        # ... and the frozen absolute bars (test_gpu_bf16.BARS: the naive cast's depth-2 figures, for this depth-5 model)
+        assert_close(img, ref, 3.1e-2, "bf16 G image (absolute bar)")
+        assert_close(score, ref_s, 2e-2, "bf16 D score (absolute bar)")
     # one full bf16 iteration runs and its losses are close to the fp64 losses
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "step_mid.npz"))
     sg = make_stylegan(torch.bfloat16)

@@ -273,6 +273,10 @@ def test_bf16_storage_vs_fp64_truth(name, golden_dir):
     e_g = abs(g_loss - float(g["f64_g_loss"])) / abs(float(g["f64_g_loss"]))
     print(f"[real{name}] bf16 vs fp64: image rel {e_full:.2e} (pooled {e_img:.2e}), D(real) score rel {e_score:.2e}, "
           f"d_loss rel {e_d:.2e}, g_loss rel {e_g:.2e}")
+    # the parity claim: frozen absolute bars (naive whole-model bf16 cast figures of SURVEY.md 8c at SHALLOWER depths; losses 5e-2)
+    bar_img, bar_score = {"128": (3.1e-2, 2e-2), "1024": (6.7e-2, 1.6e-1)}[name]
+    assert e_full <= bar_img and e_score <= bar_score and e_d <= 5e-2 and e_g <= 5e-2, (e_full, e_score, e_d, e_g)
+    # the tripwire: 2 x what this code measured (round 2)
     m = BF16_MEASURED[name]
     assert e_full <= 2 * m[0] and e_score <= 2 * m[1] and e_d <= 2 * m[2] and e_g <= 2 * m[3], (e_full, e_score, e_d, e_g, m)
     for p in list(sg.gen.parameters()) + list(sg.dis.parameters()):
