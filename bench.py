@@ -62,7 +62,75 @@ def parse():
     ap.add_argument("--layer-table", default=None, help="write a per-layer conv/wgrad timing table (TSV) to this path (+ .b32.tsv for the batch-32 block)")
     ap.add_argument("--no-b32", action="store_true", help="skip the second measured block (batch 32 on one GPU)")
     ap.add_argument("--b32-steps", type=int, default=8)
+    ap.add_argument("--sweep", action="store_true",
+                    help="BASELINE configs[4]: the progressive-growing sweep, depth index 0..8 of the 1024 model with the reference's per-depth "
+                         "batch sizes (config.py:40-41), the fade-in ramp of models/GAN.py:748-753 and style mixing on; per-depth img/s")
+    ap.add_argument("--sweep-steps", type=int, default=8, help="timed iterations per depth (first half on the alpha ramp, second half at alpha = 1)")
+    ap.add_argument("--sweep-batch-scale", type=float, default=1.0,
+                    help="multiply the reference's per-depth batch sizes (its schedule fits an 11 GB card; kept a multiple of 4 where >= 4)")
     return ap.parse_args()
+
+
+# reference config.py:37-42 (cfg.sched): per-depth batch sizes for resolutions 4 .. 1024 and the fade-in share of a depth's iterations
+REF_BATCH_SIZES = [128, 128, 128, 64, 32, 16, 8, 4, 2]
+REF_FADE_IN_PERCENTAGE = 50
+# algorithmic conv+GEMM GFLOP per image of one full G+D iteration (logistic + R1, 8 mapping layers), by depth index
+SWEEP_GFLOP_PER_IMG = [1.60, 13.10, 59.05, 242.87, 518.72, 692.85, 867.73, 1044.05, 1223.27]
+
+
+def sweep(sg, a, cfg, dev):
+    """The progressive-growing schedule as a measured workload (one GPU): for every depth index the reference's batch size, real
+    batches at the FULL resolution (the reference's loader yields 1024^2 images at every depth and the step average-pools them
+    down, models/GAN.py:557-589), alpha = ticker / fade_point up to the fade point and 1 after it (:748-753) with the fade point
+    in the middle of the timed iterations (fade_in_percentage 50), style mixing on, eager launches (what StyleGAN.train runs).
+    -> list of per-depth dicts."""
+    from stylegan.pytorch_amd import native
+    from stylegan.pytorch_amd.GAN import StyleGAN
+    res = cfg["resolution"]
+    K = max(2, a.sweep_steps)
+    fade_point = StyleGAN.fade_point_of(REF_FADE_IN_PERCENTAGE, 1, K)
+    rows = []
+    gen = torch.Generator(device=dev); gen.manual_seed(4321)
+    import random
+    random.seed(4321)
+    for depth in range(cfg["depth"] + 1):
+        B = REF_BATCH_SIZES[depth]
+        if a.sweep_batch_scale != 1.0:
+            B = max(1, int(round(B * a.sweep_batch_scale)))
+            if B >= 4:
+                B -= B % 4
+        reals = [torch.randn(B, res, res, 3, device=dev, generator=gen).permute(0, 3, 1, 2) for _ in range(2)]
+        lats = [torch.randn(B, 512, device=dev, generator=gen) for _ in range(2)]
+        alphas = [StyleGAN.alpha_at(t, fade_point) for t in range(1, K + 1)]
+
+        def step(i, alpha):
+            sg.optimize_discriminator(lats[i % 2], reals[i % 2], depth, alpha)
+            sg.optimize_generator(lats[i % 2], reals[i % 2], depth, alpha)
+        for i in range(2):                                   # untimed: first use of this depth's kernels, packs, gradient buffers
+            step(i, alphas[0])
+        torch.cuda.synchronize()
+        native.prof_start(1)                                 # one surveyed iteration: launches per step, kernel time
+        step(0, alphas[0])
+        torch.cuda.synchronize()
+        native.prof_start(0)
+        recs = native.prof_records()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(i, alphas[i])
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        img_s = B * K / dt
+        useful = img_s * SWEEP_GFLOP_PER_IMG[depth] * 1e9
+        rows.append({"depth": depth, "resolution": 4 << depth, "batch": B, "alphas": [round(float(x), 4) for x in alphas],
+                     "img_per_s": round(img_s, 2), "ms_per_step": round(dt / K * 1e3, 3), "host_enqueue_ms_per_step": round(t_enq / K * 1e3, 3),
+                     "useful_tflops": round(useful / 1e12, 2), "frac_of_mfma_peak": round(useful / PEAK[a.dtype], 5),
+                     "library_launches_per_step": len(recs), "library_kernel_ms_per_step": round(sum(r[1] for r in recs), 3),
+                     "reference_gflop_per_img": SWEEP_GFLOP_PER_IMG[depth]})
+        del reals, lats
+        torch.cuda.empty_cache()
+    return rows
 
 
 def cpu_baseline_subprocess(config, timeout_s):
@@ -80,7 +148,16 @@ def cpu_baseline_subprocess(config, timeout_s):
                                          "the reference's own CPU numbers"}
 
 
-def cpu_baseline_reference(cfg, batch=1):
+CPU_BATCH = 4            # the CPU legs run the metric's batch (4 = one minibatch-stddev group of four, as on the GPU)
+
+# the REFERENCE ITSELF timed in the build container (its sources do not exist on the GPU boxes, where the
+# port below is what can be timed) -- carried in the line as a labelled, not-measured-here field
+REFERENCE_CONTAINER = {"value": 0.126, "unit": "img/s", "cores": 8, "kind": "reference",
+                       "sample": "reference models/GAN.py optimize_discriminator + optimize_generator, 1024x1024 depth index 8, batch 2, fp32, "
+                                 "8-core Xeon @ 2.1 GHz of the build container (BASELINE.md section 2; NOT measured in this run)"}
+
+
+def cpu_baseline_reference(cfg, batch=CPU_BATCH):
     """One iteration of the REFERENCE ITSELF on this host's cores (kind "reference"), when its sources are present
     (/root/reference: the build container; the GPU boxes do not have it -> None, and the port below is timed instead).
     Imported with the shims of tests/golden/make_golden.py: a stub ``data`` module (models/GAN.py:25 pulls torchvision in
@@ -115,8 +192,8 @@ def cpu_baseline_reference(cfg, batch=1):
                       f"(models/GAN.py:591-659), batch {batch}, {res}x{res} depth index {depth}, fp32 CPU, {cores} threads, {dt:.1f} s"}
 
 
-def cpu_baseline(cfg, batch=1):
-    """One iteration of the CPU oracle (fp32, torch CPU ops) at a reduced batch.  Threads are capped: the step is
+def cpu_baseline(cfg, batch=CPU_BATCH):
+    """One iteration of the CPU oracle (fp32, torch CPU ops) at the metric's batch (4).  Threads are capped: the step is
     thousands of small ATen ops, and a 256-thread fork/join per op is slower than 16 threads."""
     import random
     from oracle import stylegan_oracle as O
@@ -338,7 +415,7 @@ def measure(sg, a, cfg, dev, B, steps, warmup, rank, world, want_graphs, stream_
             # HBM bytes per launch of this instantiation from the committed PMC passes of this same workload (rocprofv3
             # cannot run inside the benchmark): tools/gpu_final3.sh -> tools/pmc_traffic.py, corrected as the guide prescribes
             import glob
-            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_bf16_b4.json")), reverse=True):   # newest round first
+            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_bf16_b{B}.json")), reverse=True):   # newest round first
                 ent = json.load(open(pmc))["kernels"].get(dom_name)
                 if ent:
                     traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/" + os.path.basename(pmc)
@@ -346,6 +423,8 @@ def measure(sg, a, cfg, dev, B, steps, warmup, rank, world, want_graphs, stream_
         roof = {"bound": bound, "kernel": dom_name, "launches": len(recs), "avg_us": ms * 1e3 / len(recs),
                 "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak if (fl or nb) else None, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": nb / len(recs), "flops_per_launch": fl / len(recs),
+                "avg_us_note": "HIP events around each launch on its stream: ~3 us more than rocprofv3's kernel duration on 8-20 us launches "
+                               "(profiles/*_kernel_stats.csv holds the profiler's figure for the same command)",
                 "library_kernels_ms_per_step": round(sum(v[0] for v in agg.values()), 3),
                 "library_launches_per_step": len(survey),
                 "algorithmic_gbytes_per_step": round(algorithmic_bytes / 1e9, 2),
@@ -368,6 +447,9 @@ def measure(sg, a, cfg, dev, B, steps, warmup, rank, world, want_graphs, stream_
            "batch_per_gpu": B, "global_batch": B * world, "input_ring": RING,
            "host_enqueue_ms_per_step": t_enq / steps * 1e3,
            "hip_graphs": bool(graphs), "aux_stream": bool(sg.aux_stream), "side_stream": bool(sg.param_stream),
+           # SURVEY 8d asks for a median over per-iteration syncs; this is the MEAN of one region of `steps` iterations with the
+           # losses deferred and a single final synchronize (a per-iteration sync would stall the launch queue every 16 ms)
+           "timing": "mean over one timed region: barrier + synchronize, `steps` iterations enqueued back to back (losses deferred), synchronize + barrier",
            "launch_mode_calibration": calib or None,
            # useful-work convention: the reference step's algorithmic conv+GEMM FLOPs per image, whatever
            # the kernels execute; beside it the FLOPs the kernels really execute (one D(real) forward instead of two, no
@@ -392,7 +474,11 @@ def main():
             out = cpu_baseline_reference(cfg)                # the reference itself where its sources exist
         except Exception as e:                               # noqa: BLE001 -- fall back to the port, say why
             sys.stderr.write(f"reference CPU leg failed ({type(e).__name__}: {e}); timing the port\n")
-        print(json.dumps(out or cpu_baseline(cfg)))
+        out = out or cpu_baseline(cfg)
+        if a.config == "ffhq1024":
+            out["reference_container"] = REFERENCE_CONTAINER
+        out["timing"] = "wall clock of ONE iteration (D step + G step) after model construction, no warm-up iteration"
+        print(json.dumps(out))
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -419,6 +505,23 @@ def main():
 
     sg = make_stylegan(a, cfg, dev, dp)
     B, res, depth = a.batch_per_gpu, cfg["resolution"], cfg["depth"]
+    if a.sweep:
+        assert world == 1 and a.config == "ffhq1024", "--sweep: one GPU, the 1024 model (BASELINE configs[4] on one device)"
+        sg.use_graphs = False
+        rows = sweep(sg, a, cfg, dev)
+        worst = min(rows, key=lambda r: r["frac_of_mfma_peak"])
+        total_img = sum(r["batch"] * a.sweep_steps for r in rows)
+        total_s = sum(r["ms_per_step"] * a.sweep_steps for r in rows) / 1e3
+        print(json.dumps({"metric": "img/s per progressive depth, full G+D train step, 4x4 -> 1024x1024 sweep", "unit": "img/s",
+                          "value": total_img / total_s, "n_gpus": 1, "steps": a.sweep_steps, "warmup": 2, "higher_is_better": True,
+                          "dtype": a.dtype, "data": "synthetic (full-resolution real batches, down-sampled by the step as the reference does)",
+                          "config": {"workload": "ffhq1024 model, depth index 0..8, batch sizes " + str([r["batch"] for r in rows])
+                                                 + " (reference config.py:40-41), fade-in over the first half of each depth's timed iterations, "
+                                                   "style mixing on, eager launches"},
+                          "value_note": "images of all depths / time of all depths (equal iteration counts per depth: not the reference's epoch mix)",
+                          "worst_depth": {"depth": worst["depth"], "frac_of_mfma_peak": worst["frac_of_mfma_peak"]},
+                          "sweep": rows}))
+        return
     want_graphs = [False] if a.graphs == "off" else ([True] if a.graphs == "on" else [False, True])
     stream_opts = {"auto": [(True, True), (False, True), (False, False)], "11": [(True, True)], "01": [(False, True)], "00": [(False, False)]}[a.streams]
     headline = a.config == "ffhq1024" and a.dtype == "bf16"
@@ -433,7 +536,7 @@ def main():
         sg._step_graphs.clear()
         b32 = measure(sg, a, cfg, dev, 32, a.b32_steps, 2, rank, world, [False],
                       [(True, True), (False, False)] if a.streams == "auto" else stream_opts,
-                      layer_table=(a.layer_table + ".b32.tsv") if a.layer_table else None)
+                      layer_table=(a.layer_table + ".b32.tsv") if a.layer_table else None, traffic_ok=True)
 
     if rank == 0:
         out = {"metric": "img/s full G+D train step, 1024x1024 depth-9 bf16" if headline

@@ -262,6 +262,61 @@ def test_progressive_depths_step_vs_oracle(depth, alpha):
     assert touched >= 4
 
 
+def test_two_iterations_across_a_depth_switch_vs_oracle():
+    """The moment the progressive schedule moves on (reference models/GAN.py:730-797, BASELINE configs[4]): the last iteration
+    of depth 2 (alpha = 1) and the first of depth 3 (alpha = 1/fade_point: the new block barely faded in), on ONE StyleGAN
+    object -- optimizer states, weight-pack caches, gradient buffers and the EMA shadow all carry over -- against the fp64
+    oracle doing the same two iterations with persistent Adam states.  Parameters that enter at depth 3 take their FIRST Adam
+    step (bias correction t = 1) while the shared ones take their second: a per-parameter step count, as torch.optim.Adam."""
+    B = 4
+    sg = make_stylegan()
+    gp, dp = mid_params(torch.float64)
+    load_into(sg.gen, gp); load_into(sg.dis, dp); load_into(sg.gen_shadow, gp)
+    sg.gen.train(); sg.dis.train()
+    noises = mid_noises(B)
+    pin_noise(sg.gen, noises)
+    plan = [(2, 1.0), (3, 0.25)]
+    ours = []
+    for it, (depth, alpha) in enumerate(plan):
+        z = gu.seeded((B, 512), 131 + it); real = gu.seeded((B, 3, 128, 128), 141 + it)
+        torch.manual_seed(17 + it); random.seed(17 + it)
+        dl = float(sg.optimize_discriminator(z.to(DEV), real.to(DEV), depth, alpha))
+        torch.manual_seed(27 + it); random.seed(27 + it)
+        gl = float(sg.optimize_generator(z.to(DEV), real.to(DEV), depth, alpha))
+        ours.append((dl, gl))
+    shadow = {k: v.detach().clone() for k, v in gp.items()}
+    d_opt, g_opt = O.AdamState(), O.AdamState()
+    kw = dict(total_depth=MID_DEPTH, mapping_layers=MID["mapping_layers"], noises=noises)
+    for it, (depth, alpha) in enumerate(plan):
+        z = gu.seeded((B, 512), 131 + it); real = gu.seeded((B, 3, 128, 128), 141 + it)
+        torch.manual_seed(17 + it); random.seed(17 + it)
+        l2, cut = O.draw_mixing(z.shape, depth)
+        od, _ = O.d_step(gp, dp, d_opt, z.double(), real.double(), depth, alpha, latents2=l2.double(), mixing_cutoff=cut, **kw)
+        torch.manual_seed(27 + it); random.seed(27 + it)
+        l2, cut = O.draw_mixing(z.shape, depth)
+        og, _ = O.g_step(gp, dp, g_opt, z.double(), depth, alpha, latents2=l2.double(), mixing_cutoff=cut, shadow=shadow, **kw)
+        # iteration 1 sharp; iteration 2 sees parameters in which Adam (beta1 = 0) turned round-off of ~zero gradients into
+        # +-lr flips (a per cent of the elements, as the parameter check below allows): its losses move by ~1e-4..1e-3
+        tol = 1e-4 if it == 0 else 3e-3
+        assert abs(ours[it][0] - od) <= tol * abs(od), (it, ours[it][0], od)
+        assert abs(ours[it][1] - og) <= tol * abs(og), (it, ours[it][1], og)
+    assert any(t == 1 for t in d_opt.t.values()) and any(t == 2 for t in d_opt.t.values())     # the switch really mixed step counts
+    assert any(t == 1 for t in g_opt.t.values()) and any(t == 2 for t in g_opt.t.values())
+    for name, mod, ref, opt in (("dis", sg.dis, dp, d_opt), ("gen", sg.gen, gp, g_opt), ("shadow", sg.gen_shadow, shadow, None)):
+        for k, p in mod.named_parameters():
+            if k.endswith("init_block.bias"):
+                continue
+            r = ref[k].detach()
+            d = (p.detach().double().cpu() - r).abs()
+            frac_bad = float((d > 1e-5 * (1 + r.abs())).double().mean())
+            assert frac_bad <= max(5e-2, 2.0 / p.numel()), (name, k, frac_bad)
+            if opt is not None and opt.t.get(k) == 1 and p.numel() >= 256:
+                # first Adam step at beta1 = 0: every element moves by lr * sign(g) exactly -- a wrong step count would not
+                init = gu.fill_value(k, p.shape, torch.float64)
+                moved = (p.detach().double().cpu() - init).abs()
+                assert float(((moved - 0.003).abs() < 2e-5).double().mean()) >= 0.95, (name, k)
+
+
 @pytest.mark.parametrize("loss", ["hinge", "relativistic-hinge", "standard-gan"])
 def test_other_losses_vs_oracle(loss):
     """StandardGAN / HingeGAN / RelativisticAverageHingeGAN (models/Losses.py:96-189): one full D+G iteration on the HIP
