@@ -234,6 +234,34 @@ int sgx_conv4x4s2_up_blur(const void* x, const void* w, void* y, const void* mas
                           int dtype, void* stream);
 int sgx_conv3x3_stats(const void* x, const void* w, void* y, const float* ebias, const float* noise, const float* nw, double* part,
                       size_t part_bytes, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
+
+/* ---- the discriminator's first layer pair at the current resolution as ONE 3-channel convolution (round 4).
+ * Discriminator.forward applies from_rgb -- a 1x1 EqualizedConv2d with NO activation (models/GAN.py:353,413-427) -- and then the
+ * block's conv0 (3x3), LeakyReLU and blur (models/Blocks.py:137-142).  The two linear maps compose into a 3x3 convolution of the
+ * RGB image:  W'[o][j][tap] = s0 sr sum_i W0[o][i][tap] Wr[i][j];  from_rgb's bias br reaches conv0 only through taps that fall
+ * inside the image (conv0 zero-pads from_rgb's OUTPUT), T[o][tap] = s0 bscale sum_i W0[o][i][tap] br[i], carried by a 4th input
+ * channel that is 1 inside the image.  img, gi: fp32 [B][H][W][3];  w0: conv0.weight [C][C][3][3], s0 = its w_mul;  wr:
+ * from_rgb.weight [C][3][1][1], sr = its w_mul;  br: from_rgb.bias (bscale = its b_mul) or NULL;  b0: conv0.bias * b_mul or NULL.
+ * bf16 activations, C in {16, 32}, H % 16 == 0, W % 64 == 0 (sgx_rgbconv_ok); other shapes: sgx_rgb_in + sgx_conv3x3 + sgx_blur3x3_act.
+ *   sgx_rgbconv_pack : wf [3][C][16] and wd [9][16][C] (activation dtype): the operand packs of the forward / image-gradient kernels.
+ *   sgx_rgbconv_fwd  : epi 1: y = blur3x3(lrelu(conv(img) + b0)) and bits[pixel][C/8] = sign bits of the pre-activation (the
+ *                      LeakyReLU-backward mask, as sgx_conv3x3_signbits writes them; may be NULL);  epi 0: y = conv(img) (no b0).
+ *                      ones: 1 = with from_rgb's bias channel, 0 = without (the adjoint's own backward under R1's double backward).
+ *   sgx_rgbconv_dgrad: gi = the gradient w.r.t. img given gz = the gradient w.r.t. the pre-activation (R1, models/Losses.py:197-211;
+ *                      the generator step, models/GAN.py:640-655).
+ *   sgx_rgbconv_wgrad: gradients of all four parameters from (img, gz) by the chain rule through the composition, written -- or, per
+ *                      bit of `acc` (1: dw0, 2: db0, 4: dwr, 8: dbr), accumulated -- in the parameters' own layouts; NULL outputs
+ *                      are skipped; ones = 0: no bias terms (db0 and dbr must be NULL).  ws: sgx_rgbconv_wgrad_ws_bytes. */
+int sgx_rgbconv_ok(int B, int H, int W, int C, int dtype);
+int sgx_rgbconv_pack(const float* w0, float s0, const float* wr, float sr, const float* br, float bscale, void* wf, void* wd, int C,
+                     void* stream);
+int sgx_rgbconv_fwd(const float* img, const void* wf, const float* b0, void* y, void* bits, int B, int H, int W, int C, int epi, int ones,
+                    int dtype, void* stream);
+int sgx_rgbconv_dgrad(const void* gz, const void* wd, float* gi, int B, int H, int W, int C, int dtype, void* stream);
+size_t sgx_rgbconv_wgrad_ws_bytes(int B, int H, int W, int C);
+int sgx_rgbconv_wgrad(const float* img, const void* gz, int ones, const float* w0, float s0, const float* wr, float sr, const float* br,
+                      float bscale, float* dw0, float* db0, float* dwr, float* dbr, int acc, void* ws, size_t ws_bytes, int B, int H, int W,
+                      int C, int dtype, void* stream);
 int sgx_blur3x3_stats(const void* x, void* y, const float* bias, const float* noise, const float* nw, double* part,
                       size_t part_bytes, int B, int H, int W, int C, int act, int dtype, void* stream);
 int sgx_gepi_bwd(const void* dy, const void* x, const float* bias, const float* noise, const float* nw,

@@ -161,6 +161,23 @@ class DiscriminatorBlock(nn.Module):
         self.act1 = activation_layer
         self._act = act_code(activation_layer)
 
+    def fused_from_rgb_ok(self, img_shape, from_rgb, dtype):
+        """True if ``from_rgb -> conv0 -> LeakyReLU -> blur`` of this block has the composed 3-channel kernel for an NHWC image of
+        ``img_shape`` (functional.RgbConvBlurFn: bf16, 16 or 32 channels, the default blur and activation; A/B: SGX_RGBCONV=0)."""
+        c0 = self.conv0
+        return (FUSE_BLUR_BWD and self.blur._is_121 and self._act == ACT_LRELU and len(img_shape) == 4 and img_shape[3] == 3
+                and from_rgb.kernel_size == 1 and tuple(from_rgb.weight.shape[1:]) == (3, 1, 1) and c0.b_mul == 1 and from_rgb.b_mul == 1
+                and from_rgb.weight.shape[0] == c0.weight.shape[1] == c0.weight.shape[0]
+                and F.rgbconv_ok(img_shape[0], img_shape[1], img_shape[2], c0.weight.shape[0], dtype))
+
+    def forward_from_image(self, img, from_rgb, defer_out=False):
+        """The block applied to ``from_rgb(img)`` with from_rgb and conv0 composed into one convolution of the fp32 NHWC image
+        (reference models/GAN.py:425 + models/Blocks.py:139-146): neither from_rgb's output nor conv0's pre-activation exists in
+        memory; the backward gets the activation mask from the sign bits the kernel writes."""
+        c0 = self.conv0
+        xb, zbits = F.rgbconv_blur(img, c0.weight, c0.scaled_bias(), from_rgb.weight, from_rgb.scaled_bias(), c0.w_mul, from_rgb.w_mul)
+        return self.conv1_down.forward_nhwc(xb, act=ACT_LRELU, defer_act=defer_out and self._act == ACT_LRELU, x_pre=None, x_pre_bits=zbits)
+
     def forward_nhwc(self, x, x_masked=False, defer_out=False):
         """``x_masked``: x is the previous block's LeakyReLU output whose activation backward was deferred to this block
         (conv0's data gradient leaves its kernel already masked); ``defer_out``: this block's final activation backward is

@@ -365,10 +365,20 @@ class Discriminator(nn.Module):
         self.from_rgb = nn.ModuleList(from_rgb)
         self.temporaryDownsampler = lambda x: F.nchw_view(F.call(F.Pool2Fn, F.nhwc(x), 0.25))
 
+    def prepack(self, depth=None, img_shape=None):
+        """Operand packs of every convolution whose weights changed since they were last packed (one launch), plus -- given the
+        depth and the NHWC image shape -- the composed from_rgb/conv0 pack of the newest block.  The step calls this BEFORE it forks
+        the fake branch to its own stream, so both branches find the packs made."""
+        F.prepack(_conv_weights(self))
+        if depth is not None and img_shape is not None and self.structure == 'linear' and depth > 0 and not self.conditional:
+            top, top_rgb = self.blocks[self.depth - depth - 1], self.from_rgb[self.depth - depth - 1]
+            if top.fused_from_rgb_ok(img_shape, top_rgb, self.act_dtype):
+                F.rgb_packs(top.conv0.weight, top.conv0.w_mul, top_rgb.weight, top_rgb.w_mul, top_rgb.scaled_bias())
+
     def forward(self, images_in, depth, alpha=1., labels_in=None):
         assert depth < self.depth, "Requested output depth cannot be produced"
-        F.prepack(_conv_weights(self))                                      # all stale MFMA operand packs: one launch
         img = F.nhwc(images_in, torch.float32)                              # [B,R,R,3] fp32
+        self.prepack(depth, img.shape)                                      # all stale MFMA operand packs: one launch
         dt = self.act_dtype
         if self.conditional:
             # :395-400,:415-421,:431-436: embedding [B, 3*R*R] viewed as [B,3,R,R], concatenated to the image channels
@@ -398,8 +408,13 @@ class Discriminator(nn.Module):
                 pre = fuse and not isinstance(alpha, torch.Tensor) and not self.conditional
                 residual = self.from_rgb[self.depth - depth].forward_nhwc(F.call(F.Pool2Fn, img, 0.25), out_dtype=dt,
                                                                           out_scale=float(1 - alpha) if pre else 1.0)
-                straight = self.blocks[self.depth - depth - 1].forward_nhwc(
-                    self.from_rgb[self.depth - depth - 1].forward_nhwc(img, out_dtype=dt), defer_out=fuse)
+                top, top_rgb = self.blocks[self.depth - depth - 1], self.from_rgb[self.depth - depth - 1]
+                if not self.conditional and top.fused_from_rgb_ok(img.shape, top_rgb, dt):
+                    # from_rgb and the newest block's conv0 (no activation between them) as ONE convolution of the image, with
+                    # the LeakyReLU and the blur in its store (functional.RgbConvBlurFn)
+                    straight = top.forward_from_image(img, top_rgb, defer_out=fuse)
+                else:
+                    straight = top.forward_nhwc(top_rgb.forward_nhwc(img, out_dtype=dt), defer_out=fuse)
                 x = F.fade(straight, residual, alpha,                                      # GAN.py:427
                            a_act=fuse and self.blocks[self.depth - depth - 1]._act == ACT_LRELU, b_prescaled=pre)
                 x = chain(x, list(self.blocks[(self.depth - depth):]), False)
@@ -633,7 +648,7 @@ class StyleGAN:
             # the whole fake branch -- generator forward AND D(fake) forward, hence also D(fake)'s backward, which autograd
             # runs on the stream of its forward -- lives on the auxiliary stream; the real branch (D(real), the R1
             # gradient pass, their backward) on the main one.  D's operand packs are made before the fork.
-            F.prepack(_conv_weights(self.dis))
+            self.dis.prepack(depth, (real_samples.shape[0], real_samples.shape[2], real_samples.shape[3], real_samples.shape[1]))
             cur = torch.cuda.current_stream()
             aux.wait_stream(cur)
             with torch.cuda.stream(aux):

@@ -1,0 +1,533 @@
+// The discriminator's FIRST layer pair at the current resolution as ONE 3-channel convolution (round 4).
+//
+// Reference: Discriminator.forward (models/GAN.py:413-427) feeds the image through from_rgb -- a 1x1 EqualizedConv2d WITHOUT an
+// activation (models/GAN.py:353) -- and then through DiscriminatorBlock.conv0, a 3x3 EqualizedConv2d, LeakyReLU and the blur
+// (models/Blocks.py:137-142).  Two linear maps in a row compose:
+//     conv0(from_rgb(img))[p][o] = b0[o] + sum_{tap valid at p} sum_j W'[o][j][tap] img[p + tap][j] + sum_{tap valid at p} T[o][tap]
+//     W'[o][j][tap] = s0 sr sum_i W0[o][i][tap] Wr[i][j],     T[o][tap] = s0 sum_i W0[o][i][tap] br[i]
+// (from_rgb's bias reaches conv0 only through taps that fall INSIDE the image: conv0 pads from_rgb's output with zeros, not with
+// its bias.)  T rides in a 4th input channel that is 1 inside the image and 0 outside, so the border needs no special case.
+// What this removes per discriminator pass at 1024^2: the from_rgb pass (12 B/pixel read, 32 written), conv0's 32 B/pixel read, the
+// write + read of the pre-activation around the blur, and in the backward conv0's data gradient, from_rgb's weight-gradient pass
+// and (where the image needs a gradient: R1, generator step) the to-RGB adjoint -- ~120 B/pixel forward become 46.
+//
+// Kernels (bf16 activations; fp32 images, parameters, gradients):
+//   rgbconv_pack_kernel        W0, Wr, br -> the two MFMA operand packs (forward: [ky][o][kx*4+j]; adjoint: [tap][j][o])
+//   rgbconv_fwd_kernel<CB,EPI> EPI 1: xb = blur(lrelu(conv + b0)) + sign bits of the pre-activation; EPI 0: the plain convolution
+//                              (the adjoint's own backward under the R1 double backward).  Image tile with halo -> LDS as bf16
+//                              (r,g,b,1); 16 pixels x 16 channels per v_mfma_f32_16x16x16_bf16 triple (one per kernel row, K =
+//                              3 pixels x 4 channels + 4 padding); activated tile (+1 halo) -> LDS; separable blur from LDS
+//   rgbconv_dgrad_kernel<CB>   image gradient  gi[q][j] = sum_{tap,o} gz[q - tap][o] W'[o][j][tap]  (9 MFMAs per 16 pixels)
+//   rgbconv_wgrad_kernel<CB>   dW'[o][tap][j] = sum_p gz[p][o] img1[p + tap][j]: persistent blocks over 8x64-pixel tiles, operands
+//                              transposed into planar LDS images so that 4 consecutive PIXELS are one aligned 8-byte fragment read
+//   rgbconv_wfinish_kernel     deterministic sum of the block partials; rgbconv_chain_kernel: dW' -> dW0, db0, dWr, dbr (chain rule
+//                              through the composition), written or accumulated in the parameters' own layouts
+#include "common.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+static __device__ __forceinline__ f32x4_t mma16(s16x4 a, s16x4 b, f32x4_t c) {
+    // A[i = lane & 15][k = 4 (lane >> 4) + 0..3], B[k][j = lane & 15], D[i = 4 (lane >> 4) + reg][j = lane & 15]
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------------------ packs
+// wf: [3 ky][C o][16 k], k = kx * 4 + j (j = 3: the bias channel), k 12..15 zero.   wd: [9 tap'][16 j][C o] (j >= 3 zero), tap'
+// = (ky', kx') reads gz at q + (ky' - 1, kx' - 1), i.e. it is forward tap (2 - ky', 2 - kx').
+__global__ void rgbconv_pack_kernel(const float* __restrict__ w0, float s0, const float* __restrict__ wr, float sr,
+                                    const float* __restrict__ br, float bscale, bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, int C) {
+    const int tid = threadIdx.x + blockIdx.x * blockDim.x, nth = blockDim.x * gridDim.x;
+    for (int e = tid; e < 3 * C * 16; e += nth) {
+        const int ky = e / (C * 16), o = (e / 16) % C, k = e % 16, kx = k >> 2, j = k & 3;
+        float v = 0.f;
+        if (kx < 3) {
+            for (int i = 0; i < C; ++i) {
+                const float w = w0[((o * C + i) * 3 + ky) * 3 + kx];
+                v += w * (j < 3 ? wr[i * 3 + j] : (br ? br[i] * bscale : 0.f));
+            }
+            v *= j < 3 ? s0 * sr : s0;
+        }
+        wf[e] = f2bf(v);
+    }
+    for (int e = tid; e < 9 * 16 * C; e += nth) {
+        const int tap = e / (16 * C), j = (e / C) % 16, o = e % C, ky = 2 - tap / 3, kx = 2 - tap % 3;
+        float v = 0.f;
+        if (j < 3) {
+            for (int i = 0; i < C; ++i) v += w0[((o * C + i) * 3 + ky) * 3 + kx] * wr[i * 3 + j];
+            v *= s0 * sr;
+        }
+        wd[e] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ forward
+template <int CB, int EPI> struct RcFwd {
+    static constexpr int C = 16 * CB, R = EPI ? 2 : 1;
+    static constexpr int TH = EPI ? (CB == 1 ? 16 : 8) : 16, TW = 64;
+    static constexpr int IH = TH + 2 * R, IW = TW + 2 * R;                 // staged image region
+    static constexpr int ZH = TH + 2 * (R - 1), ZW = TW + 2 * (R - 1);     // convolution outputs the block computes
+    static constexpr int NPX = ZH * ZW, NG = (NPX + 15) / 16;
+    static constexpr int IPX = IH * IW + 4;                                // + 4 pixels of padding: the k-group of the last pixel reads 3 beyond
+    static constexpr int IMG_BYTES = (IPX * 8 + 15) / 16 * 16;
+    static constexpr int LDS = IMG_BYTES + (EPI ? NPX * C * 2 : 0);
+};
+
+template <int CB, int EPI>
+__global__ __launch_bounds__(256) void rgbconv_fwd_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wf, const float* __restrict__ b0,
+                                                          bf16_t* __restrict__ y, unsigned char* __restrict__ bits, int B, int H, int W, int ones,
+                                                          int tiles_x, int tiles_y) {
+    using G = RcFwd<CB, EPI>;
+    constexpr int C = G::C, R = G::R, TH = G::TH, TW = G::TW, IH = G::IH, IW = G::IW, ZW = G::ZW, NPX = G::NPX, NG = G::NG, IPX = G::IPX;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint2* imgl = reinterpret_cast<uint2*>(smem);
+    char* zl = smem + G::IMG_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int ty0 = ty * TH, tx0 = tx * TW;
+
+    // ---- phase A: image region (+halo) -> LDS as bf16 (r, g, b, 1 | 0); zero outside the image (the convolution's padding)
+    constexpr int NIT = (IPX + 255) / 256;
+    float v0[NIT], v1[NIT], v2[NIT];
+    bool ok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 256 + tid, r = idx / IW, c = idx - r * IW;
+        const int gy = ty0 - R + r, gx = tx0 - R + c;
+        ok[it] = idx < IH * IW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        v0[it] = v1[it] = v2[it] = 0.f;
+        if (ok[it]) {
+            const float* p = img + (((size_t)b * H + gy) * W + gx) * 3;
+            v0[it] = p[0]; v1[it] = p[1]; v2[it] = p[2];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 256 + tid;
+        if (idx < IPX) imgl[idx] = make_uint2(pack_bf16x2(v0[it], v1[it]), pack_bf16x2(v2[it], (ok[it] && ones) ? 1.f : 0.f));
+    }
+    // weights of this lane: A[i = o][k] for the three kernel rows
+    s16x4 wfr[CB][3];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) wfr[cb][ky] = *reinterpret_cast<const s16x4*>(wf + ((ky * C + cb * 16 + l15) * 16 + 4 * l4));
+    float4 bias[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+        bias[cb] = (EPI && b0) ? *reinterpret_cast<const float4*>(b0 + cb * 16 + 4 * l4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    // ---- phase B: 16 pixels x 16 channels per MFMA triple
+    for (int g = wave; g < NG; g += 4) {
+        const int px = g * 16 + l15, pxc = px < NPX ? px : NPX - 1;
+        const int zr = pxc / ZW, zc = pxc - zr * ZW;
+        f32x4_t acc[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const uint2 raw = imgl[(zr + ky) * IW + zc + l4];
+            s16x4 bf;
+            bf[0] = (short)(raw.x & 0xffffu); bf[1] = (short)(raw.x >> 16); bf[2] = (short)(raw.y & 0xffffu); bf[3] = (short)(raw.y >> 16);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[cb] = mma16(wfr[cb][ky], bf, acc[cb]);
+        }
+        const int gy = ty0 - (R - 1) + zr, gx = tx0 - (R - 1) + zc;
+        const bool inimg = px < NPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            if constexpr (EPI == 0) {
+                if (inimg)
+                    *reinterpret_cast<uint2*>(y + (((size_t)b * H + gy) * W + gx) * C + cb * 16 + 4 * l4) =
+                        make_uint2(pack_bf16x2(acc[cb][0], acc[cb][1]), pack_bf16x2(acc[cb][2], acc[cb][3]));
+            } else {
+                // pre-activation + bias -> LeakyReLU; positions outside the image are the BLUR's zero padding
+                const float a0 = inimg ? lrelu(acc[cb][0] + bias[cb].x) : 0.f, a1 = inimg ? lrelu(acc[cb][1] + bias[cb].y) : 0.f;
+                const float a2 = inimg ? lrelu(acc[cb][2] + bias[cb].z) : 0.f, a3 = inimg ? lrelu(acc[cb][3] + bias[cb].w) : 0.f;
+                if (px < NPX) *reinterpret_cast<uint2*>(zl + ((size_t)px * C + cb * 16 + 4 * l4) * 2) = make_uint2(pack_bf16x2(a0, a1), pack_bf16x2(a2, a3));
+            }
+        }
+    }
+    if constexpr (EPI == 1) {
+        __syncthreads();
+        // ---- phase C: separable [1,2,1]x[1,2,1]/16 down a column strip: thread = (column, 8-channel vector[, row half])
+        constexpr int VPP = C / 8, NSTRIP = TW * VPP, RSPLIT = 256 / NSTRIP, RPT = TH / RSPLIT;
+        static_assert(256 % NSTRIP == 0 && TH % RSPLIT == 0, "strip geometry");
+        const int s = tid % NSTRIP, half = tid / NSTRIP, c = s / VPP, v = s % VPP, r0 = half * RPT;
+        float h0[8], h1[8];
+        uint4 cprev = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { h0[q] = 0.f; h1[q] = 0.f; }
+#pragma unroll
+        for (int rr = 0; rr < RPT + 2; ++rr) {
+            const char* rowp = zl + ((size_t)((r0 + rr) * ZW + c) * C + v * 8) * 2;
+            const uint4 Lq = *reinterpret_cast<const uint4*>(rowp), Mq = *reinterpret_cast<const uint4*>(rowp + C * 2),
+                        Rq = *reinterpret_cast<const uint4*>(rowp + 2 * C * 2);
+            const unsigned lw[4] = {Lq.x, Lq.y, Lq.z, Lq.w}, mw[4] = {Mq.x, Mq.y, Mq.z, Mq.w}, rw[4] = {Rq.x, Rq.y, Rq.z, Rq.w};
+            float h[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                h[2 * q] = __uint_as_float(lw[q] << 16) + 2.f * __uint_as_float(mw[q] << 16) + __uint_as_float(rw[q] << 16);
+                h[2 * q + 1] = __uint_as_float(lw[q] & 0xffff0000u) + 2.f * __uint_as_float(mw[q] & 0xffff0000u) + __uint_as_float(rw[q] & 0xffff0000u);
+            }
+            if (rr >= 2) {
+                const int gy = ty0 + r0 + rr - 2, gx = tx0 + c;
+                if (gy < H && gx < W) {
+                    unsigned ow[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        ow[q] = pack_bf16x2((h0[2 * q] + 2.f * h1[2 * q] + h[2 * q]) * 0.0625f, (h0[2 * q + 1] + 2.f * h1[2 * q + 1] + h[2 * q + 1]) * 0.0625f);
+                    const size_t pix = ((size_t)b * H + gy) * W + gx;
+                    *reinterpret_cast<uint4*>(y + pix * C + v * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                    if (bits) {
+                        // sign bits of the pre-activation = of the stored activation (LeakyReLU keeps the sign): bit j = channel 8v + j
+                        const unsigned cw[4] = {cprev.x, cprev.y, cprev.z, cprev.w};
+                        unsigned bb = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            bb |= ((short)(cw[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q);
+                            bb |= ((short)(cw[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
+                        }
+                        bits[pix * VPP + v] = (unsigned char)bb;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { h0[q] = h1[q]; h1[q] = h[q]; }
+            cprev = Mq;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ image gradient
+template <int CB> struct RcDg {
+    static constexpr int C = 16 * CB, TH = CB == 1 ? 16 : 8, TW = 64, GH = TH + 2, GW = TW + 2, VPP = C / 8;
+    static constexpr int LDS = GH * GW * C * 2;
+};
+
+template <int CB>
+__global__ __launch_bounds__(256) void rgbconv_dgrad_kernel(const bf16_t* __restrict__ gz, const bf16_t* __restrict__ wd, float* __restrict__ gi,
+                                                            int B, int H, int W, int tiles_x, int tiles_y) {
+    using G = RcDg<CB>;
+    constexpr int C = G::C, TH = G::TH, TW = G::TW, GH = G::GH, GW = G::GW, VPP = G::VPP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int ty0 = ty * TH, tx0 = tx * TW;
+    constexpr int NV = GH * GW * VPP, NIT = (NV + 255) / 256;
+    uint4 val[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 256 + tid, p = idx / VPP, v = idx - p * VPP, r = p / GW, c = p - r * GW;
+        const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
+        val[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (idx < NV && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+            val[it] = *reinterpret_cast<const uint4*>(gz + (((size_t)b * H + gy) * W + gx) * C + v * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 256 + tid;
+        if (idx < NV) *reinterpret_cast<uint4*>(smem + (size_t)idx * 16) = val[it];       // [pixel][C] == [idx] x 16 bytes
+    }
+    s16x4 wfr[9][CB];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) wfr[tap][cb] = *reinterpret_cast<const s16x4*>(wd + ((tap * 16 + l15) * C + cb * 16 + 4 * l4));
+    __syncthreads();
+    for (int g = wave; g < TH * 4; g += 4) {
+        const int r = g >> 2, c = (g & 3) * 16 + l15;
+        f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const s16x4 bf = *reinterpret_cast<const s16x4*>(smem + ((size_t)((r + ky) * GW + c + kx) * C + cb * 16 + 4 * l4) * 2);
+                    acc = mma16(wfr[ky * 3 + kx][cb], bf, acc);
+                }
+        const int gy = ty0 + r, gx = tx0 + c;
+        if (l4 == 0 && gy < H && gx < W) {            // D rows 0..2 = the three colour channels of pixel (lane & 15)
+            float* p = gi + (((size_t)b * H + gy) * W + gx) * 3;
+            p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ weight gradient
+template <int CB> struct RcWg {
+    static constexpr int C = 16 * CB, TH = 8, TW = 64, TP = TH * TW, RH = TH + 2;
+    static constexpr int GZT = C * TP * 2;                    // gzT[C][TP] bf16
+    static constexpr int IMT = 12 * RH * TW * 2;              // imgT[3 kx][4 j][RH][64] bf16
+    static constexpr int RED = 4 * CB * 3 * 256 * 4;          // cross-wave reduction of the accumulators (reuses the stage area)
+    static constexpr int LDS = (GZT + IMT > RED ? GZT + IMT : RED);
+    static constexpr int NOUT = C * 48;                       // dW'[o][ky][16 n], n = kx * 4 + j (12..15 unused)
+};
+
+template <int CB>
+__global__ __launch_bounds__(256) void rgbconv_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ gz, float* __restrict__ part,
+                                                            int B, int H, int W, int ones, int tiles_x, int tiles_y, int ntiles) {
+    using G = RcWg<CB>;
+    constexpr int C = G::C, TH = G::TH, TW = G::TW, TP = G::TP, RH = G::RH, VPP = C / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* gzT = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* imgT = reinterpret_cast<bf16_t*>(smem + G::GZT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    f32x4_t acc[CB][3];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) acc[cb][ky] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // B operand of this lane: column n = lane & 15 -> (kx, j); columns 12..15 are padding (any valid address: their results are dropped)
+    const int nkx = (l15 >> 2) < 3 ? (l15 >> 2) : 0, nj = l15 & 3;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int tt = t;
+        const int tx = tt % tiles_x; tt /= tiles_x;
+        const int ty = tt % tiles_y, b = tt / tiles_y;
+        const int ty0 = ty * TH, tx0 = tx * TW;
+        // gz tile -> planar gzT[channel][pixel]
+        constexpr int NGV = TP * VPP / 256;
+        uint4 gv[NGV];
+#pragma unroll
+        for (int it = 0; it < NGV; ++it) {
+            const int idx = it * 256 + tid, p = idx / VPP, v = idx - p * VPP, r = p / TW, c = p - r * TW;
+            const int gy = ty0 + r, gx = tx0 + c;
+            gv[it] = (gy < H && gx < W) ? *reinterpret_cast<const uint4*>(gz + (((size_t)b * H + gy) * W + gx) * C + v * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        // image region (one halo pixel) as bf16 (r, g, b, 1 | 0)
+        constexpr int NIP = RH * (TW + 2), NII = (NIP + 255) / 256;
+        float i0[NII], i1[NII], i2[NII];
+        bool iok[NII];
+#pragma unroll
+        for (int it = 0; it < NII; ++it) {
+            const int idx = it * 256 + tid, rr = idx / (TW + 2), cr = idx - rr * (TW + 2);
+            const int gy = ty0 - 1 + rr, gx = tx0 - 1 + cr;
+            iok[it] = idx < NIP && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            i0[it] = i1[it] = i2[it] = 0.f;
+            if (iok[it]) {
+                const float* p = img + (((size_t)b * H + gy) * W + gx) * 3;
+                i0[it] = p[0]; i1[it] = p[1]; i2[it] = p[2];
+            }
+        }
+        __syncthreads();                                   // the previous tile's fragment reads are done
+#pragma unroll
+        for (int it = 0; it < NGV; ++it) {
+            const int idx = it * 256 + tid, p = idx / VPP, v = idx - p * VPP;
+            const unsigned w[4] = {gv[it].x, gv[it].y, gv[it].z, gv[it].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                gzT[(v * 8 + 2 * q) * TP + p] = (bf16_t)(w[q] & 0xffffu);
+                gzT[(v * 8 + 2 * q + 1) * TP + p] = (bf16_t)(w[q] >> 16);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NII; ++it) {
+            const int idx = it * 256 + tid, rr = idx / (TW + 2), cr = idx - rr * (TW + 2);
+            if (idx < NIP) {
+                const unsigned p01 = pack_bf16x2(i0[it], i1[it]), p23 = pack_bf16x2(i2[it], (iok[it] && ones) ? 1.f : 0.f);
+                const bf16_t vj[4] = {(bf16_t)(p01 & 0xffffu), (bf16_t)(p01 >> 16), (bf16_t)(p23 & 0xffffu), (bf16_t)(p23 >> 16)};
+                // imgT[kx][j][rr][c] = image(row ty0 - 1 + rr, column tx0 + c + kx - 1): region column cr = c + kx
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int c = cr - kx;
+                    if (c >= 0 && c < TW) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) imgT[((kx * 4 + j) * RH + rr) * TW + c] = vj[j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int g = wave; g < TH * 4; g += 4) {
+            const int r = g >> 2, c0 = (g & 3) * 16 + 4 * l4;
+            s16x4 af[CB];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) af[cb] = *reinterpret_cast<const s16x4*>(gzT + (cb * 16 + l15) * TP + r * TW + c0);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const s16x4 bf = *reinterpret_cast<const s16x4*>(imgT + ((nkx * 4 + nj) * RH + r + ky) * TW + c0);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) acc[cb][ky] = mma16(af[cb], bf, acc[cb][ky]);
+            }
+        }
+    }
+    // ---- the four waves' accumulators -> one partial per block: part[block][(o * 3 + ky) * 16 + n]
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) red[((wave * CB + cb) * 3 + ky) * 256 + rg * 64 + lane] = acc[cb][ky][rg];
+    __syncthreads();
+    for (int e = tid; e < CB * 3 * 256; e += 256) {
+        const int cbky = e >> 8, rem = e & 255, rg = rem >> 6, ln = rem & 63, cb = cbky / 3, ky = cbky - cb * 3;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[(w * CB * 3 + cbky) * 256 + rem];
+        const int o = cb * 16 + 4 * (ln >> 4) + rg, n = ln & 15;
+        part[(size_t)blockIdx.x * G::NOUT + (o * 3 + ky) * 16 + n] = s;
+    }
+}
+
+// sum of the block partials, deterministic: block = 8 outputs x 32 slices of the partial list
+__global__ __launch_bounds__(256) void rgbconv_wfinish_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int nout) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x, el = tid & 7, sl = tid >> 3, e = blockIdx.x * 8 + el;
+    float s = 0.f;
+    if (e < nout)
+        for (int k = sl; k < nblk; k += 32) s += part[(size_t)k * nout + e];
+    red[tid] = s;
+    __syncthreads();
+    if (tid < 8 && e < nout) {
+        float tsum = 0.f;
+        for (int k = 0; k < 32; ++k) tsum += red[k * 8 + tid];
+        out[e] = tsum;
+    }
+}
+
+// chain rule through W' = s0 sr W0 (x) Wr, T = s0 W0 br:   dwp[(o * 3 + ky) * 16 + kx * 4 + j]
+//   dW0[o][i][ky][kx] = s0 sr sum_j dW'[o][j][ky][kx] Wr[i][j] + s0 dW'[o][3][ky][kx] br[i] bscale
+//   dWr[i][j] = s0 sr sum_{o,ky,kx} dW'[o][j][ky][kx] W0[o][i][ky][kx];   dbr[i] = s0 bscale sum_{o,ky,kx} dW'[o][3][ky][kx] W0[o][i][ky][kx]
+//   db0[o] = dW'[o][3][1][1]  (the bias channel under the centre tap counts every pixel of the image once)
+// acc bit 0: dW0, 1: db0, 2: dWr, 3: dbr accumulate into the existing gradient instead of overwriting it.  NULL outputs are skipped.
+__global__ __launch_bounds__(256) void rgbconv_chain_kernel(const float* __restrict__ dwp, const float* __restrict__ w0, float s0, const float* __restrict__ wr,
+                                                            float sr, const float* __restrict__ br, float bscale, float* __restrict__ dw0, float* __restrict__ db0,
+                                                            float* __restrict__ dwr, float* __restrict__ dbr, int acc, int C) {
+    const int tid = threadIdx.x;
+    if (dw0) {
+        for (int e = tid; e < C * C * 9; e += 256) {
+            const int o = e / (C * 9), i = (e / 9) % C, tap = e % 9, ky = tap / 3, kx = tap % 3;
+            const float* d = dwp + (o * 3 + ky) * 16 + kx * 4;
+            float v = s0 * sr * (d[0] * wr[i * 3] + d[1] * wr[i * 3 + 1] + d[2] * wr[i * 3 + 2]);
+            if (br) v += s0 * d[3] * br[i] * bscale;
+            dw0[e] = (acc & 1) ? dw0[e] + v : v;
+        }
+    }
+    if (db0)
+        for (int o = tid; o < C; o += 256) {
+            const float v = dwp[(o * 3 + 1) * 16 + 4 + 3];
+            db0[o] = (acc & 2) ? db0[o] + v : v;
+        }
+    for (int e = tid; e < C * 4; e += 256) {
+        const int i = e >> 2, j = e & 3;
+        float* dst = j < 3 ? (dwr ? dwr + i * 3 + j : nullptr) : (dbr ? dbr + i : nullptr);
+        if (!dst) continue;
+        float v = 0.f;
+        for (int o = 0; o < C; ++o)
+            for (int tap = 0; tap < 9; ++tap) v += dwp[(o * 3 + tap / 3) * 16 + (tap % 3) * 4 + j] * w0[(o * C + i) * 9 + tap];
+        v *= j < 3 ? s0 * sr : s0 * bscale;
+        const bool a = j < 3 ? (acc & 4) : (acc & 8);
+        *dst = a ? *dst + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ host side
+static bool rgbconv_shape_ok(int B, int H, int W, int C, int dtype) {
+    static const int on = [] { const char* e = getenv("SGX_RGBCONV"); return e ? atoi(e) : 1; }();     // A/B switch
+    return on && dtype == SGX_BF16 && (C == 16 || C == 32) && B >= 1 && H >= 16 && W >= 64 && H % 16 == 0 && W % 64 == 0;
+}
+extern "C" int sgx_rgbconv_ok(int B, int H, int W, int C, int dtype) { return rgbconv_shape_ok(B, H, W, C, dtype) ? 1 : 0; }
+
+extern "C" int sgx_rgbconv_pack(const float* w0, float s0, const float* wr, float sr, const float* br, float bscale, void* wf, void* wd, int C,
+                                void* stream) {
+    SGX_REQUIRE(w0 && wr && wf && wd, SGX_EINVAL, "rgbconv_pack: null argument");
+    SGX_REQUIRE(C == 16 || C == 32, SGX_EUNSUPPORTED, "rgbconv_pack: %d channels (16 or 32)", C);
+    SGX_NOTE(0.0, 0.0, "rgbconv_pack C%d", C);
+    hipLaunchKernelGGL(rgbconv_pack_kernel, dim3(C == 16 ? 12 : 24), dim3(256), 0, (hipStream_t)stream, w0, s0, wr, sr, br, bscale,
+                       static_cast<bf16_t*>(wf), static_cast<bf16_t*>(wd), C);
+    SGX_LAUNCH_CHECK("rgbconv_pack_kernel");
+    return 0;
+}
+
+template <int CB, int EPI>
+static int launch_rgbconv_fwd(const float* img, const bf16_t* wf, const float* b0, bf16_t* y, unsigned char* bits, int B, int H, int W, int ones,
+                              hipStream_t st) {
+    using G = RcFwd<CB, EPI>;
+    const int tiles_x = W / G::TW, tiles_y = H / G::TH;
+    sgx_lds_opt_in<rgbconv_fwd_kernel<CB, EPI>>(G::LDS);
+    hipLaunchKernelGGL((rgbconv_fwd_kernel<CB, EPI>), dim3((unsigned)(B * tiles_x * tiles_y)), dim3(256), G::LDS, st, img, wf, b0, y, bits, B, H, W, ones,
+                       tiles_x, tiles_y);
+    SGX_LAUNCH_CHECK("rgbconv_fwd_kernel");
+    return 0;
+}
+extern "C" int sgx_rgbconv_fwd(const float* img, const void* wf, const float* b0, void* y, void* bits, int B, int H, int W, int C, int epi, int ones,
+                               int dtype, void* stream) {
+    SGX_REQUIRE(img && wf && y, SGX_EINVAL, "rgbconv_fwd: null argument");
+    SGX_REQUIRE(rgbconv_shape_ok(B, H, W, C, dtype), SGX_EUNSUPPORTED, "rgbconv_fwd: shape B%d %dx%d C%d dtype %d (sgx_rgbconv_ok == 0)", B, H, W, C, dtype);
+    SGX_REQUIRE(epi == 0 || epi == 1, SGX_EINVAL, "rgbconv_fwd: epilogue %d", epi);
+    const double px = (double)B * H * W;
+    SGX_NOTE(2.0 * 27 * C * px, px * (12.0 + 2.0 * C + (epi && bits ? C / 8.0 : 0.0)), "rgbconv%s B%d %dx%d 3->%d", epi ? "+act+blur" : "", B, H, W, C);
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t* w = static_cast<const bf16_t*>(wf);
+    bf16_t* out = static_cast<bf16_t*>(y);
+    unsigned char* bt = static_cast<unsigned char*>(bits);
+    if (C == 16) return epi ? launch_rgbconv_fwd<1, 1>(img, w, b0, out, bt, B, H, W, ones, st) : launch_rgbconv_fwd<1, 0>(img, w, b0, out, bt, B, H, W, ones, st);
+    return epi ? launch_rgbconv_fwd<2, 1>(img, w, b0, out, bt, B, H, W, ones, st) : launch_rgbconv_fwd<2, 0>(img, w, b0, out, bt, B, H, W, ones, st);
+}
+
+template <int CB>
+static int launch_rgbconv_dgrad(const bf16_t* gz, const bf16_t* wd, float* gi, int B, int H, int W, hipStream_t st) {
+    using G = RcDg<CB>;
+    const int tiles_x = W / G::TW, tiles_y = H / G::TH;
+    sgx_lds_opt_in<rgbconv_dgrad_kernel<CB>>(G::LDS);
+    hipLaunchKernelGGL((rgbconv_dgrad_kernel<CB>), dim3((unsigned)(B * tiles_x * tiles_y)), dim3(256), G::LDS, st, gz, wd, gi, B, H, W, tiles_x, tiles_y);
+    SGX_LAUNCH_CHECK("rgbconv_dgrad_kernel");
+    return 0;
+}
+extern "C" int sgx_rgbconv_dgrad(const void* gz, const void* wd, float* gi, int B, int H, int W, int C, int dtype, void* stream) {
+    SGX_REQUIRE(gz && wd && gi, SGX_EINVAL, "rgbconv_dgrad: null argument");
+    SGX_REQUIRE(rgbconv_shape_ok(B, H, W, C, dtype), SGX_EUNSUPPORTED, "rgbconv_dgrad: shape B%d %dx%d C%d dtype %d (sgx_rgbconv_ok == 0)", B, H, W, C, dtype);
+    const double px = (double)B * H * W;
+    SGX_NOTE(2.0 * 27 * C * px, px * (12.0 + 2.0 * C), "rgbconv_dgrad B%d %dx%d %d->3", B, H, W, C);
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 16) return launch_rgbconv_dgrad<1>(static_cast<const bf16_t*>(gz), static_cast<const bf16_t*>(wd), gi, B, H, W, st);
+    return launch_rgbconv_dgrad<2>(static_cast<const bf16_t*>(gz), static_cast<const bf16_t*>(wd), gi, B, H, W, st);
+}
+
+static int rgbconv_wgrad_blocks(int B, int H, int W) {
+    const long ntiles = (long)B * (H / 8) * (W / 64);
+    return (int)(ntiles < 1024 ? ntiles : 1024);
+}
+extern "C" size_t sgx_rgbconv_wgrad_ws_bytes(int B, int H, int W, int C) {
+    if (B < 1 || H < 8 || W < 64 || (C != 16 && C != 32)) return 0;
+    return ((size_t)rgbconv_wgrad_blocks(B, H, W) + 1) * C * 48 * sizeof(float);
+}
+extern "C" int sgx_rgbconv_wgrad(const float* img, const void* gz, int ones, const float* w0, float s0, const float* wr, float sr, const float* br,
+                                 float bscale, float* dw0, float* db0, float* dwr, float* dbr, int acc, void* ws, size_t ws_bytes, int B, int H, int W,
+                                 int C, int dtype, void* stream) {
+    SGX_REQUIRE(img && gz && w0 && wr && ws, SGX_EINVAL, "rgbconv_wgrad: null argument");
+    SGX_REQUIRE(rgbconv_shape_ok(B, H, W, C, dtype), SGX_EUNSUPPORTED, "rgbconv_wgrad: shape B%d %dx%d C%d dtype %d (sgx_rgbconv_ok == 0)", B, H, W, C, dtype);
+    SGX_REQUIRE(ws_bytes >= sgx_rgbconv_wgrad_ws_bytes(B, H, W, C), SGX_EWORKSPACE, "rgbconv_wgrad: workspace %zu < %zu", ws_bytes,
+                sgx_rgbconv_wgrad_ws_bytes(B, H, W, C));
+    SGX_REQUIRE(ones || (!db0 && !dbr), SGX_EINVAL, "rgbconv_wgrad: bias gradients need the bias channel (ones = 1)");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = rgbconv_wgrad_blocks(B, H, W), nout = C * 48;
+    const int tiles_x = W / 64, tiles_y = H / 8, ntiles = B * tiles_x * tiles_y;
+    float* part = static_cast<float*>(ws);
+    float* dwp = part + (size_t)nblk * nout;
+    const double px = (double)B * H * W;
+    SGX_NOTE(2.0 * 36 * C * px, px * (12.0 + 2.0 * C), "rgbconv_wgrad B%d %dx%d 3x%d", B, H, W, C);
+    if (C == 16) {
+        sgx_lds_opt_in<rgbconv_wgrad_kernel<1>>(RcWg<1>::LDS);
+        hipLaunchKernelGGL((rgbconv_wgrad_kernel<1>), dim3((unsigned)nblk), dim3(256), RcWg<1>::LDS, st, img, static_cast<const bf16_t*>(gz), part, B, H, W,
+                           ones, tiles_x, tiles_y, ntiles);
+    } else {
+        sgx_lds_opt_in<rgbconv_wgrad_kernel<2>>(RcWg<2>::LDS);
+        hipLaunchKernelGGL((rgbconv_wgrad_kernel<2>), dim3((unsigned)nblk), dim3(256), RcWg<2>::LDS, st, img, static_cast<const bf16_t*>(gz), part, B, H, W,
+                           ones, tiles_x, tiles_y, ntiles);
+    }
+    SGX_LAUNCH_CHECK("rgbconv_wgrad_kernel");
+    hipLaunchKernelGGL(rgbconv_wfinish_kernel, dim3((unsigned)((nout + 7) / 8)), dim3(256), 0, st, (const float*)part, dwp, nblk, nout);
+    SGX_LAUNCH_CHECK("rgbconv_wfinish_kernel");
+    hipLaunchKernelGGL(rgbconv_chain_kernel, dim3(1), dim3(256), 0, st, (const float*)dwp, w0, s0, wr, sr, br, bscale, dw0, db0, dwr, dbr, acc, C);
+    SGX_LAUNCH_CHECK("rgbconv_chain_kernel");
+    return 0;
+}

@@ -390,11 +390,12 @@ class ConvFn(Function):
             gy = _bcall(LReluBwdFn, gy, y, 0.2, 1.0)
         gx = gw = gb = None
         x_pre = getattr(ctx, "x_pre", None)
+        xb = getattr(ctx, "x_pre_bits", None)
         if ctx.needs_input_grad[0]:
-            if x_pre is not None:
+            if x_pre is not None or xb is not None:
                 assert not x_masked
-                xb = getattr(ctx, "x_pre_bits", None)
-                if conv_blur_ok(gy, weight.shape[1] if not adjoint else weight.shape[0], mode, not adjoint):
+                # (x_pre None: the producer never materialised the pre-activation -- RgbConvBlurFn -- and only its sign bits exist)
+                if x_pre is not None and conv_blur_ok(gy, weight.shape[1] if not adjoint else weight.shape[0], mode, not adjoint):
                     gx = _bcall(ConvBlurFn, gy, weight, mode, scale, ipad, not adjoint, x_pre)      # one kernel
                 else:
                     gx = _bcall(BlurMaskFn, _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0), x_pre, xb)
@@ -569,6 +570,222 @@ def _conv_stats_launch(x, wq, ebias, noise, nw):
                                 N.ptr(_c(nw.detach())), N.ptr(part), part.numel() * 8, B, H, W, Cin, Cout, N.dt(x), N.stream()),
             "sgx_conv3x3_stats")
     return y, part
+
+
+# ---------------------------------------------------------------------------------------------------
+# The discriminator's first layer pair at the current resolution -- from_rgb (1x1, no activation) -> conv0 (3x3) -> LeakyReLU ->
+# blur, reference models/GAN.py:353,413-427 + models/Blocks.py:137-142 -- as ONE 3-channel convolution of the RGB image
+# (csrc/rgbconv.hip; the algebra is in its header).  Three Functions, closed under differentiation like the ConvFn family:
+#   RgbConvBlurFn : img -> (xb = blur(lrelu(conv(img) + b0)), sign bits of the pre-activation); its "gradient" input is the gradient
+#                   w.r.t. the PRE-ACTIVATION z (its only consumer is the stride-2 ConvFn called with x_pre_bits, whose backward
+#                   applies the blur and the activation mask -- the ActBlurPassFn convention)
+#   RgbConvAdjFn  : gz -> gradient w.r.t. the image;  RgbConvPlainFn: img -> conv(img), the adjoint's own adjoint (R1 double backward)
+# Parameters stay the reference's four tensors (conv0.weight/bias, from_rgb.weight/bias): their gradients come from the composed
+# weight gradient by the chain rule inside sgx_rgbconv_wgrad, in the parameters' own layouts.
+_RGB_PACKS = {}
+
+
+RGBCONV = os.environ.get("SGX_RGBCONV", "1") != "0"        # A/B (tests flip the attribute; the library reads the same variable)
+
+
+def rgbconv_ok(B, H, W, C, dtype):
+    return RGBCONV and dtype == torch.bfloat16 and bool(N.lib().sgx_rgbconv_ok(int(B), int(H), int(W), int(C), N.BF16))
+
+
+def rgb_packs(w0, s0, wr, sr, br):
+    """(wf, wd): operand packs of the composed convolution, cached per version of the three parameters they are made of."""
+    key = (id(w0), id(wr))
+    tag = (_pack_tag(w0), _pack_tag(wr), None if br is None else _pack_tag(br), float(s0), float(sr))
+    ent = _RGB_PACKS.get(key)
+    if ent is None or ent[0]() is not w0 or ent[1]() is not wr:
+        ent = [weakref.ref(w0, lambda _r, k=key: _RGB_PACKS.pop(k, None)), weakref.ref(wr), None, None, None]
+        _RGB_PACKS[key] = ent
+    if ent[2] != tag:
+        C = w0.shape[0]
+        if w0.dtype != torch.float32 or wr.dtype != torch.float32 or tuple(w0.shape) != (C, C, 3, 3) or tuple(wr.shape) != (C, 3, 1, 1):
+            raise N.SgxError("rgb_packs: conv0.weight [C,C,3,3] and from_rgb.weight [C,3,1,1] (fp32) expected")
+        wf = torch.empty((3, C, 16), dtype=torch.bfloat16, device=w0.device)
+        wd = torch.empty((9, 16, C), dtype=torch.bfloat16, device=w0.device)
+        N.check(N.lib().sgx_rgbconv_pack(N.ptr(_c(w0.detach())), float(s0), N.ptr(_c(wr.detach())), float(sr),
+                                         N.ptr(None if br is None else _c(br.detach())), 1.0, N.ptr(wf), N.ptr(wd), C, N.stream()), "sgx_rgbconv_pack")
+        ent[2], ent[3], ent[4] = tag, (wf, wd), _pack_mark()
+    else:
+        raw = N.stream()
+        if raw not in ent[4][2]:                               # packed on another stream: wait once per consumer stream
+            _stream_of(raw).wait_event(ent[4][0])
+            ent[4][2].add(raw)
+    return ent[3]
+
+
+def _rgb_wgrad(img, gz, ones, w0, b0, wr, br, s0, sr, want):
+    """Gradients of (conv0.weight, conv0.bias, from_rgb.weight, from_rgb.bias) -- ``want`` says which -- from the image (or, for
+    the adjoint op, the gradient that flowed into it) and the pre-activation gradient gz.  Training step: accumulated straight into
+    ``.grad`` on the weight-gradient side stream, nothing handed to autograd (-> four Nones); otherwise -> the four tensors."""
+    params = (w0, b0, wr, br)
+    want = [bool(w) and p is not None for w, p in zip(want, params)]
+    if not ones:
+        want[1] = want[3] = False                              # the adjoint / plain ops do not involve the biases
+    if not any(want):
+        return None, None, None, None
+    accum = _ACCUM_PARAM_GRADS and not torch.is_grad_enabled() and all(p.is_leaf for p, w in zip(params, want) if w)
+    outs, acc = [], 0
+    for k, (p, w) in enumerate(zip(params, want)):
+        if not w:
+            outs.append(None)
+        elif accum and p.grad is not None:
+            outs.append(p.grad); acc |= 1 << k
+        else:
+            outs.append(torch.empty(p.shape, dtype=torch.float32, device=gz.device))
+
+    def launch():
+        L = N.lib()
+        B, H, W, C = gz.shape
+        wsb = L.sgx_rgbconv_wgrad_ws_bytes(B, H, W, C)
+        ws = N.workspace(wsb, gz.device)
+        N.check(L.sgx_rgbconv_wgrad(N.ptr(img), N.ptr(gz), int(bool(ones)), N.ptr(_c(w0.detach())), float(s0), N.ptr(_c(wr.detach())), float(sr),
+                                    N.ptr(_c(br.detach())) if (ones and br is not None) else None, 1.0, N.ptr(outs[0]), N.ptr(outs[1]), N.ptr(outs[2]),
+                                    N.ptr(outs[3]), acc, N.ptr(ws), wsb, B, H, W, C, N.BF16, N.stream()), "sgx_rgbconv_wgrad")
+    side = _PARAM_GRAD_STREAM if accum else None
+    cur_raw = N.stream()
+    if side is None or side.cuda_stream == cur_raw:
+        launch()
+    else:                                                      # as _param_grads: fork to the side stream on raw handles
+        cur = _stream_of(cur_raw)
+        N.check(N.lib().sgx_stream_wait_stream(side.cuda_stream, cur_raw), "sgx_stream_wait_stream")
+        _set_stream(stream_id=side.stream_id, device_index=side.device_index, device_type=side.device_type)
+        try:
+            launch()
+        finally:
+            _set_stream(stream_id=cur.stream_id, device_index=cur.device_index, device_type=cur.device_type)
+        img.record_stream(side); gz.record_stream(side)
+        for o in outs:
+            if o is not None:
+                o.record_stream(cur)
+    if not accum:
+        return tuple(outs)
+    for p, w, o in zip(params, want, outs):
+        if w:
+            if p.grad is None:
+                p.grad = o
+            if GRAD_NOTE is not None:
+                GRAD_NOTE(p)
+    return None, None, None, None
+
+
+class RgbConvBlurFn(Function):
+    @staticmethod
+    def forward(ctx, img, w0, b0, wr, br, s0, sr):
+        img = _c(img)
+        if img.dtype != torch.float32 or img.dim() != 4 or img.shape[3] != 3:
+            raise N.SgxError("RgbConvBlurFn: fp32 NHWC RGB image expected")
+        B, H, W, _ = img.shape
+        C = w0.shape[0]
+        wf, wd = rgb_packs(w0, s0, wr, sr, br)
+        xb = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=img.device)
+        bits = torch.empty((B, H, W, C // 8), dtype=torch.uint8, device=img.device)
+        N.check(N.lib().sgx_rgbconv_fwd(N.ptr(img), N.ptr(wf), N.ptr(None if b0 is None else _c(b0.detach())), N.ptr(xb), N.ptr(bits), B, H, W, C,
+                                        1, 1, N.BF16, N.stream()), "sgx_rgbconv_fwd")
+        ctx.cfg = (float(s0), float(sr))
+        ctx.save_for_backward(img, w0, b0, wr, br)
+        ctx.mark_non_differentiable(bits)
+        ctx.set_materialize_grads(False)
+        return xb, bits
+
+    @staticmethod
+    def backward(ctx, gz, _gbits=None):
+        if gz is None:
+            return (None,) * 7
+        img, w0, b0, wr, br = ctx.saved_tensors
+        s0, sr = ctx.cfg
+        gz = _c(gz)
+        gi = _bcall(RgbConvAdjFn, gz, w0, wr, br, s0, sr) if ctx.needs_input_grad[0] else None
+        gw0 = gb0 = gwr = gbr = None
+        if not _DATA_GRAD_ONLY:
+            gw0, gb0, gwr, gbr = _bcall_wgrad(img, gz, True, w0, b0, wr, br, s0, sr, ctx.needs_input_grad[1:5])
+        return gi, gw0, gb0, gwr, gbr, None, None
+
+
+class RgbConvAdjFn(Function):
+    @staticmethod
+    def forward(ctx, gz, w0, wr, br, s0, sr):
+        gz = _c(gz)
+        B, H, W, C = gz.shape
+        wf, wd = rgb_packs(w0, s0, wr, sr, br)
+        gi = torch.empty((B, H, W, 3), dtype=torch.float32, device=gz.device)
+        N.check(N.lib().sgx_rgbconv_dgrad(N.ptr(gz), N.ptr(wd), N.ptr(gi), B, H, W, C, N.dt(gz), N.stream()), "sgx_rgbconv_dgrad")
+        ctx.cfg = (float(s0), float(sr))
+        ctx.save_for_backward(gz, w0, wr, br)
+        return gi
+
+    @staticmethod
+    def backward(ctx, gg):
+        gz, w0, wr, br = ctx.saved_tensors
+        s0, sr = ctx.cfg
+        gg = _c(gg.float())
+        ggz = _bcall(RgbConvPlainFn, gg, w0, wr, br, s0, sr) if ctx.needs_input_grad[0] else None
+        gw0 = gwr = None
+        if not _DATA_GRAD_ONLY:
+            gw0, _, gwr, _ = _bcall_wgrad(gg, gz, False, w0, None, wr, br, s0, sr, (ctx.needs_input_grad[1], False, ctx.needs_input_grad[2], False))
+        return ggz, gw0, gwr, None, None, None
+
+
+class RgbConvPlainFn(Function):
+    @staticmethod
+    def forward(ctx, img, w0, wr, br, s0, sr):
+        img = _c(img)
+        B, H, W, _ = img.shape
+        C = w0.shape[0]
+        wf, wd = rgb_packs(w0, s0, wr, sr, br)
+        z = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=img.device)
+        N.check(N.lib().sgx_rgbconv_fwd(N.ptr(img), N.ptr(wf), None, N.ptr(z), None, B, H, W, C, 0, 0, N.BF16, N.stream()), "sgx_rgbconv_fwd")
+        ctx.cfg = (float(s0), float(sr))
+        ctx.save_for_backward(img, w0, wr, br)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        img, w0, wr, br = ctx.saved_tensors
+        s0, sr = ctx.cfg
+        gz = _c(gz)
+        gi = _bcall(RgbConvAdjFn, gz, w0, wr, br, s0, sr) if ctx.needs_input_grad[0] else None
+        gw0 = gwr = None
+        if not _DATA_GRAD_ONLY:
+            gw0, _, gwr, _ = _bcall_wgrad(img, gz, False, w0, None, wr, br, s0, sr, (ctx.needs_input_grad[1], False, ctx.needs_input_grad[2], False))
+        return gi, gw0, gwr, None, None, None
+
+
+class RgbConvWgradFn(Function):
+    """The parameter gradients as autograd outputs (first order only; the training step accumulates in-kernel instead)."""
+
+    @staticmethod
+    def forward(ctx, img, gz, ones, w0, b0, wr, br, s0, sr, want):
+        outs = _rgb_wgrad(img, gz, ones, w0, b0, wr, br, s0, sr, want)
+        ctx.set_materialize_grads(False)
+        return tuple(o if o is not None else torch.zeros((), device=gz.device) for o in outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *g):
+        raise NotImplementedError("second derivative through a weight gradient is not part of the training path")
+
+
+def _bcall_wgrad(img, gz, ones, w0, b0, wr, br, s0, sr, want):
+    """Parameter gradients of the composed convolution: in-kernel accumulation in the training step, else tensors for autograd
+    (None where not wanted)."""
+    want = tuple(bool(w) for w in want)
+    if not any(want):
+        return None, None, None, None
+    if not torch.is_grad_enabled():
+        return _rgb_wgrad(_c(img), gz, ones, w0, b0, wr, br, s0, sr, want)
+    params = (w0, b0, wr, br)
+    outs = RgbConvWgradFn.apply(_c(img), gz, ones, w0, b0, wr, br, s0, sr, want)
+    real = [w and p is not None and (ones or k in (0, 2)) for k, (w, p) in enumerate(zip(want, params))]
+    return tuple(o if r else None for o, r in zip(outs, real))
+
+
+def rgbconv_blur(img, w0, b0, wr, br, s0, sr):
+    """-> (blur(lrelu(conv0(from_rgb(img)))), sign bits of conv0's pre-activation)."""
+    return call(RgbConvBlurFn, img, w0, b0, wr, br, float(s0), float(sr))
 
 
 # ---------------------------------------------------------------------------------------------------

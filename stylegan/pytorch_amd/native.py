@@ -76,6 +76,12 @@ SIGNATURES = {
     "sgx_blur3x3_bits": (I, [P, P, P, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_up_blur_ok": (I, [I, I, I, I, I, I]),
     "sgx_conv4x4s2_up_blur": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "sgx_rgbconv_ok": (I, [I, I, I, I, I]),
+    "sgx_rgbconv_pack": (I, [P, F, P, F, P, F, P, P, I, P]),
+    "sgx_rgbconv_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "sgx_rgbconv_dgrad": (I, [P, P, P, I, I, I, I, I, P]),
+    "sgx_rgbconv_wgrad_ws_bytes": (Z, [I, I, I, I]),
+    "sgx_rgbconv_wgrad": (I, [P, P, I, P, F, P, F, P, F, P, P, P, P, I, P, Z, I, I, I, I, I, P]),
     "sgx_conv3x3_stats": (I, [P, P, P, P, P, P, P, Z, I, I, I, I, I, I, P]),
     "sgx_blur3x3_stats": (I, [P, P, P, P, P, P, Z, I, I, I, I, I, I, P]),
     "sgx_gepi_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, P]),
@@ -238,14 +244,18 @@ class PinnedRing:
             self.owners[i] = None
         ev = self.events[i]
         if ev is not None:
-            ev.synchronize()                                        # (long done: ``slots`` requests ago)
+            ev[0].synchronize()                                     # (long done: ``slots`` requests ago)
         return self.buf[i * self.slot_bytes:i * self.slot_bytes + nbytes], i
 
     def mark(self, i, owner=None):
         """Record the slot's event on the current stream (after the copy that uses the slot) -> the event."""
-        ev = self.events[i]
-        if ev is None:
-            ev = self.events[i] = torch.cuda.Event()
+        # (a torch Event is bound to the device of its first record(): a process that drives several GPUs gets a fresh event when
+        # the slot is next used from another device; the old one was synchronised by _take before the slot was handed out)
+        dev = _get_device()
+        ent = self.events[i]
+        if ent is None or ent[1] != dev:
+            ent = self.events[i] = (torch.cuda.Event(), dev)
+        ev = ent[0]
         ev.record()
         if owner is not None:
             import weakref

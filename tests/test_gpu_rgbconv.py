@@ -1,0 +1,203 @@
+"""-m gpu: the discriminator's first layer pair as ONE convolution of the RGB image (csrc/rgbconv.hip, round 4).
+
+Reference composition: ``from_rgb`` (1x1 EqualizedConv2d, no activation, models/GAN.py:353,425) -> ``DiscriminatorBlock.conv0`` ->
+LeakyReLU -> BlurLayer (models/Blocks.py:137-142).  Every kernel against the fp64 CPU oracle of that chain (forward, image
+gradient, the four parameter gradients through the chain rule, the plain convolution of the double backward), and the whole
+discriminator -- scores, R1 image gradient, every parameter gradient of the logistic + R1 loss -- with the composed kernel ON
+against the same network with it OFF, both measured against the fp64 oracle.  bf16 storage: tolerances are those of one bf16
+rounding of the operands (2^-9 per element) plus the store, written next to each check."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from gpu_util import DEV, MID, MID_DEPTH, load_into, mid_params, rel_err
+from oracle import stylegan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    from stylegan.pytorch_amd import native
+    assert torch.cuda.is_available()
+    native.lib()
+
+
+def make_params(C, dtype=torch.float64):
+    p = {"w0": gu.seeded((C, C, 3, 3), 11, dtype), "b0": 0.3 * gu.seeded((C,), 12, dtype),
+         "wr": gu.seeded((C, 3, 1, 1), 13, dtype), "br": 0.5 * gu.seeded((C,), 14, dtype)}
+    return {k: v.requires_grad_(True) for k, v in p.items()}
+
+
+def scales(C):
+    return O.he_w_mul(C * 9, 2 ** 0.5), O.he_w_mul(3, 2 ** 0.5)
+
+
+def chain64(img, p, bias=True):
+    """fp64: from_rgb -> conv0 (pre-activation z) -> lrelu -> blur, reference models/GAN.py:425 + models/Blocks.py:139-142."""
+    f = O.eq_conv2d(img, p["wr"], p["br"] if bias else None)
+    z = O.eq_conv2d(f, p["w0"], p["b0"] if bias else None)
+    return z, O.blur3(O.leaky_relu(z))
+
+
+def dev_params(p):
+    return {k: v.detach().float().to(DEV).requires_grad_(True) for k, v in p.items()}
+
+
+CASES = [(16, 2, 32, 64), (16, 1, 48, 192), (32, 2, 16, 64), (32, 1, 40, 128)]
+
+
+@pytest.mark.parametrize("C,B,H,W", CASES)
+def test_forward_blur_and_sign_bits_vs_oracle(C, B, H, W):
+    from stylegan.pytorch_amd import functional as F
+    p = make_params(C)
+    d = dev_params(p)
+    img = gu.seeded((B, 3, H, W), 21, torch.float64)
+    s0, sr = scales(C)
+    with torch.no_grad():
+        z, xb = chain64(img, p)
+        x_nhwc = img.float().permute(0, 2, 3, 1).contiguous().to(DEV)
+        assert F.rgbconv_ok(B, H, W, C, torch.bfloat16)
+        got, bits = F.RgbConvBlurFn.apply(x_nhwc, d["w0"], d["b0"], d["wr"], d["br"], s0, sr)
+        assert got.dtype == torch.bfloat16 and got.shape == (B, H, W, C) and bits.shape == (B, H, W, C // 8)
+        e = rel_err(got.permute(0, 3, 1, 2), xb)
+        # the unfused library path in bf16 (from_rgb output rounded, conv0 output rounded, blur output rounded) for scale
+        f_old = F.call(F.RgbInFn, x_nhwc, d["wr"], d["br"], sr, torch.bfloat16)
+        z_old = F.conv(f_old, d["w0"], d["b0"], "S", s0, ipad=C)
+        e_old = rel_err(F.call(F.ActBlurFn, z_old).permute(0, 3, 1, 2), xb)
+        print(f"[rgbconv fwd C{C} {H}x{W}] rel {e:.2e} (unfused bf16 path {e_old:.2e})")
+        assert e <= 6e-3 and e <= 1.5 * e_old + 1e-3, (e, e_old)
+        # sign bits: bit j of byte v = (pre-activation of channel 8v + j > 0); elements within bf16 noise of zero may differ
+        zz = z.permute(0, 2, 3, 1)                                                         # [B,H,W,C]
+        want = (zz > 0)
+        b = bits.cpu().numpy()
+        gotbits = np.unpackbits(b[..., None], axis=-1, bitorder="little").reshape(B, H, W, C).astype(bool)
+        sure = (zz.abs() > 2e-2 * zz.abs().mean()).numpy()
+        assert (gotbits[sure] == want.numpy()[sure]).all()
+        assert (gotbits != want.numpy()).mean() < 2e-2
+
+
+@pytest.mark.parametrize("C,B,H,W", CASES[:1] + CASES[2:3])
+def test_plain_convolution_and_image_gradient_vs_oracle(C, B, H, W):
+    from stylegan.pytorch_amd import functional as F
+    p = make_params(C)
+    d = dev_params(p)
+    s0, sr = scales(C)
+    img = gu.seeded((B, 3, H, W), 31, torch.float64).requires_grad_(True)
+    gz = gu.seeded((B, C, H, W), 32, torch.float64)
+    z, _ = chain64(img, p, bias=False)                       # the double-backward ops carry no biases
+    (gi,) = torch.autograd.grad((z * gz).sum(), img)
+    with torch.no_grad():
+        x_nhwc = img.detach().float().permute(0, 2, 3, 1).contiguous().to(DEV)
+        got_z = F.RgbConvPlainFn.apply(x_nhwc, d["w0"], d["wr"], d["br"], s0, sr)
+        e_z = rel_err(got_z.permute(0, 3, 1, 2), z)
+        gz_dev = gz.float().permute(0, 2, 3, 1).contiguous().to(DEV).bfloat16()
+        got_gi = F.RgbConvAdjFn.apply(gz_dev, d["w0"], d["wr"], d["br"], s0, sr)
+        assert got_gi.dtype == torch.float32 and got_gi.shape == (B, H, W, 3)
+        e_g = rel_err(got_gi.permute(0, 3, 1, 2), gi)
+    print(f"[rgbconv C{C}] plain conv rel {e_z:.2e}, image gradient rel {e_g:.2e}")
+    assert e_z <= 6e-3 and e_g <= 6e-3, (e_z, e_g)
+
+
+@pytest.mark.parametrize("C,B,H,W", [(16, 2, 32, 64), (32, 3, 24, 128), (16, 5, 64, 256)])
+def test_parameter_gradients_through_the_chain_rule_vs_oracle(C, B, H, W):
+    """dW0, db0, dWr, dbr from (image, gradient of the pre-activation): written, accumulated, and without the bias channel."""
+    from stylegan.pytorch_amd import functional as F
+    p = make_params(C)
+    d = dev_params(p)
+    s0, sr = scales(C)
+    img = gu.seeded((B, 3, H, W), 41, torch.float64)
+    gz = gu.seeded((B, C, H, W), 42, torch.float64)
+    x_nhwc = img.float().permute(0, 2, 3, 1).contiguous().to(DEV)
+    gz_dev = gz.float().permute(0, 2, 3, 1).contiguous().to(DEV).bfloat16()
+    gz_r = gz_dev.double().cpu().permute(0, 3, 1, 2)         # the oracle sees the same (bf16-rounded) upstream gradient
+    names = ["w0", "b0", "wr", "br"]
+    for ones in (True, False):
+        z, _ = chain64(img, p, bias=ones)
+        ks = names if ones else ["w0", "wr"]
+        want = dict(zip(ks, torch.autograd.grad((z * gz_r).sum(), [p[k] for k in ks])))
+        with torch.no_grad():
+            outs = F._rgb_wgrad(x_nhwc, gz_dev, ones, d["w0"], d["b0"] if ones else None, d["wr"], d["br"], s0, sr, (True, True, True, True))
+        got = dict(zip(names, outs))
+        for k in names:
+            if k not in ks:
+                assert got[k] is None
+                continue
+            e = rel_err(got[k], want[k])
+            print(f"[rgbconv wgrad C{C} B{B} ones={ones}] {k}: rel {e:.2e}")
+            assert e <= 8e-3, (k, e)
+    # accumulation into existing .grad tensors (the training step's mode): twice the gradient, bit-deterministic
+    for k in names:
+        d[k].grad = None
+    with torch.no_grad(), F.accumulate_param_grads():
+        for _ in range(2):
+            assert F._rgb_wgrad(x_nhwc, gz_dev, True, d["w0"], d["b0"], d["wr"], d["br"], s0, sr, (True, True, True, True)) == (None,) * 4
+    z, _ = chain64(img, p, bias=True)
+    want = dict(zip(names, torch.autograd.grad((z * gz_r).sum(), [p[k] for k in names])))
+    for k in names:
+        assert rel_err(d[k].grad, 2 * want[k]) <= 8e-3, k
+
+
+# ---- the whole discriminator with the composed kernel on / off, against the fp64 oracle ------------------------------------
+def build_dis(depth_total=MID_DEPTH):
+    from stylegan.pytorch_amd.GAN import Discriminator
+    dis = Discriminator(resolution=MID["resolution"], num_channels=3, use_wscale=True, blur_filter=[1, 2, 1], fmap_base=MID["fmap_base"],
+                        fmap_max=MID["fmap_max"], structure="linear", act_dtype=torch.bfloat16).to(DEV)
+    _, dp = mid_params(torch.float64)
+    load_into(dis, dp)
+    return dis.train(), dp
+
+
+def d_loss_grads(dis, real, fake, depth, alpha):
+    from stylegan.pytorch_amd import Losses
+    for q in dis.parameters():
+        q.grad = None
+    loss = Losses.LogisticGAN(dis).dis_loss(real, fake, depth, alpha)
+    loss.backward()
+    rimg = real.detach().requires_grad_(True)
+    (g_img,) = torch.autograd.grad(dis(rimg, depth, alpha).sum(), rimg)
+    return float(loss), {k: q.grad.detach().clone() for k, q in dis.named_parameters() if q.grad is not None}, g_img
+
+
+@pytest.mark.parametrize("depth", [5, 4])          # newest block at 128^2 with 16 channels / at 64^2 with 32
+def test_discriminator_step_with_the_composed_first_layer(depth, monkeypatch):
+    from stylegan.pytorch_amd import functional as F
+    B, alpha = 4, 0.6
+    R = 4 << depth
+    real = gu.seeded((B, 3, R, R), 51); fake = gu.seeded((B, 3, R, R), 52)
+    dis, dp = build_dis()
+    top = dis.blocks[dis.depth - depth - 1]
+    assert top.fused_from_rgb_ok((B, R, R, 3), dis.from_rgb[dis.depth - depth - 1], torch.bfloat16)
+    used = []
+    orig = F.rgbconv_blur
+    monkeypatch.setattr(F, "rgbconv_blur", lambda *a: (used.append(1), orig(*a))[1])
+    loss_on, g_on, gi_on = d_loss_grads(dis, real.to(DEV), fake.to(DEV), depth, alpha)
+    assert len(used) == 3                                                  # D(real), D(fake), the extra forward of this helper
+    monkeypatch.setattr(F, "RGBCONV", False)
+    assert not top.fused_from_rgb_ok((B, R, R, 3), dis.from_rgb[dis.depth - depth - 1], torch.bfloat16)
+    loss_off, g_off, gi_off = d_loss_grads(dis, real.to(DEV), fake.to(DEV), depth, alpha)
+    assert len(used) == 3
+    # fp64 oracle
+    want_loss = O.logistic_d_loss(dp, real.double(), fake.double(), depth, alpha, MID_DEPTH)
+    names = [k for k, v in dp.items() if v.requires_grad]
+    grads = dict(zip(names, torch.autograd.grad(want_loss, [dp[k] for k in names], allow_unused=True)))
+    rimg = real.double().requires_grad_(True)
+    (want_gi,) = torch.autograd.grad(O.discriminator(dp, rimg, depth, alpha, MID_DEPTH).sum(), rimg)
+    e_on, e_off = rel_err(gi_on, want_gi), rel_err(gi_off, want_gi)
+    print(f"[rgbconv D depth {depth}] loss on {loss_on:.6f} off {loss_off:.6f} fp64 {float(want_loss):.6f}; image gradient rel on {e_on:.2e} off {e_off:.2e}")
+    assert abs(loss_on - float(want_loss)) <= 2e-2 * abs(float(want_loss))
+    assert e_on <= 1.25 * e_off + 2e-3
+    assert sorted(g_on) == sorted(g_off) == sorted(k for k in names if grads[k] is not None)
+    rows = []
+    for k in sorted(g_on):
+        a, b = rel_err(g_on[k], grads[k]), rel_err(g_off[k], grads[k])
+        rows.append((a, b, k))
+        # no tensor's gradient gets worse than the unfused bf16 path's by more than a quarter (+ a floor for tensors that are
+        # accurate to begin with); the four parameters of the composed layers themselves are listed in the print below
+        assert a <= 1.25 * b + 1e-2, (k, a, b)
+    rows.sort(reverse=True)
+    print("   worst (on, off): " + ", ".join(f"{k} {a:.1e}/{b:.1e}" for a, b, k in rows[:5]))
+    med_on, med_off = float(np.median([r[0] for r in rows])), float(np.median([r[1] for r in rows]))
+    print(f"   median gradient rel-L2 vs fp64: on {med_on:.3e}, off {med_off:.3e}")
+    assert med_on <= 1.1 * med_off + 1e-3
