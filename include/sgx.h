@@ -232,6 +232,9 @@ int sgx_conv3x3_signbits(const void* x, const void* w, const float* bias, void* 
 int sgx_conv4x4s2_up_blur_ok(int B, int H, int W, int Cin, int Cout, int dtype);
 int sgx_conv4x4s2_up_blur(const void* x, const void* w, void* y, const void* mask, int B, int H, int W, int Cin, int Cout,
                           int dtype, void* stream);
+/* the same with the mask given as SIGN BITS of z, bits[B][2H][2W][Cout/8] as sgx_conv3x3_signbits / sgx_rgbconv_fwd write them */
+int sgx_conv4x4s2_up_blur_bits(const void* x, const void* w, void* y, const void* bits, int B, int H, int W, int Cin, int Cout,
+                               int dtype, void* stream);
 int sgx_conv3x3_stats(const void* x, const void* w, void* y, const float* ebias, const float* noise, const float* nw, double* part,
                       size_t part_bytes, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
 

@@ -62,6 +62,8 @@ struct Conv2Args {
     // C2_S, register epilogue: one SIGN bit per stored element (1 = value > 0), [pixel][Cout / 8] bytes, bit j = channel 8v + j --
     // what the LeakyReLU backward of the discriminator block needs of the pre-activation (1/16 of re-reading it)
     unsigned char* signbits;
+    // EPI_BLUR: the activation mask as those sign bits (1 bit per element instead of 16) -- overrides `mask`
+    const unsigned char* maskbits;
 };
 enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BLUR = 2 };
 
@@ -449,7 +451,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                     for (int i = 0; i < NSU; ++i) {
                         int fpx, v, ox; bool cok;
                         col_of(i, fpx, v, ox, cok);
-                        m[i] = (a.mask && rok && cok) ? *reinterpret_cast<const uint4*>(a.mask + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8) : ones4;
+                        if (a.maskbits) {
+                            // one byte = the signs of this lane's 8 channels (bit j = channel 8v + j): expanded to +-1.0 bf16 pairs so that
+                            // the multiply below is the same code as for a mask tensor
+                            const unsigned bb = (rok && cok) ? a.maskbits[((((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0) / 8 + v] : 0xffu;
+                            unsigned w4[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                w4[q] = (((bb >> (2 * q)) & 1u) ? 0x3f80u : 0xbf80u) | ((((bb >> (2 * q + 1)) & 1u) ? 0x3f80u : 0xbf80u) << 16);
+                            m[i] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                        } else {
+                            m[i] = (a.mask && rok && cok) ? *reinterpret_cast<const uint4*>(a.mask + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8) : ones4;
+                        }
                     }
                 };
                 load_mask(0, mk[0]);
@@ -820,16 +833,27 @@ extern "C" int sgx_conv4x4s2_up_blur_ok(int B, int H, int W, int Cin, int Cout, 
     if (!on) return 0;
     return conv2_pick(C2_U, B, H, W, Cin, Cout, -1, true).nw ? 1 : 0;
 }
+static int conv_up_blur_launch(const void* x, const void* w, void* y, const void* mask, const void* maskbits, int B, int H, int W, int Cin, int Cout,
+                               int dtype, void* stream);
 extern "C" int sgx_conv4x4s2_up_blur(const void* x, const void* w, void* y, const void* mask, int B, int H, int W, int Cin, int Cout,
                                      int dtype, void* stream) {
+    return conv_up_blur_launch(x, w, y, mask, nullptr, B, H, W, Cin, Cout, dtype, stream);
+}
+extern "C" int sgx_conv4x4s2_up_blur_bits(const void* x, const void* w, void* y, const void* bits, int B, int H, int W, int Cin, int Cout,
+                                          int dtype, void* stream) {
+    SGX_REQUIRE(bits && Cout % 8 == 0, SGX_EINVAL, "conv4x4s2_up_blur_bits: sign bits [B][2H][2W][Cout/8] expected");
+    return conv_up_blur_launch(x, w, y, nullptr, bits, B, H, W, Cin, Cout, dtype, stream);
+}
+static int conv_up_blur_launch(const void* x, const void* w, void* y, const void* mask, const void* maskbits, int B, int H, int W, int Cin, int Cout,
+                               int dtype, void* stream) {
     SGX_REQUIRE(dtype == SGX_BF16, SGX_EUNSUPPORTED, "conv4x4s2_up_blur: bf16 only");
     SGX_REQUIRE(x && w && y, SGX_EINVAL, "conv4x4s2_up_blur: null argument");
     const Conv2Pick p = conv2_pick(C2_U, B, H, W, Cin, Cout, -1, true);
     SGX_REQUIRE(p.nw, SGX_EUNSUPPORTED, "conv4x4s2_up_blur: shape B%d %dx%d %d->%d has no fused variant (sgx_conv4x4s2_up_blur_ok == 0)", B, H, W, Cin, Cout);
-    SGX_NOTE(2.0 * 16 * Cin * Cout * B * H * W, 2.0 * ((double)B * H * W * (Cin + 4.0 * Cout * (mask ? 2 : 1)) + 16.0 * Cin * Cout),
-             "convU+blur%s B%d %dx%d %d->%d", mask ? "*mask" : "", B, H, W, Cin, Cout);
+    SGX_NOTE(2.0 * 16 * Cin * Cout * B * H * W, 2.0 * ((double)B * H * W * (Cin + 4.0 * Cout * (mask ? 2 : 1)) + 16.0 * Cin * Cout) + (maskbits ? 0.5 * B * H * W * Cout : 0.0),
+             "convU+blur%s B%d %dx%d %d->%d", mask ? "*mask" : (maskbits ? "*bits" : ""), B, H, W, Cin, Cout);
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), nullptr, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
-                2 * H, 2 * W, Cin, Cout, SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+                2 * H, 2 * W, Cin, Cout, SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<const unsigned char*>(maskbits)};
     hipStream_t st = (hipStream_t)stream;
     if (p.k16) return p.nw == 8 ? launch_conv2<C2_U, 8, 1, 32, true, EPI_BLUR>(a, st) : launch_conv2<C2_U, 4, 1, 32, true, EPI_BLUR>(a, st);
     return p.nw == 8 ? launch_conv2<C2_U, 8, 1, 32, false, EPI_BLUR>(a, st) : launch_conv2<C2_U, 4, 1, 32, false, EPI_BLUR>(a, st);

@@ -73,41 +73,32 @@ template <int CB, int EPI> struct RcFwd {
     static constexpr int LDS = IMG_BYTES + (EPI ? NPX * C * 2 : 0);
 };
 
+// Tile schedule of the persistent kernels below: the grid is a multiple of 8 blocks; block b runs on XCD b & 7 (round-robin
+// dispatch) and walks every (grid / 8)-th tile of that XCD's contiguous eighth of the tile raster, so tiles that share halo rows
+// are processed by neighbouring blocks of ONE XCD close in time (their re-reads hit that XCD's L2).
+struct RcSched { int first, end, stride; };
+static __device__ __forceinline__ RcSched rc_sched(int ntiles) {
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, per = gridDim.x >> 3, band = (ntiles + 7) >> 3;
+    RcSched s;
+    s.first = xcd * band + slot;
+    s.end = (xcd + 1) * band < ntiles ? (xcd + 1) * band : ntiles;
+    s.stride = per;
+    return s;
+}
+struct rgb3 { float r, g, b; };                            // 12 bytes, 4-byte aligned: one global_load_dwordx3
+
 template <int CB, int EPI>
 __global__ __launch_bounds__(256) void rgbconv_fwd_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wf, const float* __restrict__ b0,
                                                           bf16_t* __restrict__ y, unsigned char* __restrict__ bits, int B, int H, int W, int ones,
-                                                          int tiles_x, int tiles_y) {
+                                                          int tiles_x, int tiles_y, int ntiles) {
     using G = RcFwd<CB, EPI>;
     constexpr int C = G::C, R = G::R, TH = G::TH, TW = G::TW, IH = G::IH, IW = G::IW, ZW = G::ZW, NPX = G::NPX, NG = G::NG, IPX = G::IPX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2* imgl = reinterpret_cast<uint2*>(smem);
     char* zl = smem + G::IMG_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y, b = t / tiles_y;
-    const int ty0 = ty * TH, tx0 = tx * TW;
-
-    // ---- phase A: image region (+halo) -> LDS as bf16 (r, g, b, 1 | 0); zero outside the image (the convolution's padding)
-    constexpr int NIT = (IPX + 255) / 256;
-    float v0[NIT], v1[NIT], v2[NIT];
-    bool ok[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = it * 256 + tid, r = idx / IW, c = idx - r * IW;
-        const int gy = ty0 - R + r, gx = tx0 - R + c;
-        ok[it] = idx < IH * IW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        v0[it] = v1[it] = v2[it] = 0.f;
-        if (ok[it]) {
-            const float* p = img + (((size_t)b * H + gy) * W + gx) * 3;
-            v0[it] = p[0]; v1[it] = p[1]; v2[it] = p[2];
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = it * 256 + tid;
-        if (idx < IPX) imgl[idx] = make_uint2(pack_bf16x2(v0[it], v1[it]), pack_bf16x2(v2[it], (ok[it] && ones) ? 1.f : 0.f));
-    }
+    const RcSched sc = rc_sched(ntiles);
+    if (sc.first >= sc.end) return;
     // weights of this lane: A[i = o][k] for the three kernel rows
     s16x4 wfr[CB][3];
 #pragma unroll
@@ -118,86 +109,124 @@ __global__ __launch_bounds__(256) void rgbconv_fwd_kernel(const float* __restric
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
         bias[cb] = (EPI && b0) ? *reinterpret_cast<const float4*>(b0 + cb * 16 + 4 * l4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
 
-    // ---- phase B: 16 pixels x 16 channels per MFMA triple
-    for (int g = wave; g < NG; g += 4) {
-        const int px = g * 16 + l15, pxc = px < NPX ? px : NPX - 1;
-        const int zr = pxc / ZW, zc = pxc - zr * ZW;
-        f32x4_t acc[CB];
+    // ---- image region (+halo) of a tile -> registers (the NEXT tile's loads are in flight while this one is computed)
+    constexpr int NIT = (IPX + 255) / 256;
+    rgb3 pv[NIT];
+    unsigned okm = 0;
+    auto tile_at = [&](int t, int& b, int& ty0, int& tx0) {
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        b = t / tiles_y; ty0 = ty * TH; tx0 = tx * TW;
+    };
+    auto load_tile = [&](int t) {
+        int b, ty0, tx0;
+        tile_at(t, b, ty0, tx0);
+        okm = 0;
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const uint2 raw = imgl[(zr + ky) * IW + zc + l4];
-            s16x4 bf;
-            bf[0] = (short)(raw.x & 0xffffu); bf[1] = (short)(raw.x >> 16); bf[2] = (short)(raw.y & 0xffffu); bf[3] = (short)(raw.y >> 16);
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) acc[cb] = mma16(wfr[cb][ky], bf, acc[cb]);
-        }
-        const int gy = ty0 - (R - 1) + zr, gx = tx0 - (R - 1) + zc;
-        const bool inimg = px < NPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            if constexpr (EPI == 0) {
-                if (inimg)
-                    *reinterpret_cast<uint2*>(y + (((size_t)b * H + gy) * W + gx) * C + cb * 16 + 4 * l4) =
-                        make_uint2(pack_bf16x2(acc[cb][0], acc[cb][1]), pack_bf16x2(acc[cb][2], acc[cb][3]));
-            } else {
-                // pre-activation + bias -> LeakyReLU; positions outside the image are the BLUR's zero padding
-                const float a0 = inimg ? lrelu(acc[cb][0] + bias[cb].x) : 0.f, a1 = inimg ? lrelu(acc[cb][1] + bias[cb].y) : 0.f;
-                const float a2 = inimg ? lrelu(acc[cb][2] + bias[cb].z) : 0.f, a3 = inimg ? lrelu(acc[cb][3] + bias[cb].w) : 0.f;
-                if (px < NPX) *reinterpret_cast<uint2*>(zl + ((size_t)px * C + cb * 16 + 4 * l4) * 2) = make_uint2(pack_bf16x2(a0, a1), pack_bf16x2(a2, a3));
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 256 + tid, r = idx / IW, c = idx - r * IW;
+            const int gy = ty0 - R + r, gx = tx0 - R + c;
+            const bool ok = idx < IH * IW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            pv[it] = rgb3{0.f, 0.f, 0.f};
+            if (ok) {
+                pv[it] = *reinterpret_cast<const rgb3*>(img + (((size_t)b * H + gy) * W + gx) * 3);
+                okm |= 1u << it;
             }
         }
-    }
-    if constexpr (EPI == 1) {
-        __syncthreads();
-        // ---- phase C: separable [1,2,1]x[1,2,1]/16 down a column strip: thread = (column, 8-channel vector[, row half])
-        constexpr int VPP = C / 8, NSTRIP = TW * VPP, RSPLIT = 256 / NSTRIP, RPT = TH / RSPLIT;
-        static_assert(256 % NSTRIP == 0 && TH % RSPLIT == 0, "strip geometry");
-        const int s = tid % NSTRIP, half = tid / NSTRIP, c = s / VPP, v = s % VPP, r0 = half * RPT;
-        float h0[8], h1[8];
-        uint4 cprev = make_uint4(0u, 0u, 0u, 0u);
+    };
+    load_tile(sc.first);
+    for (int t = sc.first; t < sc.end; t += sc.stride) {
+        int b, ty0, tx0;
+        tile_at(t, b, ty0, tx0);
+        // ---- phase A: registers -> LDS as bf16 (r, g, b, 1 | 0); zero outside the image (the convolution's padding)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { h0[q] = 0.f; h1[q] = 0.f; }
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < IPX) imgl[idx] = make_uint2(pack_bf16x2(pv[it].r, pv[it].g), pack_bf16x2(pv[it].b, (((okm >> it) & 1u) && ones) ? 1.f : 0.f));
+        }
+        __syncthreads();                                   // the region is staged; everybody is done with the previous tile's blur
+        if (t + sc.stride < sc.end) load_tile(t + sc.stride);
+
+        // ---- phase B: 16 pixels x 16 channels per MFMA triple
+        for (int g = wave; g < NG; g += 4) {
+            const int px = g * 16 + l15, pxc = px < NPX ? px : NPX - 1;
+            const int zr = pxc / ZW, zc = pxc - zr * ZW;
+            f32x4_t acc[CB];
 #pragma unroll
-        for (int rr = 0; rr < RPT + 2; ++rr) {
-            const char* rowp = zl + ((size_t)((r0 + rr) * ZW + c) * C + v * 8) * 2;
-            const uint4 Lq = *reinterpret_cast<const uint4*>(rowp), Mq = *reinterpret_cast<const uint4*>(rowp + C * 2),
-                        Rq = *reinterpret_cast<const uint4*>(rowp + 2 * C * 2);
-            const unsigned lw[4] = {Lq.x, Lq.y, Lq.z, Lq.w}, mw[4] = {Mq.x, Mq.y, Mq.z, Mq.w}, rw[4] = {Rq.x, Rq.y, Rq.z, Rq.w};
-            float h[8];
+            for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                h[2 * q] = __uint_as_float(lw[q] << 16) + 2.f * __uint_as_float(mw[q] << 16) + __uint_as_float(rw[q] << 16);
-                h[2 * q + 1] = __uint_as_float(lw[q] & 0xffff0000u) + 2.f * __uint_as_float(mw[q] & 0xffff0000u) + __uint_as_float(rw[q] & 0xffff0000u);
+            for (int ky = 0; ky < 3; ++ky) {
+                const uint2 raw = imgl[(zr + ky) * IW + zc + l4];
+                s16x4 bf;
+                bf[0] = (short)(raw.x & 0xffffu); bf[1] = (short)(raw.x >> 16); bf[2] = (short)(raw.y & 0xffffu); bf[3] = (short)(raw.y >> 16);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) acc[cb] = mma16(wfr[cb][ky], bf, acc[cb]);
             }
-            if (rr >= 2) {
-                const int gy = ty0 + r0 + rr - 2, gx = tx0 + c;
-                if (gy < H && gx < W) {
-                    unsigned ow[4];
+            const int gy = ty0 - (R - 1) + zr, gx = tx0 - (R - 1) + zc;
+            const bool inimg = px < NPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        ow[q] = pack_bf16x2((h0[2 * q] + 2.f * h1[2 * q] + h[2 * q]) * 0.0625f, (h0[2 * q + 1] + 2.f * h1[2 * q + 1] + h[2 * q + 1]) * 0.0625f);
-                    const size_t pix = ((size_t)b * H + gy) * W + gx;
-                    *reinterpret_cast<uint4*>(y + pix * C + v * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-                    if (bits) {
-                        // sign bits of the pre-activation = of the stored activation (LeakyReLU keeps the sign): bit j = channel 8v + j
-                        const unsigned cw[4] = {cprev.x, cprev.y, cprev.z, cprev.w};
-                        unsigned bb = 0;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            bb |= ((short)(cw[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q);
-                            bb |= ((short)(cw[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
-                        }
-                        bits[pix * VPP + v] = (unsigned char)bb;
-                    }
+            for (int cb = 0; cb < CB; ++cb) {
+                if constexpr (EPI == 0) {
+                    if (inimg)
+                        *reinterpret_cast<uint2*>(y + (((size_t)b * H + gy) * W + gx) * C + cb * 16 + 4 * l4) =
+                            make_uint2(pack_bf16x2(acc[cb][0], acc[cb][1]), pack_bf16x2(acc[cb][2], acc[cb][3]));
+                } else {
+                    // pre-activation + bias -> LeakyReLU; positions outside the image are the BLUR's zero padding
+                    const float a0 = inimg ? lrelu(acc[cb][0] + bias[cb].x) : 0.f, a1 = inimg ? lrelu(acc[cb][1] + bias[cb].y) : 0.f;
+                    const float a2 = inimg ? lrelu(acc[cb][2] + bias[cb].z) : 0.f, a3 = inimg ? lrelu(acc[cb][3] + bias[cb].w) : 0.f;
+                    if (px < NPX) *reinterpret_cast<uint2*>(zl + ((size_t)px * C + cb * 16 + 4 * l4) * 2) = make_uint2(pack_bf16x2(a0, a1), pack_bf16x2(a2, a3));
                 }
             }
+        }
+        __syncthreads();                                   // the activated tile is complete; the image region may be overwritten
+        if constexpr (EPI == 1) {
+            // ---- phase C: separable [1,2,1]x[1,2,1]/16 down a column strip: thread = (column, 8-channel vector[, row half])
+            constexpr int VPP = C / 8, NSTRIP = TW * VPP, RSPLIT = 256 / NSTRIP, RPT = TH / RSPLIT;
+            static_assert(256 % NSTRIP == 0 && TH % RSPLIT == 0, "strip geometry");
+            const int s = tid % NSTRIP, half = tid / NSTRIP, c = s / VPP, v = s % VPP, r0 = half * RPT;
+            float h0[8], h1[8];
+            uint4 cprev = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { h0[q] = h1[q]; h1[q] = h[q]; }
-            cprev = Mq;
+            for (int q = 0; q < 8; ++q) { h0[q] = 0.f; h1[q] = 0.f; }
+#pragma unroll
+            for (int rr = 0; rr < RPT + 2; ++rr) {
+                const char* rowp = zl + ((size_t)((r0 + rr) * ZW + c) * C + v * 8) * 2;
+                const uint4 Lq = *reinterpret_cast<const uint4*>(rowp), Mq = *reinterpret_cast<const uint4*>(rowp + C * 2),
+                            Rq = *reinterpret_cast<const uint4*>(rowp + 2 * C * 2);
+                const unsigned lw[4] = {Lq.x, Lq.y, Lq.z, Lq.w}, mw[4] = {Mq.x, Mq.y, Mq.z, Mq.w}, rw[4] = {Rq.x, Rq.y, Rq.z, Rq.w};
+                float h[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    h[2 * q] = __uint_as_float(lw[q] << 16) + 2.f * __uint_as_float(mw[q] << 16) + __uint_as_float(rw[q] << 16);
+                    h[2 * q + 1] = __uint_as_float(lw[q] & 0xffff0000u) + 2.f * __uint_as_float(mw[q] & 0xffff0000u) + __uint_as_float(rw[q] & 0xffff0000u);
+                }
+                if (rr >= 2) {
+                    const int gy = ty0 + r0 + rr - 2, gx = tx0 + c;
+                    if (gy < H && gx < W) {
+                        unsigned ow[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            ow[q] = pack_bf16x2((h0[2 * q] + 2.f * h1[2 * q] + h[2 * q]) * 0.0625f, (h0[2 * q + 1] + 2.f * h1[2 * q + 1] + h[2 * q + 1]) * 0.0625f);
+                        const size_t pix = ((size_t)b * H + gy) * W + gx;
+                        *reinterpret_cast<uint4*>(y + pix * C + v * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                        if (bits) {
+                            // sign bits of the pre-activation = of the stored activation (LeakyReLU keeps the sign): bit j = channel 8v + j
+                            const unsigned cw[4] = {cprev.x, cprev.y, cprev.z, cprev.w};
+                            unsigned bb = 0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                bb |= ((short)(cw[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q);
+                                bb |= ((short)(cw[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
+                            }
+                            bits[pix * VPP + v] = (unsigned char)bb;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { h0[q] = h1[q]; h1[q] = h[q]; }
+                cprev = Mq;
+            }
         }
     }
 }
@@ -210,61 +239,76 @@ template <int CB> struct RcDg {
 
 template <int CB>
 __global__ __launch_bounds__(256) void rgbconv_dgrad_kernel(const bf16_t* __restrict__ gz, const bf16_t* __restrict__ wd, float* __restrict__ gi,
-                                                            int B, int H, int W, int tiles_x, int tiles_y) {
+                                                            int B, int H, int W, int tiles_x, int tiles_y, int ntiles) {
     using G = RcDg<CB>;
     constexpr int C = G::C, TH = G::TH, TW = G::TW, GH = G::GH, GW = G::GW, VPP = G::VPP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y, b = t / tiles_y;
-    const int ty0 = ty * TH, tx0 = tx * TW;
-    constexpr int NV = GH * GW * VPP, NIT = (NV + 255) / 256;
-    uint4 val[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = it * 256 + tid, p = idx / VPP, v = idx - p * VPP, r = p / GW, c = p - r * GW;
-        const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
-        val[it] = make_uint4(0u, 0u, 0u, 0u);
-        if (idx < NV && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-            val[it] = *reinterpret_cast<const uint4*>(gz + (((size_t)b * H + gy) * W + gx) * C + v * 8);
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = it * 256 + tid;
-        if (idx < NV) *reinterpret_cast<uint4*>(smem + (size_t)idx * 16) = val[it];       // [pixel][C] == [idx] x 16 bytes
-    }
+    const RcSched sc = rc_sched(ntiles);
+    if (sc.first >= sc.end) return;
     s16x4 wfr[9][CB];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) wfr[tap][cb] = *reinterpret_cast<const s16x4*>(wd + ((tap * 16 + l15) * C + cb * 16 + 4 * l4));
-    __syncthreads();
-    for (int g = wave; g < TH * 4; g += 4) {
-        const int r = g >> 2, c = (g & 3) * 16 + l15;
-        f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int NV = GH * GW * VPP, NIT = (NV + 255) / 256;
+    uint4 val[NIT];
+    auto tile_at = [&](int t, int& b, int& ty0, int& tx0) {
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        b = t / tiles_y; ty0 = ty * TH; tx0 = tx * TW;
+    };
+    auto load_tile = [&](int t) {
+        int b, ty0, tx0;
+        tile_at(t, b, ty0, tx0);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    const s16x4 bf = *reinterpret_cast<const s16x4*>(smem + ((size_t)((r + ky) * GW + c + kx) * C + cb * 16 + 4 * l4) * 2);
-                    acc = mma16(wfr[ky * 3 + kx][cb], bf, acc);
-                }
-        const int gy = ty0 + r, gx = tx0 + c;
-        if (l4 == 0 && gy < H && gx < W) {            // D rows 0..2 = the three colour channels of pixel (lane & 15)
-            float* p = gi + (((size_t)b * H + gy) * W + gx) * 3;
-            p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2];
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 256 + tid, p = idx / VPP, v = idx - p * VPP, r = p / GW, c = p - r * GW;
+            const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
+            val[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (idx < NV && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                val[it] = *reinterpret_cast<const uint4*>(gz + (((size_t)b * H + gy) * W + gx) * C + v * 8);
         }
+    };
+    load_tile(sc.first);
+    for (int t = sc.first; t < sc.end; t += sc.stride) {
+        int b, ty0, tx0;
+        tile_at(t, b, ty0, tx0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < NV) *reinterpret_cast<uint4*>(smem + (size_t)idx * 16) = val[it];       // [pixel][C] == [idx] x 16 bytes
+        }
+        __syncthreads();
+        if (t + sc.stride < sc.end) load_tile(t + sc.stride);
+        for (int g = wave; g < TH * 4; g += 4) {
+            const int r = g >> 2, c = (g & 3) * 16 + l15;
+            f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) {
+                        const s16x4 bf = *reinterpret_cast<const s16x4*>(smem + ((size_t)((r + ky) * GW + c + kx) * C + cb * 16 + 4 * l4) * 2);
+                        acc = mma16(wfr[ky * 3 + kx][cb], bf, acc);
+                    }
+            const int gy = ty0 + r, gx = tx0 + c;
+            if (l4 == 0 && gy < H && gx < W)              // D rows 0..2 = the three colour channels of pixel (lane & 15)
+                *reinterpret_cast<rgb3*>(gi + (((size_t)b * H + gy) * W + gx) * 3) = rgb3{acc[0], acc[1], acc[2]};
+        }
+        __syncthreads();                                   // the fragment reads are done: the next tile may be staged
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------ weight gradient
 template <int CB> struct RcWg {
     static constexpr int C = 16 * CB, TH = 8, TW = 64, TP = TH * TW, RH = TH + 2;
-    static constexpr int GZT = C * TP * 2;                    // gzT[C][TP] bf16
-    static constexpr int IMT = 12 * RH * TW * 2;              // imgT[3 kx][4 j][RH][64] bf16
+    // plane strides == 16 bytes mod 256: the 16 rows (channels / (kx, j) planes) a fragment read touches fall on 16 different
+    // 16-byte bank slots (ds_read_b64: 32 lanes per LDS cycle over 64 banks -- unpadded planes were a 16-way conflict)
+    static constexpr int TPS = TP + 8, IPS = RH * TW + 8;
+    static constexpr int GZT = C * TPS * 2;                   // gzT[C][TPS] bf16
+    static constexpr int IMT = 12 * IPS * 2;                  // imgT[3 kx][4 j][IPS] bf16, row rr at rr * TW
     static constexpr int RED = 4 * CB * 3 * 256 * 4;          // cross-wave reduction of the accumulators (reuses the stage area)
     static constexpr int LDS = (GZT + IMT > RED ? GZT + IMT : RED);
     static constexpr int NOUT = C * 48;                       // dW'[o][ky][16 n], n = kx * 4 + j (12..15 unused)
@@ -274,7 +318,7 @@ template <int CB>
 __global__ __launch_bounds__(256) void rgbconv_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ gz, float* __restrict__ part,
                                                             int B, int H, int W, int ones, int tiles_x, int tiles_y, int ntiles) {
     using G = RcWg<CB>;
-    constexpr int C = G::C, TH = G::TH, TW = G::TW, TP = G::TP, RH = G::RH, VPP = C / 8;
+    constexpr int C = G::C, TH = G::TH, TW = G::TW, TP = G::TP, TPS = G::TPS, IPS = G::IPS, RH = G::RH, VPP = C / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* gzT = reinterpret_cast<bf16_t*>(smem);
     bf16_t* imgT = reinterpret_cast<bf16_t*>(smem + G::GZT);
@@ -286,51 +330,58 @@ __global__ __launch_bounds__(256) void rgbconv_wgrad_kernel(const float* __restr
         for (int ky = 0; ky < 3; ++ky) acc[cb][ky] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // B operand of this lane: column n = lane & 15 -> (kx, j); columns 12..15 are padding (any valid address: their results are dropped)
     const int nkx = (l15 >> 2) < 3 ? (l15 >> 2) : 0, nj = l15 & 3;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        int tt = t;
-        const int tx = tt % tiles_x; tt /= tiles_x;
-        const int ty = tt % tiles_y, b = tt / tiles_y;
-        const int ty0 = ty * TH, tx0 = tx * TW;
-        // gz tile -> planar gzT[channel][pixel]
-        constexpr int NGV = TP * VPP / 256;
-        uint4 gv[NGV];
+    const RcSched sc = rc_sched(ntiles);
+    constexpr int NGV = TP * VPP / 256;
+    constexpr int NIP = RH * (TW + 2), NII = (NIP + 255) / 256;
+    uint4 gv[NGV];
+    rgb3 iv[NII];
+    unsigned okm = 0;
+    auto tile_at = [&](int t, int& b, int& ty0, int& tx0) {
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        b = t / tiles_y; ty0 = ty * TH; tx0 = tx * TW;
+    };
+    auto load_tile = [&](int t) {
+        int b, ty0, tx0;
+        tile_at(t, b, ty0, tx0);
 #pragma unroll
         for (int it = 0; it < NGV; ++it) {
             const int idx = it * 256 + tid, p = idx / VPP, v = idx - p * VPP, r = p / TW, c = p - r * TW;
             const int gy = ty0 + r, gx = tx0 + c;
             gv[it] = (gy < H && gx < W) ? *reinterpret_cast<const uint4*>(gz + (((size_t)b * H + gy) * W + gx) * C + v * 8) : make_uint4(0u, 0u, 0u, 0u);
         }
-        // image region (one halo pixel) as bf16 (r, g, b, 1 | 0)
-        constexpr int NIP = RH * (TW + 2), NII = (NIP + 255) / 256;
-        float i0[NII], i1[NII], i2[NII];
-        bool iok[NII];
+        okm = 0;
 #pragma unroll
         for (int it = 0; it < NII; ++it) {
             const int idx = it * 256 + tid, rr = idx / (TW + 2), cr = idx - rr * (TW + 2);
             const int gy = ty0 - 1 + rr, gx = tx0 - 1 + cr;
-            iok[it] = idx < NIP && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            i0[it] = i1[it] = i2[it] = 0.f;
-            if (iok[it]) {
-                const float* p = img + (((size_t)b * H + gy) * W + gx) * 3;
-                i0[it] = p[0]; i1[it] = p[1]; i2[it] = p[2];
+            const bool ok = idx < NIP && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            iv[it] = rgb3{0.f, 0.f, 0.f};
+            if (ok) {
+                iv[it] = *reinterpret_cast<const rgb3*>(img + (((size_t)b * H + gy) * W + gx) * 3);
+                okm |= 1u << it;
             }
         }
-        __syncthreads();                                   // the previous tile's fragment reads are done
+    };
+    if (sc.first < sc.end) load_tile(sc.first);
+    for (int t = sc.first; t < sc.end; t += sc.stride) {
+        // gz tile -> planar gzT[channel][pixel]
 #pragma unroll
         for (int it = 0; it < NGV; ++it) {
             const int idx = it * 256 + tid, p = idx / VPP, v = idx - p * VPP;
             const unsigned w[4] = {gv[it].x, gv[it].y, gv[it].z, gv[it].w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                gzT[(v * 8 + 2 * q) * TP + p] = (bf16_t)(w[q] & 0xffffu);
-                gzT[(v * 8 + 2 * q + 1) * TP + p] = (bf16_t)(w[q] >> 16);
+                gzT[(v * 8 + 2 * q) * TPS + p] = (bf16_t)(w[q] & 0xffffu);
+                gzT[(v * 8 + 2 * q + 1) * TPS + p] = (bf16_t)(w[q] >> 16);
             }
         }
+        // image region (one halo pixel) as bf16 (r, g, b, 1 | 0), one pre-shifted copy per kernel column
 #pragma unroll
         for (int it = 0; it < NII; ++it) {
             const int idx = it * 256 + tid, rr = idx / (TW + 2), cr = idx - rr * (TW + 2);
             if (idx < NIP) {
-                const unsigned p01 = pack_bf16x2(i0[it], i1[it]), p23 = pack_bf16x2(i2[it], (iok[it] && ones) ? 1.f : 0.f);
+                const unsigned p01 = pack_bf16x2(iv[it].r, iv[it].g), p23 = pack_bf16x2(iv[it].b, (((okm >> it) & 1u) && ones) ? 1.f : 0.f);
                 const bf16_t vj[4] = {(bf16_t)(p01 & 0xffffu), (bf16_t)(p01 >> 16), (bf16_t)(p23 & 0xffffu), (bf16_t)(p23 >> 16)};
                 // imgT[kx][j][rr][c] = image(row ty0 - 1 + rr, column tx0 + c + kx - 1): region column cr = c + kx
 #pragma unroll
@@ -338,27 +389,28 @@ __global__ __launch_bounds__(256) void rgbconv_wgrad_kernel(const float* __restr
                     const int c = cr - kx;
                     if (c >= 0 && c < TW) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) imgT[((kx * 4 + j) * RH + rr) * TW + c] = vj[j];
+                        for (int j = 0; j < 4; ++j) imgT[(kx * 4 + j) * IPS + rr * TW + c] = vj[j];
                     }
                 }
             }
         }
         __syncthreads();
+        if (t + sc.stride < sc.end) load_tile(t + sc.stride);
         for (int g = wave; g < TH * 4; g += 4) {
             const int r = g >> 2, c0 = (g & 3) * 16 + 4 * l4;
             s16x4 af[CB];
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) af[cb] = *reinterpret_cast<const s16x4*>(gzT + (cb * 16 + l15) * TP + r * TW + c0);
+            for (int cb = 0; cb < CB; ++cb) af[cb] = *reinterpret_cast<const s16x4*>(gzT + (cb * 16 + l15) * TPS + r * TW + c0);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const s16x4 bf = *reinterpret_cast<const s16x4*>(imgT + ((nkx * 4 + nj) * RH + r + ky) * TW + c0);
+                const s16x4 bf = *reinterpret_cast<const s16x4*>(imgT + (nkx * 4 + nj) * IPS + (r + ky) * TW + c0);
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) acc[cb][ky] = mma16(af[cb], bf, acc[cb][ky]);
             }
         }
+        __syncthreads();                                   // the fragment reads are done: the next tile may be staged
     }
     // ---- the four waves' accumulators -> one partial per block: part[block][(o * 3 + ky) * 16 + n]
-    __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -447,14 +499,38 @@ extern "C" int sgx_rgbconv_pack(const float* w0, float s0, const float* wr, floa
     return 0;
 }
 
+// persistent grid: as many blocks as fit the chip at once (by LDS; at most 4 per CU), a multiple of 8 (one share per XCD), not
+// more than there are tiles
+static int rc_ncu() {
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        return n;
+    }();
+    return ncu;
+}
+template <typename K>
+static int rc_per_cu(K kern, int lds_bytes) {              // resident 256-thread blocks per CU (registers AND LDS), at most 4
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, (size_t)lds_bytes) != hipSuccess || n < 1) n = 1;
+    return n > 4 ? 4 : n;
+}
+static int rc_grid(int ntiles, int per_cu) {
+    long g = (long)rc_ncu() * per_cu;
+    if (g > ntiles) g = ntiles;
+    g = (g + 7) / 8 * 8;
+    return (int)g;
+}
+
 template <int CB, int EPI>
 static int launch_rgbconv_fwd(const float* img, const bf16_t* wf, const float* b0, bf16_t* y, unsigned char* bits, int B, int H, int W, int ones,
                               hipStream_t st) {
     using G = RcFwd<CB, EPI>;
-    const int tiles_x = W / G::TW, tiles_y = H / G::TH;
+    const int tiles_x = W / G::TW, tiles_y = H / G::TH, ntiles = B * tiles_x * tiles_y;
     sgx_lds_opt_in<rgbconv_fwd_kernel<CB, EPI>>(G::LDS);
-    hipLaunchKernelGGL((rgbconv_fwd_kernel<CB, EPI>), dim3((unsigned)(B * tiles_x * tiles_y)), dim3(256), G::LDS, st, img, wf, b0, y, bits, B, H, W, ones,
-                       tiles_x, tiles_y);
+    static const int per_cu = rc_per_cu(rgbconv_fwd_kernel<CB, EPI>, G::LDS);
+    hipLaunchKernelGGL((rgbconv_fwd_kernel<CB, EPI>), dim3((unsigned)rc_grid(ntiles, per_cu)), dim3(256), G::LDS, st, img, wf, b0, y, bits, B, H, W, ones,
+                       tiles_x, tiles_y, ntiles);
     SGX_LAUNCH_CHECK("rgbconv_fwd_kernel");
     return 0;
 }
@@ -476,9 +552,11 @@ extern "C" int sgx_rgbconv_fwd(const float* img, const void* wf, const float* b0
 template <int CB>
 static int launch_rgbconv_dgrad(const bf16_t* gz, const bf16_t* wd, float* gi, int B, int H, int W, hipStream_t st) {
     using G = RcDg<CB>;
-    const int tiles_x = W / G::TW, tiles_y = H / G::TH;
+    const int tiles_x = W / G::TW, tiles_y = H / G::TH, ntiles = B * tiles_x * tiles_y;
     sgx_lds_opt_in<rgbconv_dgrad_kernel<CB>>(G::LDS);
-    hipLaunchKernelGGL((rgbconv_dgrad_kernel<CB>), dim3((unsigned)(B * tiles_x * tiles_y)), dim3(256), G::LDS, st, gz, wd, gi, B, H, W, tiles_x, tiles_y);
+    static const int per_cu = rc_per_cu(rgbconv_dgrad_kernel<CB>, G::LDS);
+    hipLaunchKernelGGL((rgbconv_dgrad_kernel<CB>), dim3((unsigned)rc_grid(ntiles, per_cu)), dim3(256), G::LDS, st, gz, wd, gi, B, H, W, tiles_x, tiles_y,
+                       ntiles);
     SGX_LAUNCH_CHECK("rgbconv_dgrad_kernel");
     return 0;
 }
@@ -494,7 +572,7 @@ extern "C" int sgx_rgbconv_dgrad(const void* gz, const void* wd, float* gi, int 
 
 static int rgbconv_wgrad_blocks(int B, int H, int W) {
     const long ntiles = (long)B * (H / 8) * (W / 64);
-    return (int)(ntiles < 1024 ? ntiles : 1024);
+    return rc_grid((int)(ntiles < (1 << 30) ? ntiles : (1 << 30)), 3);     // 3 resident blocks per CU for both channel counts (registers / LDS)
 }
 extern "C" size_t sgx_rgbconv_wgrad_ws_bytes(int B, int H, int W, int C) {
     if (B < 1 || H < 8 || W < 64 || (C != 16 && C != 32)) return 0;

@@ -395,8 +395,8 @@ class ConvFn(Function):
             if x_pre is not None or xb is not None:
                 assert not x_masked
                 # (x_pre None: the producer never materialised the pre-activation -- RgbConvBlurFn -- and only its sign bits exist)
-                if x_pre is not None and conv_blur_ok(gy, weight.shape[1] if not adjoint else weight.shape[0], mode, not adjoint):
-                    gx = _bcall(ConvBlurFn, gy, weight, mode, scale, ipad, not adjoint, x_pre)      # one kernel
+                if conv_blur_ok(gy, weight.shape[1] if not adjoint else weight.shape[0], mode, not adjoint):
+                    gx = _bcall(ConvBlurFn, gy, weight, mode, scale, ipad, not adjoint, None if xb is not None else x_pre, xb)      # one kernel
                 else:
                     gx = _bcall(BlurMaskFn, _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0), x_pre, xb)
             else:
@@ -458,7 +458,9 @@ class ConvBlurFn(Function):
     own pass, then exactly ``ConvFn``'s backward -- so the op composes under ``create_graph`` like the separate ops did."""
 
     @staticmethod
-    def forward(ctx, x, weight, mode, scale, ipad, adjoint, z=None):
+    def forward(ctx, x, weight, mode, scale, ipad, adjoint, z=None, zbits=None):
+        """``zbits``: the sign bits of z ([B,2H,2W,C/8] uint8) -- read instead of z where the producer wrote them (1 bit per
+        element instead of 16; z itself may then be None: functional.RgbConvBlurFn never materialises it)."""
         x = _c(x)
         geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
         assert geo == "U"
@@ -471,21 +473,28 @@ class ConvBlurFn(Function):
         y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
         if z is not None and (z.shape != y.shape or z.dtype != y.dtype):
             raise N.SgxError("conv+blur: the mask must have the output's shape and dtype")
-        N.check(N.lib().sgx_conv4x4s2_up_blur(N.ptr(x), N.ptr(wq), N.ptr(y), N.ptr(None if z is None else _c(z)), B, H, W, Cin, Cout,
-                                              N.dt(x), N.stream()), "sgx_conv4x4s2_up_blur")
+        if zbits is not None:
+            if tuple(zbits.shape) != (B, 2 * H, 2 * W, Cout // 8) or zbits.dtype != torch.uint8:
+                raise N.SgxError("conv+blur: sign bits [B, 2H, 2W, Cout/8] uint8 expected")
+            N.check(N.lib().sgx_conv4x4s2_up_blur_bits(N.ptr(x), N.ptr(wq), N.ptr(y), N.ptr(_c(zbits)), B, H, W, Cin, Cout, N.dt(x), N.stream()),
+                    "sgx_conv4x4s2_up_blur_bits")
+        else:
+            N.check(N.lib().sgx_conv4x4s2_up_blur(N.ptr(x), N.ptr(wq), N.ptr(y), N.ptr(None if z is None else _c(z)), B, H, W, Cin, Cout,
+                                                  N.dt(x), N.stream()), "sgx_conv4x4s2_up_blur")
         ctx.cfg = (mode, scale, ipad, adjoint, 0, False, False, False)
         ctx.bias_ref = lambda: None
         ctx.x_pre = None
         ctx.save_for_backward(x, weight, None, None)
-        ctx.z = z
+        ctx.z, ctx.zbits = z, zbits
         return y
 
     @staticmethod
     def backward(ctx, gg):
         gg = _c(gg)
-        m = _bcall(MaskBlurFn, gg, ctx.z) if ctx.z is not None else _bcall(BlurFn, gg)
+        masked = ctx.z is not None or ctx.zbits is not None
+        m = _bcall(MaskBlurFn, gg, ctx.z, ctx.zbits) if masked else _bcall(BlurFn, gg)
         out = ConvFn.backward(ctx, m)                      # (gx, gw, gb, ...): same saved tensors / cfg layout
-        return out[0], out[1], None, None, None, None, None
+        return out[0], out[1], None, None, None, None, None, None
 
 
 class ActBlurPassFn(Function):

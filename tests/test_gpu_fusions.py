@@ -159,6 +159,24 @@ def test_conv_up_blur_fused_vs_separate_and_oracle(cin, cout, B, H, W, masked):
     assert d1 <= 2.0 * d0 + 1e-3 and d1 < 0.05 * ref.abs().max().item(), (d1, d0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W", [(32, 16, 2, 256, 256), (64, 32, 2, 120, 256), (32, 32, 5, 17, 64), (128, 64, 1, 128, 128)])
+def test_conv_up_blur_with_the_mask_as_sign_bits(cin, cout, B, H, W):
+    """sgx_conv4x4s2_up_blur_bits (round 4): the activation mask read as one sign bit per element -- the same bits as the mask-tensor
+    variant of the kernel produces, for every position (tile seams, borders, ragged tiles)."""
+    from stylegan.pytorch_amd import functional as F
+    w = gu.seeded((cout, cin, 3, 3), 5).to(DEV)
+    scale = O.he_w_mul(cin * 9, 2 ** 0.5)
+    x = gu.seeded((B, H, W, cin), 7).to(DEV).bfloat16()
+    z = gu.seeded((B, 2 * H, 2 * W, cout), 8).to(DEV).bfloat16()
+    zb = (z > 0).cpu().numpy().reshape(B, 2 * H, 2 * W, cout // 8, 8)
+    import numpy as np
+    bits = torch.from_numpy(np.packbits(zb, axis=-1, bitorder="little").reshape(B, 2 * H, 2 * W, cout // 8)).to(DEV)
+    with torch.no_grad():
+        y_z = F.ConvBlurFn.apply(x, w, "U", scale, cin, False, z)
+        y_b = F.ConvBlurFn.apply(x, w, "U", scale, cin, False, None, bits)
+    assert torch.equal(y_z, y_b)
+
+
 @pytest.mark.parametrize("cin,cout,B,H", [(32, 64, 2, 256), (16, 32, 4, 512), (64, 128, 2, 128)])
 def test_discriminator_block_backward_with_fused_blur(cin, cout, B, H):
     """DiscriminatorBlock in bf16: first-order gradients and the R1-style double backward with the blur + mask folded into

@@ -45,7 +45,7 @@ def dev_params(p):
     return {k: v.detach().float().to(DEV).requires_grad_(True) for k, v in p.items()}
 
 
-CASES = [(16, 2, 32, 64), (16, 1, 48, 192), (32, 2, 16, 64), (32, 1, 40, 128)]
+CASES = [(16, 2, 32, 64), (16, 1, 48, 192), (32, 2, 16, 64), (32, 1, 48, 128), (16, 3, 160, 320)]
 
 
 @pytest.mark.parametrize("C,B,H,W", CASES)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Host-side profile of the training iteration (cProfile over a few steps, GPU running asynchronously): shows where the
 Python/ctypes/autograd launch path spends its time when the step becomes launch-bound.
-    python tools/host_profile.py [steps] [single]        ("single": one stream, deferred losses -- the mode bench.py times at batch 4)"""
+    python tools/host_profile.py [steps] [single] [depth=D] [batch=B]
+("single": one stream, deferred losses -- the mode bench.py times at batch 4; depth / batch: another point of the progressive
+schedule, e.g. depth=0 batch=128 -- real batches stay at the full resolution, as bench.py --sweep feeds them)"""
 import cProfile
 import os
 import pstats
@@ -25,12 +27,16 @@ def main():
     if "single" in sys.argv[2:]:
         sg.aux_stream = sg.param_stream = False
         sg.deferred_losses = True
-    z = torch.randn(4, 512, device=dev)
-    x = torch.randn(4, 1024, 1024, 3, device=dev).permute(0, 3, 1, 2)
+    kv = dict(a.split("=") for a in sys.argv[2:] if "=" in a)
+    depth, batch = int(kv.get("depth", 8)), int(kv.get("batch", 4))
+    if "depth" in kv or "batch" in kv:
+        sg.deferred_losses = True
+    z = torch.randn(batch, 512, device=dev)
+    x = torch.randn(batch, 1024, 1024, 3, device=dev).permute(0, 3, 1, 2)
 
     def step():
-        sg.optimize_discriminator(z, x, 8, 0.5)
-        sg.optimize_generator(z, x, 8, 0.5)
+        sg.optimize_discriminator(z, x, depth, 0.5)
+        sg.optimize_generator(z, x, depth, 0.5)
 
     for _ in range(2):
         step()

@@ -130,12 +130,12 @@ def wgrad(img, gz, B,H,W,CB,ones,nblk):
         accs=[copy.deepcopy(accs[0]) for _ in range(4)]
         for t in range(blk, ntiles, nblk):
             tt=t; tx=tt%tiles_x; tt//=tiles_x; ty=tt%tiles_y; b=tt//tiles_y; ty0=ty*TH; tx0=tx*TW
-            gzT=np.zeros(C*TP); imgT=np.zeros(12*RH*TW)
+            TPS=TP+8; IPS=RH*TW+8; gzT=np.zeros(C*TPS); imgT=np.zeros(12*IPS)
             for idx in range(TP*VPP):
                 p=idx//VPP; v=idx-p*VPP; r=p//TW; c=p-r*TW; gy=ty0+r; gx=tx0+c
                 val = gz[b,gy,gx,v*8:v*8+8] if (gy<H and gx<W) else np.zeros(8)
                 for q in range(4):
-                    gzT[(v*8+2*q)*TP+p]=val[2*q]; gzT[(v*8+2*q+1)*TP+p]=val[2*q+1]
+                    gzT[(v*8+2*q)*TPS+p]=val[2*q]; gzT[(v*8+2*q+1)*TPS+p]=val[2*q+1]
             NIP=RH*(TW+2)
             for idx in range(NIP):
                 rr=idx//(TW+2); cr=idx-rr*(TW+2); gy=ty0-1+rr; gx=tx0-1+cr
@@ -145,17 +145,17 @@ def wgrad(img, gz, B,H,W,CB,ones,nblk):
                 for kx in range(3):
                     c=cr-kx
                     if 0<=c<TW:
-                        for j in range(4): imgT[((kx*4+j)*RH+rr)*TW+c]=vj[j]
+                        for j in range(4): imgT[(kx*4+j)*IPS+rr*TW+c]=vj[j]
             for wave in range(4):
                 for g in range(wave, TH*4, 4):
                     r=g>>2
-                    af=[[ [gzT[(cb*16+(l&15))*TP+r*TW+(g&3)*16+4*(l>>4)+e] for e in range(4)] for l in range(64)] for cb in range(CB)]
+                    af=[[ [gzT[(cb*16+(l&15))*TPS+r*TW+(g&3)*16+4*(l>>4)+e] for e in range(4)] for l in range(64)] for cb in range(CB)]
                     for ky in range(3):
                         bf=[]
                         for l in range(64):
                             l15=l&15; nkx=(l15>>2) if (l15>>2)<3 else 0; nj=l15&3
                             c0=(g&3)*16+4*(l>>4)
-                            bf.append([imgT[((nkx*4+nj)*RH+r+ky)*TW+c0+e] for e in range(4)])
+                            bf.append([imgT[(nkx*4+nj)*IPS+(r+ky)*TW+c0+e] for e in range(4)])
                         for cb in range(CB): accs[wave][cb][ky]=mma16(af[cb], bf, accs[wave][cb][ky])
         for cb in range(CB):
             for ky in range(3):
