@@ -66,6 +66,7 @@ def parse():
                     help="BASELINE configs[4]: the progressive-growing sweep, depth index 0..8 of the 1024 model with the reference's per-depth "
                          "batch sizes (config.py:40-41), the fade-in ramp of models/GAN.py:748-753 and style mixing on; per-depth img/s")
     ap.add_argument("--sweep-steps", type=int, default=8, help="timed iterations per depth (first half on the alpha ramp, second half at alpha = 1)")
+    ap.add_argument("--sweep-depths", default=None, help="comma-separated depth indices to measure (default: all)")
     ap.add_argument("--sweep-batch-scale", type=float, default=1.0,
                     help="multiply the reference's per-depth batch sizes (its schedule fits an 11 GB card; kept a multiple of 4 where >= 4)")
     return ap.parse_args()
@@ -93,7 +94,8 @@ def sweep(sg, a, cfg, dev):
     gen = torch.Generator(device=dev); gen.manual_seed(4321)
     import random
     random.seed(4321)
-    for depth in range(cfg["depth"] + 1):
+    depths = range(cfg["depth"] + 1) if not a.sweep_depths else [int(d) for d in a.sweep_depths.split(",")]
+    for depth in depths:
         B = REF_BATCH_SIZES[depth]
         if a.sweep_batch_scale != 1.0:
             B = max(1, int(round(B * a.sweep_batch_scale)))

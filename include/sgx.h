@@ -246,7 +246,7 @@ int sgx_conv3x3_stats(const void* x, const void* w, void* y, const float* ebias,
  * channel that is 1 inside the image.  img, gi: fp32 [B][H][W][3];  w0: conv0.weight [C][C][3][3], s0 = its w_mul;  wr:
  * from_rgb.weight [C][3][1][1], sr = its w_mul;  br: from_rgb.bias (bscale = its b_mul) or NULL;  b0: conv0.bias * b_mul or NULL.
  * bf16 activations, C in {16, 32}, H % 16 == 0, W % 64 == 0 (sgx_rgbconv_ok); other shapes: sgx_rgb_in + sgx_conv3x3 + sgx_blur3x3_act.
- *   sgx_rgbconv_pack : wf [3][C][16] and wd [9][16][C] (activation dtype): the operand packs of the forward / image-gradient kernels.
+ *   sgx_rgbconv_pack : wf [3][C][16] and wd [3][16][C] (activation dtype): the operand packs of the forward / image-gradient kernels.
  *   sgx_rgbconv_fwd  : epi 1: y = blur3x3(lrelu(conv(img) + b0)) and bits[pixel][C/8] = sign bits of the pre-activation (the
  *                      LeakyReLU-backward mask, as sgx_conv3x3_signbits writes them; may be NULL);  epi 0: y = conv(img) (no b0).
  *                      ones: 1 = with from_rgb's bias channel, 0 = without (the adjoint's own backward under R1's double backward).

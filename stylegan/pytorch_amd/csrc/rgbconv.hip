@@ -17,7 +17,9 @@
 //                              (the adjoint's own backward under the R1 double backward).  Image tile with halo -> LDS as bf16
 //                              (r,g,b,1); 16 pixels x 16 channels per v_mfma_f32_16x16x16_bf16 triple (one per kernel row, K =
 //                              3 pixels x 4 channels + 4 padding); activated tile (+1 halo) -> LDS; separable blur from LDS
-//   rgbconv_dgrad_kernel<CB>   image gradient  gi[q][j] = sum_{tap,o} gz[q - tap][o] W'[o][j][tap]  (9 MFMAs per 16 pixels)
+//   rgbconv_fwdblur_kernel<CB> the same result as EPI 1 from a row-streaming wave (no LDS tile, no barrier): the default
+//   rgbconv_dgrad_kernel<CB>   image gradient  gi[q][j] = sum_{tap,o} gz[q - tap][o] W'[o][j][tap], row-streaming: M = (kernel column, colour),
+//                              K = (kernel row, channel): 3 MFMAs per 16 pixels, the three kernel columns summed across lanes
 //   rgbconv_wgrad_kernel<CB>   dW'[o][tap][j] = sum_p gz[p][o] img1[p + tap][j]: persistent blocks over 8x64-pixel tiles, operands
 //                              transposed into planar LDS images so that 4 consecutive PIXELS are one aligned 8-byte fragment read
 //   rgbconv_wfinish_kernel     deterministic sum of the block partials; rgbconv_chain_kernel: dW' -> dW0, db0, dWr, dbr (chain rule
@@ -33,8 +35,8 @@ static __device__ __forceinline__ f32x4_t mma16(s16x4 a, s16x4 b, f32x4_t c) {
 }
 
 // ------------------------------------------------------------------------------------------------------------ packs
-// wf: [3 ky][C o][16 k], k = kx * 4 + j (j = 3: the bias channel), k 12..15 zero.   wd: [9 tap'][16 j][C o] (j >= 3 zero), tap'
-// = (ky', kx') reads gz at q + (ky' - 1, kx' - 1), i.e. it is forward tap (2 - ky', 2 - kx').
+// wf: [3 ky][C o][16 k], k = kx * 4 + j (j = 3: the bias channel), k 12..15 zero.   wd: [3 ky'][16 i][C o], i = kx' * 4 + j (j = 3 and
+// kx' = 3 zero): tap (ky', kx') reads gz at q + (ky' - 1, kx' - 1), i.e. it is forward tap (2 - ky', 2 - kx').
 __global__ void rgbconv_pack_kernel(const float* __restrict__ w0, float s0, const float* __restrict__ wr, float sr,
                                     const float* __restrict__ br, float bscale, bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, int C) {
     const int tid = threadIdx.x + blockIdx.x * blockDim.x, nth = blockDim.x * gridDim.x;
@@ -50,11 +52,11 @@ __global__ void rgbconv_pack_kernel(const float* __restrict__ w0, float s0, cons
         }
         wf[e] = f2bf(v);
     }
-    for (int e = tid; e < 9 * 16 * C; e += nth) {
-        const int tap = e / (16 * C), j = (e / C) % 16, o = e % C, ky = 2 - tap / 3, kx = 2 - tap % 3;
+    for (int e = tid; e < 3 * 16 * C; e += nth) {
+        const int kyp = e / (16 * C), i = (e / C) % 16, o = e % C, kxp = i >> 2, j = i & 3, ky = 2 - kyp, kx = 2 - kxp;
         float v = 0.f;
-        if (j < 3) {
-            for (int i = 0; i < C; ++i) v += w0[((o * C + i) * 3 + ky) * 3 + kx] * wr[i * 3 + j];
+        if (j < 3 && kxp < 3) {
+            for (int ii = 0; ii < C; ++ii) v += w0[((o * C + ii) * 3 + ky) * 3 + kx] * wr[ii * 3 + j];
             v *= s0 * sr;
         }
         wd[e] = f2bf(v);
@@ -231,73 +233,159 @@ __global__ __launch_bounds__(256) void rgbconv_fwd_kernel(const float* __restric
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------ image gradient
-template <int CB> struct RcDg {
-    static constexpr int C = 16 * CB, TH = CB == 1 ? 16 : 8, TW = 64, GH = TH + 2, GW = TW + 2, VPP = C / 8;
-    static constexpr int LDS = GH * GW * C * 2;
-};
+// ------------------------------------------------------------------------------------------------------------ row-streaming kernels
+// The forward with the blur (the hot one: three launches per step) and the image gradient as ROW-STREAMING kernels: a wave owns a
+// strip of 14 output columns (16 MFMA columns: one neighbour each side for the horizontal taps) and walks down a block of rows,
+// keeping the three input rows a 3x3 window needs as MFMA B fragments in registers -- each new row is one small global load per lane
+// (prefetched two rows ahead).  No LDS tile, no barrier: the horizontal [1,2,1] of the blur is a DPP row shift (an MFMA result row
+// of 16 lanes = 16 consecutive pixels), the vertical one a two-row history in registers.  First version of these kernels (tile in
+// LDS, activated tile back through LDS, three phases between barriers): 500-608 us at batch 32, 1024^2 against 276 us for the same
+// convolution without the blur -- at three resident blocks per CU the phases did not overlap.
+static __device__ __forceinline__ float dpp_row_shr1(float v) {     // lane l <- lane l - 1 inside each row of 16 lanes (0 into lane 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+}
+static __device__ __forceinline__ float dpp_row_shl1(float v) {     // lane l <- lane l + 1 (0 into lane 15)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));
+}
+enum { RC_STRIP = 14, RC_ROWS = 32 };
+
+template <int CB>
+__global__ __launch_bounds__(256) void rgbconv_fwdblur_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wf, const float* __restrict__ b0,
+                                                              bf16_t* __restrict__ y, unsigned char* __restrict__ bits, int B, int H, int W, int ones,
+                                                              int nstrips, int nrb) {
+    constexpr int C = 16 * CB;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int sx = item % nstrips; item /= nstrips;
+    const int rbk = item % nrb, b = item / nrb;
+    if (b >= B) return;
+    const int r_begin = rbk * RC_ROWS, r_end = r_begin + RC_ROWS < H ? r_begin + RC_ROWS : H;
+    const int zc = sx * RC_STRIP - 1 + l15;                // image column of this lane's convolution output
+    const int pc = zc - 1 + l4;                            // image column of this lane's B-operand pixel (kernel column l4; l4 = 3: padding)
+    const bool pc_ok = l4 < 3 && (unsigned)pc < (unsigned)W;
+    s16x4 wfr[CB][3];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) wfr[cb][ky] = *reinterpret_cast<const s16x4*>(wf + ((ky * C + cb * 16 + l15) * 16 + 4 * l4));
+    float4 bias[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) bias[cb] = b0 ? *reinterpret_cast<const float4*>(b0 + cb * 16 + 4 * l4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* ibase = img + (size_t)b * H * W * 3;
+    auto load_row = [&](int gy) -> rgb3 {                  // this lane's pixel of image row gy (zeros outside the image)
+        rgb3 v{0.f, 0.f, 0.f};
+        if (pc_ok && (unsigned)gy < (unsigned)H) v = *reinterpret_cast<const rgb3*>(ibase + ((size_t)gy * W + pc) * 3);
+        return v;
+    };
+    auto frag_of = [&](const rgb3& v, int gy) -> s16x4 {   // bf16 (r, g, b, 1 inside the image | 0)
+        const bool in = pc_ok && (unsigned)gy < (unsigned)H;
+        const unsigned p01 = pack_bf16x2(v.r, v.g), p23 = pack_bf16x2(v.b, (in && ones) ? 1.f : 0.f);
+        s16x4 f;
+        f[0] = (short)(p01 & 0xffffu); f[1] = (short)(p01 >> 16); f[2] = (short)(p23 & 0xffffu); f[3] = (short)(p23 >> 16);
+        return f;
+    };
+    // window of image rows zrow - 1, zrow, zrow + 1 for the convolution row zrow; two more rows in flight
+    int zrow = r_begin - 1;
+    s16x4 f0 = frag_of(load_row(zrow - 1), zrow - 1), f1 = frag_of(load_row(zrow), zrow);
+    rgb3 n0 = load_row(zrow + 1), n1 = load_row(zrow + 2), n2 = load_row(zrow + 3);
+    float h1[CB][4], h2[CB][4], a1[CB][4];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { h1[cb][i] = 0.f; h2[cb][i] = 0.f; a1[cb][i] = 0.f; }
+    const bool col_in = (unsigned)zc < (unsigned)W;
+    const bool col_out = l15 >= 1 && l15 <= RC_STRIP && zc < W;       // this lane stores an output column (zc >= 0 there)
+    for (; zrow <= r_end; ++zrow) {
+        const s16x4 f2 = frag_of(n0, zrow + 1);
+        n0 = n1; n1 = n2; n2 = load_row(zrow + 4);
+        const bool z_in = col_in && (unsigned)zrow < (unsigned)H;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            acc = mma16(wfr[cb][0], f0, acc);
+            acc = mma16(wfr[cb][1], f1, acc);
+            acc = mma16(wfr[cb][2], f2, acc);
+            const float bb[4] = {bias[cb].x, bias[cb].y, bias[cb].z, bias[cb].w};
+            float a[4], h[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = z_in ? lrelu(acc[i] + bb[i]) : 0.f;               // outside the image: the blur's zero padding
+                h[i] = dpp_row_shr1(a[i]) + 2.f * a[i] + dpp_row_shl1(a[i]);
+            }
+            const int orow = zrow - 1;                                   // centre row of (h2, h1, h)
+            if (orow >= r_begin) {
+                const size_t pix = ((size_t)b * H + orow) * W + zc;
+                if (col_out)
+                    *reinterpret_cast<uint2*>(y + pix * C + cb * 16 + 4 * l4) =
+                        make_uint2(pack_bf16x2((h2[cb][0] + 2.f * h1[cb][0] + h[0]) * 0.0625f, (h2[cb][1] + 2.f * h1[cb][1] + h[1]) * 0.0625f),
+                                   pack_bf16x2((h2[cb][2] + 2.f * h1[cb][2] + h[2]) * 0.0625f, (h2[cb][3] + 2.f * h1[cb][3] + h[3]) * 0.0625f));
+                if (bits) {
+                    // sign bits of the centre row's pre-activation: 4 channels per lane, the partner lane (l4 ^ 1) has the other nibble
+                    unsigned nib = (a1[cb][0] > 0.f ? 1u : 0u) | (a1[cb][1] > 0.f ? 2u : 0u) | (a1[cb][2] > 0.f ? 4u : 0u) | (a1[cb][3] > 0.f ? 8u : 0u);
+                    const unsigned other = (unsigned)__shfl_xor((int)nib, 16, 64);
+                    if (col_out && !(l4 & 1)) bits[pix * (C / 8) + cb * 2 + (l4 >> 1)] = (unsigned char)(nib | (other << 4));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { h2[cb][i] = h1[cb][i]; h1[cb][i] = h[i]; a1[cb][i] = a[i]; }
+        }
+        f0 = f1; f1 = f2;
+    }
+}
 
 template <int CB>
 __global__ __launch_bounds__(256) void rgbconv_dgrad_kernel(const bf16_t* __restrict__ gz, const bf16_t* __restrict__ wd, float* __restrict__ gi,
-                                                            int B, int H, int W, int tiles_x, int tiles_y, int ntiles) {
-    using G = RcDg<CB>;
-    constexpr int C = G::C, TH = G::TH, TW = G::TW, GH = G::GH, GW = G::GW, VPP = G::VPP;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    const RcSched sc = rc_sched(ntiles);
-    if (sc.first >= sc.end) return;
-    s16x4 wfr[9][CB];
+                                                            int B, int H, int W, int nstrips, int nrb) {
+    constexpr int C = 16 * CB;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int sx = item % nstrips; item /= nstrips;
+    const int rbk = item % nrb, b = item / nrb;
+    if (b >= B) return;
+    const int r_begin = rbk * RC_ROWS, r_end = r_begin + RC_ROWS < H ? r_begin + RC_ROWS : H;
+    const int pc = sx * RC_STRIP - 1 + l15;                // column of this lane's gz pixel AND of the output it assembles
+    const bool pc_ok = (unsigned)pc < (unsigned)W;
+    // A[i = kx' * 4 + j][k = channel] per kernel row ky': E[kx'][j][p] = sum_{ky', o} wd[ky'][kx' * 4 + j][o] gz[r + ky' - 1][p][o]
+    s16x4 wfr[3][CB];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) wfr[tap][cb] = *reinterpret_cast<const s16x4*>(wd + ((tap * 16 + l15) * C + cb * 16 + 4 * l4));
-    constexpr int NV = GH * GW * VPP, NIT = (NV + 255) / 256;
-    uint4 val[NIT];
-    auto tile_at = [&](int t, int& b, int& ty0, int& tx0) {
-        const int tx = t % tiles_x; t /= tiles_x;
-        const int ty = t % tiles_y;
-        b = t / tiles_y; ty0 = ty * TH; tx0 = tx * TW;
+        for (int cb = 0; cb < CB; ++cb) wfr[ky][cb] = *reinterpret_cast<const s16x4*>(wd + ((ky * 16 + l15) * C + cb * 16 + 4 * l4));
+    const bf16_t* gbase = gz + (size_t)b * H * W * C;
+    struct Row { uint2 v[CB]; };
+    auto load_row = [&](int gy) -> Row {                   // 4 channels per channel block of this lane's pixel in row gy (zeros outside)
+        Row r;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            r.v[cb] = make_uint2(0u, 0u);
+            if (pc_ok && (unsigned)gy < (unsigned)H) r.v[cb] = *reinterpret_cast<const uint2*>(gbase + ((size_t)gy * W + pc) * C + cb * 16 + 4 * l4);
+        }
+        return r;
     };
-    auto load_tile = [&](int t) {
-        int b, ty0, tx0;
-        tile_at(t, b, ty0, tx0);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = it * 256 + tid, p = idx / VPP, v = idx - p * VPP, r = p / GW, c = p - r * GW;
-            const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
-            val[it] = make_uint4(0u, 0u, 0u, 0u);
-            if (idx < NV && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-                val[it] = *reinterpret_cast<const uint4*>(gz + (((size_t)b * H + gy) * W + gx) * C + v * 8);
-        }
+    auto frag_of = [&](const uint2& u) -> s16x4 {
+        s16x4 f;
+        f[0] = (short)(u.x & 0xffffu); f[1] = (short)(u.x >> 16); f[2] = (short)(u.y & 0xffffu); f[3] = (short)(u.y >> 16);
+        return f;
     };
-    load_tile(sc.first);
-    for (int t = sc.first; t < sc.end; t += sc.stride) {
-        int b, ty0, tx0;
-        tile_at(t, b, ty0, tx0);
+    int r = r_begin;
+    Row g0 = load_row(r - 1), g1 = load_row(r), n0 = load_row(r + 1), n1 = load_row(r + 2), n2 = load_row(r + 3);
+    const bool col_out = l4 == 1 && l15 >= 1 && l15 <= RC_STRIP && pc < W;
+    for (; r < r_end; ++r) {
+        const Row g2 = n0;
+        n0 = n1; n1 = n2; n2 = load_row(r + 4);
+        f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = it * 256 + tid;
-            if (idx < NV) *reinterpret_cast<uint4*>(smem + (size_t)idx * 16) = val[it];       // [pixel][C] == [idx] x 16 bytes
+        for (int cb = 0; cb < CB; ++cb) {
+            acc = mma16(wfr[0][cb], frag_of(g0.v[cb]), acc);
+            acc = mma16(wfr[1][cb], frag_of(g1.v[cb]), acc);
+            acc = mma16(wfr[2][cb], frag_of(g2.v[cb]), acc);
         }
-        __syncthreads();
-        if (t + sc.stride < sc.end) load_tile(t + sc.stride);
-        for (int g = wave; g < TH * 4; g += 4) {
-            const int r = g >> 2, c = (g & 3) * 16 + l15;
-            f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // this lane (kernel column l4, pixel l15) holds E[l4][j = reg]; the output pixel q sums E[0][q - 1] + E[1][q] + E[2][q + 1]
+        float o3[3];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) {
-                        const s16x4 bf = *reinterpret_cast<const s16x4*>(smem + ((size_t)((r + ky) * GW + c + kx) * C + cb * 16 + 4 * l4) * 2);
-                        acc = mma16(wfr[ky * 3 + kx][cb], bf, acc);
-                    }
-            const int gy = ty0 + r, gx = tx0 + c;
-            if (l4 == 0 && gy < H && gx < W)              // D rows 0..2 = the three colour channels of pixel (lane & 15)
-                *reinterpret_cast<rgb3*>(gi + (((size_t)b * H + gy) * W + gx) * 3) = rgb3{acc[0], acc[1], acc[2]};
-        }
-        __syncthreads();                                   // the fragment reads are done: the next tile may be staged
+        for (int j = 0; j < 3; ++j) o3[j] = __shfl(acc[j], l15 - 1, 64) + acc[j] + __shfl(acc[j], 32 + l15 + 1, 64);
+        if (col_out) *reinterpret_cast<rgb3*>(gi + (((size_t)b * H + r) * W + pc) * 3) = rgb3{o3[0], o3[1], o3[2]};
+        g0 = g1; g1 = g2;
     }
 }
 
@@ -545,29 +633,31 @@ extern "C" int sgx_rgbconv_fwd(const float* img, const void* wf, const float* b0
     const bf16_t* w = static_cast<const bf16_t*>(wf);
     bf16_t* out = static_cast<bf16_t*>(y);
     unsigned char* bt = static_cast<unsigned char*>(bits);
-    if (C == 16) return epi ? launch_rgbconv_fwd<1, 1>(img, w, b0, out, bt, B, H, W, ones, st) : launch_rgbconv_fwd<1, 0>(img, w, b0, out, bt, B, H, W, ones, st);
-    return epi ? launch_rgbconv_fwd<2, 1>(img, w, b0, out, bt, B, H, W, ones, st) : launch_rgbconv_fwd<2, 0>(img, w, b0, out, bt, B, H, W, ones, st);
+    if (epi) {
+        static const int tile_variant = [] { const char* e = getenv("SGX_RGBCONV_FWD_TILE"); return e ? atoi(e) : 0; }();   // A/B: the first (LDS-tile) version
+        if (tile_variant) return C == 16 ? launch_rgbconv_fwd<1, 1>(img, w, b0, out, bt, B, H, W, ones, st) : launch_rgbconv_fwd<2, 1>(img, w, b0, out, bt, B, H, W, ones, st);
+        const int nstrips = (W + RC_STRIP - 1) / RC_STRIP, nrb = (H + RC_ROWS - 1) / RC_ROWS;
+        const unsigned grid = (unsigned)(((long)B * nstrips * nrb + 3) / 4);
+        if (C == 16) hipLaunchKernelGGL((rgbconv_fwdblur_kernel<1>), dim3(grid), dim3(256), 0, st, img, w, b0, out, bt, B, H, W, ones, nstrips, nrb);
+        else hipLaunchKernelGGL((rgbconv_fwdblur_kernel<2>), dim3(grid), dim3(256), 0, st, img, w, b0, out, bt, B, H, W, ones, nstrips, nrb);
+        SGX_LAUNCH_CHECK("rgbconv_fwdblur_kernel");
+        return 0;
+    }
+    return C == 16 ? launch_rgbconv_fwd<1, 0>(img, w, b0, out, bt, B, H, W, ones, st) : launch_rgbconv_fwd<2, 0>(img, w, b0, out, bt, B, H, W, ones, st);
 }
 
-template <int CB>
-static int launch_rgbconv_dgrad(const bf16_t* gz, const bf16_t* wd, float* gi, int B, int H, int W, hipStream_t st) {
-    using G = RcDg<CB>;
-    const int tiles_x = W / G::TW, tiles_y = H / G::TH, ntiles = B * tiles_x * tiles_y;
-    sgx_lds_opt_in<rgbconv_dgrad_kernel<CB>>(G::LDS);
-    static const int per_cu = rc_per_cu(rgbconv_dgrad_kernel<CB>, G::LDS);
-    hipLaunchKernelGGL((rgbconv_dgrad_kernel<CB>), dim3((unsigned)rc_grid(ntiles, per_cu)), dim3(256), G::LDS, st, gz, wd, gi, B, H, W, tiles_x, tiles_y,
-                       ntiles);
-    SGX_LAUNCH_CHECK("rgbconv_dgrad_kernel");
-    return 0;
-}
 extern "C" int sgx_rgbconv_dgrad(const void* gz, const void* wd, float* gi, int B, int H, int W, int C, int dtype, void* stream) {
     SGX_REQUIRE(gz && wd && gi, SGX_EINVAL, "rgbconv_dgrad: null argument");
     SGX_REQUIRE(rgbconv_shape_ok(B, H, W, C, dtype), SGX_EUNSUPPORTED, "rgbconv_dgrad: shape B%d %dx%d C%d dtype %d (sgx_rgbconv_ok == 0)", B, H, W, C, dtype);
     const double px = (double)B * H * W;
     SGX_NOTE(2.0 * 27 * C * px, px * (12.0 + 2.0 * C), "rgbconv_dgrad B%d %dx%d %d->3", B, H, W, C);
     hipStream_t st = (hipStream_t)stream;
-    if (C == 16) return launch_rgbconv_dgrad<1>(static_cast<const bf16_t*>(gz), static_cast<const bf16_t*>(wd), gi, B, H, W, st);
-    return launch_rgbconv_dgrad<2>(static_cast<const bf16_t*>(gz), static_cast<const bf16_t*>(wd), gi, B, H, W, st);
+    const int nstrips = (W + RC_STRIP - 1) / RC_STRIP, nrb = (H + RC_ROWS - 1) / RC_ROWS;
+    const unsigned grid = (unsigned)(((long)B * nstrips * nrb + 3) / 4);
+    if (C == 16) hipLaunchKernelGGL((rgbconv_dgrad_kernel<1>), dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(gz), static_cast<const bf16_t*>(wd), gi, B, H, W, nstrips, nrb);
+    else hipLaunchKernelGGL((rgbconv_dgrad_kernel<2>), dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(gz), static_cast<const bf16_t*>(wd), gi, B, H, W, nstrips, nrb);
+    SGX_LAUNCH_CHECK("rgbconv_dgrad_kernel");
+    return 0;
 }
 
 static int rgbconv_wgrad_blocks(int B, int H, int W) {

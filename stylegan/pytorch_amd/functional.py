@@ -395,8 +395,11 @@ class ConvFn(Function):
             if x_pre is not None or xb is not None:
                 assert not x_masked
                 # (x_pre None: the producer never materialised the pre-activation -- RgbConvBlurFn -- and only its sign bits exist)
-                if conv_blur_ok(gy, weight.shape[1] if not adjoint else weight.shape[0], mode, not adjoint):
-                    gx = _bcall(ConvBlurFn, gy, weight, mode, scale, ipad, not adjoint, None if xb is not None else x_pre, xb)      # one kernel
+                # (the fused kernel reads the mask TENSOR: with the mask as sign bits its blur epilogue, already the limit of that
+                # kernel, gets another ~16 VALU operations per element -- measured 990 us against 342 + 553 for the two passes at
+                # batch 32, 1024^2, profiles/r04_rgbconv_probe.txt -- so layers that only have the bits take the two passes)
+                if x_pre is not None and conv_blur_ok(gy, weight.shape[1] if not adjoint else weight.shape[0], mode, not adjoint):
+                    gx = _bcall(ConvBlurFn, gy, weight, mode, scale, ipad, not adjoint, x_pre)      # one kernel
                 else:
                     gx = _bcall(BlurMaskFn, _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0), x_pre, xb)
             else:
@@ -614,7 +617,7 @@ def rgb_packs(w0, s0, wr, sr, br):
         if w0.dtype != torch.float32 or wr.dtype != torch.float32 or tuple(w0.shape) != (C, C, 3, 3) or tuple(wr.shape) != (C, 3, 1, 1):
             raise N.SgxError("rgb_packs: conv0.weight [C,C,3,3] and from_rgb.weight [C,3,1,1] (fp32) expected")
         wf = torch.empty((3, C, 16), dtype=torch.bfloat16, device=w0.device)
-        wd = torch.empty((9, 16, C), dtype=torch.bfloat16, device=w0.device)
+        wd = torch.empty((3, 16, C), dtype=torch.bfloat16, device=w0.device)
         N.check(N.lib().sgx_rgbconv_pack(N.ptr(_c(w0.detach())), float(s0), N.ptr(_c(wr.detach())), float(sr),
                                          N.ptr(None if br is None else _c(br.detach())), 1.0, N.ptr(wf), N.ptr(wd), C, N.stream()), "sgx_rgbconv_pack")
         ent[2], ent[3], ent[4] = tag, (wf, wd), _pack_mark()

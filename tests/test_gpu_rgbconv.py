@@ -100,7 +100,7 @@ def test_plain_convolution_and_image_gradient_vs_oracle(C, B, H, W):
     assert e_z <= 6e-3 and e_g <= 6e-3, (e_z, e_g)
 
 
-@pytest.mark.parametrize("C,B,H,W", [(16, 2, 32, 64), (32, 3, 24, 128), (16, 5, 64, 256)])
+@pytest.mark.parametrize("C,B,H,W", [(16, 2, 32, 64), (32, 3, 32, 128), (16, 5, 64, 256)])
 def test_parameter_gradients_through_the_chain_rule_vs_oracle(C, B, H, W):
     """dW0, db0, dWr, dbr from (image, gradient of the pre-activation): written, accumulated, and without the bias channel."""
     from stylegan.pytorch_amd import functional as F

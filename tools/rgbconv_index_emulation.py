@@ -28,11 +28,12 @@ def pack(w0, s0, wr, sr, br, C):
                 v += w * (wr[i*3+j] if j<3 else br[i])
             v *= s0*sr if j<3 else s0
         wf[e] = v
-    for e in range(9*16*C):
-        tap = e // (16*C); j = (e//C) % 16; o = e % C; ky = 2 - tap//3; kx = 2 - tap%3
+    wd = np.zeros(3*16*C)
+    for e in range(3*16*C):
+        kyp = e // (16*C); i = (e//C) % 16; o = e % C; kxp = i>>2; j = i&3; ky = 2-kyp; kx = 2-kxp
         v = 0.0
-        if j < 3:
-            for i in range(C): v += w0[((o*C+i)*3+ky)*3+kx]*wr[i*3+j]
+        if j < 3 and kxp < 3:
+            for ii in range(C): v += w0[((o*C+ii)*3+ky)*3+kx]*wr[ii*3+j]
             v *= s0*sr
         wd[e] = v
     return wf, wd
@@ -93,29 +94,69 @@ def fwd(img, wf, b0, B, H, W, CB, EPI, ones):
                     h0=h1.copy(); h1=h.copy(); cprev=M.copy()
     return y,bits
 
+RC_STRIP=14; RC_ROWS=32
+def lrelu(v): return v if v>0 else 0.2*v
+def fwdblur(img, wf, b0, B,H,W,CB,ones):
+    C=16*CB; nstrips=(W+RC_STRIP-1)//RC_STRIP; nrb=(H+RC_ROWS-1)//RC_ROWS
+    y=np.zeros((B,H,W,C)); bits=np.zeros((B,H,W,C//8),dtype=np.uint8)
+    for item0 in range(B*nstrips*nrb):
+        item=item0; sx=item%nstrips; item//=nstrips; rbk=item%nrb; b=item//nrb
+        r_begin=rbk*RC_ROWS; r_end=min(r_begin+RC_ROWS,H)
+        L=range(64)
+        zc=[sx*RC_STRIP-1+(l&15) for l in L]; pc=[zc[l]-1+(l>>4) for l in L]
+        pc_ok=[(l>>4)<3 and 0<=pc[l]<W for l in L]
+        wfr=[[ [[wf[(ky*C+cb*16+(l&15))*16+4*(l>>4)+e] for e in range(4)] for l in L] for ky in range(3)] for cb in range(CB)]
+        def load_row(gy): return [ (list(img[b,gy,pc[l]]) if (pc_ok[l] and 0<=gy<H) else [0.,0.,0.]) for l in L]
+        def frag_of(v,gy): return [ v[l]+[1.0 if (pc_ok[l] and 0<=gy<H and ones) else 0.0] for l in L]
+        zrow=r_begin-1
+        f0=frag_of(load_row(zrow-1),zrow-1); f1=frag_of(load_row(zrow),zrow)
+        n0=load_row(zrow+1); n1=load_row(zrow+2); n2=load_row(zrow+3)
+        h1=[[[0.]*4 for l in L] for cb in range(CB)]; h2=[[[0.]*4 for l in L] for cb in range(CB)]; a1=[[[0.]*4 for l in L] for cb in range(CB)]
+        while zrow<=r_end:
+            f2=frag_of(n0,zrow+1); n0=n1; n1=n2; n2=load_row(zrow+4)
+            for cb in range(CB):
+                acc=[[0.]*4 for l in L]
+                acc=mma16(wfr[cb][0],f0,acc); acc=mma16(wfr[cb][1],f1,acc); acc=mma16(wfr[cb][2],f2,acc)
+                a=[[ (lrelu(acc[l][i]+b0[cb*16+4*(l>>4)+i]) if (0<=zc[l]<W and 0<=zrow<H) else 0.0) for i in range(4)] for l in L]
+                def shr(l,i): return a[l-1][i] if (l&15)>0 else 0.0
+                def shl(l,i): return a[l+1][i] if (l&15)<15 else 0.0
+                h=[[shr(l,i)+2*a[l][i]+shl(l,i) for i in range(4)] for l in L]
+                orow=zrow-1
+                if orow>=r_begin:
+                    for l in L:
+                        l15=l&15; l4=l>>4
+                        col_out = 1<=l15<=RC_STRIP and zc[l]<W
+                        if col_out:
+                            for i in range(4): y[b,orow,zc[l],cb*16+4*l4+i]=(h2[cb][l][i]+2*h1[cb][l][i]+h[l][i])*0.0625
+                        nib=sum((1<<i) for i in range(4) if a1[cb][l][i]>0)
+                        lo=l^16; other=sum((1<<i) for i in range(4) if a1[cb][lo][i]>0)
+                        if col_out and not (l4&1): bits[b,orow,zc[l],cb*2+(l4>>1)]=nib|(other<<4)
+                h2[cb]=h1[cb]; h1[cb]=h; a1[cb]=a
+            f0=f1; f1=f2; zrow+=1
+    return y,bits
+
 def dgrad(gz, wd, B,H,W,CB):
-    C=16*CB; TH=16 if CB==1 else 8; TW=64; GH=TH+2; GW=TW+2; VPP=C//8
-    tiles_x=W//TW; tiles_y=H//TH
+    C=16*CB; nstrips=(W+RC_STRIP-1)//RC_STRIP; nrb=(H+RC_ROWS-1)//RC_ROWS
     gi=np.zeros((B,H,W,3))
-    for blk in range(B*tiles_x*tiles_y):
-        t=blk; tx=t%tiles_x; t//=tiles_x; ty=t%tiles_y; b=t//tiles_y; ty0=ty*TH; tx0=tx*TW
-        gl=np.zeros((GH*GW,C))
-        for idx in range(GH*GW*VPP):
-            p=idx//VPP; v=idx-p*VPP; r=p//GW; c=p-r*GW; gy=ty0-1+r; gx=tx0-1+c
-            if 0<=gy<H and 0<=gx<W: gl[p,v*8:v*8+8]=gz[b,gy,gx,v*8:v*8+8]
-        for wave in range(4):
-            wfr=[[ [[wd[(tap*16+(l&15))*C+cb*16+4*(l>>4)+e] for e in range(4)] for l in range(64)] for cb in range(CB)] for tap in range(9)]
-            for g in range(wave, TH*4, 4):
-                r=g>>2
-                acc=[[0.0]*4 for l in range(64)]
-                for ky in range(3):
-                    for kx in range(3):
-                        for cb in range(CB):
-                            bf=[list(gl[(r+ky)*GW+((g&3)*16+(l&15))+kx, cb*16+4*(l>>4):cb*16+4*(l>>4)+4]) for l in range(64)]
-                            acc=mma16(wfr[ky*3+kx][cb], bf, acc)
-                for l in range(64):
-                    c=(g&3)*16+(l&15); gy=ty0+r; gx=tx0+c
-                    if (l>>4)==0 and gy<H and gx<W: gi[b,gy,gx]=acc[l][:3]
+    for item0 in range(B*nstrips*nrb):
+        item=item0; sx=item%nstrips; item//=nstrips; rbk=item%nrb; b=item//nrb
+        r_begin=rbk*RC_ROWS; r_end=min(r_begin+RC_ROWS,H)
+        L=range(64)
+        pc=[sx*RC_STRIP-1+(l&15) for l in L]; pc_ok=[0<=pc[l]<W for l in L]
+        wfr=[[ [[wd[(ky*16+(l&15))*C+cb*16+4*(l>>4)+e] for e in range(4)] for l in L] for cb in range(CB)] for ky in range(3)]
+        def load_row(gy): return [[ (list(gz[b,gy,pc[l],cb*16+4*(l>>4):cb*16+4*(l>>4)+4]) if (pc_ok[l] and 0<=gy<H) else [0.]*4) for l in L] for cb in range(CB)]
+        r=r_begin
+        g0=load_row(r-1); g1=load_row(r); n0=load_row(r+1); n1=load_row(r+2); n2=load_row(r+3)
+        while r<r_end:
+            g2=n0; n0=n1; n1=n2; n2=load_row(r+4)
+            acc=[[0.]*4 for l in L]
+            for cb in range(CB):
+                acc=mma16(wfr[0][cb],g0[cb],acc); acc=mma16(wfr[1][cb],g1[cb],acc); acc=mma16(wfr[2][cb],g2[cb],acc)
+            for l in L:
+                l15=l&15; l4=l>>4
+                if l4==1 and 1<=l15<=RC_STRIP and pc[l]<W:
+                    gi[b,r,pc[l]]=[acc[(l15-1)&63][j]+acc[l][j]+acc[(32+l15+1)&63][j] for j in range(3)]
+            g0=g1; g1=g2; r+=1
     return gi
 
 def wgrad(img, gz, B,H,W,CB,ones,nblk):
@@ -196,7 +237,9 @@ if __name__=="__main__":
     wf,wd=pack(w0.detach().numpy().ravel(),s0,wr.detach().numpy().ravel(),sr,br.detach().numpy(),C)
     imgn=img.permute(0,2,3,1).numpy()
     y,bits=fwd(imgn,wf,b0.detach().numpy(),B,H,W,CB,1,1)
-    print("fwd epi1 err", np.abs(y-xb.detach().permute(0,2,3,1).numpy()).max())
+    print("fwd epi1 (LDS tile) err", np.abs(y-xb.detach().permute(0,2,3,1).numpy()).max())
+    y,bits=fwdblur(imgn,wf,b0.detach().numpy(),B,H,W,CB,1)
+    print("fwd+blur (row streaming) err", np.abs(y-xb.detach().permute(0,2,3,1).numpy()).max())
     want_bits=(z.detach().permute(0,2,3,1).numpy()>0)
     got=np.unpackbits(bits[...,None],axis=-1,bitorder="little").reshape(B,H,W,C).astype(bool)
     print("bits mismatches", (got!=want_bits).sum())
