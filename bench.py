@@ -117,12 +117,20 @@ def sweep(sg, a, cfg, dev):
         native.prof_start(0)
         recs = native.prof_records()
         torch.cuda.synchronize()
+        prof = None
+        if os.environ.get("SGX_SWEEP_PROFILE"):              # where the host spends the timed loop (stderr)
+            import cProfile
+            prof = cProfile.Profile(); prof.enable()
         t0 = time.perf_counter()
         for i in range(K):
             step(i, alphas[i])
         t_enq = time.perf_counter() - t0
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(12)
         img_s = B * K / dt
         useful = img_s * SWEEP_GFLOP_PER_IMG[depth] * 1e9
         rows.append({"depth": depth, "resolution": 4 << depth, "batch": B, "alphas": [round(float(x), 4) for x in alphas],

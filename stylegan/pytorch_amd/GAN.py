@@ -290,7 +290,9 @@ class Generator(nn.Module):
     def draw_mixing(self, shape, depth, device):
         latents2, cutoff = self.draw_mixing_host(shape, depth)
         if device.type == "cuda":
-            latents2 = latents2.pin_memory().to(device, non_blocking=True)               # no host wait on the queue
+            # through persistent pinned staging (native.upload): no host wait on the queue, and no hipHostMalloc per call either
+            # (``.pin_memory()`` here cost 21 ms per call at batch 128 whenever the host ran ahead of the GPU)
+            latents2 = native.upload(latents2.contiguous(), device)[0]
         return latents2, cutoff
 
     def forward(self, latents_in, depth, alpha, labels_in=None):

@@ -247,12 +247,13 @@ static __device__ __forceinline__ float dpp_row_shr1(float v) {     // lane l <-
 static __device__ __forceinline__ float dpp_row_shl1(float v) {     // lane l <- lane l + 1 (0 into lane 15)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));
 }
-enum { RC_STRIP = 14, RC_ROWS = 32 };
+enum { RC_STRIP = 14, RC_ROWS = 32, RC_PF = 8 };
 
 template <int CB>
 __global__ __launch_bounds__(256) void rgbconv_fwdblur_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wf, const float* __restrict__ b0,
                                                               bf16_t* __restrict__ y, unsigned char* __restrict__ bits, int B, int H, int W, int ones,
-                                                              int nstrips, int nrb) {
+                                                              int nstrips, int nrb, int dbg) {
+    // dbg (SGX_RGBCONV_DBG, profiling ablations -- wrong results by design): 1 no MFMA, 2 no image loads, 4 no output stores, 8 no sign bits
     constexpr int C = 16 * CB;
     const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
     int item = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void rgbconv_fwdblur_kernel(const float* __res
     const float* ibase = img + (size_t)b * H * W * 3;
     auto load_row = [&](int gy) -> rgb3 {                  // this lane's pixel of image row gy (zeros outside the image)
         rgb3 v{0.f, 0.f, 0.f};
-        if (pc_ok && (unsigned)gy < (unsigned)H) v = *reinterpret_cast<const rgb3*>(ibase + ((size_t)gy * W + pc) * 3);
+        if (pc_ok && (unsigned)gy < (unsigned)H && !(dbg & 2)) v = *reinterpret_cast<const rgb3*>(ibase + ((size_t)gy * W + pc) * 3);
         return v;
     };
     auto frag_of = [&](const rgb3& v, int gy) -> s16x4 {   // bf16 (r, g, b, 1 inside the image | 0)
@@ -284,10 +285,14 @@ __global__ __launch_bounds__(256) void rgbconv_fwdblur_kernel(const float* __res
         f[0] = (short)(p01 & 0xffffu); f[1] = (short)(p01 >> 16); f[2] = (short)(p23 & 0xffffu); f[3] = (short)(p23 >> 16);
         return f;
     };
-    // window of image rows zrow - 1, zrow, zrow + 1 for the convolution row zrow; two more rows in flight
-    int zrow = r_begin - 1;
-    s16x4 f0 = frag_of(load_row(zrow - 1), zrow - 1), f1 = frag_of(load_row(zrow), zrow);
-    rgb3 n0 = load_row(zrow + 1), n1 = load_row(zrow + 2), n2 = load_row(zrow + 3);
+    // window of image rows zrow - 1, zrow, zrow + 1 for the convolution row zrow, and RC_PF more rows in flight: a wave waits ~1.5 us
+    // for a row under load, so with three rows in flight (the first version) the kernel ran at 2.6 TB/s, latency-bound -- the ring
+    // is indexed statically in a loop unrolled RC_PF times, so nothing is moved between registers
+    const int z0 = r_begin - 1;
+    s16x4 f0 = frag_of(load_row(z0 - 1), z0 - 1), f1 = frag_of(load_row(z0), z0);
+    rgb3 ring[RC_PF];
+#pragma unroll
+    for (int u = 0; u < RC_PF; ++u) ring[u] = load_row(z0 + 1 + u);
     float h1[CB][4], h2[CB][4], a1[CB][4];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -295,41 +300,51 @@ __global__ __launch_bounds__(256) void rgbconv_fwdblur_kernel(const float* __res
         for (int i = 0; i < 4; ++i) { h1[cb][i] = 0.f; h2[cb][i] = 0.f; a1[cb][i] = 0.f; }
     const bool col_in = (unsigned)zc < (unsigned)W;
     const bool col_out = l15 >= 1 && l15 <= RC_STRIP && zc < W;       // this lane stores an output column (zc >= 0 there)
-    for (; zrow <= r_end; ++zrow) {
-        const s16x4 f2 = frag_of(n0, zrow + 1);
-        n0 = n1; n1 = n2; n2 = load_row(zrow + 4);
-        const bool z_in = col_in && (unsigned)zrow < (unsigned)H;
+    for (int zb = z0; zb <= r_end; zb += RC_PF) {
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            acc = mma16(wfr[cb][0], f0, acc);
-            acc = mma16(wfr[cb][1], f1, acc);
-            acc = mma16(wfr[cb][2], f2, acc);
-            const float bb[4] = {bias[cb].x, bias[cb].y, bias[cb].z, bias[cb].w};
-            float a[4], h[4];
+        for (int u = 0; u < RC_PF; ++u) {
+            const int zrow = zb + u;
+            if (zrow <= r_end) {                                         // (wave-uniform)
+                const s16x4 f2 = frag_of(ring[u], zrow + 1);
+                ring[u] = load_row(zrow + 1 + RC_PF);
+                const bool z_in = col_in && (unsigned)zrow < (unsigned)H;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = z_in ? lrelu(acc[i] + bb[i]) : 0.f;               // outside the image: the blur's zero padding
-                h[i] = dpp_row_shr1(a[i]) + 2.f * a[i] + dpp_row_shl1(a[i]);
-            }
-            const int orow = zrow - 1;                                   // centre row of (h2, h1, h)
-            if (orow >= r_begin) {
-                const size_t pix = ((size_t)b * H + orow) * W + zc;
-                if (col_out)
-                    *reinterpret_cast<uint2*>(y + pix * C + cb * 16 + 4 * l4) =
-                        make_uint2(pack_bf16x2((h2[cb][0] + 2.f * h1[cb][0] + h[0]) * 0.0625f, (h2[cb][1] + 2.f * h1[cb][1] + h[1]) * 0.0625f),
-                                   pack_bf16x2((h2[cb][2] + 2.f * h1[cb][2] + h[2]) * 0.0625f, (h2[cb][3] + 2.f * h1[cb][3] + h[3]) * 0.0625f));
-                if (bits) {
-                    // sign bits of the centre row's pre-activation: 4 channels per lane, the partner lane (l4 ^ 1) has the other nibble
-                    unsigned nib = (a1[cb][0] > 0.f ? 1u : 0u) | (a1[cb][1] > 0.f ? 2u : 0u) | (a1[cb][2] > 0.f ? 4u : 0u) | (a1[cb][3] > 0.f ? 8u : 0u);
-                    const unsigned other = (unsigned)__shfl_xor((int)nib, 16, 64);
-                    if (col_out && !(l4 & 1)) bits[pix * (C / 8) + cb * 2 + (l4 >> 1)] = (unsigned char)(nib | (other << 4));
+                for (int cb = 0; cb < CB; ++cb) {
+                    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (!(dbg & 1)) {
+                        acc = mma16(wfr[cb][0], f0, acc);
+                        acc = mma16(wfr[cb][1], f1, acc);
+                        acc = mma16(wfr[cb][2], f2, acc);
+                    } else {
+                        acc[0] = (float)f0[0] + (float)f1[1] + (float)f2[2]; acc[1] = acc[0]; acc[2] = acc[0]; acc[3] = acc[0];
+                    }
+                    const float bb[4] = {bias[cb].x, bias[cb].y, bias[cb].z, bias[cb].w};
+                    float a[4], h[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a[i] = z_in ? lrelu(acc[i] + bb[i]) : 0.f;       // outside the image: the blur's zero padding
+                        h[i] = dpp_row_shr1(a[i]) + 2.f * a[i] + dpp_row_shl1(a[i]);
+                    }
+                    const int orow = zrow - 1;                           // centre row of (h2, h1, h)
+                    if (orow >= r_begin) {
+                        const size_t pix = ((size_t)b * H + orow) * W + zc;
+                        if (col_out && !(dbg & 4))
+                            *reinterpret_cast<uint2*>(y + pix * C + cb * 16 + 4 * l4) =
+                                make_uint2(pack_bf16x2((h2[cb][0] + 2.f * h1[cb][0] + h[0]) * 0.0625f, (h2[cb][1] + 2.f * h1[cb][1] + h[1]) * 0.0625f),
+                                           pack_bf16x2((h2[cb][2] + 2.f * h1[cb][2] + h[2]) * 0.0625f, (h2[cb][3] + 2.f * h1[cb][3] + h[3]) * 0.0625f));
+                        if (bits && !(dbg & 8)) {
+                            // sign bits of the centre row's pre-activation: 4 channels per lane, the partner lane (l4 ^ 1) has the other nibble
+                            unsigned nib = (a1[cb][0] > 0.f ? 1u : 0u) | (a1[cb][1] > 0.f ? 2u : 0u) | (a1[cb][2] > 0.f ? 4u : 0u) | (a1[cb][3] > 0.f ? 8u : 0u);
+                            const unsigned other = (unsigned)__shfl_xor((int)nib, 16, 64);
+                            if (col_out && !(l4 & 1)) bits[pix * (C / 8) + cb * 2 + (l4 >> 1)] = (unsigned char)(nib | (other << 4));
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { h2[cb][i] = h1[cb][i]; h1[cb][i] = h[i]; a1[cb][i] = a[i]; }
                 }
+                f0 = f1; f1 = f2;
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { h2[cb][i] = h1[cb][i]; h1[cb][i] = h[i]; a1[cb][i] = a[i]; }
         }
-        f0 = f1; f1 = f2;
     }
 }
 
@@ -367,25 +382,33 @@ __global__ __launch_bounds__(256) void rgbconv_dgrad_kernel(const bf16_t* __rest
         f[0] = (short)(u.x & 0xffffu); f[1] = (short)(u.x >> 16); f[2] = (short)(u.y & 0xffffu); f[3] = (short)(u.y >> 16);
         return f;
     };
-    int r = r_begin;
-    Row g0 = load_row(r - 1), g1 = load_row(r), n0 = load_row(r + 1), n1 = load_row(r + 2), n2 = load_row(r + 3);
+    Row g0 = load_row(r_begin - 1), g1 = load_row(r_begin);
+    Row ring[RC_PF];                                       // rows r + 1 .. r + RC_PF in flight (see the forward kernel)
+#pragma unroll
+    for (int u = 0; u < RC_PF; ++u) ring[u] = load_row(r_begin + 1 + u);
     const bool col_out = l4 == 1 && l15 >= 1 && l15 <= RC_STRIP && pc < W;
-    for (; r < r_end; ++r) {
-        const Row g2 = n0;
-        n0 = n1; n1 = n2; n2 = load_row(r + 4);
-        f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int rb = r_begin; rb < r_end; rb += RC_PF) {
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            acc = mma16(wfr[0][cb], frag_of(g0.v[cb]), acc);
-            acc = mma16(wfr[1][cb], frag_of(g1.v[cb]), acc);
-            acc = mma16(wfr[2][cb], frag_of(g2.v[cb]), acc);
+        for (int u = 0; u < RC_PF; ++u) {
+            const int r = rb + u;
+            if (r < r_end) {                                             // (wave-uniform)
+                const Row g2 = ring[u];
+                ring[u] = load_row(r + 1 + RC_PF);
+                f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    acc = mma16(wfr[0][cb], frag_of(g0.v[cb]), acc);
+                    acc = mma16(wfr[1][cb], frag_of(g1.v[cb]), acc);
+                    acc = mma16(wfr[2][cb], frag_of(g2.v[cb]), acc);
+                }
+                // this lane (kernel column l4, pixel l15) holds E[l4][j = reg]; the output pixel q sums E[0][q - 1] + E[1][q] + E[2][q + 1]
+                float o3[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) o3[j] = __shfl(acc[j], l15 - 1, 64) + acc[j] + __shfl(acc[j], 32 + l15 + 1, 64);
+                if (col_out) *reinterpret_cast<rgb3*>(gi + (((size_t)b * H + r) * W + pc) * 3) = rgb3{o3[0], o3[1], o3[2]};
+                g0 = g1; g1 = g2;
+            }
         }
-        // this lane (kernel column l4, pixel l15) holds E[l4][j = reg]; the output pixel q sums E[0][q - 1] + E[1][q] + E[2][q + 1]
-        float o3[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) o3[j] = __shfl(acc[j], l15 - 1, 64) + acc[j] + __shfl(acc[j], 32 + l15 + 1, 64);
-        if (col_out) *reinterpret_cast<rgb3*>(gi + (((size_t)b * H + r) * W + pc) * 3) = rgb3{o3[0], o3[1], o3[2]};
-        g0 = g1; g1 = g2;
     }
 }
 
@@ -638,8 +661,10 @@ extern "C" int sgx_rgbconv_fwd(const float* img, const void* wf, const float* b0
         if (tile_variant) return C == 16 ? launch_rgbconv_fwd<1, 1>(img, w, b0, out, bt, B, H, W, ones, st) : launch_rgbconv_fwd<2, 1>(img, w, b0, out, bt, B, H, W, ones, st);
         const int nstrips = (W + RC_STRIP - 1) / RC_STRIP, nrb = (H + RC_ROWS - 1) / RC_ROWS;
         const unsigned grid = (unsigned)(((long)B * nstrips * nrb + 3) / 4);
-        if (C == 16) hipLaunchKernelGGL((rgbconv_fwdblur_kernel<1>), dim3(grid), dim3(256), 0, st, img, w, b0, out, bt, B, H, W, ones, nstrips, nrb);
-        else hipLaunchKernelGGL((rgbconv_fwdblur_kernel<2>), dim3(grid), dim3(256), 0, st, img, w, b0, out, bt, B, H, W, ones, nstrips, nrb);
+        const char* de = getenv("SGX_RGBCONV_DBG");
+        const int dbg = de ? atoi(de) : 0;
+        if (C == 16) hipLaunchKernelGGL((rgbconv_fwdblur_kernel<1>), dim3(grid), dim3(256), 0, st, img, w, b0, out, bt, B, H, W, ones, nstrips, nrb, dbg);
+        else hipLaunchKernelGGL((rgbconv_fwdblur_kernel<2>), dim3(grid), dim3(256), 0, st, img, w, b0, out, bt, B, H, W, ones, nstrips, nrb, dbg);
         SGX_LAUNCH_CHECK("rgbconv_fwdblur_kernel");
         return 0;
     }

@@ -267,10 +267,34 @@ class PinnedRing:
 RING = PinnedRing()
 
 
+_BIG = {}                       # size class (power of two) -> {"slots": [[pinned buffer, (event, device) or None], ...], "next": i}
+_BIG_SLOTS = 8
+
+
+def _big_slot(nbytes: int):
+    """A pinned staging buffer of at least ``nbytes`` for uploads that do not fit a ring slot (the style-mixing latents of a big
+    batch: 256 KB at batch 128): ``_BIG_SLOTS`` buffers per power-of-two size class, allocated once and reused round-robin after
+    waiting for the event of the copy that last used them.  ``Tensor.pin_memory()`` per upload instead costs a hipHostMalloc each
+    time the host runs ahead of the GPU (torch's pinned cache only recycles a block the GPU is done with): measured 21 ms per
+    call at batch 128, i.e. 87 ms per iteration of a 4 ms step (profiles/r04_sweep_pin_memory.txt)."""
+    key = 1 << max(13, (int(nbytes) - 1).bit_length())
+    with _lock:
+        ring = _BIG.setdefault(key, {"slots": [], "next": 0})
+        if len(ring["slots"]) < _BIG_SLOTS:
+            ent = [torch.empty(key, dtype=torch.uint8).pin_memory(), None]
+            ring["slots"].append(ent)
+            return ent
+        ent = ring["slots"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % _BIG_SLOTS
+    if ent[1] is not None:
+        ent[1][0].synchronize()                            # (_BIG_SLOTS uploads of this size ago)
+    return ent
+
+
 def upload(t: torch.Tensor, device):
-    """-> (device tensor, pinned staging tensor).  Outside a capture: a slot of the pinned ring (a pinned temporary from
-    torch's cache if it is too big).  Inside: a slice of the pre-reserved arena that lives as long as the process (the graph
-    re-reads it at every replay)."""
+    """-> (device tensor, pinned staging tensor).  Outside a capture: a slot of the pinned ring (one of a few persistent pinned
+    buffers of its size class if it is too big for a slot).  Inside: a slice of the pre-reserved arena that lives as long as the
+    process (the graph re-reads it at every replay)."""
     nbytes = t.numel() * t.element_size()
     if capturing():
         pinned = _arena_take(nbytes)[:nbytes].view(t.dtype).view(t.shape)
@@ -283,7 +307,14 @@ def upload(t: torch.Tensor, device):
             dev = pinned.to(device, non_blocking=True)
             RING.mark(slot)
             return dev, pinned
-        pinned = t.pin_memory()
+        ent = _big_slot(nbytes)
+        pinned = ent[0][:nbytes].view(t.dtype).view(t.shape)
+        pinned.copy_(t)
+        dev = pinned.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ent[1] = (ev, _get_device())
+        return dev, pinned
     return pinned.to(device, non_blocking=True), pinned
 
 
