@@ -130,7 +130,9 @@ def sweep(sg, a, cfg, dev):
         if prof is not None:
             import pstats
             prof.disable()
-            pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(12)
+            st = pstats.Stats(prof, stream=sys.stderr)
+            st.sort_stats("tottime").print_stats(12)
+            st.print_callers("copy_|pin_memory")
         img_s = B * K / dt
         useful = img_s * SWEEP_GFLOP_PER_IMG[depth] * 1e9
         rows.append({"depth": depth, "resolution": 4 << depth, "batch": B, "alphas": [round(float(x), 4) for x in alphas],

@@ -1028,7 +1028,7 @@ class _StepGraph:
                 self.latents2_host = torch.empty(noise.shape, dtype=noise.dtype).pin_memory()
         if self._mixing():
             l2, cut = self.sg.gen.draw_mixing_host(noise.shape, self.depth)
-            self.latents2_host.copy_(l2); self.cutoff_host[0] = cut
+            native._host_copy(self.latents2_host, l2); self.cutoff_host[0] = cut
             self.latents2.copy_(self.latents2_host, non_blocking=True)
             self.cutoff.copy_(self.cutoff_host, non_blocking=True)
         self.ab_host[0] = float(alpha); self.ab_host[1] = 1.0 - float(alpha)

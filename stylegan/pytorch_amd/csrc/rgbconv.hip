@@ -247,7 +247,8 @@ static __device__ __forceinline__ float dpp_row_shr1(float v) {     // lane l <-
 static __device__ __forceinline__ float dpp_row_shl1(float v) {     // lane l <- lane l + 1 (0 into lane 15)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));
 }
-enum { RC_STRIP = 14, RC_ROWS = 32, RC_PF = 8 };
+enum { RC_FWD_DEFAULT = 0 };
+enum { RC_STRIP = 14, RC_ROWS = 32, RC_PF = 3 };     // RC_PF: rows in flight per wave (8 measured slower: 110 registers, 4 waves per SIMD)
 
 template <int CB>
 __global__ __launch_bounds__(256) void rgbconv_fwdblur_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wf, const float* __restrict__ b0,
@@ -635,12 +636,12 @@ static int rc_grid(int ntiles, int per_cu) {
 
 template <int CB, int EPI>
 static int launch_rgbconv_fwd(const float* img, const bf16_t* wf, const float* b0, bf16_t* y, unsigned char* bits, int B, int H, int W, int ones,
-                              hipStream_t st) {
+                              hipStream_t st, bool one_shot = false) {
     using G = RcFwd<CB, EPI>;
     const int tiles_x = W / G::TW, tiles_y = H / G::TH, ntiles = B * tiles_x * tiles_y;
     sgx_lds_opt_in<rgbconv_fwd_kernel<CB, EPI>>(G::LDS);
     static const int per_cu = rc_per_cu(rgbconv_fwd_kernel<CB, EPI>, G::LDS);
-    hipLaunchKernelGGL((rgbconv_fwd_kernel<CB, EPI>), dim3((unsigned)rc_grid(ntiles, per_cu)), dim3(256), G::LDS, st, img, wf, b0, y, bits, B, H, W, ones,
+    hipLaunchKernelGGL((rgbconv_fwd_kernel<CB, EPI>), dim3((unsigned)(one_shot ? (ntiles + 7) / 8 * 8 : rc_grid(ntiles, per_cu))), dim3(256), G::LDS, st, img, wf, b0, y, bits, B, H, W, ones,
                        tiles_x, tiles_y, ntiles);
     SGX_LAUNCH_CHECK("rgbconv_fwd_kernel");
     return 0;
@@ -657,8 +658,12 @@ extern "C" int sgx_rgbconv_fwd(const float* img, const void* wf, const float* b0
     bf16_t* out = static_cast<bf16_t*>(y);
     unsigned char* bt = static_cast<unsigned char*>(bits);
     if (epi) {
-        static const int tile_variant = [] { const char* e = getenv("SGX_RGBCONV_FWD_TILE"); return e ? atoi(e) : 0; }();   // A/B: the first (LDS-tile) version
-        if (tile_variant) return C == 16 ? launch_rgbconv_fwd<1, 1>(img, w, b0, out, bt, B, H, W, ones, st) : launch_rgbconv_fwd<2, 1>(img, w, b0, out, bt, B, H, W, ones, st);
+        // A/B (read per launch: tools/rgbconv_probe.py): 0 = row-streaming kernel, 1 = LDS-tile kernel with persistent blocks, 2 = LDS-tile
+        // kernel with one tile per block
+        const char* ve = getenv("SGX_RGBCONV_FWD");
+        const int variant = ve ? atoi(ve) : RC_FWD_DEFAULT;
+        if (variant) return C == 16 ? launch_rgbconv_fwd<1, 1>(img, w, b0, out, bt, B, H, W, ones, st, variant == 2)
+                                    : launch_rgbconv_fwd<2, 1>(img, w, b0, out, bt, B, H, W, ones, st, variant == 2);
         const int nstrips = (W + RC_STRIP - 1) / RC_STRIP, nrb = (H + RC_ROWS - 1) / RC_ROWS;
         const unsigned grid = (unsigned)(((long)B * nstrips * nrb + 3) / 4);
         const char* de = getenv("SGX_RGBCONV_DBG");

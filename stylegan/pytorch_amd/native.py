@@ -267,6 +267,20 @@ class PinnedRing:
 RING = PinnedRing()
 
 
+def _host_copy(dst: torch.Tensor, src: torch.Tensor):
+    """dst.copy_(src) for two host tensors as ONE memcpy on this thread.  torch's CPU copy goes parallel above 32768 elements: on
+    the 256-core hosts of the GPU boxes waking that thread pool cost 5-20 ms per 256 KB copy (the style-mixing latents of a batch
+    of 128), i.e. 60-90 ms per iteration of a step whose kernels take 4 ms (profiles/r04_sweep_host_copy.txt)."""
+    if src.device.type == "cpu" and src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype and not src.requires_grad:
+        import numpy as np
+        try:
+            np.copyto(dst.numpy(), src.numpy())
+            return
+        except (TypeError, RuntimeError):                    # (a dtype numpy does not have: bfloat16)
+            pass
+    dst.copy_(src)
+
+
 _BIG = {}                       # size class (power of two) -> {"slots": [[pinned buffer, (event, device) or None], ...], "next": i}
 _BIG_SLOTS = 8
 
@@ -303,13 +317,13 @@ def upload(t: torch.Tensor, device):
         view, slot = RING.take(nbytes)
         if view is not None:
             pinned = view.view(t.dtype).view(t.shape)
-            pinned.copy_(t)
+            _host_copy(pinned, t)
             dev = pinned.to(device, non_blocking=True)
             RING.mark(slot)
             return dev, pinned
         ent = _big_slot(nbytes)
         pinned = ent[0][:nbytes].view(t.dtype).view(t.shape)
-        pinned.copy_(t)
+        _host_copy(pinned, t)
         dev = pinned.to(device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()

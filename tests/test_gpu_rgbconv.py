@@ -190,13 +190,16 @@ def test_discriminator_step_with_the_composed_first_layer(depth, monkeypatch):
     assert e_on <= 1.25 * e_off + 2e-3
     assert sorted(g_on) == sorted(g_off) == sorted(k for k in names if grads[k] is not None)
     rows = []
+    gmax = max(float(torch.linalg.vector_norm(grads[k])) for k in g_on)
     for k in sorted(g_on):
         a, b = rel_err(g_on[k], grads[k]), rel_err(g_off[k], grads[k])
         rows.append((a, b, k))
-        # no tensor's gradient gets worse than the unfused bf16 path's by more than a quarter (+ a floor for tensors that are
-        # accurate to begin with: a bf16 discriminator gradient is typically 5-7e-2 from fp64, tests/golden/bf16_gates.json, and a
-        # small tensor at the head moves by 1-2e-2 with ANY change of the roundings upstream); the worst tensors are printed below
-        assert a <= 1.25 * b + 2.5e-2, (k, a, b)
+        # no tensor's gradient gets worse than the unfused bf16 path's by more than a quarter, plus a floor: a bf16 discriminator
+        # gradient is typically 5-7e-2 from fp64 (tests/golden/bf16_gates.json), a small tensor at the head moves by 1-2e-2 with
+        # ANY change of the roundings upstream, and a tensor whose gradient is tiny next to the network's largest (cancellation:
+        # both paths are tens of per cent off there) is bounded on the network's scale instead
+        n = float(torch.linalg.vector_norm(grads[k]))
+        assert a * n <= (1.25 * b + 2.5e-2) * n + 2e-3 * gmax, (k, a, b, n, gmax)
     rows.sort(reverse=True)
     print("   worst (on, off): " + ", ".join(f"{k} {a:.1e}/{b:.1e}" for a, b, k in rows[:5]))
     med_on, med_off = float(np.median([r[0] for r in rows])), float(np.median([r[1] for r in rows]))

@@ -38,6 +38,11 @@ def main():
                 us = timeit(lambda: F.RgbConvBlurFn.apply(img, w0, b0, wr, br, 0.1, 0.5))
                 rows.append((what, us, px * 46.0 / us / 1e6))
             os.environ["SGX_RGBCONV_DBG"] = "0"
+            for v, what in ((1, "forward, LDS-tile kernel, persistent blocks"), (2, "forward, LDS-tile kernel, one tile per block")):
+                os.environ["SGX_RGBCONV_FWD"] = str(v)
+                us = timeit(lambda: F.RgbConvBlurFn.apply(img, w0, b0, wr, br, 0.1, 0.5))
+                rows.append((what, us, px * 46.0 / us / 1e6))
+            os.environ.pop("SGX_RGBCONV_FWD")
             us = timeit(lambda: F.RgbConvPlainFn.apply(img, w0, wr, br, 0.1, 0.5)); rows.append(("plain convolution (LDS tile kernel)", us, px * 44.0 / us / 1e6))
             us = timeit(lambda: F.RgbConvAdjFn.apply(gz, w0, wr, br, 0.1, 0.5)); rows.append(("image gradient", us, px * 44.0 / us / 1e6))
             us = timeit(lambda: F._rgb_wgrad(img, gz, True, w0, b0, wr, br, 0.1, 0.5, (True,) * 4)); rows.append(("weight gradients (3 launches)", us, px * 44.0 / us / 1e6))
