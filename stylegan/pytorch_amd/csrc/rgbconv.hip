@@ -273,12 +273,6 @@ __global__ __launch_bounds__(256) void rgbconv_fwdblur_kernel(const float* __res
     float4 bias[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) bias[cb] = b0 ? *reinterpret_cast<const float4*>(b0 + cb * 16 + 4 * l4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    // Store staging, wave-private (LDS is in order per wave: no barrier): the MFMA result layout gives a lane 4 channels of one pixel,
-    // i.e. 8-byte stores scattered over the row's 32-byte pixels -- measured 270 us of a 700 us kernel at batch 32; through this
-    // buffer lane k stores the k-th 16-byte chunk of the strip's row instead (one contiguous 14 x C x 2 byte segment per row)
-    __shared__ __attribute__((aligned(16))) char stage_all[4][16 * C * 2 + 16 * (C / 4)];
-    char* const stg = stage_all[threadIdx.x >> 6];
-    char* const stn = stg + 16 * C * 2;                    // sign nibbles: [pixel][C / 4] bytes
     const float* ibase = img + (size_t)b * H * W * 3;
     auto load_row = [&](int gy) -> rgb3 {                  // this lane's pixel of image row gy (zeros outside the image)
         rgb3 v{0.f, 0.f, 0.f};
@@ -332,34 +326,22 @@ __global__ __launch_bounds__(256) void rgbconv_fwdblur_kernel(const float* __res
                         a[i] = z_in ? lrelu(acc[i] + bb[i]) : 0.f;       // outside the image: the blur's zero padding
                         h[i] = dpp_row_shr1(a[i]) + 2.f * a[i] + dpp_row_shl1(a[i]);
                     }
-                    if (zrow - 1 >= r_begin) {                           // centre row of (h2, h1, h) = output row zrow - 1
-                        *reinterpret_cast<uint2*>(stg + (l15 * C + cb * 16 + 4 * l4) * 2) =
-                            make_uint2(pack_bf16x2((h2[cb][0] + 2.f * h1[cb][0] + h[0]) * 0.0625f, (h2[cb][1] + 2.f * h1[cb][1] + h[1]) * 0.0625f),
-                                       pack_bf16x2((h2[cb][2] + 2.f * h1[cb][2] + h[2]) * 0.0625f, (h2[cb][3] + 2.f * h1[cb][3] + h[3]) * 0.0625f));
-                        // sign bits of the centre row's pre-activation: 4 channels per lane = one nibble
-                        stn[l15 * (C / 4) + cb * 4 + l4] =
-                            (char)((a1[cb][0] > 0.f ? 1 : 0) | (a1[cb][1] > 0.f ? 2 : 0) | (a1[cb][2] > 0.f ? 4 : 0) | (a1[cb][3] > 0.f ? 8 : 0));
+                    const int orow = zrow - 1;                           // centre row of (h2, h1, h)
+                    if (orow >= r_begin) {
+                        const size_t pix = ((size_t)b * H + orow) * W + zc;
+                        if (col_out && !(dbg & 4))
+                            *reinterpret_cast<uint2*>(y + pix * C + cb * 16 + 4 * l4) =
+                                make_uint2(pack_bf16x2((h2[cb][0] + 2.f * h1[cb][0] + h[0]) * 0.0625f, (h2[cb][1] + 2.f * h1[cb][1] + h[1]) * 0.0625f),
+                                           pack_bf16x2((h2[cb][2] + 2.f * h1[cb][2] + h[2]) * 0.0625f, (h2[cb][3] + 2.f * h1[cb][3] + h[3]) * 0.0625f));
+                        if (bits && !(dbg & 8)) {
+                            // sign bits of the centre row's pre-activation: 4 channels per lane, the partner lane (l4 ^ 1) has the other nibble
+                            unsigned nib = (a1[cb][0] > 0.f ? 1u : 0u) | (a1[cb][1] > 0.f ? 2u : 0u) | (a1[cb][2] > 0.f ? 4u : 0u) | (a1[cb][3] > 0.f ? 8u : 0u);
+                            const unsigned other = (unsigned)__shfl_xor((int)nib, 16, 64);
+                            if (col_out && !(l4 & 1)) bits[pix * (C / 8) + cb * 2 + (l4 >> 1)] = (unsigned char)(nib | (other << 4));
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { h2[cb][i] = h1[cb][i]; h1[cb][i] = h[i]; a1[cb][i] = a[i]; }
-                }
-                const int orow = zrow - 1;
-                if (orow >= r_begin) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    constexpr int CPP = C / 8;                           // 16-byte chunks (= bytes of sign bits) per pixel
-                    const int k = lane;                                  // chunk k of the row segment: pixel 1 + k / CPP of the strip
-                    const int px = k / CPP, v = k - px * CPP, ox = sx * RC_STRIP + px;
-                    if (k < RC_STRIP * CPP && ox < W) {
-                        const size_t pix = ((size_t)b * H + orow) * W + ox;
-                        if (!(dbg & 4)) *reinterpret_cast<uint4*>(y + pix * C + v * 8) = *reinterpret_cast<const uint4*>(stg + ((px + 1) * C + v * 8) * 2);
-                        if (bits && !(dbg & 8)) {
-                            const unsigned w2 = *reinterpret_cast<const unsigned short*>(stn + (px + 1) * (C / 4) + 2 * v);
-                            bits[pix * CPP + v] = (unsigned char)((w2 & 0xfu) | ((w2 >> 8) << 4));
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
                 }
                 f0 = f1; f1 = f2;
             }
