@@ -134,6 +134,17 @@ int sgx_bias_act(const void* x, const float* bias, float bscale, void* y, size_t
  * the branch the activation sits on (x = alpha*straight + (1-alpha)*residual, models/GAN.py:427) into the same pass    */
 int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, float slope, float scale, const float* scale_dev, int dtype,
                   void* stream);
+/* sgx_lrelu_bwd with y given as sign bits (1 bit per element, bits[i] = the 8 channels of 16-byte vector i); bf16 */
+int sgx_lrelu_bwd_bits(const void* dy, const void* bits, void* dx, size_t n, float slope, float scale, const float* scale_dev, int dtype,
+                       void* stream);
+/* The newest discriminator block's tail in one kernel (models/Blocks.py:143-146 + models/GAN.py:425-427): the stride-2 convolution,
+ * its bias and LeakyReLU, and the fade-in lerp with the residual branch:  y = alpha * lrelu(conv(x) + bias) + beta * resid  (resid shaped
+ * like y; the lerp is applied to the bf16-rounded activation, exactly as sgx_axpby on the stored tensor).  bits [B][H/2][W/2][Cout/8]:
+ * the sign bits of the activation -- its LeakyReLU-backward mask (sgx_lrelu_bwd_bits); the activation itself is not stored.
+ * _ok: 1 if the shape has the variant (bf16, second-generation stride-2 kernel), else sgx_conv4x4s2_down + sgx_axpby. */
+int sgx_conv4x4s2_down_fade_ok(int B, int H, int W, int Cin, int Cout, int dtype);
+int sgx_conv4x4s2_down_fade(const void* x, const void* w, const float* bias, const void* resid, float alpha, float beta, void* y, void* bits,
+                            int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
 /* out = alpha*a + beta*b (b may be NULL)    fade-in lerp: models/GAN.py:202,427,586                                 */
 int sgx_axpby(const void* a, const void* b, void* out, float alpha, float beta, size_t n, int dtype, void* stream);
 /* same with the coefficients read from device memory (alpha_dev[0], beta_dev[0]): the fade-in alpha changes every

@@ -170,16 +170,21 @@ class DiscriminatorBlock(nn.Module):
                 and from_rgb.weight.shape[0] == c0.weight.shape[1] == c0.weight.shape[0]
                 and F.rgbconv_ok(img_shape[0], img_shape[1], img_shape[2], c0.weight.shape[0], dtype))
 
-    def forward_from_image(self, img, from_rgb, defer_out=False):
+    def forward_from_image(self, img, from_rgb, defer_out=False, fade=None):
         """The block applied to ``from_rgb(img)`` with from_rgb and conv0 composed into one convolution of the fp32 NHWC image
         (reference models/GAN.py:425 + models/Blocks.py:139-146): neither from_rgb's output nor conv0's pre-activation exists in
         memory; the backward gets the activation mask from the sign bits the kernel writes."""
         c0 = self.conv0
         xb, zbits = F.rgbconv_blur(img, c0.weight, c0.scaled_bias(), from_rgb.weight, from_rgb.scaled_bias(), c0.w_mul, from_rgb.w_mul)
-        return self.conv1_down.forward_nhwc(xb, act=ACT_LRELU, defer_act=defer_out and self._act == ACT_LRELU, x_pre=None, x_pre_bits=zbits)
+        if fade is not None and F.conv_down_fade_ok(xb, self.conv1_down.weight.shape[0]):
+            return self.conv1_down.forward_nhwc(xb, act=ACT_LRELU, x_pre=None, x_pre_bits=zbits, fade=fade), True
+        y = self.conv1_down.forward_nhwc(xb, act=ACT_LRELU, defer_act=defer_out and self._act == ACT_LRELU, x_pre=None, x_pre_bits=zbits)
+        return (y, False) if fade is not None else y
 
-    def forward_nhwc(self, x, x_masked=False, defer_out=False):
-        """``x_masked``: x is the previous block's LeakyReLU output whose activation backward was deferred to this block
+    def forward_nhwc(self, x, x_masked=False, defer_out=False, fade=None):
+        """``fade`` = (residual branch, alpha, beta) (newest block, LeakyReLU networks): the fade-in lerp rides in conv1_down's store
+        where that kernel exists -> returns (output, True) with the lerp applied, else (block output, False).
+        ``x_masked``: x is the previous block's LeakyReLU output whose activation backward was deferred to this block
         (conv0's data gradient leaves its kernel already masked); ``defer_out``: this block's final activation backward is
         applied by the consumer of its output (the next block, or the fade-in lerp).  Set by Discriminator.forward for the
         LeakyReLU networks: one elementwise pass less per block and backward."""
@@ -191,15 +196,20 @@ class DiscriminatorBlock(nn.Module):
             # SIGN BITS that conv0's store wrote next to z (1 bit per element instead of 16) where conv0 has that variant
             z, zbits = self.conv0.forward_nhwc(x, act=ACT_NONE, x_masked=x_masked, sign_bits=True)
             x = F.call(F.ActBlurPassFn, z)
-            return self.conv1_down.forward_nhwc(x, act=ACT_LRELU, defer_act=defer_out, x_pre=z, x_pre_bits=zbits)
+            if fade is not None and F.conv_down_fade_ok(x, self.conv1_down.weight.shape[0]):
+                return self.conv1_down.forward_nhwc(x, act=ACT_LRELU, x_pre=z, x_pre_bits=zbits, fade=fade), True
+            y = self.conv1_down.forward_nhwc(x, act=ACT_LRELU, defer_act=defer_out, x_pre=z, x_pre_bits=zbits)
+            return (y, False) if fade is not None else y
         z = self.conv0.forward_nhwc(x, act=ACT_NONE, x_masked=x_masked)   # bias fused in the conv store; pre-activation
         if self.blur._is_121 and self._act == ACT_LRELU:
             x = F.call(F.ActBlurFn, z)                                      # LeakyReLU folded into the blur pass (both ways)
         else:                                                               # ReLU / another blur filter: stage by stage
             x = self.blur.forward_nhwc(apply_act(z, self._act))
         if self._act == ACT_LRELU:
-            return self.conv1_down.forward_nhwc(x, act=ACT_LRELU, defer_act=defer_out)
-        return apply_act(self.conv1_down.forward_nhwc(x, act=ACT_NONE), self._act)
+            y = self.conv1_down.forward_nhwc(x, act=ACT_LRELU, defer_act=defer_out)
+        else:
+            y = apply_act(self.conv1_down.forward_nhwc(x, act=ACT_NONE), self._act)
+        return (y, False) if fade is not None else y
 
     def forward(self, x):
         return F.nchw_view(self.forward_nhwc(F.nhwc(x)))

@@ -211,7 +211,7 @@ class EqualizedConv2d(nn.Module):
         return self.bias * self.b_mul if self.b_mul != 1 else self.bias
 
     def forward_nhwc(self, x, act=ACT_NONE, skip_bias=False, out_dtype=None, defer_act=False, x_masked=False, out_scale=1.0,
-                     epi_stats=None, x_pre=None, sign_bits=False, x_pre_bits=None):
+                     epi_stats=None, x_pre=None, sign_bits=False, x_pre_bits=None, fade=None):
         """x: NHWC.  ``skip_bias``: the caller folds the bias into the next kernel (generator epilogue).
         ``defer_act`` / ``x_masked``: the LeakyReLU backward of this layer is applied by its consumer / this layer's input is
         such an output and its data gradient leaves the kernel already masked (functional.ConvFn; discriminator chain only).
@@ -274,6 +274,13 @@ class EqualizedConv2d(nn.Module):
             return y
         if self.downscale is not None:
             assert self.intermediate is None                              # reference :167
+            if fade is not None:
+                # (residual branch, alpha, beta): the fade-in lerp of the discriminator's newest block in this layer's store
+                # (functional.ConvDownFadeFn; the caller checked functional.conv_down_fade_ok)
+                assert act == ACT_LRELU and not x_masked
+                resid, alpha, beta = fade
+                return F.call(F.ConvDownFadeFn, x, self.weight, bias, resid, float(self.w_mul), int(self.weight.shape[1]), float(alpha), float(beta),
+                              x_pre, x_pre_bits)
             return F.conv(x, self.weight, bias, "D", self.w_mul, act, defer_act=defer_act and act == ACT_LRELU,
                           x_pre=x_pre, x_pre_bits=x_pre_bits)             # bias after the 2x2 mean == bias in the fused store
         if self.intermediate is None:

@@ -411,14 +411,18 @@ class Discriminator(nn.Module):
                 residual = self.from_rgb[self.depth - depth].forward_nhwc(F.call(F.Pool2Fn, img, 0.25), out_dtype=dt,
                                                                           out_scale=float(1 - alpha) if pre else 1.0)
                 top, top_rgb = self.blocks[self.depth - depth - 1], self.from_rgb[self.depth - depth - 1]
+                # the fade-in lerp in the store of the newest block's stride-2 convolution (functional.ConvDownFadeFn) where alpha
+                # is a host number (the residual then already carries its 1 - alpha) and the shape has that kernel
+                fade_arg = (residual, float(alpha), 1.0) if (pre and top._act == ACT_LRELU) else None
                 if not self.conditional and top.fused_from_rgb_ok(img.shape, top_rgb, dt):
                     # from_rgb and the newest block's conv0 (no activation between them) as ONE convolution of the image, with
                     # the LeakyReLU and the blur in its store (functional.RgbConvBlurFn)
-                    straight = top.forward_from_image(img, top_rgb, defer_out=fuse)
+                    out = top.forward_from_image(img, top_rgb, defer_out=fuse, fade=fade_arg)
                 else:
-                    straight = top.forward_nhwc(top_rgb.forward_nhwc(img, out_dtype=dt), defer_out=fuse)
-                x = F.fade(straight, residual, alpha,                                      # GAN.py:427
-                           a_act=fuse and self.blocks[self.depth - depth - 1]._act == ACT_LRELU, b_prescaled=pre)
+                    out = top.forward_nhwc(top_rgb.forward_nhwc(img, out_dtype=dt), defer_out=fuse, fade=fade_arg)
+                straight, lerped = out if fade_arg is not None else (out, False)
+                x = straight if lerped else F.fade(straight, residual, alpha,            # GAN.py:427
+                                                   a_act=fuse and top._act == ACT_LRELU, b_prescaled=pre)
                 x = chain(x, list(self.blocks[(self.depth - depth):]), False)
             else:
                 x = self.from_rgb[-1].forward_nhwc(img, out_dtype=dt)

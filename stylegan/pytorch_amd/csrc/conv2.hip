@@ -64,6 +64,12 @@ struct Conv2Args {
     unsigned char* signbits;
     // EPI_BLUR: the activation mask as those sign bits (1 bit per element instead of 16) -- overrides `mask`
     const unsigned char* maskbits;
+    // C2_D, register epilogue: the fade-in lerp of the discriminator's newest block (models/GAN.py:427) in the store,
+    // y = fade_alpha * act(conv + bias) + fade_beta * fade_resid, on the bf16-ROUNDED activation (bit for bit what sgx_axpby computes from
+    // the stored tensor); `signbits` then receives the sign bits of the activation (its LeakyReLU-backward mask: the activation itself
+    // is never stored)
+    const bf16_t* fade_resid;
+    float fade_alpha, fade_beta;
 };
 enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BLUR = 2 };
 
@@ -577,8 +583,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                             if (inimg) {
                                 const size_t doff = pix + m * 32 + 16 * k;
                                 if (GEO == C2_S && a.mask) val = lrelu_mask_bf16x8(val, *reinterpret_cast<const uint4*>(a.mask + doff));
-                                *reinterpret_cast<uint4*>(a.y + doff) = val;
-                                if (GEO == C2_S && a.signbits) {
+                                if ((GEO == C2_S || GEO == C2_D) && a.signbits) {
                                     const unsigned wv[4] = {val.x, val.y, val.z, val.w};
                                     unsigned bits = 0;
 #pragma unroll
@@ -588,6 +593,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                                     }
                                     a.signbits[doff >> 3] = (unsigned char)bits;
                                 }
+                                if (GEO == C2_D && a.fade_resid) {
+                                    const uint4 rq = *reinterpret_cast<const uint4*>(a.fade_resid + doff);
+                                    const unsigned yv[4] = {val.x, val.y, val.z, val.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w};
+                                    unsigned ov[4];
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q)
+                                        ov[q] = pack_bf16x2(a.fade_alpha * __uint_as_float(yv[q] << 16) + a.fade_beta * __uint_as_float(rv[q] << 16),
+                                                            a.fade_alpha * __uint_as_float(yv[q] & 0xffff0000u) + a.fade_beta * __uint_as_float(rv[q] & 0xffff0000u));
+                                    val = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+                                }
+                                *reinterpret_cast<uint4*>(a.y + doff) = val;
                             }
                         }
                     }
@@ -882,4 +898,29 @@ extern "C" int sgx_conv3x3_signbits(const void* x, const void* w, const float* b
     if (p.k16) return nw == 8 ? launch_conv2<C2_S, 8, 1, 16, true>(a, st) : launch_conv2<C2_S, 4, 1, 16, true>(a, st);
     if (p.mf2) return nw == 8 ? launch_conv2<C2_S, 8, 2>(a, st) : launch_conv2<C2_S, 4, 2>(a, st);
     return nw == 8 ? launch_conv2<C2_S, 8, 1>(a, st) : launch_conv2<C2_S, 4, 1>(a, st);
+}
+
+// ---- stride-2 convolution whose store applies the fade-in lerp of the discriminator's newest block and writes the activation's sign
+// bits instead of the activation (models/GAN.py:425-427 over models/Blocks.py:143-146):  y = alpha * lrelu(conv(x) + bias) + beta * resid.
+extern "C" int sgx_conv4x4s2_down_fade_ok(int B, int H, int W, int Cin, int Cout, int dtype) {
+    if (dtype != SGX_BF16 || Cout % 8) return 0;
+    static const int on = [] { const char* e = getenv("SGX_FUSE_FADE"); return e ? atoi(e) : 1; }();   // A/B switch
+    return on && conv2_pick(C2_D, B, H, W, Cin, Cout, -1).nw ? 1 : 0;
+}
+extern "C" int sgx_conv4x4s2_down_fade(const void* x, const void* w, const float* bias, const void* resid, float alpha, float beta, void* y, void* bits,
+                                       int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    SGX_REQUIRE(dtype == SGX_BF16, SGX_EUNSUPPORTED, "conv4x4s2_down_fade: bf16 only");
+    SGX_REQUIRE(x && w && resid && y && bits, SGX_EINVAL, "conv4x4s2_down_fade: null argument");
+    const Conv2Pick p = conv2_pick(C2_D, B, H, W, Cin, Cout, -1);
+    SGX_REQUIRE(p.nw && Cout % 8 == 0, SGX_EUNSUPPORTED, "conv4x4s2_down_fade: shape B%d %dx%d %d->%d has no variant (sgx_conv4x4s2_down_fade_ok == 0)", B, H, W, Cin, Cout);
+    const double opx = (double)B * (H / 2) * (W / 2);
+    SGX_NOTE(2.0 * 16 * Cin * Cout * opx, 2.0 * ((double)B * H * W * Cin + 2.0 * opx * Cout + 16.0 * Cin * Cout) + opx * Cout / 8.0, "convD+fade B%d %dx%d %d->%d", B, H, W, Cin, Cout);
+    Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), nullptr, B, H, W, H / 2, W / 2, Cin, Cout,
+                SGX_ACT_LRELU, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, static_cast<unsigned char*>(bits), nullptr,
+                static_cast<const bf16_t*>(resid), alpha, beta};
+    hipStream_t st = (hipStream_t)stream;
+    const int nw = p.nw;
+    if (p.k16) return nw == 8 ? launch_conv2<C2_D, 8, 1, 16, false>(a, st) : launch_conv2<C2_D, 4, 1, 16, false>(a, st);
+    if (p.mf2) return nw == 8 ? launch_conv2<C2_D, 8, 2>(a, st) : launch_conv2<C2_D, 4, 2>(a, st);
+    return nw == 8 ? launch_conv2<C2_D, 8, 1>(a, st) : launch_conv2<C2_D, 4, 1>(a, st);
 }

@@ -89,6 +89,31 @@ extern "C" int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, 
     return 0;
 }
 
+// the same with the activation given as SIGN BITS (bits[i] = the signs of the 8 channels of vector i, as sgx_conv3x3_signbits /
+// sgx_conv4x4s2_down_fade write them): the activation itself need not exist
+__global__ void lrelu_bwd_bits_kernel(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ bits, bf16_t* __restrict__ dx, size_t nvec, float slope,
+                                      float scale, const float* __restrict__ scale_dev) {
+    if (scale_dev) scale = scale_dev[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        float g[8];
+        VecTraits<bf16_t>::load(dy + i * 8, g);
+        const unsigned bb = bits[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = (scale * g[j]) * (((bb >> j) & 1u) ? 1.f : slope);
+        VecTraits<bf16_t>::store(dx + i * 8, g);
+    }
+}
+extern "C" int sgx_lrelu_bwd_bits(const void* dy, const void* bits, void* dx, size_t n, float slope, float scale, const float* scale_dev, int dtype,
+                                  void* stream) {
+    SGX_REQUIRE(dtype == SGX_BF16 && n % 8 == 0, SGX_EUNSUPPORTED, "lrelu_bwd_bits: bf16, n %% 8 == 0");
+    SGX_REQUIRE(dy && bits && dx, SGX_EINVAL, "lrelu_bwd_bits: null argument");
+    SGX_NOTE(0.0, 4.125 * n, "lrelu_bwd_bits %zu", n);
+    hipLaunchKernelGGL(lrelu_bwd_bits_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const unsigned char*)bits, (bf16_t*)dx,
+                       n / 8, slope, scale, scale_dev);
+    SGX_LAUNCH_CHECK("lrelu_bwd_bits");
+    return 0;
+}
+
 // ---------------------------------------------------------------- out = alpha*a + beta*b
 template <typename T>
 __global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, float alpha, float beta,

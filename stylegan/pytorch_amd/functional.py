@@ -823,6 +823,78 @@ class LReluBwdFn(Function):
         return _bcall(LReluBwdFn, gg, y, ctx.slope, ctx.scale), None, None, None
 
 
+class LReluBwdBitsFn(Function):
+    """scale * g * (bit ? 1 : slope): ``LReluBwdFn`` with the activation's output given as its SIGN BITS ([..., C/8] uint8, one
+    byte per 8 channels) -- for activations that were never stored (``ConvDownFadeFn``).  Linear in g: its own backward."""
+
+    @staticmethod
+    def forward(ctx, g, bits, slope, scale=1.0):
+        g = _c(g)
+        if g.dtype != torch.bfloat16 or bits.dtype != torch.uint8 or bits.numel() * 8 != g.numel():
+            raise N.SgxError("LReluBwdBitsFn: bf16 gradient and one sign byte per 8 channels expected")
+        out = torch.empty_like(g)
+        N.check(N.lib().sgx_lrelu_bwd_bits(N.ptr(g), N.ptr(bits), N.ptr(out), g.numel(), float(slope), float(scale), None, N.dt(g), N.stream()),
+                "sgx_lrelu_bwd_bits")
+        ctx.slope, ctx.scale = float(slope), float(scale)
+        ctx.save_for_backward(bits)
+        return out
+
+    @staticmethod
+    def backward(ctx, gg):
+        (bits,) = ctx.saved_tensors
+        return _bcall(LReluBwdBitsFn, gg, bits, ctx.slope, ctx.scale), None, None, None
+
+
+FUSE_FADE = os.environ.get("SGX_FUSE_FADE", "1") != "0"        # A/B (tests flip the attribute; the library reads the same variable)
+
+
+def conv_down_fade_ok(x, cout):
+    """True if ``ConvDownFadeFn`` has a kernel for the stride-2 convolution of NHWC ``x`` to ``cout`` channels."""
+    if not FUSE_FADE or x.dtype != torch.bfloat16:
+        return False
+    B, H, W, Cin = x.shape
+    return bool(N.lib().sgx_conv4x4s2_down_fade_ok(B, H, W, Cin, int(cout), N.BF16))
+
+
+class ConvDownFadeFn(Function):
+    """alpha * lrelu(conv_down(x) + bias) + beta * resid in ONE kernel: the tail of the discriminator's newest block with the
+    fade-in lerp (reference models/Blocks.py:143-146 + models/GAN.py:425-427) in the convolution's store; the activation itself is
+    never written, its sign bits are (the mask of its backward).  Backward: d resid = beta * g; the convolution's upstream gradient
+    alpha * g * slope(bits) is one pass (``LReluBwdBitsFn``), then exactly ``ConvFn``'s backward (incl. ``x_pre_bits``: the blur and
+    activation mask in front of this layer)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, resid, scale, ipad, alpha, beta, x_pre=None, x_pre_bits=None):
+        x, resid = _c(x), _c(resid)
+        fwd, adj = packs(weight, "D", scale, ipad, x.dtype)
+        B, H, W, Cin = x.shape
+        taps, Cout, K = fwd.shape
+        if K != Cin or tuple(resid.shape) != (B, H // 2, W // 2, Cout) or resid.dtype != x.dtype:
+            raise N.SgxError("conv+fade: residual branch must have the output's shape and dtype")
+        y = torch.empty((B, H // 2, W // 2, Cout), dtype=x.dtype, device=x.device)
+        bits = torch.empty((B, H // 2, W // 2, Cout // 8), dtype=torch.uint8, device=x.device)
+        N.check(N.lib().sgx_conv4x4s2_down_fade(N.ptr(x), N.ptr(fwd), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(resid), float(alpha),
+                                                float(beta), N.ptr(y), N.ptr(bits), B, H, W, Cin, Cout, N.dt(x), N.stream()), "sgx_conv4x4s2_down_fade")
+        # ConvFn.backward's view of this op: the stride-2 layer with its activation already undone (see backward)
+        ctx.cfg = ("D", scale, ipad, False, 0, bias is not None, False, False)
+        ctx.bias_ref = weakref.ref(bias) if bias is not None else (lambda: None)
+        ctx.x_pre, ctx.x_pre_bits = x_pre, x_pre_bits
+        ctx.fade = (float(alpha), float(beta), bits)
+        ctx.save_for_backward(x, weight, None, None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        alpha, beta, bits = ctx.fade
+        g_res = None
+        if ctx.needs_input_grad[3]:
+            g_res = g if beta == 1.0 else _bcall(ScaleFn, g, beta)
+        gy = _bcall(LReluBwdBitsFn, g, bits, 0.2, alpha)
+        out = ConvFn.backward(ctx, gy)                     # (x, weight, bias are inputs 0..2 of both Functions)
+        return out[0], out[1], out[2], g_res, None, None, None, None, None, None
+
+
 class ColSumFn(Function):
     """[..., C] -> fp32 [C], times ``scale`` (bias gradient)."""
 

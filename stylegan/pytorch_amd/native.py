@@ -52,6 +52,9 @@ SIGNATURES = {
     "sgx_wgrad4x4s2_param": (I, [P, P, P, P, P, Z, I, I, I, I, I, I, F, I, I, I, I, P]),
     "sgx_bias_act": (I, [P, P, F, P, Z, I, I, I, P]),
     "sgx_lrelu_bwd": (I, [P, P, P, Z, F, F, P, I, P]),
+    "sgx_lrelu_bwd_bits": (I, [P, P, P, Z, F, F, P, I, P]),
+    "sgx_conv4x4s2_down_fade_ok": (I, [I, I, I, I, I, I]),
+    "sgx_conv4x4s2_down_fade": (I, [P, P, P, P, F, F, P, P, I, I, I, I, I, I, P]),
     "sgx_axpby": (I, [P, P, P, F, F, Z, I, P]),
     "sgx_axpby_dev": (I, [P, P, P, P, P, Z, I, P]),
     "sgx_blur3x3": (I, [P, P, I, I, I, I, I, P]),

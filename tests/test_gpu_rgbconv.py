@@ -207,3 +207,30 @@ def test_discriminator_step_with_the_composed_first_layer(depth, monkeypatch):
     med_on, med_off = float(np.median([r[0] for r in rows])), float(np.median([r[1] for r in rows]))
     print(f"   median gradient rel-L2 vs fp64: on {med_on:.3e}, off {med_off:.3e}")
     assert med_on <= 1.1 * med_off + 1e-3
+
+
+@pytest.mark.parametrize("depth,composed", [(5, True), (4, True), (3, False), (5, False)])
+def test_fade_in_lerp_in_the_store_of_the_stride2_convolution(depth, composed, monkeypatch):
+    """functional.ConvDownFadeFn (round 4): alpha * lrelu(conv1_down(.)) + (1 - alpha) * from_rgb(pool(img)) with the lerp in the
+    convolution's store and the activation kept only as sign bits -- the SAME roundings as the separate passes (the lerp is applied
+    to the bf16-rounded activation; the backward multiplies by the same slope), so scores, the R1 image gradient and every parameter
+    gradient agree with the unfused path to the order in which autograd sums contributions (reference models/GAN.py:423-427)."""
+    from stylegan.pytorch_amd import functional as F
+    B, alpha = 4, 0.3
+    R = 4 << depth
+    real = gu.seeded((B, 3, R, R), 61); fake = gu.seeded((B, 3, R, R), 62)
+    dis, dp = build_dis()
+    monkeypatch.setattr(F, "RGBCONV", composed)
+    calls = []
+    orig = F.ConvDownFadeFn.forward
+    monkeypatch.setattr(F.ConvDownFadeFn, "forward", staticmethod(lambda ctx, *a: (calls.append(1), orig(ctx, *a))[1]))
+    loss_on, g_on, gi_on = d_loss_grads(dis, real.to(DEV), fake.to(DEV), depth, alpha)
+    assert len(calls) == 3, calls
+    monkeypatch.setattr(F, "FUSE_FADE", False)
+    loss_off, g_off, gi_off = d_loss_grads(dis, real.to(DEV), fake.to(DEV), depth, alpha)
+    assert len(calls) == 3
+    assert abs(loss_on - loss_off) <= 1e-6 * abs(loss_off), (loss_on, loss_off)
+    assert rel_err(gi_on, gi_off) <= 1e-5
+    assert sorted(g_on) == sorted(g_off)
+    for k in g_on:
+        assert rel_err(g_on[k], g_off[k]) <= 1e-5, (k, rel_err(g_on[k], g_off[k]))
