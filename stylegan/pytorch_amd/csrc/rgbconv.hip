@@ -71,8 +71,8 @@ template <int CB, int EPI> struct RcFwd {
     static constexpr int ZH = TH + 2 * (R - 1), ZW = TW + 2 * (R - 1);     // convolution outputs the block computes
     static constexpr int NPX = ZH * ZW, NG = (NPX + 15) / 16;
     static constexpr int IPX = IH * IW + 4;                                // + 4 pixels of padding: the k-group of the last pixel reads 3 beyond
-    static constexpr int IMG_BYTES = (IPX * 8 + 15) / 16 * 16;          // one bf16 (r, g, b, 1) image; a second one holds the LOW parts
-    static constexpr int LDS = 2 * IMG_BYTES + (EPI ? NPX * C * 2 : 0);
+    static constexpr int IMG_BYTES = (IPX * 8 + 15) / 16 * 16;
+    static constexpr int LDS = IMG_BYTES + (EPI ? NPX * C * 2 : 0);
 };
 
 // Tile schedule of the persistent kernels below: the grid is a multiple of 8 blocks; block b runs on XCD b & 7 (round-robin
@@ -97,8 +97,7 @@ __global__ __launch_bounds__(256) void rgbconv_fwd_kernel(const float* __restric
     constexpr int C = G::C, R = G::R, TH = G::TH, TW = G::TW, IH = G::IH, IW = G::IW, ZW = G::ZW, NPX = G::NPX, NG = G::NG, IPX = G::IPX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2* imgl = reinterpret_cast<uint2*>(smem);
-    uint2* imgl_lo = reinterpret_cast<uint2*>(smem + G::IMG_BYTES);
-    char* zl = smem + 2 * G::IMG_BYTES;
+    char* zl = smem + G::IMG_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const RcSched sc = rc_sched(ntiles);
     if (sc.first >= sc.end) return;
@@ -146,14 +145,7 @@ __global__ __launch_bounds__(256) void rgbconv_fwd_kernel(const float* __restric
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = it * 256 + tid;
-            if (idx < IPX) {
-                // the image as TWO bf16 terms, hi + lo (16 mantissa bits together): rounding the INPUT to bf16 alone raised the
-                // discriminator's gradient error from 0.075 to 0.10 median rel-L2 (every activation downstream inherits it)
-                const uint2 hi = make_uint2(pack_bf16x2(pv[it].r, pv[it].g), pack_bf16x2(pv[it].b, (((okm >> it) & 1u) && ones) ? 1.f : 0.f));
-                imgl[idx] = hi;
-                imgl_lo[idx] = make_uint2(pack_bf16x2(pv[it].r - __uint_as_float(hi.x << 16), pv[it].g - __uint_as_float(hi.x & 0xffff0000u)),
-                                          pack_bf16x2(pv[it].b - __uint_as_float(hi.y << 16), 0.f));
-            }
+            if (idx < IPX) imgl[idx] = make_uint2(pack_bf16x2(pv[it].r, pv[it].g), pack_bf16x2(pv[it].b, (((okm >> it) & 1u) && ones) ? 1.f : 0.f));
         }
         __syncthreads();                                   // the region is staged; everybody is done with the previous tile's blur
         if (t + sc.stride < sc.end) load_tile(t + sc.stride);
@@ -167,15 +159,11 @@ __global__ __launch_bounds__(256) void rgbconv_fwd_kernel(const float* __restric
             for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const uint2 raw = imgl[(zr + ky) * IW + zc + l4], rlo = imgl_lo[(zr + ky) * IW + zc + l4];
-                s16x4 bf, bl;
+                const uint2 raw = imgl[(zr + ky) * IW + zc + l4];
+                s16x4 bf;
                 bf[0] = (short)(raw.x & 0xffffu); bf[1] = (short)(raw.x >> 16); bf[2] = (short)(raw.y & 0xffffu); bf[3] = (short)(raw.y >> 16);
-                bl[0] = (short)(rlo.x & 0xffffu); bl[1] = (short)(rlo.x >> 16); bl[2] = (short)(rlo.y & 0xffffu); bl[3] = (short)(rlo.y >> 16);
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    acc[cb] = mma16(wfr[cb][ky], bl, acc[cb]);
-                    acc[cb] = mma16(wfr[cb][ky], bf, acc[cb]);
-                }
+                for (int cb = 0; cb < CB; ++cb) acc[cb] = mma16(wfr[cb][ky], bf, acc[cb]);
             }
             const int gy = ty0 - (R - 1) + zr, gx = tx0 - (R - 1) + zc;
             const bool inimg = px < NPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
@@ -291,22 +279,18 @@ __global__ __launch_bounds__(256) void rgbconv_fwdblur_kernel(const float* __res
         if (pc_ok && (unsigned)gy < (unsigned)H && !(dbg & 2)) v = *reinterpret_cast<const rgb3*>(ibase + ((size_t)gy * W + pc) * 3);
         return v;
     };
-    struct Frag2 { s16x4 hi, lo; };                        // the pixel as two bf16 terms (see the tile kernel): hi = (r, g, b, 1 | 0)
-    auto frag_of = [&](const rgb3& v, int gy) -> Frag2 {
+    auto frag_of = [&](const rgb3& v, int gy) -> s16x4 {   // bf16 (r, g, b, 1 inside the image | 0)
         const bool in = pc_ok && (unsigned)gy < (unsigned)H;
         const unsigned p01 = pack_bf16x2(v.r, v.g), p23 = pack_bf16x2(v.b, (in && ones) ? 1.f : 0.f);
-        const unsigned q01 = pack_bf16x2(v.r - __uint_as_float(p01 << 16), v.g - __uint_as_float(p01 & 0xffff0000u));
-        const unsigned q23 = pack_bf16x2(v.b - __uint_as_float(p23 << 16), 0.f);
-        Frag2 f;
-        f.hi[0] = (short)(p01 & 0xffffu); f.hi[1] = (short)(p01 >> 16); f.hi[2] = (short)(p23 & 0xffffu); f.hi[3] = (short)(p23 >> 16);
-        f.lo[0] = (short)(q01 & 0xffffu); f.lo[1] = (short)(q01 >> 16); f.lo[2] = (short)(q23 & 0xffffu); f.lo[3] = (short)(q23 >> 16);
+        s16x4 f;
+        f[0] = (short)(p01 & 0xffffu); f[1] = (short)(p01 >> 16); f[2] = (short)(p23 & 0xffffu); f[3] = (short)(p23 >> 16);
         return f;
     };
     // window of image rows zrow - 1, zrow, zrow + 1 for the convolution row zrow, and RC_PF more rows in flight: a wave waits ~1.5 us
     // for a row under load, so with three rows in flight (the first version) the kernel ran at 2.6 TB/s, latency-bound -- the ring
     // is indexed statically in a loop unrolled RC_PF times, so nothing is moved between registers
     const int z0 = r_begin - 1;
-    Frag2 f0 = frag_of(load_row(z0 - 1), z0 - 1), f1 = frag_of(load_row(z0), z0);
+    s16x4 f0 = frag_of(load_row(z0 - 1), z0 - 1), f1 = frag_of(load_row(z0), z0);
     rgb3 ring[RC_PF];
 #pragma unroll
     for (int u = 0; u < RC_PF; ++u) ring[u] = load_row(z0 + 1 + u);
@@ -322,21 +306,18 @@ __global__ __launch_bounds__(256) void rgbconv_fwdblur_kernel(const float* __res
         for (int u = 0; u < RC_PF; ++u) {
             const int zrow = zb + u;
             if (zrow <= r_end) {                                         // (wave-uniform)
-                const Frag2 f2 = frag_of(ring[u], zrow + 1);
+                const s16x4 f2 = frag_of(ring[u], zrow + 1);
                 ring[u] = load_row(zrow + 1 + RC_PF);
                 const bool z_in = col_in && (unsigned)zrow < (unsigned)H;
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) {
                     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
                     if (!(dbg & 1)) {
-                        acc = mma16(wfr[cb][0], f0.lo, acc);
-                        acc = mma16(wfr[cb][1], f1.lo, acc);
-                        acc = mma16(wfr[cb][2], f2.lo, acc);
-                        acc = mma16(wfr[cb][0], f0.hi, acc);
-                        acc = mma16(wfr[cb][1], f1.hi, acc);
-                        acc = mma16(wfr[cb][2], f2.hi, acc);
+                        acc = mma16(wfr[cb][0], f0, acc);
+                        acc = mma16(wfr[cb][1], f1, acc);
+                        acc = mma16(wfr[cb][2], f2, acc);
                     } else {
-                        acc[0] = (float)f0.hi[0] + (float)f1.hi[1] + (float)f2.lo[2]; acc[1] = acc[0]; acc[2] = acc[0]; acc[3] = acc[0];
+                        acc[0] = (float)f0[0] + (float)f1[1] + (float)f2[2]; acc[1] = acc[0]; acc[2] = acc[0]; acc[3] = acc[0];
                     }
                     const float bb[4] = {bias[cb].x, bias[cb].y, bias[cb].z, bias[cb].w};
                     float a[4], h[4];
