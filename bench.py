@@ -538,7 +538,7 @@ def main():
     stream_opts = {"auto": [(True, True), (False, True), (False, False)], "11": [(True, True)], "01": [(False, True)], "00": [(False, False)]}[a.streams]
     headline = a.config == "ffhq1024" and a.dtype == "bf16"
     blk = measure(sg, a, cfg, dev, B, a.steps, a.warmup, rank, world, want_graphs, stream_opts, layer_table=a.layer_table,
-                  traffic_ok=headline and B == 4)
+                  traffic_ok=headline and B in (4, 32))
     b32 = None
     if headline and world == 1 and B != 32 and not a.no_b32:
         # second measured block: the north-star target configuration (BASELINE.json: >= 40 % of the bf16 MFMA peak at batch 32
