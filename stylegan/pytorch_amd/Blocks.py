@@ -195,7 +195,7 @@ class DiscriminatorBlock(nn.Module):
             # gradient (ConvFn x_pre): one kernel where that wins, else the blur-and-mask pass -- which reads the mask as the
             # SIGN BITS that conv0's store wrote next to z (1 bit per element instead of 16) where conv0 has that variant
             z, zbits = self.conv0.forward_nhwc(x, act=ACT_NONE, x_masked=x_masked, sign_bits=True)
-            x = F.call(F.ActBlurPassFn, z)
+            x = F.act_blur_pass(z)
             if fade is not None and F.conv_down_fade_ok(x, self.conv1_down.weight.shape[0]):
                 return self.conv1_down.forward_nhwc(x, act=ACT_LRELU, x_pre=z, x_pre_bits=zbits, fade=fade), True
             y = self.conv1_down.forward_nhwc(x, act=ACT_LRELU, defer_act=defer_out, x_pre=z, x_pre_bits=zbits)

@@ -278,6 +278,8 @@ class EqualizedConv2d(nn.Module):
                 # (residual branch, alpha, beta): the fade-in lerp of the discriminator's newest block in this layer's store
                 # (functional.ConvDownFadeFn; the caller checked functional.conv_down_fade_ok)
                 assert act == ACT_LRELU and not x_masked
+                if x_pre is not None and getattr(x, "_sgx_pre_of", None) is not x_pre:
+                    raise F.N.SgxError("conv+fade: x_pre given, but x is not the ActBlurPassFn output of that tensor")
                 resid, alpha, beta = fade
                 return F.call(F.ConvDownFadeFn, x, self.weight, bias, resid, float(self.w_mul), int(self.weight.shape[1]), float(alpha), float(beta),
                               x_pre, x_pre_bits)

@@ -70,6 +70,7 @@ struct Conv2Args {
     // is never stored)
     const bf16_t* fade_resid;
     float fade_alpha, fade_beta;
+    int part_slots;                           // EPI_STATS: the slot count `part` was sized for (launch_conv2 refuses any other nslots)
 };
 enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BLUR = 2 };
 
@@ -721,6 +722,8 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
     a.nslots = per * 8;
     static const int bands_on = [] { const char* e = getenv("SGX_TILE_BANDS"); return e ? atoi(e) : 1; }();   // measured (round 2): halo over-fetch gone (PMC), 80.8 vs 81.2 ms at batch 32, nothing at batch 4
     a.bands = (bands_on && a.ntiles >= 8 * a.nslots) ? 1 : 0;      // enough tiles per slot for the order to matter
+    if constexpr (EPI == EPI_STATS)
+        SGX_REQUIRE(a.part_slots == 0 || a.part_slots == a.nslots, SGX_EINVAL, "conv2 statistics: partials sized for %d tile slots, the launch uses %d", a.part_slots, a.nslots);
     hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.ncb * per)), dim3(NW * 64), LDS, st, a);
     SGX_LAUNCH_CHECK("conv2_kernel");
     return 0;
@@ -834,6 +837,7 @@ extern "C" int sgx_conv3x3_stats(const void* x, const void* w, void* y, const fl
     SGX_NOTE(2.0 * 9 * Cin * Cout * B * H * W, 2.0 * ((double)B * H * W * (Cin + Cout) + 9.0 * Cin * Cout), "convS+stats B%d %dx%d %d->%d", B, H, W, Cin, Cout);
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), nullptr, static_cast<bf16_t*>(y), nullptr, B, H, W, H, W, Cin, Cout,
                 SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, ebias, noise, nw_, part, nullptr};
+    a.part_slots = npart;
     hipStream_t st = (hipStream_t)stream;
     const int nw = p.nw;
     if (p.k16) return nw == 8 ? launch_conv2<C2_S, 8, 1, 16, true, EPI_STATS>(a, st) : launch_conv2<C2_S, 4, 1, 16, true, EPI_STATS>(a, st);

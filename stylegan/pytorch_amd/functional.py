@@ -513,6 +513,14 @@ class ActBlurPassFn(Function):
         return g
 
 
+def act_blur_pass(z):
+    """blur(lrelu(z)) for a consumer that is called with ``x_pre=z`` (``ActBlurPassFn``: identity backward); the output is tagged with
+    its source so that ``conv`` / ``ConvDownFadeFn`` callers cannot pair it with another tensor."""
+    x = call(ActBlurPassFn, z)
+    x._sgx_pre_of = z
+    return x
+
+
 class WgradFn(Function):
     """Parameter gradient(s) of ConvFn (first order only: nothing in the training step differentiates through it)."""
 
@@ -528,6 +536,10 @@ class WgradFn(Function):
 
 def conv(x, weight, bias, mode, scale, act=N.ACT_NONE, ipad=None, defer_act=False, x_masked=False, stats=None, x_pre=None,
          bits_out=False, x_pre_bits=None):
+    if x_pre is not None and getattr(x, "_sgx_pre_of", None) is not x_pre:
+        # x_pre makes this op's backward return the gradient w.r.t. x_pre (blur and mask folded in): only right if x really is the
+        # pass-through blur of x_pre, whose own backward is the identity
+        raise N.SgxError("conv: x_pre given, but x is not the ActBlurPassFn output of that tensor (functional.act_blur_pass)")
     return call(ConvFn, x, weight, bias, mode, float(scale), int(ipad if ipad is not None else weight.shape[1]), False, act, None,
                 bool(defer_act), bool(x_masked), stats, x_pre, bool(bits_out), x_pre_bits)
 
