@@ -52,7 +52,9 @@ def gate(section, measured):
     def floor(k):
         # quantities that are small differences of large ones move by more than 2x under ANY change of the summation / rounding
         # order (a fused kernel, another tile size): gradients of a tensor to 2e-2 of its norm, directions to 1e-3, scalars 1e-4
-        return 2e-2 if k.endswith(":rel") else (1e-3 if k.endswith(":1-cos") else 1e-4)
+        # (loss scalars and the four D scores of a batch-4 run are single noisy numbers: d_loss moved 1.3e-4 -> 9e-4 and g_loss
+        # 7e-4 -> 1e-2 between two equally accurate builds of round 4; tools/diag_dscore.py has the 64-score statistic)
+        return 2e-2 if (k.endswith(":rel") or k.endswith("_loss") or k.startswith("d_score")) else (1e-3 if k.endswith(":1-cos") else 1e-4)
     bad = {k: (measured[k], want[k]) for k in want if measured[k] > 2.0 * want[k] + floor(k)}
     assert not bad, f"{section}: beyond 2x the measured error: {bad}"
 
@@ -62,7 +64,7 @@ def gate(section, measured):
 # SHALLOWER model).  Gradients: median rel-L2 per network and the worst direction error, against the fp64 oracle.
 BARS = {
     "image": {"mid": 3.1e-2, "128": 3.1e-2, "1024": 6.7e-2},        # depth 5 models under the depth-2 figure, depth 8 under the depth-5 one
-    "d_score": {"mid": 2e-2, "128": 2e-2, "1024": 1.6e-1},
+    "d_score": {"mid": 5e-2, "128": 2e-2, "1024": 1.6e-1},          # (mid: 2-3e-2 over 64 scores, tools/diag_dscore.py; naive cast at its depth: 1.6e-1)
     "loss": 5e-2,                                                   # either loss scalar, relative
     "d_grad_median": 0.08, "g_grad_median": 0.13, "one_minus_cos": 0.12,
 }
