@@ -333,6 +333,25 @@ int sgx_style_bwd_data(const float* gy, const void* table, float* glm, int G, in
 int sgx_style_bwd_param(const float* gy, const float* lm, const void* table, float* dw, float* db, int G, int B, int D,
                         int total_tiles, void* stream);
 
+/* ---- the generator's LAST layer epilogue inside to_rgb (round 4).  The last LayerEpilogue of the synthesis network feeds only to_rgb
+ * (models/GAN.py:199-202 after models/Blocks.py:87-88 / models/CustomLayers.py:219-248): instead of writing x2 = StyleMod(InstanceNorm(
+ * lrelu(y + bias + nw noise))) and reading it back in the 1x1 convolution, to_rgb reads the convolution's output y and applies the
+ * epilogue per element on the fly.  Default stack only (activation + instance norm + style; flags = SGX_EPI_ACT | SGX_EPI_NORM).
+ *   sgx_gepi_stats    : mean / rstd [B][C] of the epilogue (the statistics half of sgx_gepi_fwd; pre_part as there).
+ *   sgx_rgb_out_epi   : img = alpha * (wscale W x2 + rbias) + beta * nearest_up2(low)   (low may be NULL: then beta is ignored)
+ *   sgx_rgb_wgrad_epi : dw = scale * sum_p g[p][j] x2[p][c] in the parameter's layout, db[j] = bscale * sum_p g[p][j] (db nullable);
+ *                       g = the image gradient [B][HW][3] fp32.  ws: sgx_rgb_wgrad_epi_ws_bytes.
+ * The data gradient is sgx_rgb_in (g -> d x2) followed by sgx_gepi_bwd on y, as for the separate ops. */
+int sgx_gepi_stats(const void* x, const float* bias, const float* noise, const float* nw, float* mean, float* rstd, void* ws, size_t ws_bytes,
+                   const double* pre_part, int pre_npart, int B, int HW, int C, int flags, int dtype, void* stream);
+int sgx_rgb_out_epi(const void* y, const float* ebias, const float* noise, const float* nw, const float* style, const float* mean,
+                    const float* rstd, const float* w, int sj, int sc, float wscale, const float* rbias, const float* low, float alpha, float beta,
+                    float* img, int B, int H, int W, int C, int dtype, void* stream);
+size_t sgx_rgb_wgrad_epi_ws_bytes(int B, int HW, int C);
+int sgx_rgb_wgrad_epi(const void* y, const float* g, const float* ebias, const float* noise, const float* nw, const float* style, const float* mean,
+                      const float* rstd, float* dw, float* db, int sj, int sc, float scale, float bscale, void* ws, size_t ws_bytes, int B, int HW,
+                      int C, int dtype, void* stream);
+
 /* ---------------------------------------------------------------- optimizer step (multi-tensor, fp32)
  * torch.optim.Adam step (models/GAN.py:529-533, 616-618, 652) over n tensors described by DEVICE arrays of
  * pointers/sizes.  Per tensor t (torch keeps a step count per parameter; parameters of inactive resolutions have

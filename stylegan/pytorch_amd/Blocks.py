@@ -87,7 +87,10 @@ class GSynthesisBlock(nn.Module):
         self.epi2 = LayerEpilogue(out_channels, dlatent_size, use_wscale, use_noise, use_pixel_norm,
                                   use_instance_norm, use_styles, activation_layer)
 
-    def forward_nhwc(self, x, dlatents_in_range):
+    def forward_nhwc(self, x, dlatents_in_range, defer_epi2=False):
+        """``defer_epi2`` (the LAST block of a forward, default epilogue stack): epi2 is not applied -- returns (conv1's output,
+        (epilogue bias, noise, noise weight, style, producer statistics or None)) for ``functional.EpiRgbOutFn``, which applies the
+        epilogue inside the to_rgb convolution that is its only consumer."""
         up = self.conv0_up
         if (FUSE_EPI_STATS & 1) and self.epi1._fusable and up.intermediate is not None and up.intermediate._is_121:
             # the blur after the upscale-conv also emits the epilogue's instance-norm statistics (one pass less over the tensor)
@@ -98,10 +101,17 @@ class GSynthesisBlock(nn.Module):
         else:
             x = up.forward_nhwc(x, skip_bias=True)                        # transposed conv + blur; bias folded below
             x = self.epi1.forward_nhwc(x, _lat(dlatents_in_range, 0), conv_bias=up.scaled_bias())
+        defer_epi2 = defer_epi2 and self.epi2._fusable
         if (FUSE_EPI_STATS & 2) and self.epi2._fusable and x.numel() >= FUSE_EPI_STATS_MIN:
             nin = self.epi2.noise_inputs(x.shape, x.device)               # conv1 keeps the shape
             x, part = self.conv1.forward_nhwc(x, skip_bias=True, epi_stats=(self.conv1.scaled_bias(),) + nin)
+            if defer_epi2:
+                return x, (self.conv1.scaled_bias(), nin[0], nin[1], self.epi2._style(_lat(dlatents_in_range, 1)), part)
             return self.epi2.forward_nhwc(x, _lat(dlatents_in_range, 1), conv_bias=self.conv1.scaled_bias(), noise_in=nin, pre_stats=part)
+        if defer_epi2:
+            nin = self.epi2.noise_inputs(x.shape, x.device)
+            x = self.conv1.forward_nhwc(x, skip_bias=True)
+            return x, (self.conv1.scaled_bias(), nin[0], nin[1], self.epi2._style(_lat(dlatents_in_range, 1)), None)
         x = self.conv1.forward_nhwc(x, skip_bias=True)
         return self.epi2.forward_nhwc(x, _lat(dlatents_in_range, 1), conv_bias=self.conv1.scaled_bias())
 

@@ -238,8 +238,15 @@ class GSynthesis(nn.Module):
                 # reference GAN.py:199 applies to_rgb AFTER the nearest upsample; a 1x1 conv commutes with
                 # replication, so convert at the low resolution (4x fewer bytes) and upsample the RGB image.
                 low = self.to_rgb[depth - 1].forward_nhwc(x)                                      # RGB at the previous resolution
-                xs = self.blocks[depth - 1].forward_nhwc(x, dl[2 * depth:2 * (depth + 1)])
                 rgb = self.to_rgb[depth]
+                last = self.blocks[depth - 1]
+                if (F.FUSE_EPI_RGB and FUSE_RGB_FADE and last.epi2._fusable and rgb.weight.shape[0] == 3 and low.dtype == torch.float32
+                        and not isinstance(alpha, torch.Tensor)):
+                    # the last epilogue inside to_rgb (+ upsample of ``low`` + fade-in lerp): one pass over conv1's output
+                    y2, (ebias, noise, nw, style, part) = last.forward_nhwc(x, dl[2 * depth:2 * (depth + 1)], defer_epi2=True)
+                    return F.nchw_view(F.call(F.EpiRgbOutFn, y2, ebias, noise, nw, style, rgb.weight, rgb.scaled_bias(), float(rgb.w_mul), low,
+                                              float(alpha), part))
+                xs = last.forward_nhwc(x, dl[2 * depth:2 * (depth + 1)])
                 if FUSE_RGB_FADE and rgb.weight.shape[0] == 3 and low.dtype == torch.float32:
                     # to_rgb + upsample of ``low`` + fade-in lerp in one pass over xs (GAN.py:199-202)
                     images = F.call(F.RgbOutFadeFn, xs, rgb.weight, rgb.scaled_bias(), float(rgb.w_mul), low, alpha)

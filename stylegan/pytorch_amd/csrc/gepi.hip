@@ -476,6 +476,38 @@ extern "C" int sgx_gepi_fwd(const void* x, const float* bias, const float* noise
     return gepi_fwd_t<bf16_t>(x, bias, noise, nw, style, y, mean, rstd, ws, pre_part, pre_npart, B, HW, C, flags, (hipStream_t)stream);
 }
 
+// The statistics half of sgx_gepi_fwd alone: mean / rstd of a = act(x + bias + nw * noise) per (image, channel), from the pass
+// over x or from the partials the producer of x already wrote -- for a consumer that applies the normalisation and style itself
+// (sgx_rgb_out_epi: the LAST epilogue of the generator, whose output only feeds to_rgb).
+template <typename T>
+static int gepi_stats_t(const void* x, const float* bias, const float* noise, const float* nw, float* mean, float* rstd, void* ws,
+                        const double* pre_part, int pre_npart, int B, int HW, int C, int flags, hipStream_t st) {
+    const int act = (flags & SGX_EPI_ACT) ? SGX_ACT_LRELU : SGX_ACT_NONE, norm = (flags & SGX_EPI_NORM) ? 1 : 0;
+    constexpr int VE = VecTraits<T>::VE;
+    GepiGeom g = gepi_geom(B, HW, C, VE);
+    double* part = static_cast<double*>(ws);
+    if (norm && !pre_part) {
+        SGX_NOTE(0.0, (double)sizeof(T) * B * HW * C, "gepi_stats B%d HW%d C%d", B, HW, C);
+        hipLaunchKernelGGL((gepi_pass<T, 0>), dim3(g.nchunk, B), dim3(256), 256 * 2 * VE * sizeof(double), st, (const T*)x,
+                           (const T*)nullptr, (T*)nullptr, bias, noise, nw, (const float*)nullptr, mean, rstd, (const float*)nullptr, part, HW, C,
+                           g.cvt, g.rows, g.chunk, act, (const double*)nullptr, 0, 0, (float*)nullptr);
+        SGX_LAUNCH_CHECK("gepi_stats");
+    }
+    hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 15) / 16), dim3(256), 0, st, pre_part ? pre_part : (const double*)part, mean, rstd, B, C,
+                       pre_part ? pre_npart : g.nchunk, HW, norm);
+    SGX_LAUNCH_CHECK("gepi_fin_stats");
+    return 0;
+}
+extern "C" int sgx_gepi_stats(const void* x, const float* bias, const float* noise, const float* nw, float* mean, float* rstd, void* ws,
+                              size_t ws_bytes, const double* pre_part, int pre_npart, int B, int HW, int C, int flags, int dtype, void* stream) {
+    int rc = gepi_check(B, HW, C, dtype, ws_bytes);
+    if (rc) return rc;
+    SGX_REQUIRE(x && noise && nw && mean && rstd, SGX_EINVAL, "gepi_stats: null argument");
+    SGX_REQUIRE(!pre_part || pre_npart > 0, SGX_EINVAL, "gepi_stats: %d producer partials", pre_npart);
+    if (dtype == SGX_F32) return gepi_stats_t<float>(x, bias, noise, nw, mean, rstd, ws, pre_part, pre_npart, B, HW, C, flags, (hipStream_t)stream);
+    return gepi_stats_t<bf16_t>(x, bias, noise, nw, mean, rstd, ws, pre_part, pre_npart, B, HW, C, flags, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Blur with the epilogue's statistics pass folded into its store: y = blur3x3(x) (the generator's conv0_up -> blur,
 // models/CustomLayers.py:176-177) and, from the values just written (rounded to the storage type, exactly what gepi_apply

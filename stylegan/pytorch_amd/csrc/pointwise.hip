@@ -833,6 +833,211 @@ extern "C" int sgx_rgb_out_fade(const void* x, const float* w, int sj, int sc, f
     return rgb_out_launch(x, w, sj, sc, wscale, bias, img, npix, C, dtype, low, H, W, alpha, beta, ab_dev, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------- the generator's LAST layer epilogue inside to_rgb (round 4)
+// The last LayerEpilogue of the synthesis network feeds only to_rgb (models/GAN.py:199-202 after models/Blocks.py:87-88): with
+//   t = lrelu(y + ebias + nw * noise),  x2 = (t - mean) * rstd * (s0 + 1) + s1 = A t + S   per (image, channel)
+// the image is  alpha * (wscale W x2 + rbias) + beta * up(low) = sum_c (alpha wscale W[j][c] A[c]) t[c] + const[j]: one pass over
+// the convolution's output y instead of the epilogue's apply pass (read y, write x2) plus to_rgb's read of x2.  Blocks are image
+// aligned (grid.y = image), the folded weights live in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void rgb_out_epi_kernel(const T* __restrict__ y, const float* __restrict__ ebias, const float* __restrict__ noise,
+                                                          const float* __restrict__ nw, const float* __restrict__ style, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ w, int sj, int sc, float wscale,
+                                                          const float* __restrict__ rbias, float* __restrict__ img, int HW, int C, int lpp,
+                                                          const float* __restrict__ low, int Himg, int Wimg, float alpha, float beta) {
+    constexpr int VE = VecTraits<T>::VE;
+    extern __shared__ float sw[];                            // [3][C] folded weights, [C] bias, [C] noise weight, [3] constants, [256 * 3] scratch
+    float* kb = sw + 3 * C; float* kw = kb + C; float* sb = kw + C; float* red = sb + 4;
+    const int b = blockIdx.y;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;                      // this thread's share of sum_c W[j][c] S[c]
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float s0 = style ? style[(size_t)b * 2 * C + c] : 0.f, s1 = style ? style[(size_t)b * 2 * C + C + c] : 0.f;
+        const float A = rstd[(size_t)b * C + c] * (s0 + 1.f), S = s1 - mean[(size_t)b * C + c] * A;
+        const float w0 = (alpha * wscale) * w[c * sc], w1 = (alpha * wscale) * w[sj + c * sc], w2 = (alpha * wscale) * w[2 * sj + c * sc];
+        sw[c] = w0 * A; sw[C + c] = w1 * A; sw[2 * C + c] = w2 * A;
+        c0 += w0 * S; c1 += w1 * S; c2 += w2 * S;
+        kb[c] = ebias ? ebias[c] : 0.f; kw[c] = nw[c];
+    }
+    red[threadIdx.x * 3] = c0; red[threadIdx.x * 3 + 1] = c1; red[threadIdx.x * 3 + 2] = c2;
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float t = 0.f;
+        for (int k = 0; k < 256; ++k) t += red[k * 3 + threadIdx.x];
+        sb[threadIdx.x] = t + (rbias ? alpha * rbias[threadIdx.x] : 0.f);
+    }
+    __syncthreads();
+    const float b0 = sb[0], b1 = sb[1], b2 = sb[2];
+    const int cv = C / VE;
+    const int sub = threadIdx.x % lpp;
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / lpp, gstride = (gridDim.x * blockDim.x) / lpp;
+    const T* yb = y + (size_t)b * HW * C;
+    const float* nzb = noise + (size_t)b * HW;
+    const int niter = (HW + gstride - 1) / gstride;          // (uniform trip count: the shuffles below need every lane)
+    for (int it = 0; it < niter; ++it) {
+        const int p = gid + it * gstride;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        if (p < HW) {
+            const float nz = nzb[p];
+            for (int v = sub; v < cv; v += lpp) {
+                float t[VE];
+                VecTraits<T>::load(yb + ((size_t)p * cv + v) * VE, t);
+#pragma unroll
+                for (int q = 0; q < VE; ++q) {
+                    const int c = v * VE + q;
+                    const float a = lrelu(t[q] + kb[c] + kw[c] * nz);
+                    s0 += a * sw[c]; s1 += a * sw[C + c]; s2 += a * sw[2 * C + c];
+                }
+            }
+        }
+        for (int o = lpp >> 1; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64);
+        }
+        if (p < HW && sub == 0) {
+            float o0 = s0 + b0, o1 = s1 + b1, o2 = s2 + b2;
+            if (low) {
+                const int xw = p % Wimg, yy = p / Wimg;
+                const float* l = low + (((size_t)b * (Himg >> 1) + (yy >> 1)) * (Wimg >> 1) + (xw >> 1)) * 3;
+                o0 += beta * l[0]; o1 += beta * l[1]; o2 += beta * l[2];
+            }
+            float* o = img + ((size_t)b * HW + p) * 3;
+            o[0] = o0; o[1] = o1; o[2] = o2;
+        }
+    }
+}
+extern "C" int sgx_rgb_out_epi(const void* y, const float* ebias, const float* noise, const float* nw, const float* style, const float* mean,
+                               const float* rstd, const float* w, int sj, int sc, float wscale, const float* rbias, const float* low, float alpha,
+                               float beta, float* img, int B, int H, int W, int C, int dtype, void* stream) {
+    SGX_REQUIRE(y && noise && nw && mean && rstd && w && img && B > 0 && H > 0 && W > 0, SGX_EINVAL, "rgb_out_epi: bad arguments");
+    SGX_REQUIRE(!low || (H % 2 == 0 && W % 2 == 0), SGX_EINVAL, "rgb_out_epi: odd size %dx%d with a low-resolution image", H, W);
+    const int ve = dtype == SGX_F32 ? 4 : 8;
+    SGX_REQUIRE((dtype == SGX_F32 || dtype == SGX_BF16) && C % ve == 0 && C <= 2048, SGX_EUNSUPPORTED, "rgb_out_epi: C=%d", C);
+    int lpp = C / ve;
+    if (lpp > 16) lpp = 16;
+    SGX_REQUIRE((lpp & (lpp - 1)) == 0, SGX_EUNSUPPORTED, "rgb_out_epi: C=%d", C);
+    const int HW = H * W;
+    const double npix = (double)B * HW;
+    SGX_NOTE(8.0 * npix * C, npix * (12.0 + 4.0 + (low ? 3.0 : 0.0) + (dtype == SGX_F32 ? 4.0 : 2.0) * C), "epi+rgb_out%s %.0fx%d", low ? "+fade" : "", npix, C);
+    long bx = ((long)HW * lpp + 255) / 256;
+    const long cap = 4096 / B > 1 ? 4096 / B : 1;
+    if (bx > cap) bx = cap;
+    const size_t sh = (size_t)(5 * C + 4 + 256 * 3) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SGX_F32)
+        hipLaunchKernelGGL(rgb_out_epi_kernel<float>, dim3((unsigned)bx, (unsigned)B), dim3(256), sh, st, (const float*)y, ebias, noise, nw, style, mean, rstd, w, sj, sc,
+                           wscale, rbias, img, HW, C, lpp, low, H, W, alpha, beta);
+    else
+        hipLaunchKernelGGL(rgb_out_epi_kernel<bf16_t>, dim3((unsigned)bx, (unsigned)B), dim3(256), sh, st, (const bf16_t*)y, ebias, noise, nw, style, mean, rstd, w, sj,
+                           sc, wscale, rbias, img, HW, C, lpp, low, H, W, alpha, beta);
+    SGX_LAUNCH_CHECK("rgb_out_epi");
+    return 0;
+}
+
+// to_rgb's weight and bias gradient with the epilogue recomputed from y:  dW[j][c] = scale sum_b (A[b][c] G1[b][j][c] + S[b][c] G0[b][j]),
+// G1[b][j][c] = sum_{p in b} g[p][j] t[p][c],  G0[b][j] = sum_{p in b} g[p][j];  db[j] = bscale sum_b G0[b][j].
+// Stage 1: image-aligned blocks, per-block partials ws[b][blk][3 * C + 3] (fp32 per lane over <= a few hundred pixels, then fp64).
+template <typename T>
+__global__ __launch_bounds__(256) void rgb_wgrad_epi_stage1(const T* __restrict__ y, const float* __restrict__ g, const float* __restrict__ ebias,
+                                                            const float* __restrict__ noise, const float* __restrict__ nw, double* __restrict__ ws, int HW, int C) {
+    constexpr int VE = VecTraits<T>::VE;
+    extern __shared__ float shf[];                                   // [256][3 * VE + 3]
+    constexpr int NP = 3 * VE + 3;
+    const int b = blockIdx.y, nblk = gridDim.x;
+    const int cv = C / VE, rows = 256 / cv;
+    const int tc = threadIdx.x % cv, tr = threadIdx.x / cv;
+    const int per = (HW + nblk - 1) / nblk;
+    const int p0 = blockIdx.x * per, p1 = p0 + per < HW ? p0 + per : HW;
+    float kb[VE], kw[VE];
+#pragma unroll
+    for (int k = 0; k < VE; ++k) { kb[k] = ebias ? ebias[tc * VE + k] : 0.f; kw[k] = nw[tc * VE + k]; }
+    float part[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) part[k] = 0.f;
+    const T* yb = y + (size_t)b * HW * C;
+    const float* gb = g + (size_t)b * HW * 3;
+    const float* nzb = noise + (size_t)b * HW;
+    if (tr < rows) {
+        for (int p = p0 + tr; p < p1; p += rows) {
+            float v[VE];
+            VecTraits<T>::load(yb + ((size_t)p * cv + tc) * VE, v);
+            const float nz = nzb[p], r = gb[p * 3], gg = gb[p * 3 + 1], bb = gb[p * 3 + 2];
+#pragma unroll
+            for (int k = 0; k < VE; ++k) {
+                const float a = lrelu(v[k] + kb[k] + kw[k] * nz);
+                part[k] += a * r; part[VE + k] += a * gg; part[2 * VE + k] += a * bb;
+            }
+            part[3 * VE] += r; part[3 * VE + 1] += gg; part[3 * VE + 2] += bb;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) shf[threadIdx.x * NP + k] = part[k];
+    __syncthreads();
+    double* o = ws + ((size_t)b * nblk + blockIdx.x) * (3 * C + 3);
+    for (int e = threadIdx.x; e < cv * 3 * VE + 3; e += 256) {
+        double s = 0.0;
+        if (e < cv * 3 * VE) {
+            const int c = e / (3 * VE), k = e % (3 * VE);
+            for (int r = 0; r < rows; ++r) s += (double)shf[(r * cv + c) * NP + k];
+            o[(k / VE) * C + c * VE + (k % VE)] = s;
+        } else {
+            const int j = e - cv * 3 * VE;
+            for (int r = 0; r < rows; ++r) s += (double)shf[(r * cv) * NP + 3 * VE + j];      // (every channel lane of a row summed the same pixels: take lane 0)
+            o[3 * C + j] = s;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void rgb_wgrad_epi_stage2(const double* __restrict__ ws, const float* __restrict__ style, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dw, float* __restrict__ db, int B, int nblk, int C,
+                                                            int sj, int sc, float scale, float bscale) {
+    const int e = blockIdx.x * 256 + threadIdx.x;                    // e = j * C + c, then the three bias sums
+    const int stride = 3 * C + 3;
+    if (e < 3 * C) {
+        const int j = e / C, c = e % C;
+        double t = 0.0;
+        for (int b = 0; b < B; ++b) {
+            double g1 = 0.0, g0 = 0.0;
+            for (int k = 0; k < nblk; ++k) {
+                const double* o = ws + ((size_t)b * nblk + k) * stride;
+                g1 += o[j * C + c]; g0 += o[3 * C + j];
+            }
+            const float s0 = style ? style[(size_t)b * 2 * C + c] : 0.f, s1 = style ? style[(size_t)b * 2 * C + C + c] : 0.f;
+            const float A = rstd[(size_t)b * C + c] * (s0 + 1.f), S = s1 - mean[(size_t)b * C + c] * A;
+            t += (double)A * g1 + (double)S * g0;
+        }
+        dw[j * sj + c * sc] = (float)(t * scale);
+    } else if (e < 3 * C + 3 && db) {
+        const int j = e - 3 * C;
+        double t = 0.0;
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < nblk; ++k) t += ws[((size_t)b * nblk + k) * stride + 3 * C + j];
+        db[j] = (float)(t * bscale);
+    }
+}
+static int rgb_wgrad_epi_blocks(int B, int HW) {
+    int n = (HW + 255) / 256;
+    const int cap = 1024 / B > 1 ? 1024 / B : 1;
+    if (n > cap) n = cap;
+    return n < 1 ? 1 : n;
+}
+extern "C" size_t sgx_rgb_wgrad_epi_ws_bytes(int B, int HW, int C) { return (size_t)B * rgb_wgrad_epi_blocks(B, HW) * (3 * C + 3) * sizeof(double); }
+extern "C" int sgx_rgb_wgrad_epi(const void* y, const float* g, const float* ebias, const float* noise, const float* nw, const float* style, const float* mean,
+                                 const float* rstd, float* dw, float* db, int sj, int sc, float scale, float bscale, void* ws, size_t ws_bytes, int B, int HW,
+                                 int C, int dtype, void* stream) {
+    SGX_REQUIRE(y && g && noise && nw && mean && rstd && dw && ws, SGX_EINVAL, "rgb_wgrad_epi: null argument");
+    SGX_REQUIRE(ws_bytes >= sgx_rgb_wgrad_epi_ws_bytes(B, HW, C), SGX_EWORKSPACE, "rgb_wgrad_epi: workspace");
+    const int ve = dtype == SGX_F32 ? 4 : 8;
+    SGX_REQUIRE((dtype == SGX_F32 || dtype == SGX_BF16) && colsum_vec_ok(C, ve), SGX_EUNSUPPORTED, "rgb_wgrad_epi: C=%d", C);
+    const int nblk = rgb_wgrad_epi_blocks(B, HW);
+    SGX_NOTE(8.0 * (double)B * HW * C, (double)B * HW * (12.0 + 4.0 + (dtype == SGX_F32 ? 4.0 : 2.0) * C), "epi+rgb_wgrad %dx%d", B * HW, C);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sh = (size_t)256 * (3 * ve + 3) * sizeof(float);
+    if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_wgrad_epi_stage1<float>, dim3(nblk, B), dim3(256), sh, st, (const float*)y, g, ebias, noise, nw, (double*)ws, HW, C);
+    else hipLaunchKernelGGL(rgb_wgrad_epi_stage1<bf16_t>, dim3(nblk, B), dim3(256), sh, st, (const bf16_t*)y, g, ebias, noise, nw, (double*)ws, HW, C);
+    SGX_LAUNCH_CHECK("rgb_wgrad_epi_stage1");
+    hipLaunchKernelGGL(rgb_wgrad_epi_stage2, dim3((3 * C + 3 + 255) / 256), dim3(256), 0, st, (const double*)ws, style, mean, rstd, dw, db, B, nblk, C, sj, sc, scale, bscale);
+    SGX_LAUNCH_CHECK("rgb_wgrad_epi_stage2");
+    return 0;
+}
+
 // dw[j][c] = sum_p img[p][j] * f[p][c]: stage 1 partials per block in double, stage 2 sums them.
 template <typename T>
 __global__ void rgb_wgrad_stage1(const float* __restrict__ img, const T* __restrict__ f, double* __restrict__ ws, size_t npix, int C) {

@@ -1412,6 +1412,91 @@ class GEpilogueFn(Function):
         return dx, dbias, None, dnw if ctx.has_noise else None, dstyle if ctx.has_style else None, None, None
 
 
+FUSE_EPI_RGB = os.environ.get("SGX_FUSE_EPI_RGB", "1") != "0"    # A/B: the last generator epilogue inside to_rgb (EpiRgbOutFn)
+
+
+class EpiRgbOutFn(Function):
+    """img = alpha * to_rgb(epilogue(y)) + (1 - alpha) * nearest_up2(low): the LAST LayerEpilogue of the synthesis network (noise,
+    LeakyReLU, InstanceNorm, StyleMod -- reference models/CustomLayers.py:219-248) applied on the fly inside the 1x1 to_rgb convolution
+    that is its only consumer (models/GAN.py:199-202), in one pass over the convolution's output y: the epilogue's output is never
+    written.  ``low`` None: plain to_rgb(epilogue(y)).  ``pre``: producer statistics as in ``GEpilogueFn``.  First order (generator
+    only).  Backward: d x2 = to_rgb^T(g) (``sgx_rgb_in``), the epilogue's own backward on y (``sgx_gepi_bwd``), and to_rgb's weight /
+    bias gradient with x2 recomputed from y (``sgx_rgb_wgrad_epi``)."""
+
+    @staticmethod
+    def forward(ctx, y, ebias, noise, nw, style, weight, rbias, wscale, low, alpha, pre=None):
+        y = _c(y)
+        B, H, W, C = y.shape
+        L = N.lib()
+        noise_c = _c(noise.detach().reshape(B, H * W))
+        if noise_c.dtype != torch.float32:
+            noise_c = noise_c.float()
+        nw_c, style_c = _c(nw.detach()), _c(style.detach())
+        ebias_c = None if ebias is None else _c(ebias.detach())
+        rbias_c = None if rbias is None else _c(rbias.detach())
+        w = _c(weight.detach())
+        sj, sc, Cw = rgb_layout(w)
+        if Cw != C or w.shape[0] != 3 or tuple(style_c.shape) != (B, 2 * C):
+            raise N.SgxError("EpiRgbOutFn: to_rgb weight [3,C,1,1] and style [B,2C] expected")
+        mean = torch.empty((B, C), dtype=torch.float32, device=y.device)
+        rstd = torch.empty_like(mean)
+        wsb = L.sgx_gepi_ws_bytes(B, H * W, C)
+        ws = N.workspace(wsb, y.device)
+        if pre is not None and (pre.dtype != torch.float64 or pre.dim() != 4 or pre.shape[0] != B or pre.shape[2] != C):
+            raise N.SgxError("EpiRgbOutFn: producer statistics must be float64 [B, npart, C, 2]")
+        flags = N.EPI_ACT | N.EPI_NORM
+        N.check(L.sgx_gepi_stats(N.ptr(y), N.ptr(ebias_c), N.ptr(noise_c), N.ptr(nw_c), N.ptr(mean), N.ptr(rstd), N.ptr(ws), wsb, N.ptr(pre),
+                                 0 if pre is None else pre.shape[1], B, H * W, C, flags, N.dt(y), N.stream()), "sgx_gepi_stats")
+        if low is not None:
+            low = _c(low)
+            if tuple(low.shape) != (B, H // 2, W // 2, 3) or low.dtype != torch.float32:
+                raise N.SgxError("EpiRgbOutFn: low-resolution image [B,H/2,W/2,3] fp32 expected")
+            a, b = float(alpha), float(1 - alpha)
+        else:
+            a, b = 1.0, 0.0
+        img = torch.empty((B, H, W, 3), dtype=torch.float32, device=y.device)
+        N.check(L.sgx_rgb_out_epi(N.ptr(y), N.ptr(ebias_c), N.ptr(noise_c), N.ptr(nw_c), N.ptr(style_c), N.ptr(mean), N.ptr(rstd), N.ptr(w), sj, sc,
+                                  float(wscale), N.ptr(rbias_c), N.ptr(low), a, b, N.ptr(img), B, H, W, C, N.dt(y), N.stream()), "sgx_rgb_out_epi")
+        ctx.cfg = (float(wscale), a, b, ebias is not None, rbias is not None, low is not None, flags)
+        ctx.save_for_backward(y, ebias_c, noise_c, nw_c, style_c, mean, rstd, weight)
+        return img
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        y, ebias_c, noise_c, nw_c, style_c, mean, rstd, weight = ctx.saved_tensors
+        wscale, a, b, has_ebias, has_rbias, has_low, flags = ctx.cfg
+        g = _c(g)
+        B, H, W, C = y.shape
+        L = N.lib()
+        w = _c(weight.detach())
+        sj, sc, _ = rgb_layout(w)
+        dy = dbias = dnw = dstyle = None
+        if any(ctx.needs_input_grad[k] for k in (0, 1, 3, 4)):
+            gx2 = torch.empty_like(y)                                    # d x2 = alpha * wscale * W^T g
+            N.check(L.sgx_rgb_in(N.ptr(g), N.ptr(w), sj, sc, wscale * a, None, N.ptr(gx2), B * H * W, C, _dtype_code(y.dtype), N.stream()), "sgx_rgb_in")
+            dy = torch.empty_like(y)
+            dstyle = torch.empty((B, 2 * C), dtype=torch.float32, device=y.device)
+            dnw = torch.empty((C,), dtype=torch.float32, device=y.device)
+            dbias = torch.empty((C,), dtype=torch.float32, device=y.device) if has_ebias else None
+            wsb = L.sgx_gepi_ws_bytes(B, H * W, C)
+            ws = N.workspace(wsb, y.device)
+            N.check(L.sgx_gepi_bwd(N.ptr(gx2), N.ptr(y), N.ptr(ebias_c), N.ptr(noise_c), N.ptr(nw_c), N.ptr(style_c), N.ptr(mean), N.ptr(rstd), N.ptr(dy),
+                                   N.ptr(dstyle), N.ptr(dnw), N.ptr(dbias), N.ptr(ws), wsb, B, H * W, C, flags, N.dt(y), N.stream()), "sgx_gepi_bwd")
+        gw = gb = None
+        if ctx.needs_input_grad[5] or (has_rbias and ctx.needs_input_grad[6]):
+            gw = torch.empty_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
+            gb = torch.empty((3,), dtype=torch.float32, device=y.device) if has_rbias else None
+            wsb = L.sgx_rgb_wgrad_epi_ws_bytes(B, H * W, C)
+            ws = N.workspace(wsb, y.device)
+            N.check(L.sgx_rgb_wgrad_epi(N.ptr(y), N.ptr(g), N.ptr(ebias_c), N.ptr(noise_c), N.ptr(nw_c), N.ptr(style_c), N.ptr(mean), N.ptr(rstd), N.ptr(gw),
+                                        N.ptr(gb), sj, sc, wscale * a, a, N.ptr(ws), wsb, B, H * W, C, N.dt(y), N.stream()), "sgx_rgb_wgrad_epi")
+        glow = None
+        if has_low and ctx.needs_input_grad[8]:
+            glow = _bcall(Pool2Fn, g, b)                                 # adjoint of the nearest upsample, times (1 - alpha)
+        return dy, dbias, None, dnw, dstyle, gw, gb, None, glow, None, None
+
+
 class PixelNormFn(Function):
     @staticmethod
     def forward(ctx, x):

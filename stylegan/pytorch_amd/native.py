@@ -72,6 +72,10 @@ SIGNATURES = {
     "sgx_rgb_wgrad": (I, [P, P, P, I, I, F, P, Z, Z, I, I, P]),
     "sgx_gepi_ws_bytes": (Z, [I, I, I]),
     "sgx_gepi_fwd": (I, [P, P, P, P, P, P, P, P, P, Z, P, I, I, I, I, I, I, P]),
+    "sgx_gepi_stats": (I, [P, P, P, P, P, P, P, Z, P, I, I, I, I, I, I, P]),
+    "sgx_rgb_out_epi": (I, [P, P, P, P, P, P, P, P, I, I, F, P, P, F, F, P, I, I, I, I, I, P]),
+    "sgx_rgb_wgrad_epi_ws_bytes": (Z, [I, I, I]),
+    "sgx_rgb_wgrad_epi": (I, [P, P, P, P, P, P, P, P, P, P, I, I, F, F, P, Z, I, I, I, I, P]),
     "sgx_blur3x3_stats_nparts": (I, [I, I, I, I, I]),
     "sgx_conv3x3_stats_nparts": (I, [I, I, I, I, I, I]),
     "sgx_conv3x3_signbits_ok": (I, [I, I, I, I, I, I]),

@@ -378,3 +378,46 @@ def test_logistic_loss_heads_in_one_launch(B, scale):
             assert_close(ra.grad, rd.grad, 2e-6, "d/dreal", floor=1e-12)
         else:
             assert ra.grad is None
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("depth,B", [(3, 4), (5, 2), (5, 8)])
+def test_last_epilogue_inside_to_rgb(depth, B, dt, monkeypatch):
+    """functional.EpiRgbOutFn (round 4): the last LayerEpilogue of the synthesis network applied on the fly inside to_rgb (+ the
+    fade-in lerp with the upsampled previous-resolution image), against the separate epilogue and to_rgb passes: image and EVERY
+    generator parameter gradient (reference models/CustomLayers.py:219-248 + models/GAN.py:199-202).  fp32: the same arithmetic up to
+    the order of two multiplications; bf16: the fused path skips one rounding of the epilogue's output."""
+    from gpu_util import build_mid, load_into, mid_noises, mid_params, pin_noise
+    from stylegan.pytorch_amd import functional as F
+    gp, _ = mid_params(torch.float64)
+    gen, _ = build_mid(dt)
+    load_into(gen, gp)
+    gen.train(); gen.style_mixing_prob = None
+    pin_noise(gen, mid_noises(B))
+    z = gu.seeded((B, 512), 11).to(DEV)
+    R = 4 << depth
+    gimg = gu.seeded((B, 3, R, R), 12).to(DEV)
+    calls = []
+    orig = F.EpiRgbOutFn.forward
+    monkeypatch.setattr(F.EpiRgbOutFn, "forward", staticmethod(lambda ctx, *a: (calls.append(1), orig(ctx, *a))[1]))
+
+    def run():
+        for p in gen.parameters():
+            p.grad = None
+        avg = gen.truncation.avg_latent.clone()
+        img = gen(z, depth, 0.4)
+        gen.truncation.avg_latent.copy_(avg)
+        (img * gimg).sum().backward()
+        return img.detach().clone(), {k: p.grad.detach().clone() for k, p in gen.named_parameters() if p.grad is not None}
+    img_on, g_on = run()
+    assert len(calls) == 1
+    monkeypatch.setattr(F, "FUSE_EPI_RGB", False)
+    img_off, g_off = run()
+    assert len(calls) == 1
+    tol_img, tol_g = (2e-6, 5e-5) if dt == torch.float32 else (6e-3, 4e-2)
+    assert rel_err(img_on, img_off) <= tol_img, rel_err(img_on, img_off)
+    assert sorted(g_on) == sorted(g_off)
+    gmax = max(float(torch.linalg.vector_norm(v)) for v in g_off.values())
+    for k in g_on:
+        err = float(torch.linalg.vector_norm(g_on[k].double() - g_off[k].double()))
+        assert err <= tol_g * float(torch.linalg.vector_norm(g_off[k])) + 1e-6 * gmax, (k, rel_err(g_on[k], g_off[k]))
