@@ -227,9 +227,15 @@ class GSynthesis(nn.Module):
     def _forward(self, dl, dt, depth, alpha):
         if self.structure == 'fixed':
             x = self.init_block.forward_nhwc(dl[0:2], dt)
+            rgb, last = self.to_rgb[-1], (self.blocks[-1] if len(self.blocks) else None)
+            fuse_last = F.FUSE_EPI_RGB and last is not None and last.epi2._fusable and rgb.weight.shape[0] == 3
             for i, block in enumerate(self.blocks):
+                if fuse_last and block is last:
+                    # the last epilogue inside to_rgb (functional.EpiRgbOutFn; the same kernel the 'linear' structure ends with)
+                    y2, (ebias, noise, nw, style, part) = block.forward_nhwc(x, dl[2 * (i + 1):2 * (i + 2)], defer_epi2=True)
+                    return F.nchw_view(F.call(F.EpiRgbOutFn, y2, ebias, noise, nw, style, rgb.weight, rgb.scaled_bias(), float(rgb.w_mul), None, 1.0, part))
                 x = block.forward_nhwc(x, dl[2 * (i + 1):2 * (i + 2)])
-            images = self.to_rgb[-1].forward_nhwc(x)
+            images = rgb.forward_nhwc(x)
         elif self.structure == 'linear':
             x = self.init_block.forward_nhwc(dl[0:2], dt)
             if depth > 0:

@@ -988,28 +988,33 @@ __global__ __launch_bounds__(256) void rgb_wgrad_epi_stage1(const T* __restrict_
 __global__ __launch_bounds__(256) void rgb_wgrad_epi_stage2(const double* __restrict__ ws, const float* __restrict__ style, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dw, float* __restrict__ db, int B, int nblk, int C,
                                                             int sj, int sc, float scale, float bscale) {
-    const int e = blockIdx.x * 256 + threadIdx.x;                    // e = j * C + c, then the three bias sums
-    const int stride = 3 * C + 3;
+    // one block per output (e = j * C + c, then the three bias sums): its 256 threads stride over the B * nblk partials, fixed-order
+    // tree in fp64 (deterministic)
+    __shared__ double red[256];
+    const int e = blockIdx.x, stride = 3 * C + 3, n = B * nblk;
+    double t = 0.0;
     if (e < 3 * C) {
         const int j = e / C, c = e % C;
-        double t = 0.0;
-        for (int b = 0; b < B; ++b) {
-            double g1 = 0.0, g0 = 0.0;
-            for (int k = 0; k < nblk; ++k) {
-                const double* o = ws + ((size_t)b * nblk + k) * stride;
-                g1 += o[j * C + c]; g0 += o[3 * C + j];
-            }
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int b = i / nblk;
+            const double* o = ws + (size_t)i * stride;
             const float s0 = style ? style[(size_t)b * 2 * C + c] : 0.f, s1 = style ? style[(size_t)b * 2 * C + C + c] : 0.f;
             const float A = rstd[(size_t)b * C + c] * (s0 + 1.f), S = s1 - mean[(size_t)b * C + c] * A;
-            t += (double)A * g1 + (double)S * g0;
+            t += (double)A * o[j * C + c] + (double)S * o[3 * C + j];
         }
-        dw[j * sj + c * sc] = (float)(t * scale);
-    } else if (e < 3 * C + 3 && db) {
+    } else {
         const int j = e - 3 * C;
-        double t = 0.0;
-        for (int b = 0; b < B; ++b)
-            for (int k = 0; k < nblk; ++k) t += ws[((size_t)b * nblk + k) * stride + 3 * C + j];
-        db[j] = (float)(t * bscale);
+        for (int i = threadIdx.x; i < n; i += 256) t += ws[(size_t)i * stride + 3 * C + j];
+    }
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (e < 3 * C) dw[(e / C) * sj + (e % C) * sc] = (float)(red[0] * scale);
+        else if (db) db[e - 3 * C] = (float)(red[0] * bscale);
     }
 }
 static int rgb_wgrad_epi_blocks(int B, int HW) {
@@ -1033,7 +1038,7 @@ extern "C" int sgx_rgb_wgrad_epi(const void* y, const float* g, const float* ebi
     if (dtype == SGX_F32) hipLaunchKernelGGL(rgb_wgrad_epi_stage1<float>, dim3(nblk, B), dim3(256), sh, st, (const float*)y, g, ebias, noise, nw, (double*)ws, HW, C);
     else hipLaunchKernelGGL(rgb_wgrad_epi_stage1<bf16_t>, dim3(nblk, B), dim3(256), sh, st, (const bf16_t*)y, g, ebias, noise, nw, (double*)ws, HW, C);
     SGX_LAUNCH_CHECK("rgb_wgrad_epi_stage1");
-    hipLaunchKernelGGL(rgb_wgrad_epi_stage2, dim3((3 * C + 3 + 255) / 256), dim3(256), 0, st, (const double*)ws, style, mean, rstd, dw, db, B, nblk, C, sj, sc, scale, bscale);
+    hipLaunchKernelGGL(rgb_wgrad_epi_stage2, dim3(3 * C + 3), dim3(256), 0, st, (const double*)ws, style, mean, rstd, dw, db, B, nblk, C, sj, sc, scale, bscale);
     SGX_LAUNCH_CHECK("rgb_wgrad_epi_stage2");
     return 0;
 }
