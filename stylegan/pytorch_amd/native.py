@@ -289,7 +289,7 @@ def _host_copy(dst: torch.Tensor, src: torch.Tensor):
 
 
 _BIG = {}                       # size class (power of two) -> {"slots": [[pinned buffer, (event, device) or None], ...], "next": i}
-_BIG_SLOTS = 8
+_BIG_SLOTS = 4
 
 
 def _big_slot(nbytes: int):
@@ -300,11 +300,11 @@ def _big_slot(nbytes: int):
     call at batch 128, i.e. 87 ms per iteration of a 4 ms step (profiles/r04_sweep_pin_memory.txt)."""
     key = 1 << max(13, (int(nbytes) - 1).bit_length())
     with _lock:
-        ring = _BIG.setdefault(key, {"slots": [], "next": 0})
-        if len(ring["slots"]) < _BIG_SLOTS:
-            ent = [torch.empty(key, dtype=torch.uint8).pin_memory(), None]
-            ring["slots"].append(ent)
-            return ent
+        ring = _BIG.get(key)
+        if ring is None:
+            # all slots of a size class at its first use (a hipHostMalloc costs 10-40 ms: paid once, in the first iteration, not
+            # spread over the first _BIG_SLOTS uploads)
+            ring = _BIG[key] = {"slots": [[torch.empty(key, dtype=torch.uint8).pin_memory(), None] for _ in range(_BIG_SLOTS)], "next": 0}
         ent = ring["slots"][ring["next"]]
         ring["next"] = (ring["next"] + 1) % _BIG_SLOTS
     if ent[1] is not None:
