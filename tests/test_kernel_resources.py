@@ -27,7 +27,7 @@ def kernels():
 def test_second_generation_and_streaming_kernels_never_spill(kernels):
     checked = 0
     for name, k in kernels.items():
-        if k["file"] in ("conv2.hip", "wgrad2.hip", "gepi.hip", "pointwise.hip", "small.hip", "optim.hip"):
+        if k["file"] in ("conv2.hip", "wgrad2.hip", "rgbconv.hip", "gepi.hip", "pointwise.hip", "small.hip", "optim.hip"):
             if name.startswith("conv2_kernel<2, ") and name.endswith(", 2>(Conv2Args)"):
                 # transposed convolution + blur epilogue (256 registers): a dozen 64-bit DMA source descriptors are parked in
                 # scratch in the prologue and re-read once per tile (L1 hits) -- bounded, not in the MFMA loop
@@ -53,6 +53,10 @@ HOT = [
     ("conv2_kernel<1, 8, 1, 16, false, 0>(Conv2Args)", 4),                   # stride-2 1024^2 16->32
     ("wgrad16_s_kernel(Wg2Args)", 4),                                        # its 16x16-channel weight gradient
     ("conv2_kernel<0, 8, 2, 32, false, 0>(Conv2Args)", 2),                   # 3x3, 64..512 channels (the batch-32 dominant kernel)
+    # round 4: the discriminator's composed first layer (csrc/rgbconv.hip): row-streaming kernels live on waves in flight (no LDS tile)
+    ("rgbconv_fwdblur_kernel<1>(float const*, unsigned short const*, float const*, unsigned short*, unsigned char*, int, int, int, int, int, int, int)", 5),                                        # from_rgb + conv0 + LeakyReLU + blur, 3 -> 16 at 1024^2
+    ("rgbconv_dgrad_kernel<1>(unsigned short const*, unsigned short const*, float*, int, int, int, int, int)", 6),                                          # its image gradient
+    ("rgbconv_wgrad_kernel<1>(float const*, unsigned short const*, float*, int, int, int, int, int, int, int)", 4),                                          # its (composed) weight gradient: 3 resident blocks per CU
 ]
 
 
