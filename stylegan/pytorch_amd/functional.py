@@ -397,7 +397,7 @@ class ConvFn(Function):
                 # (x_pre None: the producer never materialised the pre-activation -- RgbConvBlurFn -- and only its sign bits exist)
                 # (the fused kernel reads the mask TENSOR: with the mask as sign bits its blur epilogue, already the limit of that
                 # kernel, gets another ~16 VALU operations per element -- measured 990 us against 342 + 553 for the two passes at
-                # batch 32, 1024^2, profiles/r04_rgbconv_probe.txt -- so layers that only have the bits take the two passes)
+                # batch 32, 1024^2, profiles/r04_rgbconv_probe_history.txt -- so layers that only have the bits take the two passes)
                 if x_pre is not None and conv_blur_ok(gy, weight.shape[1] if not adjoint else weight.shape[0], mode, not adjoint):
                     gx = _bcall(ConvBlurFn, gy, weight, mode, scale, ipad, not adjoint, x_pre)      # one kernel
                 else:
