@@ -143,8 +143,8 @@ int sgx_lrelu_bwd_bits(const void* dy, const void* bits, void* dx, size_t n, flo
  * the sign bits of the activation -- its LeakyReLU-backward mask (sgx_lrelu_bwd_bits); the activation itself is not stored.
  * _ok: 1 if the shape has the variant (bf16, second-generation stride-2 kernel), else sgx_conv4x4s2_down + sgx_axpby. */
 int sgx_conv4x4s2_down_fade_ok(int B, int H, int W, int Cin, int Cout, int dtype);
-int sgx_conv4x4s2_down_fade(const void* x, const void* w, const float* bias, const void* resid, float alpha, float beta, void* y, void* bits,
-                            int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
+int sgx_conv4x4s2_down_fade(const void* x, const void* w, const float* bias, const void* resid, float alpha, float beta, const float* ab_dev,
+                            void* y, void* bits, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);    /* ab_dev (nullable): [alpha, beta] in device memory instead (graph replay) */
 /* out = alpha*a + beta*b (b may be NULL)    fade-in lerp: models/GAN.py:202,427,586                                 */
 int sgx_axpby(const void* a, const void* b, void* out, float alpha, float beta, size_t n, int dtype, void* stream);
 /* same with the coefficients read from device memory (alpha_dev[0], beta_dev[0]): the fade-in alpha changes every
@@ -346,7 +346,7 @@ int sgx_gepi_stats(const void* x, const float* bias, const float* noise, const f
                    const double* pre_part, int pre_npart, int B, int HW, int C, int flags, int dtype, void* stream);
 int sgx_rgb_out_epi(const void* y, const float* ebias, const float* noise, const float* nw, const float* style, const float* mean,
                     const float* rstd, const float* w, int sj, int sc, float wscale, const float* rbias, const float* low, float alpha, float beta,
-                    float* img, int B, int H, int W, int C, int dtype, void* stream);
+                    const float* ab_dev, float* img, int B, int H, int W, int C, int dtype, void* stream);    /* ab_dev as above */
 size_t sgx_rgb_wgrad_epi_ws_bytes(int B, int HW, int C);
 int sgx_rgb_wgrad_epi(const void* y, const float* g, const float* ebias, const float* noise, const float* nw, const float* style, const float* mean,
                       const float* rstd, float* dw, float* db, int sj, int sc, float scale, float bscale, void* ws, size_t ws_bytes, int B, int HW,

@@ -281,8 +281,9 @@ class EqualizedConv2d(nn.Module):
                 if x_pre is not None and getattr(x, "_sgx_pre_of", None) is not x_pre:
                     raise F.N.SgxError("conv+fade: x_pre given, but x is not the ActBlurPassFn output of that tensor")
                 resid, alpha, beta = fade
-                return F.call(F.ConvDownFadeFn, x, self.weight, bias, resid, float(self.w_mul), int(self.weight.shape[1]), float(alpha), float(beta),
-                              x_pre, x_pre_bits)
+                if not isinstance(alpha, torch.Tensor):
+                    alpha, beta = float(alpha), float(beta)
+                return F.call(F.ConvDownFadeFn, x, self.weight, bias, resid, float(self.w_mul), int(self.weight.shape[1]), alpha, beta, x_pre, x_pre_bits)
             return F.conv(x, self.weight, bias, "D", self.w_mul, act, defer_act=defer_act and act == ACT_LRELU,
                           x_pre=x_pre, x_pre_bits=x_pre_bits)             # bias after the 2x2 mean == bias in the fused store
         if self.intermediate is None:

@@ -246,12 +246,11 @@ class GSynthesis(nn.Module):
                 low = self.to_rgb[depth - 1].forward_nhwc(x)                                      # RGB at the previous resolution
                 rgb = self.to_rgb[depth]
                 last = self.blocks[depth - 1]
-                if (F.FUSE_EPI_RGB and FUSE_RGB_FADE and last.epi2._fusable and rgb.weight.shape[0] == 3 and low.dtype == torch.float32
-                        and not isinstance(alpha, torch.Tensor)):
+                if F.FUSE_EPI_RGB and FUSE_RGB_FADE and last.epi2._fusable and rgb.weight.shape[0] == 3 and low.dtype == torch.float32:
                     # the last epilogue inside to_rgb (+ upsample of ``low`` + fade-in lerp): one pass over conv1's output
                     y2, (ebias, noise, nw, style, part) = last.forward_nhwc(x, dl[2 * depth:2 * (depth + 1)], defer_epi2=True)
                     return F.nchw_view(F.call(F.EpiRgbOutFn, y2, ebias, noise, nw, style, rgb.weight, rgb.scaled_bias(), float(rgb.w_mul), low,
-                                              float(alpha), part))
+                                              alpha if isinstance(alpha, torch.Tensor) else float(alpha), part))
                 xs = last.forward_nhwc(x, dl[2 * depth:2 * (depth + 1)])
                 if FUSE_RGB_FADE and rgb.weight.shape[0] == 3 and low.dtype == torch.float32:
                     # to_rgb + upsample of ``low`` + fade-in lerp in one pass over xs (GAN.py:199-202)
@@ -426,7 +425,10 @@ class Discriminator(nn.Module):
                 top, top_rgb = self.blocks[self.depth - depth - 1], self.from_rgb[self.depth - depth - 1]
                 # the fade-in lerp in the store of the newest block's stride-2 convolution (functional.ConvDownFadeFn) where alpha
                 # is a host number (the residual then already carries its 1 - alpha) and the shape has that kernel
-                fade_arg = (residual, float(alpha), 1.0) if (pre and top._act == ACT_LRELU) else None
+                fade_arg = None
+                if fuse and top._act == ACT_LRELU and not self.conditional:
+                    # (alpha in device memory -- graph replay: the kernel reads [alpha, 1 - alpha] itself and the residual is not prescaled)
+                    fade_arg = (residual, alpha, None) if isinstance(alpha, torch.Tensor) else ((residual, float(alpha), 1.0) if pre else None)
                 if not self.conditional and top.fused_from_rgb_ok(img.shape, top_rgb, dt):
                     # from_rgb and the newest block's conv0 (no activation between them) as ONE convolution of the image, with
                     # the LeakyReLU and the blur in its store (functional.RgbConvBlurFn)

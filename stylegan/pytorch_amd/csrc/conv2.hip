@@ -70,6 +70,7 @@ struct Conv2Args {
     // is never stored)
     const bf16_t* fade_resid;
     float fade_alpha, fade_beta;
+    const float* fade_ab;                     // ... or the two coefficients in device memory ([alpha, beta]: a captured step graph must not bake them in)
     int part_slots;                           // EPI_STATS: the slot count `part` was sized for (launch_conv2 refuses any other nslots)
 };
 enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BLUR = 2 };
@@ -595,13 +596,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                                     a.signbits[doff >> 3] = (unsigned char)bits;
                                 }
                                 if (GEO == C2_D && a.fade_resid) {
+                                    const float fade_a = a.fade_ab ? a.fade_ab[0] : a.fade_alpha, fade_b = a.fade_ab ? a.fade_ab[1] : a.fade_beta;
                                     const uint4 rq = *reinterpret_cast<const uint4*>(a.fade_resid + doff);
                                     const unsigned yv[4] = {val.x, val.y, val.z, val.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w};
                                     unsigned ov[4];
 #pragma unroll
                                     for (int q = 0; q < 4; ++q)
-                                        ov[q] = pack_bf16x2(a.fade_alpha * __uint_as_float(yv[q] << 16) + a.fade_beta * __uint_as_float(rv[q] << 16),
-                                                            a.fade_alpha * __uint_as_float(yv[q] & 0xffff0000u) + a.fade_beta * __uint_as_float(rv[q] & 0xffff0000u));
+                                        ov[q] = pack_bf16x2(fade_a * __uint_as_float(yv[q] << 16) + fade_b * __uint_as_float(rv[q] << 16),
+                                                            fade_a * __uint_as_float(yv[q] & 0xffff0000u) + fade_b * __uint_as_float(rv[q] & 0xffff0000u));
                                     val = make_uint4(ov[0], ov[1], ov[2], ov[3]);
                                 }
                                 *reinterpret_cast<uint4*>(a.y + doff) = val;
@@ -911,8 +913,8 @@ extern "C" int sgx_conv4x4s2_down_fade_ok(int B, int H, int W, int Cin, int Cout
     static const int on = [] { const char* e = getenv("SGX_FUSE_FADE"); return e ? atoi(e) : 1; }();   // A/B switch
     return on && conv2_pick(C2_D, B, H, W, Cin, Cout, -1).nw ? 1 : 0;
 }
-extern "C" int sgx_conv4x4s2_down_fade(const void* x, const void* w, const float* bias, const void* resid, float alpha, float beta, void* y, void* bits,
-                                       int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+extern "C" int sgx_conv4x4s2_down_fade(const void* x, const void* w, const float* bias, const void* resid, float alpha, float beta, const float* ab_dev,
+                                       void* y, void* bits, int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
     SGX_REQUIRE(dtype == SGX_BF16, SGX_EUNSUPPORTED, "conv4x4s2_down_fade: bf16 only");
     SGX_REQUIRE(x && w && resid && y && bits, SGX_EINVAL, "conv4x4s2_down_fade: null argument");
     const Conv2Pick p = conv2_pick(C2_D, B, H, W, Cin, Cout, -1);
@@ -921,7 +923,7 @@ extern "C" int sgx_conv4x4s2_down_fade(const void* x, const void* w, const float
     SGX_NOTE(2.0 * 16 * Cin * Cout * opx, 2.0 * ((double)B * H * W * Cin + 2.0 * opx * Cout + 16.0 * Cin * Cout) + opx * Cout / 8.0, "convD+fade B%d %dx%d %d->%d", B, H, W, Cin, Cout);
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), nullptr, B, H, W, H / 2, W / 2, Cin, Cout,
                 SGX_ACT_LRELU, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, static_cast<unsigned char*>(bits), nullptr,
-                static_cast<const bf16_t*>(resid), alpha, beta};
+                static_cast<const bf16_t*>(resid), alpha, beta, ab_dev};
     hipStream_t st = (hipStream_t)stream;
     const int nw = p.nw;
     if (p.k16) return nw == 8 ? launch_conv2<C2_D, 8, 1, 16, false>(a, st) : launch_conv2<C2_D, 4, 1, 16, false>(a, st);

@@ -844,9 +844,11 @@ __global__ __launch_bounds__(256) void rgb_out_epi_kernel(const T* __restrict__ 
                                                           const float* __restrict__ nw, const float* __restrict__ style, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ w, int sj, int sc, float wscale,
                                                           const float* __restrict__ rbias, float* __restrict__ img, int HW, int C, int lpp,
-                                                          const float* __restrict__ low, int Himg, int Wimg, float alpha, float beta) {
+                                                          const float* __restrict__ low, int Himg, int Wimg, float alpha, float beta,
+                                                          const float* __restrict__ ab_dev) {
     constexpr int VE = VecTraits<T>::VE;
     extern __shared__ float sw[];                            // [3][C] folded weights, [C] bias, [C] noise weight, [3] constants, [256 * 3] scratch
+    if (ab_dev) { alpha = ab_dev[0]; beta = ab_dev[1]; }     // (coefficients in device memory: a captured step graph)
     float* kb = sw + 3 * C; float* kw = kb + C; float* sb = kw + C; float* red = sb + 4;
     const int b = blockIdx.y;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;                      // this thread's share of sum_c W[j][c] S[c]
@@ -906,7 +908,7 @@ __global__ __launch_bounds__(256) void rgb_out_epi_kernel(const T* __restrict__ 
 }
 extern "C" int sgx_rgb_out_epi(const void* y, const float* ebias, const float* noise, const float* nw, const float* style, const float* mean,
                                const float* rstd, const float* w, int sj, int sc, float wscale, const float* rbias, const float* low, float alpha,
-                               float beta, float* img, int B, int H, int W, int C, int dtype, void* stream) {
+                               float beta, const float* ab_dev, float* img, int B, int H, int W, int C, int dtype, void* stream) {
     SGX_REQUIRE(y && noise && nw && mean && rstd && w && img && B > 0 && H > 0 && W > 0, SGX_EINVAL, "rgb_out_epi: bad arguments");
     SGX_REQUIRE(!low || (H % 2 == 0 && W % 2 == 0), SGX_EINVAL, "rgb_out_epi: odd size %dx%d with a low-resolution image", H, W);
     const int ve = dtype == SGX_F32 ? 4 : 8;
@@ -924,10 +926,10 @@ extern "C" int sgx_rgb_out_epi(const void* y, const float* ebias, const float* n
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SGX_F32)
         hipLaunchKernelGGL(rgb_out_epi_kernel<float>, dim3((unsigned)bx, (unsigned)B), dim3(256), sh, st, (const float*)y, ebias, noise, nw, style, mean, rstd, w, sj, sc,
-                           wscale, rbias, img, HW, C, lpp, low, H, W, alpha, beta);
+                           wscale, rbias, img, HW, C, lpp, low, H, W, alpha, beta, ab_dev);
     else
         hipLaunchKernelGGL(rgb_out_epi_kernel<bf16_t>, dim3((unsigned)bx, (unsigned)B), dim3(256), sh, st, (const bf16_t*)y, ebias, noise, nw, style, mean, rstd, w, sj,
-                           sc, wscale, rbias, img, HW, C, lpp, low, H, W, alpha, beta);
+                           sc, wscale, rbias, img, HW, C, lpp, low, H, W, alpha, beta, ab_dev);
     SGX_LAUNCH_CHECK("rgb_out_epi");
     return 0;
 }

@@ -845,9 +845,10 @@ class LReluBwdBitsFn(Function):
         if g.dtype != torch.bfloat16 or bits.dtype != torch.uint8 or bits.numel() * 8 != g.numel():
             raise N.SgxError("LReluBwdBitsFn: bf16 gradient and one sign byte per 8 channels expected")
         out = torch.empty_like(g)
-        N.check(N.lib().sgx_lrelu_bwd_bits(N.ptr(g), N.ptr(bits), N.ptr(out), g.numel(), float(slope), float(scale), None, N.dt(g), N.stream()),
-                "sgx_lrelu_bwd_bits")
-        ctx.slope, ctx.scale = float(slope), float(scale)
+        dev = isinstance(scale, torch.Tensor)                # a one-element device fp32 tensor (graph replay), as in LReluBwdFn
+        N.check(N.lib().sgx_lrelu_bwd_bits(N.ptr(g), N.ptr(bits), N.ptr(out), g.numel(), float(slope), 1.0 if dev else float(scale),
+                                           scale.data_ptr() if dev else None, N.dt(g), N.stream()), "sgx_lrelu_bwd_bits")
+        ctx.slope, ctx.scale = float(slope), scale
         ctx.save_for_backward(bits)
         return out
 
@@ -885,13 +886,17 @@ class ConvDownFadeFn(Function):
             raise N.SgxError("conv+fade: residual branch must have the output's shape and dtype")
         y = torch.empty((B, H // 2, W // 2, Cout), dtype=x.dtype, device=x.device)
         bits = torch.empty((B, H // 2, W // 2, Cout // 8), dtype=torch.uint8, device=x.device)
-        N.check(N.lib().sgx_conv4x4s2_down_fade(N.ptr(x), N.ptr(fwd), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(resid), float(alpha),
-                                                float(beta), N.ptr(y), N.ptr(bits), B, H, W, Cin, Cout, N.dt(x), N.stream()), "sgx_conv4x4s2_down_fade")
+        dev = isinstance(alpha, torch.Tensor)                # [alpha, 1 - alpha] in device memory (graph replay); beta is then ignored
+        if dev and not (alpha.dtype == torch.float32 and alpha.numel() == 2 and alpha.is_contiguous()):
+            raise N.SgxError("conv+fade: device coefficients must be a contiguous fp32 [alpha, beta] pair")
+        N.check(N.lib().sgx_conv4x4s2_down_fade(N.ptr(x), N.ptr(fwd), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(resid),
+                                                0.0 if dev else float(alpha), 0.0 if dev else float(beta), alpha.data_ptr() if dev else None,
+                                                N.ptr(y), N.ptr(bits), B, H, W, Cin, Cout, N.dt(x), N.stream()), "sgx_conv4x4s2_down_fade")
         # ConvFn.backward's view of this op: the stride-2 layer with its activation already undone (see backward)
         ctx.cfg = ("D", scale, ipad, False, 0, bias is not None, False, False)
         ctx.bias_ref = weakref.ref(bias) if bias is not None else (lambda: None)
         ctx.x_pre, ctx.x_pre_bits = x_pre, x_pre_bits
-        ctx.fade = (float(alpha), float(beta), bits)
+        ctx.fade = (alpha, None, bits) if dev else (float(alpha), float(beta), bits)
         ctx.save_for_backward(x, weight, None, None)
         return y
 
@@ -900,9 +905,14 @@ class ConvDownFadeFn(Function):
         g = _c(g)
         alpha, beta, bits = ctx.fade
         g_res = None
-        if ctx.needs_input_grad[3]:
-            g_res = g if beta == 1.0 else _bcall(ScaleFn, g, beta)
-        gy = _bcall(LReluBwdBitsFn, g, bits, 0.2, alpha)
+        if isinstance(alpha, torch.Tensor):
+            if ctx.needs_input_grad[3]:
+                g_res = _bcall(ScaleDevFn, g, alpha[1:2])
+            gy = _bcall(LReluBwdBitsFn, g, bits, 0.2, alpha[0:1])
+        else:
+            if ctx.needs_input_grad[3]:
+                g_res = g if beta == 1.0 else _bcall(ScaleFn, g, beta)
+            gy = _bcall(LReluBwdBitsFn, g, bits, 0.2, alpha)
         out = ConvFn.backward(ctx, gy)                     # (x, weight, bias are inputs 0..2 of both Functions)
         return out[0], out[1], out[2], g_res, None, None, None, None, None, None
 
@@ -1447,16 +1457,22 @@ class EpiRgbOutFn(Function):
         flags = N.EPI_ACT | N.EPI_NORM
         N.check(L.sgx_gepi_stats(N.ptr(y), N.ptr(ebias_c), N.ptr(noise_c), N.ptr(nw_c), N.ptr(mean), N.ptr(rstd), N.ptr(ws), wsb, N.ptr(pre),
                                  0 if pre is None else pre.shape[1], B, H * W, C, flags, N.dt(y), N.stream()), "sgx_gepi_stats")
+        ab = None                                            # [alpha, 1 - alpha] in device memory (graph replay)
         if low is not None:
             low = _c(low)
             if tuple(low.shape) != (B, H // 2, W // 2, 3) or low.dtype != torch.float32:
                 raise N.SgxError("EpiRgbOutFn: low-resolution image [B,H/2,W/2,3] fp32 expected")
-            a, b = float(alpha), float(1 - alpha)
+            if isinstance(alpha, torch.Tensor):
+                ab, a, b = alpha, 1.0, 1.0
+            else:
+                a, b = float(alpha), float(1 - alpha)
         else:
             a, b = 1.0, 0.0
         img = torch.empty((B, H, W, 3), dtype=torch.float32, device=y.device)
         N.check(L.sgx_rgb_out_epi(N.ptr(y), N.ptr(ebias_c), N.ptr(noise_c), N.ptr(nw_c), N.ptr(style_c), N.ptr(mean), N.ptr(rstd), N.ptr(w), sj, sc,
-                                  float(wscale), N.ptr(rbias_c), N.ptr(low), a, b, N.ptr(img), B, H, W, C, N.dt(y), N.stream()), "sgx_rgb_out_epi")
+                                  float(wscale), N.ptr(rbias_c), N.ptr(low), a, b, None if ab is None else ab.data_ptr(), N.ptr(img), B, H, W, C,
+                                  N.dt(y), N.stream()), "sgx_rgb_out_epi")
+        ctx.ab = ab
         ctx.cfg = (float(wscale), a, b, ebias is not None, rbias is not None, low is not None, flags)
         ctx.save_for_backward(y, ebias_c, noise_c, nw_c, style_c, mean, rstd, weight)
         return img
@@ -1467,6 +1483,10 @@ class EpiRgbOutFn(Function):
         y, ebias_c, noise_c, nw_c, style_c, mean, rstd, weight = ctx.saved_tensors
         wscale, a, b, has_ebias, has_rbias, has_low, flags = ctx.cfg
         g = _c(g)
+        glow_src = g
+        if ctx.ab is not None:                               # coefficients on the device: two scaling passes over the image gradient, then as below
+            glow_src = _bcall(ScaleDevFn, g, ctx.ab[1:2]) if (has_low and ctx.needs_input_grad[8]) else None
+            g = _bcall(ScaleDevFn, g, ctx.ab[0:1])
         B, H, W, C = y.shape
         L = N.lib()
         w = _c(weight.detach())
@@ -1493,7 +1513,7 @@ class EpiRgbOutFn(Function):
                                         N.ptr(gb), sj, sc, wscale * a, a, N.ptr(ws), wsb, B, H * W, C, N.dt(y), N.stream()), "sgx_rgb_wgrad_epi")
         glow = None
         if has_low and ctx.needs_input_grad[8]:
-            glow = _bcall(Pool2Fn, g, b)                                 # adjoint of the nearest upsample, times (1 - alpha)
+            glow = _bcall(Pool2Fn, glow_src, b)                          # adjoint of the nearest upsample, times (1 - alpha)
         return dy, dbias, None, dnw, dstyle, gw, gb, None, glow, None, None
 
 

@@ -54,7 +54,7 @@ SIGNATURES = {
     "sgx_lrelu_bwd": (I, [P, P, P, Z, F, F, P, I, P]),
     "sgx_lrelu_bwd_bits": (I, [P, P, P, Z, F, F, P, I, P]),
     "sgx_conv4x4s2_down_fade_ok": (I, [I, I, I, I, I, I]),
-    "sgx_conv4x4s2_down_fade": (I, [P, P, P, P, F, F, P, P, I, I, I, I, I, I, P]),
+    "sgx_conv4x4s2_down_fade": (I, [P, P, P, P, F, F, P, P, P, I, I, I, I, I, I, P]),
     "sgx_axpby": (I, [P, P, P, F, F, Z, I, P]),
     "sgx_axpby_dev": (I, [P, P, P, P, P, Z, I, P]),
     "sgx_blur3x3": (I, [P, P, I, I, I, I, I, P]),
@@ -73,7 +73,7 @@ SIGNATURES = {
     "sgx_gepi_ws_bytes": (Z, [I, I, I]),
     "sgx_gepi_fwd": (I, [P, P, P, P, P, P, P, P, P, Z, P, I, I, I, I, I, I, P]),
     "sgx_gepi_stats": (I, [P, P, P, P, P, P, P, Z, P, I, I, I, I, I, I, P]),
-    "sgx_rgb_out_epi": (I, [P, P, P, P, P, P, P, P, I, I, F, P, P, F, F, P, I, I, I, I, I, P]),
+    "sgx_rgb_out_epi": (I, [P, P, P, P, P, P, P, P, I, I, F, P, P, F, F, P, P, I, I, I, I, I, P]),
     "sgx_rgb_wgrad_epi_ws_bytes": (Z, [I, I, I]),
     "sgx_rgb_wgrad_epi": (I, [P, P, P, P, P, P, P, P, P, P, I, I, F, F, P, Z, I, I, I, I, P]),
     "sgx_blur3x3_stats_nparts": (I, [I, I, I, I, I]),

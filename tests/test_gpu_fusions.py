@@ -381,12 +381,13 @@ def test_logistic_loss_heads_in_one_launch(B, scale):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("depth,B", [(3, 4), (5, 2), (5, 8)])
-def test_last_epilogue_inside_to_rgb(depth, B, dt, monkeypatch):
+@pytest.mark.parametrize("depth,B,dev_alpha", [(3, 4, False), (5, 2, False), (5, 8, False), (5, 2, True), (3, 4, True)])
+def test_last_epilogue_inside_to_rgb(depth, B, dev_alpha, dt, monkeypatch):
     """functional.EpiRgbOutFn (round 4): the last LayerEpilogue of the synthesis network applied on the fly inside to_rgb (+ the
     fade-in lerp with the upsampled previous-resolution image), against the separate epilogue and to_rgb passes: image and EVERY
     generator parameter gradient (reference models/CustomLayers.py:219-248 + models/GAN.py:199-202).  fp32: the same arithmetic up to
-    the order of two multiplications; bf16: the fused path skips one rounding of the epilogue's output."""
+    the order of two multiplications; bf16: the fused path skips one rounding of the epilogue's output.  ``dev_alpha``: the fade-in
+    coefficients read from device memory, as the hipGraph-replayed step passes them."""
     from gpu_util import build_mid, load_into, mid_noises, mid_params, pin_noise
     from stylegan.pytorch_amd import functional as F
     gp, _ = mid_params(torch.float64)
@@ -405,7 +406,7 @@ def test_last_epilogue_inside_to_rgb(depth, B, dt, monkeypatch):
         for p in gen.parameters():
             p.grad = None
         avg = gen.truncation.avg_latent.clone()
-        img = gen(z, depth, 0.4)
+        img = gen(z, depth, torch.tensor([0.4, 0.6], dtype=torch.float32, device=DEV) if dev_alpha else 0.4)
         gen.truncation.avg_latent.copy_(avg)
         (img * gimg).sum().backward()
         return img.detach().clone(), {k: p.grad.detach().clone() for k, p in gen.named_parameters() if p.grad is not None}

@@ -210,14 +210,15 @@ def test_discriminator_step_with_the_composed_first_layer(depth, monkeypatch):
     assert med_on <= 1.3 * med_off + 1e-3
 
 
-@pytest.mark.parametrize("depth,B,composed", [(5, 16, True), (5, 16, False)])     # (batches at which the stride-2 layer runs on the second-generation kernel)
-def test_fade_in_lerp_in_the_store_of_the_stride2_convolution(depth, B, composed, monkeypatch):
+@pytest.mark.parametrize("depth,B,composed,dev_alpha", [(5, 16, True, False), (5, 16, False, False), (5, 16, True, True)])     # (batches at which the stride-2 layer runs on the second-generation kernel)
+def test_fade_in_lerp_in_the_store_of_the_stride2_convolution(depth, B, composed, dev_alpha, monkeypatch):
     """functional.ConvDownFadeFn (round 4): alpha * lrelu(conv1_down(.)) + (1 - alpha) * from_rgb(pool(img)) with the lerp in the
     convolution's store and the activation kept only as sign bits -- the SAME roundings as the separate passes (the lerp is applied
     to the bf16-rounded activation; the backward multiplies by the same slope), so scores, the R1 image gradient and every parameter
-    gradient agree with the unfused path to the order in which autograd sums contributions (reference models/GAN.py:423-427)."""
+    gradient agree with the unfused path to the order in which autograd sums contributions (reference models/GAN.py:423-427).
+    ``dev_alpha``: [alpha, 1 - alpha] read from device memory by the kernel (what a replayed step graph passes)."""
     from stylegan.pytorch_amd import functional as F
-    alpha = 0.3
+    alpha = torch.tensor([0.3, 0.7], dtype=torch.float32, device=DEV) if dev_alpha else 0.3
     R = 4 << depth
     real = gu.seeded((B, 3, R, R), 61); fake = gu.seeded((B, 3, R, R), 62)
     dis, dp = build_dis()
