@@ -260,6 +260,174 @@ __global__ __launch_bounds__(256) void blur3x3_kernel(const T* __restrict__ x, c
         }
     }
 }
+// ---- the same pass with ONE global load per input vector (large tensors; C / VE a power of two <= 16 and W * C / VE a multiple of 64,
+// so that a wave never straddles an image row).  The kernel above asks L1 for the left and right pixel again: 3 loads per input row of
+// which one is HBM traffic, so a wave has a third of its outstanding requests working on the stream, and the pre-op (LeakyReLU / mask) is
+// evaluated three times per element -- the pass sits at 3.0-4.6 TB/s where the one-load streaming passes reach 5.4.  Here a lane loads its
+// own vector only, PF rows ahead, and takes the neighbours' values from the lanes that loaded them (ds_bpermute: lane -+ C/VE): the raw
+// 16 bytes where there is no pre-op, the pre-processed fp32 values where there is one (MODE 1 / 5: evaluated once per element).  The first /
+// last C/VE lanes of a wave load their outer neighbour themselves (one exec-masked load; its pre-op rides along on all lanes).  The strip
+// and row bookkeeping is wave-uniform (scalar registers, scalar branches), the sums are packed fp32 pairs.  Same values, same order of
+// operations as above: bit-identical output.  MODE 3 (full-tensor mask on the input, fp32 networks) stays on the kernel above.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void raw_decode(const uint4& t, f32x2 (&v)[4]) {                  // 8 bf16
+    const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i].x = __uint_as_float(w[i] << 16); v[i].y = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void raw_decode(const uint4& t, f32x2 (&v)[2]) {                  // 4 fp32
+    v[0].x = __uint_as_float(t.x); v[0].y = __uint_as_float(t.y); v[1].x = __uint_as_float(t.z); v[1].y = __uint_as_float(t.w);
+}
+__device__ __forceinline__ unsigned lane_fetch(int byte_addr, unsigned v) { return (unsigned)__builtin_amdgcn_ds_bpermute(byte_addr, (int)v); }
+__device__ __forceinline__ float lane_fetch(int byte_addr, float v) { return __uint_as_float(lane_fetch(byte_addr, __float_as_uint(v))); }
+__device__ __forceinline__ uint4 lane_fetch(int byte_addr, const uint4& v) {
+    return make_uint4(lane_fetch(byte_addr, v.x), lane_fetch(byte_addr, v.y), lane_fetch(byte_addr, v.z), lane_fetch(byte_addr, v.w));
+}
+// v * (bit j of bits ? 1 : SGX_LRELU) without a compare: the bit, sign-extended, selects between the two products' bit patterns
+__device__ __forceinline__ float mask_mul(float v, float v_slope, unsigned bits, int j) {
+    const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)bits, j, 1);
+    return __uint_as_float((__float_as_uint(v) & m) | (__float_as_uint(v_slope) & ~m));
+}
+template <typename T, int MODE, int ROWS, int PF>
+__global__ __launch_bounds__(256) void blur3x3s_kernel(const T* __restrict__ x, const T* __restrict__ z, T* __restrict__ y, int B, int H,
+                                                       int W, int C) {
+    static_assert(MODE != 3, "blur3x3s: mode 3 is not built");
+    constexpr int VE = VecTraits<T>::VE, VP = VE / 2;
+    constexpr bool SHARE_RAW = sizeof(T) == 2 && MODE != 1 && MODE != 5;       // (fp32 tensors: the raw vector IS the four values)
+    const int cv = C / VE;
+    const unsigned rowv = (unsigned)W * cv;                                   // vectors per image row
+    const int strips = (H + ROWS - 1) / ROWS;
+    const size_t nthr = (size_t)B * strips * rowv;
+    const int lane = threadIdx.x & 63;
+    const bool edge_l = lane < cv, edge_r = lane >= 64 - cv;
+    const int src_l = ((lane - cv) & 63) << 2, src_r = ((lane + cv) & 63) << 2;
+    const unsigned char* zb = reinterpret_cast<const unsigned char*>(z);
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    const f32x2 two = {2.f, 2.f}, sixteenth = {1.f / 16.f, 1.f / 16.f}, slope = {SGX_LRELU, SGX_LRELU};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nthr; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned iv = (unsigned)(i % rowv);                              // w * cv + c: this lane's vector within the row
+        const size_t q = i / rowv;
+        const int sidx = __builtin_amdgcn_readfirstlane((int)(q % strips)), b = __builtin_amdgcn_readfirstlane((int)(q / strips));
+        const int h0 = sidx * ROWS;
+        const bool hasl = iv >= (unsigned)cv, hasr = iv + cv < rowv;
+        const bool has_edge = (edge_l && hasl) || (edge_r && hasr);           // this lane fetches its outer neighbour itself
+        const unsigned ev = edge_l ? iv - cv : iv + cv;
+        const size_t img_row0 = (size_t)b * H;
+        uint4 rc[PF], re[PF];
+        unsigned mc[PF], me[PF];                                              // MODE 5: the mask byte of the own / the outer-neighbour vector
+#pragma unroll
+        for (int s = 0; s < PF; ++s) { rc[s] = zero4; re[s] = zero4; mc[s] = 0u; me[s] = 0u; }
+        auto issue = [&](int k) {
+            const int r = h0 - 1 + k, s = k % PF;
+            if ((unsigned)r < (unsigned)H) {                                  // (wave-uniform)
+                const uint4* xr = reinterpret_cast<const uint4*>(x) + (img_row0 + r) * rowv;
+                rc[s] = xr[iv];
+                if (has_edge) re[s] = xr[ev];
+                if (MODE == 5) {
+                    const unsigned char* zr = zb + (img_row0 + r) * rowv;
+                    mc[s] = zr[iv];
+                    if (has_edge) me[s] = zr[ev];
+                }
+            }
+            if (MODE == 4 && k >= 2 && r - 1 < H) mc[s] = zb[(img_row0 + r - 1) * rowv + iv];   // the mask byte of the output row this step completes
+        };
+#pragma unroll
+        for (int k = 0; k < PF; ++k) issue(k);
+        f32x2 ha[VP], hb[VP], hc[VP];
+#pragma unroll
+        for (int j = 0; j < VP; ++j) { ha[j] = 0.f; hb[j] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < ROWS + 2; ++k) {
+            const int r = h0 - 1 + k, s = k % PF;
+            if ((unsigned)r < (unsigned)H) {                                  // (wave-uniform: every lane of the wave takes part in the exchange)
+                f32x2 l[VP], m[VP], rv[VP];
+                raw_decode(rc[s], m);
+                if (SHARE_RAW) {
+                    uint4 l4 = lane_fetch(src_l, rc[s]), r4 = lane_fetch(src_r, rc[s]);
+                    if (edge_l) l4 = re[s];                                   // (zero where there is no such pixel: never loaded)
+                    if (edge_r) r4 = re[s];
+                    raw_decode(l4, l); raw_decode(r4, rv);
+                } else {
+                    f32x2 e[VP];
+                    raw_decode(re[s], e);
+                    if (MODE == 1) {
+#pragma unroll
+                        for (int j = 0; j < VP; ++j) { m[j].x = lrelu(m[j].x); m[j].y = lrelu(m[j].y); e[j].x = lrelu(e[j].x); e[j].y = lrelu(e[j].y); }
+                    } else if (MODE == 5) {
+#pragma unroll
+                        for (int j = 0; j < VP; ++j) {
+                            const f32x2 ms = m[j] * slope, es = e[j] * slope;
+                            m[j].x = mask_mul(m[j].x, ms.x, mc[s], 2 * j); m[j].y = mask_mul(m[j].y, ms.y, mc[s], 2 * j + 1);
+                            e[j].x = mask_mul(e[j].x, es.x, me[s], 2 * j); e[j].y = mask_mul(e[j].y, es.y, me[s], 2 * j + 1);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < VP; ++j) {
+                        l[j].x = lane_fetch(src_l, m[j].x); l[j].y = lane_fetch(src_l, m[j].y);
+                        rv[j].x = lane_fetch(src_r, m[j].x); rv[j].y = lane_fetch(src_r, m[j].y);
+                        if (edge_l) l[j] = e[j];
+                        if (edge_r) rv[j] = e[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < VP; ++j) hc[j] = (l[j] + two * m[j]) + rv[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < VP; ++j) hc[j] = 0.f;
+            }
+            const unsigned obits = mc[s];
+            if (k + PF < ROWS + 2) issue(k + PF);
+            if (k >= 2) {
+                const int ro = r - 1;
+                if (ro < H) {
+                    f32x2 o2[VP];
+#pragma unroll
+                    for (int j = 0; j < VP; ++j) o2[j] = ((ha[j] + two * hb[j]) + hc[j]) * sixteenth;
+                    T* yo = y + ((img_row0 + ro) * rowv + iv) * VE;
+                    if (MODE == 2) {
+                        float mz[VE];
+                        VecTraits<T>::load(z + ((img_row0 + ro) * rowv + iv) * VE, mz);
+#pragma unroll
+                        for (int j = 0; j < VP; ++j) { o2[j].x *= lrelu_slope(mz[2 * j]); o2[j].y *= lrelu_slope(mz[2 * j + 1]); }
+                    } else if (MODE == 4) {
+                        const unsigned bits = obits;
+#pragma unroll
+                        for (int j = 0; j < VP; ++j) {
+                            const f32x2 os = o2[j] * slope;
+                            o2[j].x = mask_mul(o2[j].x, os.x, bits, 2 * j); o2[j].y = mask_mul(o2[j].y, os.y, bits, 2 * j + 1);
+                        }
+                    }
+                    float o[VE];
+#pragma unroll
+                    for (int j = 0; j < VP; ++j) { o[2 * j] = o2[j].x; o[2 * j + 1] = o2[j].y; }
+                    VecTraits<T>::store(yo, o);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < VP; ++j) { ha[j] = hb[j]; hb[j] = hc[j]; }
+        }
+    }
+}
+// SGX_BLUR_SHFL: 0 = the three-load kernel everywhere, 1..4 = the one-load kernel at that prefetch depth; unset: the depth measured best
+// per mode (tools/blur_probe.py, profiles/r04_blur_probe.txt)
+static int blur_shfl_pf(int mode) {
+    const char* e = getenv("SGX_BLUR_SHFL");
+    if (e) return atoi(e);
+    return (mode == 1 || mode == 5) ? 1 : 3;                 // (the modes with a pre-op are the register-heavier ones: more waves beat a deeper ring)
+}
+template <typename T, int PF>
+static void blur_launch_shfl(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, hipStream_t st) {
+    constexpr int VE = VecTraits<T>::VE, ROWS = BLUR_ROWS;
+    const dim3 grid(grid_for((size_t)B * ((H + ROWS - 1) / ROWS) * W * C / VE)), block(256);
+    const T* xp = (const T*)x; const T* zp = (const T*)z; T* yp = (T*)y;
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((blur3x3s_kernel<T, 0, ROWS, PF>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        case 1: hipLaunchKernelGGL((blur3x3s_kernel<T, 1, ROWS, PF>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        case 2: hipLaunchKernelGGL((blur3x3s_kernel<T, 2, ROWS, PF>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        case 4: hipLaunchKernelGGL((blur3x3s_kernel<T, 4, ROWS, PF>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+        default: hipLaunchKernelGGL((blur3x3s_kernel<T, 5, ROWS, PF>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+    }
+}
 template <typename T, int ROWS>
 static void blur_launch_rows(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, hipStream_t st) {
     constexpr int VE = VecTraits<T>::VE;
@@ -280,8 +448,14 @@ static void blur_launch_rows(const void* x, const void* z, void* y, int B, int H
 template <typename T>
 static void blur_launch(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, hipStream_t st) {
     const size_t lanes8 = (size_t)B * ((H + BLUR_ROWS - 1) / BLUR_ROWS) * W * C / VecTraits<T>::VE;
+    const int cv = C / VecTraits<T>::VE, pf = blur_shfl_pf(mode);
     if (lanes8 < (size_t)256 * 512) blur_launch_rows<T, 2>(x, z, y, B, H, W, C, mode, st);
-    else blur_launch_rows<T, BLUR_ROWS>(x, z, y, B, H, W, C, mode, st);
+    else if (pf > 0 && mode != 3 && cv <= 16 && (cv & (cv - 1)) == 0 && ((size_t)W * cv) % 64 == 0 && lanes8 < ((size_t)1 << 31)) {
+        if (pf == 1) blur_launch_shfl<T, 1>(x, z, y, B, H, W, C, mode, st);
+        else if (pf == 2) blur_launch_shfl<T, 2>(x, z, y, B, H, W, C, mode, st);
+        else if (pf == 3) blur_launch_shfl<T, 3>(x, z, y, B, H, W, C, mode, st);
+        else blur_launch_shfl<T, 4>(x, z, y, B, H, W, C, mode, st);
+    } else blur_launch_rows<T, BLUR_ROWS>(x, z, y, B, H, W, C, mode, st);
 }
 extern "C" int sgx_blur3x3_act(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;

@@ -473,6 +473,42 @@ def test_act_blur_first_and_second_order(dt):
     assert_close(dg, dgr, tol, "act_blur double backward")
 
 
+# (tensors large enough for the streaming blur kernels: 8-row strips, >= 131072 strip lanes; heights that are not strip multiples)
+@pytest.mark.parametrize("dt,B,H,W,C", [(torch.bfloat16, 6, 200, 512, 16), (torch.bfloat16, 10, 52, 256, 64), (torch.bfloat16, 16, 36, 128, 128),
+                                        (torch.bfloat16, 3, 99, 448, 32), (torch.float32, 16, 72, 256, 16)])
+def test_one_load_blur_kernel_writes_the_bits_of_the_three_load_kernel(dt, B, H, W, C, monkeypatch):
+    """csrc/pointwise.hip blur3x3s_kernel (round 4: one global load per input vector, neighbours by lane exchange, pre-op once per
+    element) against blur3x3_kernel (SGX_BLUR_SHFL=0, read at every launch): every mode, bit for bit -- and mode 0 / 1 against torch
+    (reference models/CustomLayers.py:179-217: the depthwise [1,2,1]x[1,2,1]/16 blur with zero padding)."""
+    from stylegan.pytorch_amd import native as N
+    L = N.lib()
+    torch.manual_seed(C + H)
+    x = torch.randn(B, H, W, C, device=DEV).to(dt)
+    z = torch.randn(B, H, W, C, device=DEV).to(dt)
+    bits = torch.randint(0, 256, (B, H, W, C // 8), device=DEV, dtype=torch.uint8)
+    iview = torch.int16 if dt == torch.bfloat16 else torch.int32
+    k = torch.tensor([1., 2., 1.], device=DEV); k = (k[:, None] * k[None, :] / 16.0)[None, None].repeat(C, 1, 1, 1)
+    for mode in ([0, 1, 2, 4, 5] if dt == torch.bfloat16 else [0, 1, 2]):
+        outs = []
+        for v in ("0", None, "2"):
+            if v is None:
+                monkeypatch.delenv("SGX_BLUR_SHFL", raising=False)
+            else:
+                monkeypatch.setenv("SGX_BLUR_SHFL", v)
+            y = torch.full_like(x, 7.0)
+            if mode >= 4:
+                N.check(L.sgx_blur3x3_bits(N.ptr(x), N.ptr(bits), N.ptr(y), B, H, W, C, mode - 2, N.dt(x), N.stream()), "blur_bits")
+            else:
+                N.check(L.sgx_blur3x3_act(N.ptr(x), N.ptr(z if mode == 2 else None), N.ptr(y), B, H, W, C, mode, N.dt(x), N.stream()), "blur_act")
+            outs.append(y)
+        assert torch.equal(outs[0].view(iview), outs[1].view(iview)), (mode, "default depth")
+        assert torch.equal(outs[0].view(iview), outs[2].view(iview)), (mode, "depth 2")
+        if mode in (0, 1):
+            a = x.float().permute(0, 3, 1, 2)
+            ref = TF.conv2d(TF.leaky_relu(a, 0.2) if mode == 1 else a, k, padding=1, groups=C).permute(0, 2, 3, 1)
+            assert_close(outs[1], ref, 1e-5 if dt == torch.float32 else 8e-3, f"blur mode {mode}")
+
+
 @pytest.mark.parametrize("act", [0, 1])
 @pytest.mark.parametrize("B,K,Nn", [(4, 512, 512), (8, 512, 1024), (4, 512, 32), (3, 100, 36)])
 def test_fused_linear_matches_torch(B, K, Nn, act):
