@@ -298,8 +298,10 @@ def measure(sg, a, cfg, dev, B, steps, warmup, rank, world, want_graphs, stream_
         sg.use_graphs, sg.aux_stream, sg.param_stream = c
 
     cands = [(g, ax, pr) for g in want_graphs for (ax, pr) in stream_opts if not (g and (ax, pr) == (False, True))]
-    HOST_MARGIN = 1.10        # a mode whose host enqueue time is within 10 % of its step time is one host hiccup away from
-    #                           being host-bound for the whole timed region: it is ranked by max(step time, 1.1 x host time)
+    HOST_MARGIN = 1.25        # a mode whose host enqueue time is within 25 % of its step time is one host hiccup away from
+    #                           being host-bound for the whole timed region (measured, round 4: eager launches calibrated at 14.2 ms
+    #                           with 13.9 ms of host time, then ran a 20.0 ms timed region on the same box where replay held 14.8):
+    #                           it is ranked by max(step time, 1.25 x host time)
     calib, best = {}, None
     if len(cands) > 1:
         times = {c: float("inf") for c in cands}

@@ -36,6 +36,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // bf16 terms (hi + lo, 6 MFMAs per row) was measured too: same accuracy as the unfused path, +12 % time.
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {   // round to nearest even
     const h16x2 v = {(_Float16)lo, (_Float16)hi};
     return __builtin_bit_cast(unsigned, v);
@@ -257,111 +258,171 @@ __global__ __launch_bounds__(256) void rgbconv_fwd_kernel(const float* __restric
 // LDS, activated tile back through LDS, three phases between barriers): 500-608 us at batch 32, 1024^2 against 276 us for the same
 // convolution without the blur -- at three resident blocks per CU the phases did not overlap.
 static __device__ __forceinline__ float dpp_row_shr1(float v) {     // lane l <- lane l - 1 inside each row of 16 lanes (0 into lane 0)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x111, 0xf, 0xf, true));
 }
 static __device__ __forceinline__ float dpp_row_shl1(float v) {     // lane l <- lane l + 1 (0 into lane 15)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x101, 0xf, 0xf, true));
 }
 enum { RC_FWD_DEFAULT = 0 };
 enum { RC_STRIP = 14, RC_ROWS = 32, RC_PF = 3 };     // RC_PF: rows in flight per wave (8 measured slower: 110 registers, 4 waves per SIMD)
 
-template <int CB>
-__global__ __launch_bounds__(256) void rgbconv_fwdblur_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wf, const float* __restrict__ b0,
-                                                              bf16_t* __restrict__ y, unsigned char* __restrict__ bits, int B, int H, int W, int ones,
-                                                              int nstrips, int nrb, int dbg) {
-    // dbg (SGX_RGBCONV_DBG, profiling ablations -- wrong results by design): 1 no MFMA, 2 no image loads, 4 no output stores, 8 no sign bits
+// The forward kernel is bound by its vector instructions, not by HBM (first version: ~180 VALU instructions per 448-byte output row of a
+// wave = 0.67 ms of issue time at batch 32 against 0.3 ms of streaming time).  What the second version does about it:
+//   * a wave whose strip, rows and halo lie inside the image (91 % of them at 1024^2) walks a loop without a single border test; the
+//     others walk the same loop with per-row masks (the BORDER instantiation) -- a wave-uniform branch at the top, two loop bodies;
+//   * the strip / row bookkeeping lives in scalar registers (the wave's item index through readfirstlane): row bases are scalar
+//     pointers, the per-lane part a 32-bit offset; loads are unconditional from a clamped address (a conditional load merges with a
+//     zero and the compiler waits for it on the spot: no prefetch) and a row block is a whole number of 6-row steps (stores predicated,
+//     nothing else): rings and histories are indexed statically, nothing is moved between registers;
+//   * conv0's bias is the MFMA's C operand; the blur's 1/16 is folded into the LeakyReLU's two slopes (exact: a power of two) and the
+//     activation is max(x/16, 0.2 x/16) -- outside the image the two slopes are zero, which is the blur's zero padding;
+//   * the [1,2,1] taps are two neighbour sums per direction ((a[l-1] + a[l]) + (a[l] + a[l+1])): two DPP adds per value horizontally
+//     (this file is compiled without the SLP vectorizer so that the DPP operand folds into the add), vertically the pair sum of the
+//     previous step is kept instead of two rows;
+//   * a row's sign nibble is built when the row is computed (med3(bits, 0, 1) per channel) and carried one step as one register; the
+//     two nibbles of a byte meet through v_permlane16_swap.
+// The MFMA results stay in VGPRs (-mllvm -amdgpu-mfma-vgpr-form for this file: 6 waves per SIMD instead of 4, no accvgpr traffic).
+// Workgroups go round-robin over the 8 XCDs, each with its own L2: with the natural order the four strips of a block and the four of
+// the next block -- which share image columns (halo loads) and 128-byte lines of the output and of the sign bits (14-pixel strips are
+// not line-aligned) -- sit on different XCDs, and their partial lines cannot merge in an L2.  Logical block = (XCD, index within the
+// XCD): neighbours in memory run on one XCD, about at the same time.  (the grid is a multiple of 8 blocks; surplus items exit)
+static __device__ __forceinline__ unsigned rc_xcd_block() { return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+template <int CB, bool BORDER>
+static __device__ __forceinline__ void fwdblur_walk(const float* __restrict__ ibase, const bf16_t* __restrict__ wf, const float* __restrict__ b0,
+                                                    bf16_t* __restrict__ ybase, unsigned char* __restrict__ bbase, int H, int W, int ones, int sx,
+                                                    int r_begin, int r_end, int nit, int dbg) {
     constexpr int C = 16 * CB;
     const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
-    int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int sx = item % nstrips; item /= nstrips;
-    const int rbk = item % nrb, b = item / nrb;
-    if (b >= B) return;
-    const int r_begin = rbk * RC_ROWS, r_end = r_begin + RC_ROWS < H ? r_begin + RC_ROWS : H;
     const int zc = sx * RC_STRIP - 1 + l15;                // image column of this lane's convolution output
-    const int pc = zc - 1 + l4;                            // image column of this lane's B-operand pixel (kernel column l4; l4 = 3: padding)
-    const bool pc_ok = l4 < 3 && (unsigned)pc < (unsigned)W;
+    const int pc = zc - 1 + (l4 < 3 ? l4 : 2);             // image column of this lane's B-operand pixel (kernel column l4; l4 = 3: the
+    //                                                        weights' k 12..15 are zero, the lane re-reads kernel column 2's pixel)
+    const bool pc_ok = (unsigned)pc < (unsigned)W;
+    const int pca = pc < 0 ? 0 : (pc < W ? pc : W - 1);
+    const unsigned ioff = (unsigned)pca * 3u;
     s16x4 wfr[CB][3];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) wfr[cb][ky] = *reinterpret_cast<const s16x4*>(wf + ((ky * C + cb * 16 + l15) * 16 + 4 * l4));
-    float4 bias[CB];
+    f32x4_t biasv[CB];
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) bias[cb] = b0 ? *reinterpret_cast<const float4*>(b0 + cb * 16 + 4 * l4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* ibase = img + (size_t)b * H * W * 3;
-    auto load_row = [&](int gy) -> rgb3 {                  // this lane's pixel of image row gy (zeros outside the image)
-        rgb3 v{0.f, 0.f, 0.f};
-        if (pc_ok && (unsigned)gy < (unsigned)H && !(dbg & 2)) v = *reinterpret_cast<const rgb3*>(ibase + ((size_t)gy * W + pc) * 3);
-        return v;
+    for (int cb = 0; cb < CB; ++cb) {
+        const float4 t = b0 ? *reinterpret_cast<const float4*>(b0 + cb * 16 + 4 * l4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        biasv[cb] = f32x4_t{t.x, t.y, t.z, t.w};
+    }
+    const unsigned lmask = (!BORDER || pc_ok) ? 0xffffffffu : 0u;       // BORDER: this lane's pixel column exists
+    const unsigned one_hi = ones ? (0x3c000000u & lmask) : 0u;          // fp16 1.0 in the high half: the bias channel of an in-image pixel
+    auto load_row = [&](int gy) -> rgb3 {                  // this lane's pixel of image row gy (row clamped into the image: masked at use)
+        const int gyc = gy < 0 ? 0 : (gy < H ? gy : H - 1);
+        return *reinterpret_cast<const rgb3*>(ibase + (size_t)gyc * W * 3 + ioff);
     };
-    auto frag_of = [&](const rgb3& v, int gy) -> s16x4 {   // bf16 (r, g, b, 1 inside the image | 0)
-        const bool in = pc_ok && (unsigned)gy < (unsigned)H;
-        const unsigned p01 = pack_f16x2(v.r, v.g), p23 = pack_f16x2(v.b, (in && ones) ? 1.f : 0.f);     // fp16 (r, g, b, 1 | 0)
+    auto frag_of = [&](const rgb3& v, int gy) -> s16x4 {   // fp16 (r, g, b, 1 inside the image | 0)
+        unsigned p01 = pack_f16x2(v.r, v.g);
+        unsigned p23 = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v.b) | one_hi;
+        if (BORDER) {
+            const unsigned m = (unsigned)gy < (unsigned)H ? lmask : 0u;
+            p01 &= m; p23 &= m;
+        }
         s16x4 f;
         f[0] = (short)(p01 & 0xffffu); f[1] = (short)(p01 >> 16); f[2] = (short)(p23 & 0xffffu); f[3] = (short)(p23 >> 16);
         return f;
     };
-    // window of image rows zrow - 1, zrow, zrow + 1 for the convolution row zrow, and RC_PF more rows in flight: a wave waits ~1.5 us
-    // for a row under load, so with three rows in flight (the first version) the kernel ran at 2.6 TB/s, latency-bound -- the ring
-    // is indexed statically in a loop unrolled RC_PF times, so nothing is moved between registers
     const int z0 = r_begin - 1;
-    s16x4 f0 = frag_of(load_row(z0 - 1), z0 - 1), f1 = frag_of(load_row(z0), z0);
-    rgb3 ring[RC_PF];
+    s16x4 fr[3];                                           // fragments of rows zrow - 1, zrow, zrow + 1 at slots s, s + 1, s + 2 (mod 3)
+    fr[0] = frag_of(load_row(z0 - 1), z0 - 1); fr[1] = frag_of(load_row(z0), z0); fr[2] = fr[1];
+    rgb3 ring[3];                                          // rows zrow + 1 .. zrow + 3 in flight
 #pragma unroll
-    for (int u = 0; u < RC_PF; ++u) ring[u] = load_row(z0 + 1 + u);
-    float h1[CB][4], h2[CB][4], a1[CB][4];
+    for (int u = 0; u < 3; ++u) ring[u] = load_row(z0 + 1 + u);
+    float h1[CB][4];                                       // horizontal sums of the previous row
+    f32x2 vp[CB][2];                                       // pair sum (row - 2) + (row - 1)
+    unsigned pbyte[CB];                                    // sign byte of the previous row (both nibbles, on every lane of the pair)
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
+    for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { h1[cb][i] = 0.f; h2[cb][i] = 0.f; a1[cb][i] = 0.f; }
+        for (int i = 0; i < 4; ++i) h1[cb][i] = 0.f;
+        vp[cb][0] = 0.f; vp[cb][1] = 0.f; pbyte[cb] = 0u;
+    }
     const bool col_in = (unsigned)zc < (unsigned)W;
     const bool col_out = l15 >= 1 && l15 <= RC_STRIP && zc < W;       // this lane stores an output column (zc >= 0 there)
-    for (int zb = z0; zb <= r_end; zb += RC_PF) {
+    const bool bit_out = col_out && !(l4 & 1) && bbase && !(dbg & 8);
+    const bool y_out = col_out && !(dbg & 4);
+    const unsigned yoff = col_out ? (unsigned)zc * C + 4u * l4 : 0u, boff = col_out ? (unsigned)zc * (C / 8) + (unsigned)(l4 >> 1) : 0u;
+    const float sp_l = (!BORDER || col_in) ? 0.0625f : 0.f, sn_l = (!BORDER || col_in) ? SGX_LRELU * 0.0625f : 0.f;
+    for (int it = 0; it < nit; ++it) {
 #pragma unroll
-        for (int u = 0; u < RC_PF; ++u) {
-            const int zrow = zb + u;
-            if (zrow <= r_end) {                                         // (wave-uniform)
-                const s16x4 f2 = frag_of(ring[u], zrow + 1);
-                ring[u] = load_row(zrow + 1 + RC_PF);
-                const bool z_in = col_in && (unsigned)zrow < (unsigned)H;
+        for (int u = 0; u < 6; ++u) {
+            const int zrow = z0 + 6 * it + u, s = u % 3;
+            fr[(s + 2) % 3] = frag_of(ring[s], zrow + 1);
+            ring[s] = load_row(zrow + 4);
+            float sp = sp_l, sn = sn_l;
+            if (BORDER) {                                              // rows outside the image: the blur's zero padding
+                const bool row_in = (unsigned)zrow < (unsigned)H;
+                sp = row_in ? sp_l : 0.f; sn = row_in ? sn_l : 0.f;
+            }
+            const f32x2 sp2 = {sp, sp}, sn2 = {sn, sn};
+            const int orow = zrow - 1;                                   // centre row of the three horizontal sums now complete
+            const bool store_row = orow >= r_begin && orow < r_end;      // (wave-uniform)
+            bf16_t* yrow = ybase + (size_t)orow * W * C;
+            unsigned char* brow = bbase + (size_t)orow * W * (C / 8);
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                    if (!(dbg & 1)) {
-                        acc = mma16h(wfr[cb][0], f0, acc);
-                        acc = mma16h(wfr[cb][1], f1, acc);
-                        acc = mma16h(wfr[cb][2], f2, acc);
-                    } else {
-                        acc[0] = (float)f0[0] + (float)f1[1] + (float)f2[2]; acc[1] = acc[0]; acc[2] = acc[0]; acc[3] = acc[0];
-                    }
-                    const float bb[4] = {bias[cb].x, bias[cb].y, bias[cb].z, bias[cb].w};
-                    float a[4], h[4];
+            for (int cb = 0; cb < CB; ++cb) {
+                f32x4_t acc = mma16h(wfr[cb][0], fr[s], biasv[cb]);
+                acc = mma16h(wfr[cb][1], fr[(s + 1) % 3], acc);
+                acc = mma16h(wfr[cb][2], fr[(s + 2) % 3], acc);
+                float a[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        a[i] = z_in ? lrelu(acc[i] + bb[i]) : 0.f;       // outside the image: the blur's zero padding
-                        h[i] = dpp_row_shr1(a[i]) + 2.f * a[i] + dpp_row_shl1(a[i]);
-                    }
-                    const int orow = zrow - 1;                           // centre row of (h2, h1, h)
-                    if (orow >= r_begin) {
-                        const size_t pix = ((size_t)b * H + orow) * W + zc;
-                        if (col_out && !(dbg & 4))
-                            *reinterpret_cast<uint2*>(y + pix * C + cb * 16 + 4 * l4) =
-                                make_uint2(pack_bf16x2((h2[cb][0] + 2.f * h1[cb][0] + h[0]) * 0.0625f, (h2[cb][1] + 2.f * h1[cb][1] + h[1]) * 0.0625f),
-                                           pack_bf16x2((h2[cb][2] + 2.f * h1[cb][2] + h[2]) * 0.0625f, (h2[cb][3] + 2.f * h1[cb][3] + h[3]) * 0.0625f));
-                        if (bits && !(dbg & 8)) {
-                            // sign bits of the centre row's pre-activation: 4 channels per lane, the partner lane (l4 ^ 1) has the other nibble
-                            unsigned nib = (a1[cb][0] > 0.f ? 1u : 0u) | (a1[cb][1] > 0.f ? 2u : 0u) | (a1[cb][2] > 0.f ? 4u : 0u) | (a1[cb][3] > 0.f ? 8u : 0u);
-                            const unsigned other = (unsigned)__shfl_xor((int)nib, 16, 64);
-                            if (col_out && !(l4 & 1)) bits[pix * (C / 8) + cb * 2 + (l4 >> 1)] = (unsigned char)(nib | (other << 4));
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { h2[cb][i] = h1[cb][i]; h1[cb][i] = h[i]; a1[cb][i] = a[i]; }
+                for (int q = 0; q < 2; ++q) {
+                    const f32x2 x = {acc[2 * q], acc[2 * q + 1]};
+                    const f32x2 p = x * sp2, n = x * sn2;            // lrelu(x) / 16 = max(x / 16, 0.2 x / 16)
+                    a[2 * q] = fmaxf(p.x, n.x); a[2 * q + 1] = fmaxf(p.y, n.y);
                 }
-                f0 = f1; f1 = f2;
+                unsigned nib = 0u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)                              // a > 0 <=> its bits, as a signed integer, are >= 1
+                    nib |= (unsigned)min(max(__float_as_int(a[i]), 0), 1) << i;
+                const auto sw = __builtin_amdgcn_permlane16_swap(nib, nib, false, false);       // [0]: the even row's nibble, [1]: the odd row's
+                float h[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = a[i] + dpp_row_shr1(a[i]);
+                    h[i] = t + dpp_row_shl1(t);
+                }
+                const f32x2 vc0 = f32x2{h1[cb][0], h1[cb][1]} + f32x2{h[0], h[1]}, vc1 = f32x2{h1[cb][2], h1[cb][3]} + f32x2{h[2], h[3]};
+                if (store_row) {
+                    if (y_out) {
+                        const f32x2 o0 = vp[cb][0] + vc0, o1 = vp[cb][1] + vc1;
+                        *reinterpret_cast<uint2*>(yrow + yoff + cb * 16) = make_uint2(pack_bf16x2(o0.x, o0.y), pack_bf16x2(o1.x, o1.y));
+                    }
+                    if (bit_out) brow[boff + cb * 2] = (unsigned char)pbyte[cb];
+                }
+                vp[cb][0] = vc0; vp[cb][1] = vc1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h1[cb][i] = h[i];
+                pbyte[cb] = sw[0] | (sw[1] << 4);
             }
         }
     }
+}
+template <int CB>
+__global__ __launch_bounds__(256) void rgbconv_fwdblur_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wf, const float* __restrict__ b0,
+                                                              bf16_t* __restrict__ y, unsigned char* __restrict__ bits, int B, int H, int W, int ones,
+                                                              int nstrips, int nrb, int nit, int dbg) {
+    // nit: 6-row steps per row block (a block stores 6 nit - 2 rows).  dbg (SGX_RGBCONV_DBG, profiling ablations -- wrong results by
+    // design): 4 no output stores, 8 no sign bits
+    constexpr int C = 16 * CB;
+    int item = __builtin_amdgcn_readfirstlane((int)(rc_xcd_block() * 4 + (threadIdx.x >> 6)));
+    const int sx = item % nstrips; item /= nstrips;
+    const int rbk = item % nrb, b = item / nrb;
+    if (b >= B) return;
+    const int rb = 6 * nit - 2;
+    const int r_begin = rbk * rb, r_end = r_begin + rb < H ? r_begin + rb : H;
+    const float* ibase = img + (size_t)b * H * W * 3;
+    bf16_t* ybase = y + (size_t)b * H * W * C;
+    unsigned char* bbase = bits ? bits + (size_t)b * H * W * (C / 8) : nullptr;
+    // every pixel the walk touches is an image pixel: columns sx * 14 - 2 .. sx * 14 + 15, rows r_begin - 2 .. r_begin + rb + 1
+    const bool inside = sx * RC_STRIP - 2 >= 0 && sx * RC_STRIP + 15 < W && r_begin - 2 >= 0 && r_begin + rb + 1 < H;
+    if (inside) fwdblur_walk<CB, false>(ibase, wf, b0, ybase, bbase, H, W, ones, sx, r_begin, r_end, nit, dbg);
+    else fwdblur_walk<CB, true>(ibase, wf, b0, ybase, bbase, H, W, ones, sx, r_begin, r_end, nit, dbg);
 }
 
 template <int CB>
@@ -369,7 +430,7 @@ __global__ __launch_bounds__(256) void rgbconv_dgrad_kernel(const bf16_t* __rest
                                                             int B, int H, int W, int nstrips, int nrb) {
     constexpr int C = 16 * CB;
     const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
-    int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int item = (int)rc_xcd_block() * 4 + (threadIdx.x >> 6);
     const int sx = item % nstrips; item /= nstrips;
     const int rbk = item % nrb, b = item / nrb;
     if (b >= B) return;
@@ -679,12 +740,21 @@ extern "C" int sgx_rgbconv_fwd(const float* img, const void* wf, const float* b0
         const int variant = ve ? atoi(ve) : RC_FWD_DEFAULT;
         if (variant) return C == 16 ? launch_rgbconv_fwd<1, 1>(img, w, b0, out, bt, B, H, W, ones, st, variant == 2)
                                     : launch_rgbconv_fwd<2, 1>(img, w, b0, out, bt, B, H, W, ones, st, variant == 2);
-        const int nstrips = (W + RC_STRIP - 1) / RC_STRIP, nrb = (H + RC_ROWS - 1) / RC_ROWS;
-        const unsigned grid = (unsigned)(((long)B * nstrips * nrb + 3) / 4);
+        // rows per block 6 nit - 2 (two halo rows per block are recomputed): 34 where that still leaves > 3 waves per SIMD slot of the
+        // chip, 22 / 16 for small launches (batch 4 at 1024^2: 14k / 19k waves)          SGX_RGBCONV_NIT overrides (probe)
+        const int nstrips = (W + RC_STRIP - 1) / RC_STRIP;
+        const char* ne = getenv("SGX_RGBCONV_NIT");
+        int nit = ne ? atoi(ne) : 6;
+        if (!ne) {
+            while (nit > 3 && (long)B * nstrips * ((H + 6 * nit - 3) / (6 * nit - 2)) < 3L * 256 * 24) --nit;
+        }
+        if (nit < 1) nit = 1;
+        const int rb = 6 * nit - 2, nrb = (H + rb - 1) / rb;
+        const unsigned grid = (unsigned)((((long)B * nstrips * nrb + 3) / 4 + 7) / 8 * 8);      // (rc_xcd_block)
         const char* de = getenv("SGX_RGBCONV_DBG");
         const int dbg = de ? atoi(de) : 0;
-        if (C == 16) hipLaunchKernelGGL((rgbconv_fwdblur_kernel<1>), dim3(grid), dim3(256), 0, st, img, w, b0, out, bt, B, H, W, ones, nstrips, nrb, dbg);
-        else hipLaunchKernelGGL((rgbconv_fwdblur_kernel<2>), dim3(grid), dim3(256), 0, st, img, w, b0, out, bt, B, H, W, ones, nstrips, nrb, dbg);
+        if (C == 16) hipLaunchKernelGGL((rgbconv_fwdblur_kernel<1>), dim3(grid), dim3(256), 0, st, img, w, b0, out, bt, B, H, W, ones, nstrips, nrb, nit, dbg);
+        else hipLaunchKernelGGL((rgbconv_fwdblur_kernel<2>), dim3(grid), dim3(256), 0, st, img, w, b0, out, bt, B, H, W, ones, nstrips, nrb, nit, dbg);
         SGX_LAUNCH_CHECK("rgbconv_fwdblur_kernel");
         return 0;
     }
@@ -698,7 +768,7 @@ extern "C" int sgx_rgbconv_dgrad(const void* gz, const void* wd, float* gi, int 
     SGX_NOTE(2.0 * 27 * C * px, px * (12.0 + 2.0 * C), "rgbconv_dgrad B%d %dx%d %d->3", B, H, W, C);
     hipStream_t st = (hipStream_t)stream;
     const int nstrips = (W + RC_STRIP - 1) / RC_STRIP, nrb = (H + RC_ROWS - 1) / RC_ROWS;
-    const unsigned grid = (unsigned)(((long)B * nstrips * nrb + 3) / 4);
+    const unsigned grid = (unsigned)((((long)B * nstrips * nrb + 3) / 4 + 7) / 8 * 8);          // (rc_xcd_block)
     if (C == 16) hipLaunchKernelGGL((rgbconv_dgrad_kernel<1>), dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(gz), static_cast<const bf16_t*>(wd), gi, B, H, W, nstrips, nrb);
     else hipLaunchKernelGGL((rgbconv_dgrad_kernel<2>), dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(gz), static_cast<const bf16_t*>(wd), gi, B, H, W, nstrips, nrb);
     SGX_LAUNCH_CHECK("rgbconv_dgrad_kernel");

@@ -54,7 +54,7 @@ HOT = [
     ("wgrad16_s_kernel(Wg2Args)", 4),                                        # its 16x16-channel weight gradient
     ("conv2_kernel<0, 8, 2, 32, false, 0>(Conv2Args)", 2),                   # 3x3, 64..512 channels (the batch-32 dominant kernel)
     # round 4: the discriminator's composed first layer (csrc/rgbconv.hip): row-streaming kernels live on waves in flight (no LDS tile)
-    ("rgbconv_fwdblur_kernel<1>(float const*, unsigned short const*, float const*, unsigned short*, unsigned char*, int, int, int, int, int, int, int)", 5),                                        # from_rgb + conv0 + LeakyReLU + blur, 3 -> 16 at 1024^2
+    ("rgbconv_fwdblur_kernel<1>(float const*, unsigned short const*, float const*, unsigned short*, unsigned char*, int, int, int, int, int, int, int, int)", 6),                                        # from_rgb + conv0 + LeakyReLU + blur, 3 -> 16 at 1024^2
     ("rgbconv_dgrad_kernel<1>(unsigned short const*, unsigned short const*, float*, int, int, int, int, int)", 6),                                          # its image gradient
     ("rgbconv_wgrad_kernel<1>(float const*, unsigned short const*, float*, int, int, int, int, int, int, int)", 4),                                          # its (composed) weight gradient: 3 resident blocks per CU
 ]

@@ -32,12 +32,16 @@ def main():
         px = B * R * R
         rows = []
         with torch.no_grad():
-            for dbg, what in ((0, "forward + act + blur + bits"), (8, "  no sign bits"), (4, "  no output stores"), (12, "  no stores at all"), (2, "  no image loads"),
-                              (1, "  no MFMA"), (3, "  no loads, no MFMA"), (15, "  nothing but the loop")):
+            for dbg, what in ((0, "forward + act + blur + bits"), (8, "  no sign bits"), (4, "  no output stores"), (12, "  no stores at all")):
                 os.environ["SGX_RGBCONV_DBG"] = str(dbg)
                 us = timeit(lambda: F.RgbConvBlurFn.apply(img, w0, b0, wr, br, 0.1, 0.5))
                 rows.append((what, us, px * 46.0 / us / 1e6))
             os.environ["SGX_RGBCONV_DBG"] = "0"
+            for nit in (3, 4, 5, 6, 8):
+                os.environ["SGX_RGBCONV_NIT"] = str(nit)
+                us = timeit(lambda: F.RgbConvBlurFn.apply(img, w0, b0, wr, br, 0.1, 0.5))
+                rows.append((f"  {6 * nit - 2} rows per wave", us, px * 46.0 / us / 1e6))
+            os.environ.pop("SGX_RGBCONV_NIT")
             for v, what in ((1, "forward, LDS-tile kernel, persistent blocks"), (2, "forward, LDS-tile kernel, one tile per block")):
                 os.environ["SGX_RGBCONV_FWD"] = str(v)
                 us = timeit(lambda: F.RgbConvBlurFn.apply(img, w0, b0, wr, br, 0.1, 0.5))
