@@ -66,7 +66,13 @@ BARS = {
     "image": {"mid": 3.1e-2, "128": 3.1e-2, "1024": 6.7e-2},        # depth 5 models under the depth-2 figure, depth 8 under the depth-5 one
     "d_score": {"mid": 5e-2, "128": 2e-2, "1024": 1.6e-1},          # (mid: 2-3e-2 over 64 scores, tools/diag_dscore.py; naive cast at its depth: 1.6e-1)
     "loss": 5e-2,                                                   # either loss scalar, relative
-    "d_grad_median": 0.08, "g_grad_median": 0.13, "one_minus_cos": 0.12,
+    # d_grad_median: 0.08 until the second version of the composed first layer's forward kernel (round 4).  Three bit-different
+    # builds of that ONE kernel -- the LDS-tile kernel, the first and the second row-streaming kernel; each within 1.6e-3..1.8e-3 of
+    # fp64 on its own output, identical sign bits (tools/rgbconv_check.py) -- measure 0.074 / 0.078 / 0.081 on the mid model
+    # (deterministic per build): at batch 4 the statistic moves +-5 % with the rounding realisation, the top blocks' tensors
+    # together (a common-mode error through the four scores).  0.08 was one realisation plus 3 %; 0.09 is the worst of the three
+    # plus 10 %.  What the bar has to catch stays far outside: bf16 image / weights in that layer measured 0.10 (round 4).
+    "d_grad_median": 0.09, "g_grad_median": 0.13, "one_minus_cos": 0.12,
 }
 
 
@@ -130,6 +136,7 @@ def test_bf16_step_gradients_vs_fp64(name):
     measured["median_rel"] = float(np.median([r for r, _ in rels]))
     print(f"[bf16 grads {name}] d_loss rel {measured['d_loss']:.2e} g_loss rel {measured['g_loss']:.2e}; gradient rel-L2 median "
           f"{measured['median_rel']:.2e}; worst: " + ", ".join(f"{k} {r:.1e}" for r, k in rels[:6]))
+    print(f"[bf16 grads {name}] D tensors: " + ", ".join(f"{k[2:]} {r:.3f}" for r, k in sorted(rels, key=lambda t: t[1]) if k.startswith("d:")))
     check_grad_bars(measured, f"bf16 step {name}")           # the parity claim: frozen absolute bars
     gate(f"grads_{name}", measured)                           # the tripwire: 2 x what this code once measured
 
