@@ -442,7 +442,10 @@ def test_activation_backward_fused_into_the_data_gradient_kernels(nets, monkeypa
         out[fuse] = res
     for (s0, g0, i0, p0, n0, depth), (s1, g1, i1, p1, n1, _) in zip(out["0"], out["1"]):
         assert (n1 < n0) if depth > 0 else (n1 == n0), (depth, n0, n1)    # fewer activation-backward launches (depth 0: only the head's)
-        assert_close(s1, s0, 2e-5 if dt == torch.float32 else 3e-2, "score")     # (1-alpha) folded into from_rgb: a re-association (measured 4.6e-6 / 1.2e-2)
+        # (1-alpha) folded into from_rgb: a re-association (measured 4.6e-6 in fp32, the sharp check).  bf16: four scores of magnitude
+        # 0.07, each 2-3e-2 from fp64 (tools/diag_dscore.py) -- two bf16 paths measured 1.2e-2 and 4.0e-2 apart in two equally
+        # accurate builds of round 4 (first / second forward kernel of the composed first layer)
+        assert_close(s1, s0, 2e-5 if dt == torch.float32 else 8e-2, "score")
         # parameter gradients sum a first- and a second-order contribution in the autograd engine's order, which follows node
         # creation order and so differs between the two graph shapes: equal up to that one fp32 re-association
         tol = 1e-4 if dt == torch.float32 else 1.5e-1     # bf16: two different roundings along a 10-layer bf16 backward (measured 5.4e-2 on the image gradient); fp32 is the sharp check
