@@ -32,6 +32,7 @@ def test_sample_yaml_trains_first_two_depths(tmp_path):
         def emit(self, r): lines.append(r.getMessage())
     log.addHandler(H())
     dataset = SyntheticImages(256, opt.dataset.resolution, opt.dataset.channels, seed=3)
+    torch.manual_seed(0)            # the networks' initial weights: not whatever state the tests before this one left the generator in
     style_gan = StyleGAN(structure=opt.structure, conditional=opt.conditional, n_classes=opt.n_classes,
                          resolution=opt.dataset.resolution, num_channels=opt.dataset.channels,
                          latent_size=opt.model.gen.latent_size, g_args=opt.model.gen, d_args=opt.model.dis,
@@ -50,7 +51,9 @@ def test_sample_yaml_trains_first_two_depths(tmp_path):
     assert steps == list(range(1, 13))
     for l in fb:
         d, g = float(l.split("D_Loss: ")[1].split()[0]), float(l.split("G_Loss: ")[1])
-        assert d == d and g == g and abs(d) < 1e3 and abs(g) < 1e3, l
+        # finite and not exploding.  (the first D loss of freshly initialised networks at 4x4 is dominated by the R1 term, 5 |grad|^2:
+        # hundreds to ~1.2e3 depending on the initial weights -- measured 1170.9 with the generator state another test order left)
+        assert d == d and g == g and abs(d) < 1e4 and abs(g) < 1e4, l
     assert lines[-1].startswith("Training completed")
     assert sorted(os.listdir(os.path.join(out, "samples")))[0].startswith("gen_0_1_1")
     models = os.listdir(os.path.join(out, "models"))
