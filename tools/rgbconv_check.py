@@ -21,6 +21,13 @@ def main():
         with torch.no_grad():
             os.environ.pop("SGX_RGBCONV_FWD", None)
             y, bits = F.RgbConvBlurFn.apply(img, w0, b0, wr, br, s0, sr)
+            # every row-block size (6 nit - 2 rows; the host picks by launch size: partial last blocks, one-block images) writes the same bits
+            for nit in (6, 5, 4, 3, 2, 1):
+                os.environ["SGX_RGBCONV_NIT"] = str(nit)
+                yn, bn = F.RgbConvBlurFn.apply(img, w0, b0, wr, br, s0, sr)
+                same = torch.equal(yn.view(torch.int16), y.view(torch.int16)) and torch.equal(bn, bits)
+                print(f"  B{B} {H}x{W} C{C} rows per block {6 * nit - 2}: {'identical to the default' if same else 'DIFFERENT from the default'}")
+            os.environ.pop("SGX_RGBCONV_NIT")
             os.environ["SGX_RGBCONV_FWD"] = "1"
             y1, bits1 = F.RgbConvBlurFn.apply(img, w0, b0, wr, br, s0, sr)
             os.environ.pop("SGX_RGBCONV_FWD")
