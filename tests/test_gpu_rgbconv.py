@@ -49,7 +49,7 @@ CASES = [(16, 2, 32, 64), (16, 1, 48, 192), (32, 2, 16, 64), (32, 1, 48, 128), (
 
 
 @pytest.mark.parametrize("C,B,H,W", CASES)
-def test_forward_blur_and_sign_bits_vs_oracle(C, B, H, W):
+def test_forward_blur_and_sign_bits_vs_oracle(C, B, H, W, monkeypatch):
     from stylegan.pytorch_amd import functional as F
     p = make_params(C)
     d = dev_params(p)
@@ -61,6 +61,13 @@ def test_forward_blur_and_sign_bits_vs_oracle(C, B, H, W):
         assert F.rgbconv_ok(B, H, W, C, torch.bfloat16)
         got, bits = F.RgbConvBlurFn.apply(x_nhwc, d["w0"], d["b0"], d["wr"], d["br"], s0, sr)
         assert got.dtype == torch.bfloat16 and got.shape == (B, H, W, C) and bits.shape == (B, H, W, C // 8)
+        # every row-block size the host may pick by launch size (6 nit - 2 rows per wave, SGX_RGBCONV_NIT is read per launch: partial
+        # last blocks, images of one block) writes the same bits (tools/rgbconv_check.py, profiles/r04_rgbconv_check.txt)
+        for nit in (6, 4, 1):
+            monkeypatch.setenv("SGX_RGBCONV_NIT", str(nit))
+            gn, bn = F.RgbConvBlurFn.apply(x_nhwc, d["w0"], d["b0"], d["wr"], d["br"], s0, sr)
+            assert torch.equal(gn.view(torch.int16), got.view(torch.int16)) and torch.equal(bn, bits), nit
+        monkeypatch.delenv("SGX_RGBCONV_NIT")
         e = rel_err(got.permute(0, 3, 1, 2), xb)
         # the unfused library path in bf16 (from_rgb output rounded, conv0 output rounded, blur output rounded) for scale
         f_old = F.call(F.RgbInFn, x_nhwc, d["wr"], d["br"], sr, torch.bfloat16)
