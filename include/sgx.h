@@ -271,6 +271,11 @@ int sgx_rgbconv_pack(const float* w0, float s0, const float* wr, float sr, const
                      void* stream);
 int sgx_rgbconv_fwd(const float* img, const void* wf, const float* b0, void* y, void* bits, int B, int H, int W, int C, int epi, int ones,
                     int dtype, void* stream);
+/* process-wide A/B and probe state of sgx_rgbconv_fwd's epi 1 kernel (tests, tools/rgbconv_probe.py; initial values from
+ * SGX_RGBCONV_FWD / SGX_RGBCONV_NIT, read once): fwd_variant 0 row-streaming (default), 1 / 2 the LDS-tile kernel with persistent
+ * blocks / one tile per block, -1 = the default;  nit 1..8 = six-row steps per row block, 0 = chosen by launch size;  dbg: profiling
+ * ablations of the row-streaming kernel (4 no output stores, 8 no sign bits -- wrong results by design), 0 = none. */
+int sgx_rgbconv_tune(int fwd_variant, int nit, int dbg);
 int sgx_rgbconv_dgrad(const void* gz, const void* wd, float* gi, int B, int H, int W, int C, int dtype, void* stream);
 size_t sgx_rgbconv_wgrad_ws_bytes(int B, int H, int W, int C);
 int sgx_rgbconv_wgrad(const float* img, const void* gz, int ones, const float* w0, float s0, const float* wr, float sr, const float* br,

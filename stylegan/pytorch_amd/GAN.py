@@ -228,7 +228,8 @@ class GSynthesis(nn.Module):
         if self.structure == 'fixed':
             x = self.init_block.forward_nhwc(dl[0:2], dt)
             rgb, last = self.to_rgb[-1], (self.blocks[-1] if len(self.blocks) else None)
-            fuse_last = F.FUSE_EPI_RGB and last is not None and last.epi2._fusable and rgb.weight.shape[0] == 3
+            fuse_last = (F.FUSE_EPI_RGB and last is not None and last.epi2._fusable and rgb.weight.shape[0] == 3
+                         and F.epi_rgb_out_ok(rgb.weight.shape[1], self.act_dtype))
             for i, block in enumerate(self.blocks):
                 if fuse_last and block is last:
                     # the last epilogue inside to_rgb (functional.EpiRgbOutFn; the same kernel the 'linear' structure ends with)
@@ -246,7 +247,8 @@ class GSynthesis(nn.Module):
                 low = self.to_rgb[depth - 1].forward_nhwc(x)                                      # RGB at the previous resolution
                 rgb = self.to_rgb[depth]
                 last = self.blocks[depth - 1]
-                if F.FUSE_EPI_RGB and FUSE_RGB_FADE and last.epi2._fusable and rgb.weight.shape[0] == 3 and low.dtype == torch.float32:
+                if (F.FUSE_EPI_RGB and FUSE_RGB_FADE and last.epi2._fusable and rgb.weight.shape[0] == 3 and low.dtype == torch.float32
+                        and F.epi_rgb_out_ok(rgb.weight.shape[1], x.dtype)):
                     # the last epilogue inside to_rgb (+ upsample of ``low`` + fade-in lerp): one pass over conv1's output
                     y2, (ebias, noise, nw, style, part) = last.forward_nhwc(x, dl[2 * depth:2 * (depth + 1)], defer_epi2=True)
                     return F.nchw_view(F.call(F.EpiRgbOutFn, y2, ebias, noise, nw, style, rgb.weight, rgb.scaled_bias(), float(rgb.w_mul), low,

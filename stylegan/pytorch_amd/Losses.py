@@ -106,6 +106,14 @@ class RelativisticAverageHingeGAN(GANLoss):
         return self._scaled(torch.mean(TF.relu(1 + r_f_diff)) + torch.mean(TF.relu(1 - f_r_diff)))
 
 
+def logistic_heads(f_preds, r_preds, mean_scale, gen):
+    """The softplus terms of the logistic loss (reference models/Losses.py:216-218,226) and their derivatives in ONE launch
+    (``sgx_logistic_loss``): mean softplus(f) + mean softplus(-r) for the discriminator, mean softplus(-f) for the generator, times
+    ``mean_scale``.  Device tensors only -- there is no host path in the product (the CPU-side data-parallel logic tests install their
+    own stand-in for this function: tests/test_dist_gloo.py)."""
+    return F.call(F.LogisticLossFn, f_preds, r_preds, mean_scale, bool(gen))
+
+
 class LogisticGAN(GANLoss):
     """Non-saturating logistic loss with the R1 gradient penalty -- reference models/Losses.py:192-229.
 
@@ -147,14 +155,9 @@ class LogisticGAN(GANLoss):
             if callable(fake_samps):                  # produced lazily, after D(real)
                 fake_samps = fake_samps()
             f_preds = self.dis(fake_samps, height, alpha)
-        if f_preds.is_cuda:                          # one launch for both terms and their derivatives (sgx_logistic_loss)
-            loss = F.call(F.LogisticLossFn, f_preds, r_preds, self.mean_scale, False)
-        else:                                        # (host tensors: the data-parallel logic tests drive these classes on the CPU)
-            loss = (torch.mean(TF.softplus(f_preds)) + torch.mean(TF.softplus(-r_preds))) * self.mean_scale
+        loss = logistic_heads(f_preds, r_preds, self.mean_scale, False)
         return loss if r1 is None else loss + r1
 
     def gen_loss(self, _, fake_samps, height, alpha):
         f_preds = self.dis(fake_samps, height, alpha)
-        if f_preds.is_cuda:
-            return F.call(F.LogisticLossFn, f_preds, None, self.mean_scale, True)
-        return torch.mean(TF.softplus(-f_preds)) * self.mean_scale
+        return logistic_heads(f_preds, None, self.mean_scale, True)

@@ -152,3 +152,17 @@ extern "C" int sgx_stream_wait_stream(void* waiter, void* signaler) {
     SGX_REQUIRE(e == hipSuccess, (int)e, "stream_wait_stream: %s", hipGetErrorString(e));
     return 0;
 }
+
+// Compute units of the CURRENT device, cached per device id (a process that drives several GPUs sizes each launch for the device it
+// is made on; round 4 cached the first device's count per process).
+int sgx_ncu() {
+    static int cache[32] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+    if (!cache[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        cache[dev] = n;
+    }
+    return cache[dev];
+}

@@ -110,6 +110,7 @@ void sgx_set_error(const char* fmt, ...);
     } while (0)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+int sgx_ncu();                                             // compute units of the current device (api.hip)
 
 // ---- per-launch profiler (sgx_prof_* in include/sgx.h) --------------------------------------
 // Every kernel launch of the library goes through sgx_launch.  When profiling is on it is bracketed by two HIP events

@@ -509,11 +509,7 @@ static int launch_conv(ConvArgs& a, int ngroups, hipStream_t st) {
         if (e && atoi(e) > 0 && atoi(e) < nb) nb = atoi(e);
         return nb;
     }();
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-        return n;
-    }();
+    const int ncu = sgx_ncu();
     const int per_cu = resident;
     const int yz = (a.Cout / (CT * 16)) * Geo<GEO>::NCLS;
     int gx = (ncu * per_cu + yz - 1) / yz;

@@ -682,14 +682,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
     }
 }
 
-static int conv2_ncu() {
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-        return n;
-    }();
-    return ncu;
-}
+static int conv2_ncu() { return sgx_ncu(); }
 
 template <int GEO, int NW, int MF, int KC = 32, bool CO16 = false, int EPI = EPI_NONE>
 static int launch_conv2(Conv2Args& a, hipStream_t st) {

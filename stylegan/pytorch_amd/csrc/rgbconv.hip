@@ -88,7 +88,7 @@ template <int CB, int EPI> struct RcFwd {
     static constexpr int NPX = ZH * ZW, NG = (NPX + 15) / 16;
     static constexpr int IPX = IH * IW + 4;                                // + 4 pixels of padding: the k-group of the last pixel reads 3 beyond
     static constexpr int IMG_BYTES = (IPX * 8 + 15) / 16 * 16;
-    static constexpr int LDS = IMG_BYTES + (EPI ? NPX * C * 2 : 0);
+    static constexpr int LDS = IMG_BYTES + (EPI ? NPX * C * 2 : 16);          // EPI 0: + the four waves' input maxima (power-of-two prescale)
 };
 
 // Tile schedule of the persistent kernels below: the grid is a multiple of 8 blocks; block b runs on XCD b & 7 (round-robin
@@ -157,11 +157,34 @@ __global__ __launch_bounds__(256) void rgbconv_fwd_kernel(const float* __restric
     for (int t = sc.first; t < sc.end; t += sc.stride) {
         int b, ty0, tx0;
         tile_at(t, b, ty0, tx0);
-        // ---- phase A: registers -> LDS as bf16 (r, g, b, 1 | 0); zero outside the image (the convolution's padding)
+        // EPI 0 (the plain convolution: the adjoint's own backward under the R1 double backward) is fed a GRADIENT, not an image:
+        // gamma / B * dD/dimg per pixel is 1e-6..1e-5 at 1024^2, below fp16's normal range (6.1e-5).  The operation is linear, so the
+        // tile is brought into fp16 range by a power of two taken from its own largest magnitude (exact), and the accumulators
+        // are multiplied by the inverse power (exact) before they are rounded to bf16: full fp16 precision relative to the tile's
+        // maximum whatever the magnitude of the input -- what fp32 operands would give up to 2^-11 of the largest neighbour
+        float in_scale = 1.f, out_scale = 1.f;
+        if constexpr (EPI == 0) {
+            float am = 0.f;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) am = fmaxf(fmaxf(am, fabsf(pv[it].r)), fmaxf(fabsf(pv[it].g), fabsf(pv[it].b)));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+            float* amx = reinterpret_cast<float*>(smem + G::IMG_BYTES);
+            if (lane == 0) amx[wave] = am;
+            __syncthreads();                               // (every thread read the previous tile's maxima before that tile's staging barrier)
+            am = fmaxf(fmaxf(amx[0], amx[1]), fmaxf(amx[2], amx[3]));
+            const int e = (int)((__float_as_uint(am) >> 23) & 0xffu);          // am in [2^(e-127), 2^(e-126))
+            int se = e == 0 ? 127 : 127 + 14 - (e - 127);                       // scale = 2^(14 - (e - 127)): am * scale in [2^14, 2^15)
+            se = se < 1 ? 1 : (se > 253 ? 253 : se);
+            in_scale = __uint_as_float((unsigned)se << 23);
+            out_scale = __uint_as_float((unsigned)(254 - se) << 23);
+        }
+        // ---- phase A: registers -> LDS as fp16 (r, g, b, 1 | 0); zero outside the image (the convolution's padding)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = it * 256 + tid;
-            if (idx < IPX) imgl[idx] = make_uint2(pack_f16x2(pv[it].r, pv[it].g), pack_f16x2(pv[it].b, (((okm >> it) & 1u) && ones) ? 1.f : 0.f));
+            if (idx < IPX) imgl[idx] = make_uint2(pack_f16x2(pv[it].r * in_scale, pv[it].g * in_scale),
+                                                  pack_f16x2(pv[it].b * in_scale, (((okm >> it) & 1u) && ones) ? 1.f : 0.f));
         }
         __syncthreads();                                   // the region is staged; everybody is done with the previous tile's blur
         if (t + sc.stride < sc.end) load_tile(t + sc.stride);
@@ -188,7 +211,7 @@ __global__ __launch_bounds__(256) void rgbconv_fwd_kernel(const float* __restric
                 if constexpr (EPI == 0) {
                     if (inimg)
                         *reinterpret_cast<uint2*>(y + (((size_t)b * H + gy) * W + gx) * C + cb * 16 + 4 * l4) =
-                            make_uint2(pack_bf16x2(acc[cb][0], acc[cb][1]), pack_bf16x2(acc[cb][2], acc[cb][3]));
+                            make_uint2(pack_bf16x2(acc[cb][0] * out_scale, acc[cb][1] * out_scale), pack_bf16x2(acc[cb][2] * out_scale, acc[cb][3] * out_scale));
                 } else {
                     // pre-activation + bias -> LeakyReLU; positions outside the image are the BLUR's zero padding
                     const float a0 = inimg ? lrelu(acc[cb][0] + bias[cb].x) : 0.f, a1 = inimg ? lrelu(acc[cb][1] + bias[cb].y) : 0.f;
@@ -689,14 +712,7 @@ extern "C" int sgx_rgbconv_pack(const float* w0, float s0, const float* wr, floa
 
 // persistent grid: as many blocks as fit the chip at once (by LDS; at most 4 per CU), a multiple of 8 (one share per XCD), not
 // more than there are tiles
-static int rc_ncu() {
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-        return n;
-    }();
-    return ncu;
-}
+static int rc_ncu() { return sgx_ncu(); }
 template <typename K>
 static int rc_per_cu(K kern, int lds_bytes) {              // resident 256-thread blocks per CU (registers AND LDS), at most 4
     int n = 0;
@@ -722,11 +738,38 @@ static int launch_rgbconv_fwd(const float* img, const bf16_t* wf, const float* b
     SGX_LAUNCH_CHECK("rgbconv_fwd_kernel");
     return 0;
 }
+// A/B and probe state of the forward kernel.  Read from the environment ONCE per process (SGX_RGBCONV_FWD: 0 row-streaming kernel,
+// 1 LDS-tile kernel with persistent blocks, 2 LDS-tile kernel with one tile per block; SGX_RGBCONV_NIT: 6-row steps per row block,
+// 1..8), changed afterwards only through sgx_rgbconv_tune (tests, tools/rgbconv_probe.py): no getenv on the launch path, and the
+// profiling ablations (`dbg`: 4 no output stores, 8 no sign bits -- WRONG results by design) cannot be switched on by a stray
+// environment variable.
+struct RcTune { int fwd, nit, dbg; };
+static RcTune& rc_tune() {
+    static RcTune t = [] {
+        RcTune r{RC_FWD_DEFAULT, 0, 0};
+        const char* ve = getenv("SGX_RGBCONV_FWD");
+        if (ve && atoi(ve) >= 0 && atoi(ve) <= 2) r.fwd = atoi(ve);
+        const char* ne = getenv("SGX_RGBCONV_NIT");
+        if (ne && atoi(ne) >= 1 && atoi(ne) <= 8) r.nit = atoi(ne);
+        return r;
+    }();
+    return t;
+}
+extern "C" int sgx_rgbconv_tune(int fwd_variant, int nit, int dbg) {
+    SGX_REQUIRE(fwd_variant >= -1 && fwd_variant <= 2, SGX_EINVAL, "rgbconv_tune: forward variant %d (0..2, -1 = the default)", fwd_variant);
+    SGX_REQUIRE(nit >= 0 && nit <= 8, SGX_EINVAL, "rgbconv_tune: %d six-row steps per row block (1..8, 0 = by launch size)", nit);
+    SGX_REQUIRE(dbg == 0 || dbg == 4 || dbg == 8 || dbg == 12, SGX_EINVAL, "rgbconv_tune: ablation mask %d", dbg);
+    RcTune& t = rc_tune();
+    t.fwd = fwd_variant < 0 ? RC_FWD_DEFAULT : fwd_variant; t.nit = nit; t.dbg = dbg;
+    return 0;
+}
+
 extern "C" int sgx_rgbconv_fwd(const float* img, const void* wf, const float* b0, void* y, void* bits, int B, int H, int W, int C, int epi, int ones,
                                int dtype, void* stream) {
     SGX_REQUIRE(img && wf && y, SGX_EINVAL, "rgbconv_fwd: null argument");
     SGX_REQUIRE(rgbconv_shape_ok(B, H, W, C, dtype), SGX_EUNSUPPORTED, "rgbconv_fwd: shape B%d %dx%d C%d dtype %d (sgx_rgbconv_ok == 0)", B, H, W, C, dtype);
     SGX_REQUIRE(epi == 0 || epi == 1, SGX_EINVAL, "rgbconv_fwd: epilogue %d", epi);
+    SGX_REQUIRE(epi == 1 || !ones, SGX_EINVAL, "rgbconv_fwd: the plain convolution prescales its input (a gradient) by a power of two; it has no bias channel");
     const double px = (double)B * H * W;
     SGX_NOTE(2.0 * 27 * C * px, px * (12.0 + 2.0 * C + (epi && bits ? C / 8.0 : 0.0)), "rgbconv%s B%d %dx%d 3->%d", epi ? "+act+blur" : "", B, H, W, C);
     hipStream_t st = (hipStream_t)stream;
@@ -736,23 +779,20 @@ extern "C" int sgx_rgbconv_fwd(const float* img, const void* wf, const float* b0
     if (epi) {
         // A/B (read per launch: tools/rgbconv_probe.py): 0 = row-streaming kernel, 1 = LDS-tile kernel with persistent blocks, 2 = LDS-tile
         // kernel with one tile per block
-        const char* ve = getenv("SGX_RGBCONV_FWD");
-        const int variant = ve ? atoi(ve) : RC_FWD_DEFAULT;
+        const int variant = rc_tune().fwd;
         if (variant) return C == 16 ? launch_rgbconv_fwd<1, 1>(img, w, b0, out, bt, B, H, W, ones, st, variant == 2)
                                     : launch_rgbconv_fwd<2, 1>(img, w, b0, out, bt, B, H, W, ones, st, variant == 2);
         // rows per block 6 nit - 2 (two halo rows per block are recomputed): 34 where that still leaves > 3 waves per SIMD slot of the
         // chip, 22 / 16 for small launches (batch 4 at 1024^2: 14k / 19k waves)          SGX_RGBCONV_NIT overrides (probe)
         const int nstrips = (W + RC_STRIP - 1) / RC_STRIP;
-        const char* ne = getenv("SGX_RGBCONV_NIT");
-        int nit = ne ? atoi(ne) : 6;
-        if (!ne) {
+        const int nit_env = rc_tune().nit;                  // 1..8 overrides the row-block heuristic (sgx_rgbconv_tune)
+        int nit = nit_env ? nit_env : 6;
+        if (!nit_env) {
             while (nit > 3 && (long)B * nstrips * ((H + 6 * nit - 3) / (6 * nit - 2)) < 3L * 256 * 24) --nit;
         }
-        if (nit < 1) nit = 1;
         const int rb = 6 * nit - 2, nrb = (H + rb - 1) / rb;
         const unsigned grid = (unsigned)((((long)B * nstrips * nrb + 3) / 4 + 7) / 8 * 8);      // (rc_xcd_block)
-        const char* de = getenv("SGX_RGBCONV_DBG");
-        const int dbg = de ? atoi(de) : 0;
+        const int dbg = rc_tune().dbg;                      // profiling ablations: only through sgx_rgbconv_tune, never from the environment
         if (C == 16) hipLaunchKernelGGL((rgbconv_fwdblur_kernel<1>), dim3(grid), dim3(256), 0, st, img, w, b0, out, bt, B, H, W, ones, nstrips, nrb, nit, dbg);
         else hipLaunchKernelGGL((rgbconv_fwdblur_kernel<2>), dim3(grid), dim3(256), 0, st, img, w, b0, out, bt, B, H, W, ones, nstrips, nrb, nit, dbg);
         SGX_LAUNCH_CHECK("rgbconv_fwdblur_kernel");

@@ -495,14 +495,7 @@ __global__ __launch_bounds__(512, 2) void wgrad16_s_kernel(Wg2Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------- host side
-static int wg2_ncu() {
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-        return n;
-    }();
-    return ncu;
-}
+static int wg2_ncu() { return sgx_ncu(); }
 static int wg2_switch() {                        // SGX_WGRAD2: bit 0 = the 3x3 geometry, bit 1 = the 4x4 stride-2 geometry, bit 2 = 3x3 16x16 channels (A/B)
     static const int on = [] { const char* e = getenv("SGX_WGRAD2"); return e ? atoi(e) : 7; }();
     return on;

@@ -357,31 +357,33 @@ class ConvFn(Function):
         geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
         ctx.cfg = (mode, scale, ipad, adjoint, act, bias is not None, bool(defer_act), bool(x_masked))
         ctx.bias_ref = weakref.ref(bias) if bias is not None else (lambda: None)
-        ctx.x_pre, ctx.x_pre_bits = x_pre, x_pre_bits
         # (two outputs: without this the engine hands backward a freshly zero-filled "gradient" of the non-differentiable one --
         # a fill kernel per call, 20 a step)
         ctx.set_materialize_grads(False)
+        # saved-tensor layout shared with ConvBlurFn / ConvDownFadeFn (their backward ends in ConvFn.backward on the same ctx):
+        # (x, weight, y | None, mask | None, x_pre | None, x_pre_bits | None, ...).  x_pre / x_pre_bits are SAVED, not plain ctx
+        # attributes: an in-place write to them between forward and backward is then caught by autograd's version check
         if bits_out:
             assert geo == "S" and not adjoint and stats is None
             y, bits = _conv_bits_launch(x, fwd, None if bias is None else _c(bias.detach()), act, mask)
             ctx.mark_non_differentiable(bits)
-            ctx.save_for_backward(x, weight, y if (act and not defer_act) else None, mask)
+            ctx.save_for_backward(x, weight, y if (act and not defer_act) else None, mask, x_pre, x_pre_bits)
             return y, bits
         if stats is not None:
             assert geo == "S" and not adjoint and bias is None and act == 0 and mask is None
             y, part = _conv_stats_launch(x, fwd, *stats)
             ctx.mark_non_differentiable(part)
-            ctx.save_for_backward(x, weight, None, None)
+            ctx.save_for_backward(x, weight, None, None, x_pre, x_pre_bits)
             return y, part
         y = _conv_launch(geo, x, adj if adjoint else fwd, None if bias is None else _c(bias.detach()), act, mask)
-        ctx.save_for_backward(x, weight, y if (act and not defer_act) else None, mask)
+        ctx.save_for_backward(x, weight, y if (act and not defer_act) else None, mask, x_pre, x_pre_bits)
         return y
 
     @staticmethod
     def backward(ctx, gy, _gpart=None):
         if gy is None:                                        # (only a non-differentiable output was "used")
             return (None,) * 15
-        x, weight, y, mask = ctx.saved_tensors
+        x, weight, y, mask, x_pre, xb = ctx.saved_tensors[:6]
         mode, scale, ipad, adjoint, act, has_bias, defer_act, x_masked = ctx.cfg
         gy = _c(gy)
         if mask is not None:                                  # adjoint of the output mask (reached by the R1 double backward only)
@@ -389,8 +391,6 @@ class ConvFn(Function):
         if act and not defer_act:
             gy = _bcall(LReluBwdFn, gy, y, 0.2, 1.0)
         gx = gw = gb = None
-        x_pre = getattr(ctx, "x_pre", None)
-        xb = getattr(ctx, "x_pre_bits", None)
         if ctx.needs_input_grad[0]:
             if x_pre is not None or xb is not None:
                 assert not x_masked
@@ -486,16 +486,15 @@ class ConvBlurFn(Function):
                                                   N.dt(x), N.stream()), "sgx_conv4x4s2_up_blur")
         ctx.cfg = (mode, scale, ipad, adjoint, 0, False, False, False)
         ctx.bias_ref = lambda: None
-        ctx.x_pre = None
-        ctx.save_for_backward(x, weight, None, None)
-        ctx.z, ctx.zbits = z, zbits
+        ctx.save_for_backward(x, weight, None, None, None, None, z, zbits)       # (ConvFn's layout + the mask and its sign bits)
         return y
 
     @staticmethod
     def backward(ctx, gg):
         gg = _c(gg)
-        masked = ctx.z is not None or ctx.zbits is not None
-        m = _bcall(MaskBlurFn, gg, ctx.z, ctx.zbits) if masked else _bcall(BlurFn, gg)
+        z, zbits = ctx.saved_tensors[6:8]
+        masked = z is not None or zbits is not None
+        m = _bcall(MaskBlurFn, gg, z, zbits) if masked else _bcall(BlurFn, gg)
         out = ConvFn.backward(ctx, m)                      # (gx, gw, gb, ...): same saved tensors / cfg layout
         return out[0], out[1], None, None, None, None, None, None
 
@@ -652,16 +651,19 @@ def _rgb_wgrad(img, gz, ones, w0, b0, wr, br, s0, sr, want):
     if not any(want):
         return None, None, None, None
     accum = _ACCUM_PARAM_GRADS and not torch.is_grad_enabled() and all(p.is_leaf for p, w in zip(params, want) if w)
-    outs, acc = [], 0
-    for k, (p, w) in enumerate(zip(params, want)):
-        if not w:
-            outs.append(None)
-        elif accum and p.grad is not None:
-            outs.append(p.grad); acc |= 1 << k
-        else:
-            outs.append(torch.empty(p.shape, dtype=torch.float32, device=gz.device))
+    outs, acc, fresh = [None] * 4, 0, []
 
     def launch():
+        # new gradient tensors are allocated HERE, i.e. under the stream that writes them (the side stream when forked, as in
+        # _param_grads), and the consumer stream is recorded afterwards -- not allocated under the current stream and recorded on it
+        nonlocal acc
+        for k, (p, w) in enumerate(zip(params, want)):
+            if not w:
+                continue
+            if accum and p.grad is not None:
+                outs[k] = p.grad; acc |= 1 << k
+            else:
+                outs[k] = torch.empty(p.shape, dtype=torch.float32, device=gz.device); fresh.append(outs[k])
         L = N.lib()
         B, H, W, C = gz.shape
         wsb = L.sgx_rgbconv_wgrad_ws_bytes(B, H, W, C)
@@ -673,6 +675,14 @@ def _rgb_wgrad(img, gz, ones, w0, b0, wr, br, s0, sr, want):
     cur_raw = N.stream()
     if side is None or side.cuda_stream == cur_raw:
         launch()
+    elif not _FAST_FORK or _set_stream is None:                # A/B (SGX_FAST_FORK=0) / a torch without the raw setter: the torch-level fork
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            launch()
+        img.record_stream(side); gz.record_stream(side)
+        for o in fresh:
+            o.record_stream(cur)
     else:                                                      # as _param_grads: fork to the side stream on raw handles
         cur = _stream_of(cur_raw)
         N.check(N.lib().sgx_stream_wait_stream(side.cuda_stream, cur_raw), "sgx_stream_wait_stream")
@@ -682,9 +692,8 @@ def _rgb_wgrad(img, gz, ones, w0, b0, wr, br, s0, sr, want):
         finally:
             _set_stream(stream_id=cur.stream_id, device_index=cur.device_index, device_type=cur.device_type)
         img.record_stream(side); gz.record_stream(side)
-        for o in outs:
-            if o is not None:
-                o.record_stream(cur)
+        for o in fresh:
+            o.record_stream(cur)
     if not accum:
         return tuple(outs)
     for p, w, o in zip(params, want, outs):
@@ -895,15 +904,17 @@ class ConvDownFadeFn(Function):
         # ConvFn.backward's view of this op: the stride-2 layer with its activation already undone (see backward)
         ctx.cfg = ("D", scale, ipad, False, 0, bias is not None, False, False)
         ctx.bias_ref = weakref.ref(bias) if bias is not None else (lambda: None)
-        ctx.x_pre, ctx.x_pre_bits = x_pre, x_pre_bits
-        ctx.fade = (alpha, None, bits) if dev else (float(alpha), float(beta), bits)
-        ctx.save_for_backward(x, weight, None, None)
+        ctx.fade = (None, None) if dev else (float(alpha), float(beta))
+        ctx.save_for_backward(x, weight, None, None, x_pre, x_pre_bits, bits, alpha if dev else None)   # (ConvFn's layout + bits, device coefficients)
         return y
 
     @staticmethod
     def backward(ctx, g):
         g = _c(g)
-        alpha, beta, bits = ctx.fade
+        bits, alpha_dev = ctx.saved_tensors[6:8]
+        alpha, beta = ctx.fade
+        if alpha_dev is not None:
+            alpha = alpha_dev
         g_res = None
         if isinstance(alpha, torch.Tensor):
             if ctx.needs_input_grad[3]:
@@ -1423,6 +1434,17 @@ class GEpilogueFn(Function):
 
 
 FUSE_EPI_RGB = os.environ.get("SGX_FUSE_EPI_RGB", "1") != "0"    # A/B: the last generator epilogue inside to_rgb (EpiRgbOutFn)
+
+
+def epi_rgb_out_ok(C, dtype):
+    """The widths ``sgx_rgb_out_epi`` / ``sgx_rgb_wgrad_epi`` take (the checks at the top of those entry points): whole 16-byte channel
+    vectors, min(vectors per pixel, 16) a power of two, at most 2048 channels.  Other widths (non-default ``fmap`` settings: C = 24,
+    48 ...) run the epilogue and to_rgb as separate passes instead of raising."""
+    ve = 4 if dtype == torch.float32 else 8
+    if dtype not in (torch.float32, torch.bfloat16) or C % ve or C > 2048:
+        return False
+    lpp = min(C // ve, 16)
+    return lpp & (lpp - 1) == 0
 
 
 class EpiRgbOutFn(Function):

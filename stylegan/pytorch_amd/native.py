@@ -87,6 +87,7 @@ SIGNATURES = {
     "sgx_rgbconv_ok": (I, [I, I, I, I, I]),
     "sgx_rgbconv_pack": (I, [P, F, P, F, P, F, P, P, I, P]),
     "sgx_rgbconv_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "sgx_rgbconv_tune": (I, [I, I, I]),
     "sgx_rgbconv_dgrad": (I, [P, P, P, I, I, I, I, I, P]),
     "sgx_rgbconv_wgrad_ws_bytes": (Z, [I, I, I, I]),
     "sgx_rgbconv_wgrad": (I, [P, P, I, P, F, P, F, P, F, P, P, P, P, I, P, Z, I, I, I, I, I, P]),

@@ -172,6 +172,14 @@ LOSS_HEADS = ["logistic", "hinge", "standard-gan", "relativistic-hinge", "condit
 def _head(name, dis, mean_scale, group):
     from stylegan.pytorch_amd import Losses
     if name == "logistic":
+        # the product evaluates the softplus terms in one HIP launch and has no host path: on the CPU this test stands in for that
+        # kernel with the formula it implements (reference models/Losses.py:216-218,226) -- what is under test here is the class's
+        # data-parallel scaling around it
+        def _cpu_logistic_heads(f_preds, r_preds, ms, gen):
+            if gen:
+                return torch.mean(TF.softplus(-f_preds)) * ms
+            return (torch.mean(TF.softplus(f_preds)) + torch.mean(TF.softplus(-r_preds))) * ms
+        Losses.logistic_heads = _cpu_logistic_heads
         return Losses.LogisticGAN(dis, mean_scale=mean_scale)
     if name == "hinge":
         return Losses.HingeGAN(dis, mean_scale=mean_scale)

@@ -150,34 +150,54 @@ def run_step(sg, cfg):
     return z, real, d_loss, g_loss, d_grads, g_grads
 
 
+def decoupled_oracle(cfg, gp, dp):
+    """The fp64 oracle's half of ``decoupled_step``: one D+G iteration on (gp, dp) (updated in place, as the step does), with the
+    discriminator's parameters right after ITS update kept aside -> dict(od, odg, dp_after, og, ogg).  Cacheable: nothing in it
+    depends on the HIP path."""
+    B, depth, R = cfg["batch"], cfg["depth"], cfg["resolution"]
+    z = gu.seeded((B, 512), 21); real = gu.seeded((B, 3, R, R), 22)
+    kw = dict(total_depth=cfg["total_depth"], mapping_layers=cfg["mapping_layers"], noises=noises(cfg, torch.float64), truncation_psi=cfg["psi"])
+    shadow = {k: v.detach().clone() for k, v in gp.items()}
+    avg0 = gp["truncation.avg_latent"].detach().clone() if "truncation.avg_latent" in gp else None
+    torch.manual_seed(77); random.seed(77)
+    l2, cut = O.draw_mixing(z.shape, depth)
+    od, odg = O.d_step(gp, dp, O.AdamState(), z.double(), real.double(), depth, ALPHA, latents2=l2.double(), mixing_cutoff=cut, **kw)
+    dp_after = {k: v.detach().clone() for k, v in dp.items()}
+    avg1 = gp["truncation.avg_latent"].detach().clone() if avg0 is not None else None
+    torch.manual_seed(78); random.seed(78)
+    l2, cut = O.draw_mixing(z.shape, depth)
+    og, ogg = O.g_step(gp, dp, O.AdamState(), z.double(), depth, ALPHA, latents2=l2.double(), mixing_cutoff=cut, shadow=shadow, **kw)
+    return dict(od=od, odg=odg, dp_after=dp_after, og=og, ogg=ogg, avg_after_d=avg1)
+
+
+def decoupled_hip(sg, cfg, oracle):
+    """The HIP path's half: D step, then the ORACLE's updated discriminator is loaded, then the G step -> (z, real, d_loss, g_loss,
+    d_grads, g_grads)."""
+    from stylegan.pytorch_amd import functional as F
+    B, depth, R = cfg["batch"], cfg["depth"], cfg["resolution"]
+    z = gu.seeded((B, 512), 21); real = gu.seeded((B, 3, R, R), 22)
+    torch.manual_seed(77); random.seed(77)
+    d_loss = float(sg.optimize_discriminator(z.to(DEV), real.to(DEV), depth, ALPHA))
+    d_grads = {k: p.grad.detach().clone() for k, p in sg.dis.named_parameters() if p.grad is not None}
+    load_into(sg.dis, oracle["dp_after"])                            # the oracle's D after ITS update
+    F.bump_weight_generation()
+    if sg.gen.truncation is not None and oracle["avg_after_d"] is not None:
+        sg.gen.truncation.avg_latent.copy_(oracle["avg_after_d"].float())          # (the D half's generator forward moved it: same value both sides)
+    torch.manual_seed(78); random.seed(78)
+    g_loss = float(sg.optimize_generator(z.to(DEV), real.to(DEV), depth, ALPHA))
+    g_grads = {k: p.grad.detach().clone() for k, p in sg.gen.named_parameters() if p.grad is not None}
+    return z, real, d_loss, g_loss, d_grads, g_grads
+
+
 def decoupled_step(sg, cfg, gp, dp):
     """One D+G iteration of the HIP path and of the fp64 oracle with the generator half DECOUPLED from the discriminator update:
     after both discriminator steps the oracle's updated D parameters are loaded into the HIP discriminator, so that the G half
     measures the arithmetic of the G step on identical D weights.  (Coupled, Adam at beta1 = 0 turns every near-zero D gradient whose
     sign a rounding flips into a +-lr parameter difference, and the G gradients then differ by that chaos -- 0.12..0.15 median rel-L2
     whatever the kernels do -- instead of by their own error.)  -> (z, real, d_loss, g_loss, d_grads, g_grads, od, og, odg, ogg)."""
-    from stylegan.pytorch_amd import functional as F
-    B, depth, R = cfg["batch"], cfg["depth"], cfg["resolution"]
-    z = gu.seeded((B, 512), 21); real = gu.seeded((B, 3, R, R), 22)
-    kw = dict(total_depth=cfg["total_depth"], mapping_layers=cfg["mapping_layers"], noises=noises(cfg, torch.float64), truncation_psi=cfg["psi"])
-    shadow = {k: v.detach().clone() for k, v in gp.items()}
-    torch.manual_seed(77); random.seed(77)
-    d_loss = float(sg.optimize_discriminator(z.to(DEV), real.to(DEV), depth, ALPHA))
-    d_grads = {k: p.grad.detach().clone() for k, p in sg.dis.named_parameters() if p.grad is not None}
-    torch.manual_seed(77); random.seed(77)
-    l2, cut = O.draw_mixing(z.shape, depth)
-    od, odg = O.d_step(gp, dp, O.AdamState(), z.double(), real.double(), depth, ALPHA, latents2=l2.double(), mixing_cutoff=cut, **kw)
-    load_into(sg.dis, dp)                                            # the oracle's D after ITS update
-    F.bump_weight_generation()
-    if sg.gen.truncation is not None and "truncation.avg_latent" in gp:
-        sg.gen.truncation.avg_latent.copy_(gp["truncation.avg_latent"].float())     # (the D half's generator forward moved it: same value both sides)
-    torch.manual_seed(78); random.seed(78)
-    g_loss = float(sg.optimize_generator(z.to(DEV), real.to(DEV), depth, ALPHA))
-    g_grads = {k: p.grad.detach().clone() for k, p in sg.gen.named_parameters() if p.grad is not None}
-    torch.manual_seed(78); random.seed(78)
-    l2, cut = O.draw_mixing(z.shape, depth)
-    og, ogg = O.g_step(gp, dp, O.AdamState(), z.double(), depth, ALPHA, latents2=l2.double(), mixing_cutoff=cut, shadow=shadow, **kw)
-    return z, real, d_loss, g_loss, d_grads, g_grads, od, og, odg, ogg
+    o = decoupled_oracle(cfg, gp, dp)
+    z, real, d_loss, g_loss, d_grads, g_grads = decoupled_hip(sg, cfg, o)
+    return z, real, d_loss, g_loss, d_grads, g_grads, o["od"], o["og"], o["odg"], o["ogg"]
 
 
 def oracle_step(cfg, gp, dp, z, real, dtype=torch.float64):

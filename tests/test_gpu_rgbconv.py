@@ -51,6 +51,7 @@ CASES = [(16, 2, 32, 64), (16, 1, 48, 192), (32, 2, 16, 64), (32, 1, 48, 128), (
 @pytest.mark.parametrize("C,B,H,W", CASES)
 def test_forward_blur_and_sign_bits_vs_oracle(C, B, H, W, monkeypatch):
     from stylegan.pytorch_amd import functional as F
+    from stylegan.pytorch_amd import native as N
     p = make_params(C)
     d = dev_params(p)
     img = gu.seeded((B, 3, H, W), 21, torch.float64)
@@ -61,13 +62,13 @@ def test_forward_blur_and_sign_bits_vs_oracle(C, B, H, W, monkeypatch):
         assert F.rgbconv_ok(B, H, W, C, torch.bfloat16)
         got, bits = F.RgbConvBlurFn.apply(x_nhwc, d["w0"], d["b0"], d["wr"], d["br"], s0, sr)
         assert got.dtype == torch.bfloat16 and got.shape == (B, H, W, C) and bits.shape == (B, H, W, C // 8)
-        # every row-block size the host may pick by launch size (6 nit - 2 rows per wave, SGX_RGBCONV_NIT is read per launch: partial
+        # every row-block size the host may pick by launch size (6 nit - 2 rows per wave, sgx_rgbconv_tune: partial
         # last blocks, images of one block) writes the same bits (tools/rgbconv_check.py, profiles/r04_rgbconv_check.txt)
         for nit in (6, 4, 1):
-            monkeypatch.setenv("SGX_RGBCONV_NIT", str(nit))
+            N.check(N.lib().sgx_rgbconv_tune(-1, nit, 0), "sgx_rgbconv_tune")
             gn, bn = F.RgbConvBlurFn.apply(x_nhwc, d["w0"], d["b0"], d["wr"], d["br"], s0, sr)
             assert torch.equal(gn.view(torch.int16), got.view(torch.int16)) and torch.equal(bn, bits), nit
-        monkeypatch.delenv("SGX_RGBCONV_NIT")
+        N.check(N.lib().sgx_rgbconv_tune(-1, 0, 0), "sgx_rgbconv_tune")
         e = rel_err(got.permute(0, 3, 1, 2), xb)
         # the unfused library path in bf16 (from_rgb output rounded, conv0 output rounded, blur output rounded) for scale
         f_old = F.call(F.RgbInFn, x_nhwc, d["wr"], d["br"], sr, torch.bfloat16)
@@ -105,6 +106,22 @@ def test_plain_convolution_and_image_gradient_vs_oracle(C, B, H, W):
         e_g = rel_err(got_gi.permute(0, 3, 1, 2), gi)
     print(f"[rgbconv C{C}] plain conv rel {e_z:.2e}, image gradient rel {e_g:.2e}")
     assert e_z <= 6e-3 and e_g <= 6e-3, (e_z, e_g)
+    # The plain convolution's real input is not an image but the R1 double backward's second-order gradient w.r.t. the image,
+    # gamma / B * dD/dimg per pixel: 1e-6..1e-5 at 1024^2, below fp16's normal range (6.1e-5; the forward kernels take fp16
+    # operands).  The kernel prescales each tile by a power of two from its own maximum: the relative error must not depend on the
+    # magnitude of the input -- at any scale, and with the scale varying from tile to tile by orders of magnitude.
+    with torch.no_grad():
+        for scale in (1e-6, 3e-9, 1e-30, 2e4):
+            got = F.RgbConvPlainFn.apply(x_nhwc * scale, d["w0"], d["wr"], d["br"], s0, sr)
+            e = rel_err(got.permute(0, 3, 1, 2), z * scale)
+            print(f"[rgbconv C{C}] plain conv of an input of magnitude {scale:g}: rel {e:.2e}")
+            assert e <= 1.25 * e_z + 1e-4, (scale, e, e_z)
+        ramp = torch.logspace(-8, 0, W, dtype=torch.float64)[None, None, None, :]          # eight decades across the row: every 64-column tile at its own scale
+        got = F.RgbConvPlainFn.apply((img.detach() * ramp).float().permute(0, 2, 3, 1).contiguous().to(DEV), d["w0"], d["wr"], d["br"], s0, sr)
+        zr, _ = chain64(img.detach() * ramp, p, bias=False)
+        for c0 in range(0, W, 64):
+            e = rel_err(got.permute(0, 3, 1, 2)[..., c0 + 1:c0 + 63], zr[..., c0 + 1:c0 + 63])
+            assert e <= 1.5 * e_z + 1e-4, (c0, e, e_z)
 
 
 @pytest.mark.parametrize("C,B,H,W", [(16, 2, 32, 64), (32, 3, 32, 128), (16, 5, 64, 256)])

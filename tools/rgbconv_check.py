@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Row-streaming forward of the composed first layer against the LDS-tile kernel (SGX_RGBCONV_FWD=1, an independent implementation of
+"""Row-streaming forward of the composed first layer against the LDS-tile kernel (sgx_rgbconv_tune(1, 0, 0), an independent implementation of
 the same result) and against torch fp64, by image region.   python tools/rgbconv_check.py"""
 import os
 import sys
@@ -9,6 +9,7 @@ import torch  # noqa: E402
 import torch.nn.functional as TF  # noqa: E402
 
 from stylegan.pytorch_amd import functional as F  # noqa: E402
+from stylegan.pytorch_amd import native as N  # noqa: E402
 
 
 def main():
@@ -19,18 +20,17 @@ def main():
         s0, sr = (2.0 / (C * 9)) ** 0.5, (1.0 / 3) ** 0.5
         img = torch.randn(B, H, W, 3, device=dev).clamp(-1, 1)
         with torch.no_grad():
-            os.environ.pop("SGX_RGBCONV_FWD", None)
+            N.check(N.lib().sgx_rgbconv_tune(-1, 0, 0), "sgx_rgbconv_tune")
             y, bits = F.RgbConvBlurFn.apply(img, w0, b0, wr, br, s0, sr)
             # every row-block size (6 nit - 2 rows; the host picks by launch size: partial last blocks, one-block images) writes the same bits
             for nit in (6, 5, 4, 3, 2, 1):
-                os.environ["SGX_RGBCONV_NIT"] = str(nit)
+                N.check(N.lib().sgx_rgbconv_tune(-1, nit, 0), "sgx_rgbconv_tune")
                 yn, bn = F.RgbConvBlurFn.apply(img, w0, b0, wr, br, s0, sr)
                 same = torch.equal(yn.view(torch.int16), y.view(torch.int16)) and torch.equal(bn, bits)
                 print(f"  B{B} {H}x{W} C{C} rows per block {6 * nit - 2}: {'identical to the default' if same else 'DIFFERENT from the default'}")
-            os.environ.pop("SGX_RGBCONV_NIT")
-            os.environ["SGX_RGBCONV_FWD"] = "1"
+            N.check(N.lib().sgx_rgbconv_tune(1, 0, 0), "sgx_rgbconv_tune")
             y1, bits1 = F.RgbConvBlurFn.apply(img, w0, b0, wr, br, s0, sr)
-            os.environ.pop("SGX_RGBCONV_FWD")
+            N.check(N.lib().sgx_rgbconv_tune(-1, 0, 0), "sgx_rgbconv_tune")
             x = img.double().permute(0, 3, 1, 2)
             t = TF.conv2d(x, wr.double() * sr, br.double())
             t = TF.conv2d(t, w0.double() * s0, b0.double(), padding=1)

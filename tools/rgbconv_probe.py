@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the kernels of csrc/rgbconv.hip alone (the discriminator's composed first layer) at the benchmark shapes, with the
-ablation switches of the forward kernel (SGX_RGBCONV_DBG is read at every launch).   python tools/rgbconv_probe.py [B ...]"""
+ablation switches of the forward kernel (set through sgx_rgbconv_tune).   python tools/rgbconv_probe.py [B ...]"""
 import os
 import sys
 
@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from stylegan.pytorch_amd import functional as F  # noqa: E402
+from stylegan.pytorch_amd import native as N  # noqa: E402
 
 
 def timeit(fn, n=20):
@@ -33,20 +34,20 @@ def main():
         rows = []
         with torch.no_grad():
             for dbg, what in ((0, "forward + act + blur + bits"), (8, "  no sign bits"), (4, "  no output stores"), (12, "  no stores at all")):
-                os.environ["SGX_RGBCONV_DBG"] = str(dbg)
+                N.check(N.lib().sgx_rgbconv_tune(-1, 0, dbg), "sgx_rgbconv_tune")
                 us = timeit(lambda: F.RgbConvBlurFn.apply(img, w0, b0, wr, br, 0.1, 0.5))
                 rows.append((what, us, px * 46.0 / us / 1e6))
-            os.environ["SGX_RGBCONV_DBG"] = "0"
+            N.check(N.lib().sgx_rgbconv_tune(-1, 0, 0), "sgx_rgbconv_tune")
             for nit in (3, 4, 5, 6, 8):
-                os.environ["SGX_RGBCONV_NIT"] = str(nit)
+                N.check(N.lib().sgx_rgbconv_tune(-1, nit, 0), "sgx_rgbconv_tune")
                 us = timeit(lambda: F.RgbConvBlurFn.apply(img, w0, b0, wr, br, 0.1, 0.5))
                 rows.append((f"  {6 * nit - 2} rows per wave", us, px * 46.0 / us / 1e6))
-            os.environ.pop("SGX_RGBCONV_NIT")
+            N.check(N.lib().sgx_rgbconv_tune(-1, 0, 0), "sgx_rgbconv_tune")
             for v, what in ((1, "forward, LDS-tile kernel, persistent blocks"), (2, "forward, LDS-tile kernel, one tile per block")):
-                os.environ["SGX_RGBCONV_FWD"] = str(v)
+                N.check(N.lib().sgx_rgbconv_tune(v, 0, 0), "sgx_rgbconv_tune")
                 us = timeit(lambda: F.RgbConvBlurFn.apply(img, w0, b0, wr, br, 0.1, 0.5))
                 rows.append((what, us, px * 46.0 / us / 1e6))
-            os.environ.pop("SGX_RGBCONV_FWD")
+            N.check(N.lib().sgx_rgbconv_tune(-1, 0, 0), "sgx_rgbconv_tune")
             us = timeit(lambda: F.RgbConvPlainFn.apply(img, w0, wr, br, 0.1, 0.5)); rows.append(("plain convolution (LDS tile kernel)", us, px * 44.0 / us / 1e6))
             us = timeit(lambda: F.RgbConvAdjFn.apply(gz, w0, wr, br, 0.1, 0.5)); rows.append(("image gradient", us, px * 44.0 / us / 1e6))
             us = timeit(lambda: F._rgb_wgrad(img, gz, True, w0, b0, wr, br, 0.1, 0.5, (True,) * 4)); rows.append(("weight gradients (3 launches)", us, px * 44.0 / us / 1e6))
