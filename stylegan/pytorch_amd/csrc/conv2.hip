@@ -36,6 +36,7 @@
 //            MFMA is padding -- these layers are HBM-bound by a factor of 3), the store writes 32 bytes per pixel.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -684,6 +685,348 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
 
 static int conv2_ncu() { return sgx_ncu(); }
 
+// =====================================================================================================================================
+// conv3_kernel (round 5): the same convolution, the same LDS image, the same accumulation order (bit-identical results) -- with the
+// LDS -> MFMA pipeline written by hand.  What the round-4 counters and the disassembly of conv2_kernel<S,8,2> say about its K-step:
+//   * hipcc re-serialises the software-pipelined fragment reads of the source: every batch of ds_read_b128 is followed by
+//     s_waitcnt lgkmcnt(0) and then by the 2-4 MFMAs that need it (it reuses the fragment registers at once), so a wave alternates
+//     "issue 4 MFMAs (128 cycles of pipe time) -> issue reads -> wait ~100-200 cycles of LDS latency" and leaves the matrix pipe idle
+//     a third of the time; two waves per SIMD in lockstep (one barrier per K-step) only partly fill each other's gaps: MFMA busy 0.38
+//     of the 2.4 GHz peak (0.52 of the clock the chip really runs this kernel at);
+//   * ~90 scalar instructions of integer division per K-step (tile index -> image, row, column, twice) sit between the barrier
+//     and the first fragment read of BOTH waves of a SIMD.
+// Here: fragment reads are inline-asm ds_read_b128 into explicitly double / triple buffered registers, issued PD sub-steps (one
+// sub-step = the MF x RPW MFMAs of one tap and 16 channels) ahead of their use, with COUNTED s_waitcnt lgkmcnt(N) (never 0 inside
+// a K-step) tied to the fragment registers by "+v" operands, so that neither the compiler's scheduler nor its waitcnt insertion can
+// undo the pipeline; tile coordinates are decoded once per tile, not per K-step; RPW = 4 pixel rows per wave (128 accumulators, one
+// wave per SIMD in the 4-wave block: the same 16 x 32 pixel tile, 40 % fewer fragment reads per MFMA) is a template parameter next to
+// the 2-row / 8-wave shape; DIL interleaves the next stage's LDS-DMA instructions with the sub-steps instead of issuing them all
+// behind the barrier.  Geometries S and D, 32-channel K-steps, the register epilogue with all its options (mask, sign bits, fade).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int OFF> __device__ __forceinline__ void dsr128(i32x4& d, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read immediate offset");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+// s_waitcnt lgkmcnt(N) that the registers it makes valid pass THROUGH: an MFMA that reads them cannot be scheduled above it
+template <int N> __device__ __forceinline__ void lgkm_wait(i32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lgkm_wait(i32x4& a, i32x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lgkm_wait(i32x4& a, i32x4& b, i32x4& c, i32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int GEO, int NW, int MF, int RPW> struct C3Lds {
+    static constexpr int TH = RPW * NW, PH = TH + G2<GEO>::HALO, PW = 32 + G2<GEO>::HALO, BCO = MF * 32;
+    static constexpr int PROWS = PH * PW, WROWS = G2<GEO>::NTW * BCO;
+    static constexpr int P_INSTR = (PROWS * 4 + 63) / 64, P_BYTES = P_INSTR * 1024;
+    static constexpr int W_INSTR = WROWS * 4 / 64, W_BYTES = W_INSTR * 1024;
+    static_assert(WROWS * 4 % 64 == 0, "weight stage: whole DMA instructions");
+    static constexpr int STAGE = P_BYTES + W_BYTES, TOTAL = 2 * STAGE;
+};
+
+// Issue-order bookkeeping of one K-step's fragment reads (all compile time).  Prologue: brow(group 0), af(0) .. af(PD-1).  Sub-step
+// s then issues af(s + PD) and, on the first sub-step of a group g, brow(g + 1), BEFORE it waits for its own operands.
+template <int NG, int NDY, int MF, int R, int PD> struct C3Seq {
+    static constexpr int NSUB = NG * NDY;
+    static constexpr int issued_through(int s) {            // reads issued up to and including sub-step s's issue phase (s = -1: the prologue)
+        int n = R + MF * (PD < NSUB ? PD : NSUB);
+        for (int t = 0; t <= s; ++t) {
+            if (t + PD < NSUB) n += MF;
+            if (t % NDY == 0 && t / NDY + 1 < NG) n += R;
+        }
+        return n;
+    }
+    static constexpr int last_af(int s) {                   // 1-based issue index of the last read of af(s)
+        if (s < PD) return R + MF * (s + 1);
+        const int t = s - PD;                               // issued in sub-step t, first thing
+        return issued_through(t - 1) + MF;
+    }
+    static constexpr int last_brow(int g) {
+        if (g == 0) return R;
+        const int t = (g - 1) * NDY;                        // issued in sub-step t, after its af
+        return issued_through(t - 1) + (t + PD < NSUB ? MF : 0) + R;
+    }
+    static constexpr int wait_count(int s) {                // lgkmcnt to wait for before sub-step s's MFMAs
+        const int need = (s % NDY == 0 && last_brow(s / NDY) > last_af(s)) ? last_brow(s / NDY) : last_af(s);
+        const int k = issued_through(s) - need;
+        return k > 15 ? 15 : k;
+    }
+};
+
+template <int GEO, int NW, int MF, int RPW, int PD, int DIL>
+__global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
+    using G = G2<GEO>;
+    using L = C3Lds<GEO, NW, MF, RPW>;
+    static_assert(GEO == C2_S || GEO == C2_D, "3x3 and stride-2 geometries");
+    constexpr int TH = L::TH, PW = L::PW, BCO = L::BCO, PROWS = L::PROWS;
+    constexpr int P_INSTR = L::P_INSTR, P_BYTES = L::P_BYTES, W_INSTR = L::W_INSTR, STAGE = L::STAGE;
+    constexpr int NPI = (P_INSTR + NW - 1) / NW, NWI = (W_INSTR + NW - 1) / NW;
+    constexpr int NPH = G::NPH, IS = G::IS, NDX = G::NDX, NDY = G::NDY;
+    constexpr int KS = 2, NG = NDX * KS, NSUB = NG * NDY, R = RPW + NDY - 1, NAB = PD + 1;
+    using SQ = C3Seq<NG, NDY, MF, R, PD>;
+    static_assert(MF == 1 || MF == 2, "one or two 32-channel accumulator rows");
+    static_assert(R == 3 || R == 4 || R == 5 || R == 6, "patch rows per group");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x, xcd = bid & 7, j8 = bid >> 3;
+    const int cb = j8 % a.ncb, slot = (j8 / a.ncb) * 8 + xcd;
+    const int co0 = cb * BCO;
+    const int band = (a.ntiles + 7) >> 3, per = a.nslots >> 3, lslot = j8 / a.ncb;
+    const int band_len = a.ntiles - xcd * band < band ? a.ntiles - xcd * band : band;
+    const int tile0 = a.bands ? xcd * band + lslot : slot, tstride = a.bands ? per : a.nslots;
+    const int my_tiles = a.bands ? (lslot < band_len ? (band_len - lslot + per - 1) / per : 0)
+                                 : (slot < a.ntiles ? (a.ntiles - slot + a.nslots - 1) / a.nslots : 0);
+    if (my_tiles <= 0) return;
+    const int nchunks = a.Cin / 32;
+    const int spt = nchunks * NPH;
+    const int nsteps = my_tiles * spt;
+
+    // ---- per-lane DMA descriptors (tile independent), as conv2_kernel
+    int prel[NPI], ppos[NPI], wrel[NWI];
+#pragma unroll
+    for (int jj = 0; jj < NPI; ++jj) {
+        const int s = (jj * NW + wave) * 64 + lane;
+        const int row = s >> 2, c = s & 3;
+        const int pr = row / PW, pc = row % PW;
+        prel[jj] = (IS * pr * a.W + IS * pc) * a.Cin + ((c ^ ((pc >> 2) & 3)) << 3);
+        ppos[jj] = row < PROWS ? ((pr << 8) | pc) : -1;
+    }
+#pragma unroll
+    for (int jj = 0; jj < NWI; ++jj) {
+        const int s = (jj * NW + wave) * 64 + lane;
+        const int row = s >> 2, c = s & 3;
+        const int t = row / BCO, n = row % BCO;
+        const int tg0 = GEO == C2_D ? (2 * (t >> 1) + 1) * 4 + 2 * (t & 1) + 1 : t;
+        wrel[jj] = ((tg0 * a.Cout + co0 + n) * a.Cin) + ((c ^ ((n >> 2) & 3)) << 3);
+    }
+    // ---- per-lane fragment read addresses inside a stage: one base per (column shift, k half), rows and taps by immediate offset
+    unsigned pbase[NG], wbase[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        wbase[ks] = P_BYTES + l31 * 64 + (((hi + 2 * ks) ^ ((l31 >> 2) & 3)) << 4);
+#pragma unroll
+        for (int dx = 0; dx < NDX; ++dx) {
+            const int pc = l31 + dx;
+            pbase[dx * KS + ks] = (RPW * wave * PW + pc) * 64 + (((hi + 2 * ks) ^ ((pc >> 2) & 3)) << 4);
+        }
+    }
+    const bf16_t* __restrict__ xg = a.x;
+    const bf16_t* __restrict__ wg = a.w;
+    const unsigned long long zaddr = reinterpret_cast<unsigned long long>(sgx_zero_page) + (lane & 3) * 16;
+
+    auto tile_coords = [&](int t, int& b, int& ty0, int& tx0) {
+        const int tx_i = t % a.tiles_x; t /= a.tiles_x;
+        const int ty_i = t % a.tiles_y;
+        b = t / a.tiles_y; ty0 = ty_i * TH; tx0 = tx_i * 32;
+    };
+    // ---- the ISSUE cursor: the K-step whose operands are staged next -- its tile decoded once per tile
+    int i_t = tile0, i_q = 0, i_n = 0, ib, ity0, itx0;
+    tile_coords(i_t, ib, ity0, itx0);
+    // one DMA instruction of the issue cursor's K-step: piece j < NPI = patch, else weights
+    auto dma_piece = [&](auto J, char* buf) {
+        constexpr int j = decltype(J)::value;
+        const int kc = i_q / NPH, ph = i_q - kc * NPH, py = ph >> 1, px = ph & 1;
+        if constexpr (j < NPI) {
+            const int ii = j * NW + wave;
+            if (ii < P_INSTR) {
+                const int iy0 = GEO == C2_D ? 2 * ity0 - py : ity0 - 1, ix0 = GEO == C2_D ? 2 * itx0 - px : itx0 - 1;
+                const bf16_t* base = xg + (((long)ib * a.H + iy0) * a.W + ix0) * a.Cin + kc * 32;
+                const int pp = ppos[j];
+                const int gy = iy0 + IS * (pp >> 8), gx = ix0 + IS * (pp & 255);
+                const unsigned long long ok = ((pp >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W)) ? ~0ull : 0ull;
+                const unsigned long long pa = reinterpret_cast<unsigned long long>(base + prel[j]);
+                glds16(reinterpret_cast<const void*>(zaddr + ((pa - zaddr) & ok)), buf + ii * 1024);
+            }
+        } else {
+            constexpr int jw = j - NPI;
+            const int ii = jw * NW + wave;
+            // <= 2 K-steps per tile: step q's weights live in stage q for the whole launch
+            if (ii < W_INSTR && (spt > 2 || i_n < 2)) {
+                const bf16_t* w0 = wg + kc * 32 - (GEO == C2_D ? (long)(4 * py + px) * a.Cout * a.Cin : 0);
+                glds16(w0 + wrel[jw], buf + P_BYTES + ii * 1024);
+            }
+        }
+    };
+    auto advance_issue = [&]() {
+        ++i_n;
+        if (++i_q == spt) {
+            i_q = 0; i_t += tstride;
+            if (i_n < nsteps) tile_coords(i_t, ib, ity0, itx0);
+        }
+    };
+
+    f32x16 acc[MF][RPW];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+            for (int f = 0; f < RPW; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][f][r] = 0.f;
+    };
+    zero_acc();
+
+    static_for<0, NPI + NWI>([&](auto J) { dma_piece(J, smem); });
+    advance_issue();
+    int c_t = tile0, c_q = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        const unsigned so = (step & 1) * STAGE;
+        char* const nxt = smem + (STAGE - so);
+        __syncthreads();                         // (vmcnt(0) first) stage `step` landed; everyone is done with step-1
+        const bool more = step + 1 < nsteps;
+        if constexpr (!DIL) {
+            if (more) static_for<0, NPI + NWI>([&](auto J) { dma_piece(J, nxt); });
+        }
+        unsigned pb[NG], wb[KS];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) pb[g] = pbase[g] + so;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wb[ks] = wbase[ks] + so;
+        i32x4 brow[2][R], af[NAB][MF];
+        auto ld_brow = [&](auto Gi) {
+            constexpr int g = decltype(Gi)::value;
+            static_for<0, R>([&](auto Ri) { constexpr int r = decltype(Ri)::value; dsr128<r * PW * 64>(brow[g & 1][r], pb[g]); });
+        };
+        auto ld_af = [&](auto Si) {
+            constexpr int sub = decltype(Si)::value, g = sub / NDY, dy = sub % NDY, dx = g / KS, ks = g % KS;
+            static_for<0, MF>([&](auto Mi) { constexpr int m = decltype(Mi)::value; dsr128<((dy * NDX + dx) * BCO + m * 32) * 64>(af[sub % NAB][m], wb[ks]); });
+        };
+        ld_brow(std::integral_constant<int, 0>{});
+        static_for<0, (PD < NSUB ? PD : NSUB)>([&](auto Si) { ld_af(Si); });
+        static_for<0, NSUB>([&](auto Si) {
+            constexpr int sub = decltype(Si)::value, g = sub / NDY, dy = sub % NDY;
+            if constexpr (sub + PD < NSUB) ld_af(std::integral_constant<int, sub + PD>{});
+            if constexpr (dy == 0 && g + 1 < NG) ld_brow(std::integral_constant<int, g + 1>{});
+            if constexpr (DIL) {
+                // the next stage's DMA instructions, spread over the first sub-steps (they must have landed by the next barrier)
+                constexpr int per_sub = (NPI + NWI + NSUB - 3) / (NSUB - 2), j0 = sub * per_sub;
+                if (more) static_for<j0, (j0 + per_sub < NPI + NWI ? j0 + per_sub : NPI + NWI)>([&](auto J) { dma_piece(J, nxt); });
+            }
+            constexpr int K = SQ::wait_count(sub);
+            i32x4(&A)[MF] = af[sub % NAB];
+            i32x4(&Bv)[R] = brow[g & 1];
+            if constexpr (dy == 0) {
+                // first use of this group's patch rows: everything this sub-step reads passes through the wait
+                if constexpr (MF == 2) lgkm_wait<K>(A[0], A[1]); else lgkm_wait<K>(A[0]);
+                if constexpr (R == 3) { lgkm_wait<K>(Bv[0], Bv[1]); lgkm_wait<K>(Bv[2]); }
+                else if constexpr (R == 4) lgkm_wait<K>(Bv[0], Bv[1], Bv[2], Bv[3]);
+                else if constexpr (R == 5) { lgkm_wait<K>(Bv[0], Bv[1], Bv[2], Bv[3]); lgkm_wait<K>(Bv[4]); }
+                else { lgkm_wait<K>(Bv[0], Bv[1], Bv[2], Bv[3]); lgkm_wait<K>(Bv[4], Bv[5]); }
+            } else {
+                if constexpr (MF == 2) lgkm_wait<K>(A[0], A[1]); else lgkm_wait<K>(A[0]);
+            }
+            static_for<0, MF>([&](auto Mi) {
+                constexpr int m = decltype(Mi)::value;
+                static_for<0, RPW>([&](auto Fi) {
+                    constexpr int f = decltype(Fi)::value;
+                    acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[m]), __builtin_bit_cast(bf16x8, Bv[f + dy]), acc[m][f], 0, 0, 0);
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (more) advance_issue();
+        if (++c_q == spt) {
+            c_q = 0;
+            // ---- register epilogue (conv2_kernel's, for RPW rows): bias, activation, bf16, v_permlane32_swap pairing -> 16-byte stores
+            int b, ty0, tx0;
+            tile_coords(c_t, b, ty0, tx0);
+            c_t += tstride;
+            float4 bv[MF][4];
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    bv[m][g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + co0 + m * 32 + 8 * g + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int f = 0; f < RPW; ++f) {
+                const int oy = ty0 + RPW * wave + f, ox = tx0 + l31;
+                const bool inimg = oy < a.OH && ox < a.OW;
+                const size_t pix = (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + 8 * hi;
+#pragma unroll
+                for (int m = 0; m < MF; ++m) {
+                    uint2 o2[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4] = {acc[m][f][4 * g], acc[m][f][4 * g + 1], acc[m][f][4 * g + 2], acc[m][f][4 * g + 3]};
+                        v[0] += bv[m][g].x; v[1] += bv[m][g].y; v[2] += bv[m][g].z; v[3] += bv[m][g].w;
+                        if (a.act == SGX_ACT_LRELU) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i]);
+                        }
+                        o2[g].x = pack_bf16x2(v[0], v[1]);
+                        o2[g].y = pack_bf16x2(v[2], v[3]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        uint2 lo = o2[2 * k], up = o2[2 * k + 1];
+                        auto rx = __builtin_amdgcn_permlane32_swap(lo.x, up.x, false, false);
+                        auto ry = __builtin_amdgcn_permlane32_swap(lo.y, up.y, false, false);
+                        uint4 val = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                        if (inimg) {
+                            const size_t doff = pix + m * 32 + 16 * k;
+                            if (GEO == C2_S && a.mask) val = lrelu_mask_bf16x8(val, *reinterpret_cast<const uint4*>(a.mask + doff));
+                            if (a.signbits) {
+                                const unsigned wv[4] = {val.x, val.y, val.z, val.w};
+                                unsigned bits = 0;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    bits |= ((short)(wv[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q);
+                                    bits |= ((short)(wv[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
+                                }
+                                a.signbits[doff >> 3] = (unsigned char)bits;
+                            }
+                            if (GEO == C2_D && a.fade_resid) {
+                                const float fade_a = a.fade_ab ? a.fade_ab[0] : a.fade_alpha, fade_b = a.fade_ab ? a.fade_ab[1] : a.fade_beta;
+                                const uint4 rq = *reinterpret_cast<const uint4*>(a.fade_resid + doff);
+                                const unsigned yv[4] = {val.x, val.y, val.z, val.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w};
+                                unsigned ov[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    ov[q] = pack_bf16x2(fade_a * __uint_as_float(yv[q] << 16) + fade_b * __uint_as_float(rv[q] << 16),
+                                                        fade_a * __uint_as_float(yv[q] & 0xffff0000u) + fade_b * __uint_as_float(rv[q] & 0xffff0000u));
+                                val = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+                            }
+                            *reinterpret_cast<uint4*>(a.y + doff) = val;
+                        }
+                    }
+                }
+            }
+            zero_acc();
+        }
+    }
+}
+
+template <int GEO, int NW, int MF, int RPW, int PD, int DIL>
+static int launch_conv3(Conv2Args& a, hipStream_t st) {
+    using L = C3Lds<GEO, NW, MF, RPW>;
+    constexpr int LDS = L::TOTAL;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto kern = conv3_kernel<GEO, NW, MF, RPW, PD, DIL>;
+    sgx_lds_opt_in<conv3_kernel<GEO, NW, MF, RPW, PD, DIL>>(LDS);
+    const int gh = GEO == C2_D ? a.OH : a.H, gw = GEO == C2_D ? a.OW : a.W;
+    a.tiles_x = (gw + 31) / 32; a.tiles_y = (gh + L::TH - 1) / L::TH;
+    a.ntiles = a.B * a.tiles_y * a.tiles_x;
+    a.ncb = a.Cout / L::BCO;
+    int per = sgx_ncu() / (8 * a.ncb);
+    const int need = (a.ntiles + 7) / 8;
+    if (per > need) per = need;
+    if (per < 1) per = 1;
+    a.nslots = per * 8;
+    static const int bands_on = [] { const char* e = getenv("SGX_TILE_BANDS"); return e ? atoi(e) : 1; }();
+    a.bands = (bands_on && a.ntiles >= 8 * a.nslots) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.ncb * per)), dim3(NW * 64), LDS, st, a);
+    SGX_LAUNCH_CHECK("conv3_kernel");
+    return 0;
+}
+
 template <int GEO, int NW, int MF, int KC = 32, bool CO16 = false, int EPI = EPI_NONE>
 static int launch_conv2(Conv2Args& a, hipStream_t st) {
     using L = C2Lds<GEO, NW, MF, KC>;
@@ -765,10 +1108,38 @@ static Conv2Pick conv2_pick(int geo, int B, int H, int W, int Cin, int Cout, int
     return Conv2Pick{variant > 0 ? variant : (force_nw ? force_nw : (blocks8 >= conv2_ncu() ? 8 : 4)), mf2, false};
 }
 
+// conv3_kernel by configuration id (sgx_conv_variant 30 + id): 0: 8 waves x 2 rows, fragments one sub-step ahead; 1: two ahead;
+// 2: two ahead + DMA interleaved; 3: 4 waves x 4 rows, one ahead; 4: two ahead; 5: one ahead + DMA interleaved; 6: 4 waves x 2 rows
+// (the small-grid block), two ahead.  Shapes: 3x3 / stride-2, Cin % 32 = 0, Cout % 64 = 0, tile grid width % 32 = 0.
+static int conv3_variant(int geo, Conv2Args& a, int id, hipStream_t st, int* launched) {
+    const int gw = geo == C2_D ? a.W / 2 : a.W;
+    if ((geo != C2_S && geo != C2_D) || a.Cin % 32 || a.Cout % 64 || gw % 32 || a.Cout / 64 > 32 || (geo == C2_D && ((a.H | a.W) & 1)) || id < 0 || id > 6) return 0;
+    *launched = 1;
+#define C3_CASE(ID, NW, RPW, PD, DIL)                                                                   \
+    case ID: return geo == C2_S ? launch_conv3<C2_S, NW, 2, RPW, PD, DIL>(a, st) : launch_conv3<C2_D, NW, 2, RPW, PD, DIL>(a, st);
+    switch (id) {
+        C3_CASE(0, 8, 2, 1, 0)
+        C3_CASE(1, 8, 2, 2, 0)
+        C3_CASE(2, 8, 2, 2, 1)
+        C3_CASE(3, 4, 4, 1, 0)
+        C3_CASE(4, 4, 4, 2, 0)
+        C3_CASE(5, 4, 4, 1, 1)
+        C3_CASE(6, 4, 2, 2, 0)
+    }
+#undef C3_CASE
+    return 0;
+}
+
 // *launched = 1 if the second-generation kernel ran; 0 leaves the shape to the first-generation kernel.
 int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
                   const void* mask, int variant, hipStream_t st, int* launched) {
     *launched = 0;
+    if (variant >= 30) {                          // conv3_kernel configurations (probes, tests): 30 + id of the table in conv3_variant
+        Conv2Args a3{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
+                     geo == C2_D ? H / 2 : H, geo == C2_D ? W / 2 : W, Cin, Cout, act, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+        const int rc = conv3_variant(geo, a3, variant - 30, st, launched);
+        return rc;
+    }
     const Conv2Pick p = conv2_pick(geo, B, H, W, Cin, Cout, variant);
     if (!p.nw) return 0;
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,

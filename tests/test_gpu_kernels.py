@@ -669,3 +669,31 @@ def test_conv2_variants_vs_oracle(variant, geo, cin, cout, B, H, W):
     # fp32 agreement before the rounding: at most one bf16 ulp apart anywhere
     d = (outs[variant] - ref.float().to(DEV)).abs()
     assert float((d / (ref.float().to(DEV).abs() + 1e-3)).max()) < 2 ** -7
+
+
+# conv3_kernel (round 5: hand-pipelined fragment reads, counted waits, optional 4 pixel rows per wave, optional interleaved DMA):
+# same LDS image, same accumulation order as conv2_kernel -- every configuration must write conv2's bits, on ragged rows, partial
+# last tiles, 1 / 2 / 4+ K-chunks (static vs re-staged weights), several channel blocks, and enough tiles for the XCD-band order.
+CONV3_CASES = [c for c in CONV2_CASES if c[0] in "SD" and c[1] % 32 == 0 and c[2] % 64 == 0] + [
+    ("S", 512, 512, 2, 32, 32), ("S", 128, 128, 4, 128, 128), ("D", 256, 512, 2, 64, 64), ("D", 64, 128, 3, 72, 64), ("S", 64, 64, 2, 20, 32)]
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("geo,cin,cout,B,H,W", CONV3_CASES)
+def test_conv3_configurations_write_conv2_bits(cfg, geo, cin, cout, B, H, W):
+    from stylegan.pytorch_amd import functional as F
+    from stylegan.pytorch_amd import native as N
+    w = gu.seeded((cout, cin, 3, 3), 5).to(DEV)
+    bias = (0.5 * gu.seeded((cout,), 6)).to(DEV)
+    scale = O.he_w_mul(cin * 9, math.sqrt(2))
+    xn = F.nhwc(gu.seeded((B, cin, H, W), 7).to(DEV)).bfloat16()
+    wq, _ = F.packs(w, geo, scale, cin, torch.bfloat16)
+    OH, OW = (H // 2, W // 2) if geo == "D" else (H, W)
+    L = N.lib()
+    outs = []
+    for v in (8, 30 + cfg):
+        y = torch.full((B, OH, OW, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        N.check(L.sgx_conv_variant({"S": 0, "D": 1}[geo], N.ptr(xn), N.ptr(wq), N.ptr(bias), N.ptr(y), B, H, W, cin, cout, 1, N.BF16, v, N.stream()), "variant")
+        outs.append(y)
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), f"conv3 configuration {cfg} differs from conv2 on {geo} {cin}->{cout} B{B} {H}x{W}"
