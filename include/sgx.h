@@ -243,6 +243,17 @@ int sgx_conv3x3_signbits(const void* x, const void* w, const float* bias, void* 
 int sgx_conv4x4s2_up_blur_ok(int B, int H, int W, int Cin, int Cout, int dtype);
 int sgx_conv4x4s2_up_blur(const void* x, const void* w, void* y, const void* mask, int B, int H, int W, int Cin, int Cout,
                           int dtype, void* stream);
+/* Round 5: the same operation as ONE 3x3 stride-1 convolution over the coarse grid to the four output parity classes, stored depth-to-space
+ * (blur o transposed-convolution is a 6x6 stride-2 transposed kernel = 3x3 taps per class; the blur's zero padding of the FINE grid is
+ * restored at the image border by correction taps).  Replaces conv_transpose2d + BlurLayer (models/CustomLayers.py:143-152,175-177) and, in
+ * the discriminator's backward, the adjoint of LeakyReLU -> blur -> conv1_down (models/Blocks.py:140-146) with the mask as sign bits.
+ *   sgx_pack_upblur : t4 = the transposed convolution's 16 taps in fp32, [ky*4+kx][N][K] (sgx_pack_weight's fwd pack of mode U/UF or adj
+ *                     pack of mode D, dtype f32, the blur's 1/16 in its scale) -> wc bf16 [25][4N][K] (9 composite + 16 correction taps).
+ *   sgx_conv_upblur : y[B][2H][2W][Cout] = blur3x3(conv_transpose(x)) [* slope(bits)], bits [B][2H][2W][Cout/8] or NULL.  bf16, Cin = 32,
+ *                     Cout = 16, W % 32 == 0 (sgx_conv_upblur_ok); other shapes: sgx_conv4x4s2_up_blur or the separate passes. */
+int sgx_pack_upblur(const float* t4, void* wc, int N, int K, void* stream);
+int sgx_conv_upblur_ok(int B, int H, int W, int Cin, int Cout, int dtype);
+int sgx_conv_upblur(const void* x, const void* wc, void* y, const void* maskbits, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
 /* the same with the mask given as SIGN BITS of z, bits[B][2H][2W][Cout/8] as sgx_conv3x3_signbits / sgx_rgbconv_fwd write them */
 int sgx_conv4x4s2_up_blur_bits(const void* x, const void* w, void* y, const void* bits, int B, int H, int W, int Cin, int Cout,
                                int dtype, void* stream);

@@ -73,6 +73,8 @@ struct Conv2Args {
     float fade_alpha, fade_beta;
     const float* fade_ab;                     // ... or the two coefficients in device memory ([alpha, beta]: a captured step graph must not bake them in)
     int part_slots;                           // EPI_STATS: the slot count `part` was sized for (launch_conv2 refuses any other nslots)
+    const bf16_t* wcorr;                      // conv3_kernel<UB>: the 16 border-correction taps [16][64][32] behind the 9 composite taps of the same pack
+    int dbg;                                  // conv3_kernel, probe launches only (sgx_conv_variant + SGX_CONV3_DBG): DMA ablations, WRONG results by design
 };
 enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BLUR = 2 };
 
@@ -759,7 +761,7 @@ template <int NG, int NDY, int MF, int R, int PD> struct C3Seq {
     }
 };
 
-template <int GEO, int NW, int MF, int RPW, int PD, int DIL>
+template <int GEO, int NW, int MF, int RPW, int PD, int DIL, int UB = 0>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
     using G = G2<GEO>;
     using L = C3Lds<GEO, NW, MF, RPW>;
@@ -772,6 +774,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
     using SQ = C3Seq<NG, NDY, MF, R, PD>;
     static_assert(MF == 1 || MF == 2, "one or two 32-channel accumulator rows");
     static_assert(R == 3 || R == 4 || R == 5 || R == 6, "patch rows per group");
+    // UB: the transposed 4x4 stride-2 convolution AND the [1,2,1]x[1,2,1] blur behind it as ONE 3x3 stride-1 convolution over the
+    // coarse grid to 4 x 16 "virtual" channels n = (py * 2 + px) * 16 + co (sgx_pack_upblur composes the weights: blur o convT is a
+    // 6x6 stride-2 transposed kernel = 3x3 taps per output parity class), stored depth-to-space: virtual channel (py, px, co) of
+    // coarse pixel (i, j) is channel co of fine pixel (2i + py, 2j + px).  The blur zero-pads the FINE grid, so on the image's first /
+    // last fine row and column the composite over-counts the transposed convolution's virtual outputs just outside the image; those
+    // terms are linear in one input row / column and are taken out again by a few extra MFMAs with correction taps (a.wcorr) in the
+    // tiles that touch the border (see the border block below).  Cin = 32 (one K-step per tile), Cout = 16.
+    static_assert(!UB || (GEO == C2_S && MF == 2), "UB: the 3x3 geometry to 64 virtual channels");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -836,22 +846,28 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
         const int kc = i_q / NPH, ph = i_q - kc * NPH, py = ph >> 1, px = ph & 1;
         if constexpr (j < NPI) {
             const int ii = j * NW + wave;
-            if (ii < P_INSTR) {
+            // ablations (a.dbg, probe only): 4 = no DMA at all after the first two stages, 8 = no patch DMA on odd K-steps (what staging a
+            // patch once for two channel blocks would issue), 1 = patch pieces read 1 KB of CONTIGUOUS memory (8 full lines per instruction)
+            const bool skip = a.dbg && i_n >= 2 && ((a.dbg & 4) || ((a.dbg & 8) && (i_n & 1)));
+            if (ii < P_INSTR && !skip) {
                 const int iy0 = GEO == C2_D ? 2 * ity0 - py : ity0 - 1, ix0 = GEO == C2_D ? 2 * itx0 - px : itx0 - 1;
                 const bf16_t* base = xg + (((long)ib * a.H + iy0) * a.W + ix0) * a.Cin + kc * 32;
                 const int pp = ppos[j];
                 const int gy = iy0 + IS * (pp >> 8), gx = ix0 + IS * (pp & 255);
                 const unsigned long long ok = ((pp >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W)) ? ~0ull : 0ull;
-                const unsigned long long pa = reinterpret_cast<unsigned long long>(base + prel[j]);
+                unsigned long long pa = reinterpret_cast<unsigned long long>(base + prel[j]);
+                if (a.dbg & 1) pa = reinterpret_cast<unsigned long long>(xg + (((long)ib * a.H + (ity0 > 0 ? ity0 : 0)) * a.W) * a.Cin + (ii * 64 + lane) * 8);
                 glds16(reinterpret_cast<const void*>(zaddr + ((pa - zaddr) & ok)), buf + ii * 1024);
             }
         } else {
             constexpr int jw = j - NPI;
             const int ii = jw * NW + wave;
             // <= 2 K-steps per tile: step q's weights live in stage q for the whole launch
-            if (ii < W_INSTR && (spt > 2 || i_n < 2)) {
+            // (ablations: 4 / 16 = no weight DMA after the first two stages, 2 = weight pieces read 1 KB of contiguous memory -- what a
+            // (K-chunk, tap)-contiguous weight pack would make of them)
+            if (ii < W_INSTR && (spt > 2 || i_n < 2) && !((a.dbg & 20) && i_n >= 2)) {
                 const bf16_t* w0 = wg + kc * 32 - (GEO == C2_D ? (long)(4 * py + px) * a.Cout * a.Cin : 0);
-                glds16(w0 + wrel[jw], buf + P_BYTES + ii * 1024);
+                glds16((a.dbg & 2) ? wg + ((size_t)(cb * nchunks + kc) * NPH + ph) * (W_INSTR * 512) + (ii * 64 + lane) * 8 : w0 + wrel[jw], buf + P_BYTES + ii * 1024);
             }
         }
     };
@@ -933,6 +949,110 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
             __builtin_amdgcn_sched_barrier(0);
         });
         if (more) advance_issue();
+        if constexpr (UB) {
+            // (one K-step per tile)  ---- border corrections, then the depth-to-space store
+            int b, ty0, tx0;
+            tile_coords(c_t, b, ty0, tx0);
+            c_t += tstride;
+            const int row0 = ty0 + RPW * wave;                          // this wave's coarse rows row0 .. row0 + RPW - 1
+            const bool left = tx0 == 0, right = tx0 + 32 >= a.W;        // (a.W % 32 == 0: the last column is lane 31 of the last tile column)
+            if (left || right || row0 == 0 || row0 + RPW >= a.H) {
+                // A fragment of correction tap t, M-tile m (virtual channels m * 32 .. + 31): row l31, k = ks * 16 + hi * 8 .. + 7 -- read
+                // from global memory (border tiles only; L2 hits)
+                auto corr_a = [&](int t, int m, int ks) {
+                    return *reinterpret_cast<const i32x4*>(a.wcorr + ((size_t)(t * 64 + m * 32 + l31) * 32 + ks * 16 + hi * 8));
+                };
+                // B fragment of patch row pr, column shift dx, k half ks of the stage just consumed (valid until the next barrier)
+                auto patch_b = [&](int pr, int dx, int ks) {
+                    const int pc = l31 + dx;
+                    return *reinterpret_cast<const i32x4*>(smem + so + ((RPW * wave + pr) * PW + pc) * 64 + (((hi + 2 * ks) ^ ((pc >> 2) & 3)) << 4));
+                };
+                const i32x4 zero4 = {0, 0, 0, 0};
+#pragma unroll
+                for (int f = 0; f < RPW; ++f) {
+                    const int r = row0 + f;
+                    if (r >= a.H) continue;
+                    const bool top = r == 0, bot = r == a.H - 1;
+                    if (!(top || bot || left || right)) continue;
+                    // (rolled loops: this block runs in border tiles only -- keep its registers out of the main loop's budget)
+#pragma unroll 1
+                    for (int ks = 0; ks < KS; ++ks) {
+                        if (top || bot) {
+                            // first / last fine row: the row above / below the image contributed k0 (k2) * convT(row -1 (2H)), which only
+                            // input row 0 (H - 1) reaches, through kernel row 0 (3): taps Rt / Rb (negated in the pack) on the wave's own row
+#pragma unroll 1
+                            for (int dx = 0; dx < 3; ++dx) {
+                                const i32x4 bf = patch_b(f + 1, dx, ks);
+                                if (top) acc[0][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(0 + dx, 0, ks)), __builtin_bit_cast(bf16x8, bf), acc[0][f], 0, 0, 0);
+                                if (bot) acc[1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(3 + dx, 1, ks)), __builtin_bit_cast(bf16x8, bf), acc[1][f], 0, 0, 0);
+                            }
+                        }
+                        if (left || right) {
+                            // first / last fine column: the same for input column 0 (W - 1) and kernel column 0 (3); only the border pixel's
+                            // lane contributes (the others see a zero B operand); taps Cl / Cr carry zeros in the other px class's rows
+#pragma unroll 1
+                            for (int dy = 0; dy < 3; ++dy) {
+                                const i32x4 bfull = patch_b(f + dy, 1, ks);
+                                if (left) {
+                                    const i32x4 bm = l31 == 0 ? bfull : zero4;
+#pragma unroll
+                                    for (int m = 0; m < 2; ++m)
+                                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(6 + dy, m, ks)), __builtin_bit_cast(bf16x8, bm), acc[m][f], 0, 0, 0);
+                                }
+                                if (right) {
+                                    const i32x4 bm = l31 == 31 ? bfull : zero4;
+#pragma unroll
+                                    for (int m = 0; m < 2; ++m)
+                                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(9 + dy, m, ks)), __builtin_bit_cast(bf16x8, bm), acc[m][f], 0, 0, 0);
+                                }
+                            }
+                            // corners: row AND column term both took the (row, column) cross term out: one goes back in
+                            const i32x4 bc = patch_b(f + 1, 1, ks);
+                            if (top && left) acc[0][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(12, 0, ks)), __builtin_bit_cast(bf16x8, l31 == 0 ? bc : zero4), acc[0][f], 0, 0, 0);
+                            if (top && right) acc[0][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(13, 0, ks)), __builtin_bit_cast(bf16x8, l31 == 31 ? bc : zero4), acc[0][f], 0, 0, 0);
+                            if (bot && left) acc[1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(14, 1, ks)), __builtin_bit_cast(bf16x8, l31 == 0 ? bc : zero4), acc[1][f], 0, 0, 0);
+                            if (bot && right) acc[1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(15, 1, ks)), __builtin_bit_cast(bf16x8, l31 == 31 ? bc : zero4), acc[1][f], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            // ---- depth-to-space store.  acc[m = py][f]: lane column l31 = coarse column, registers 4g .. 4g + 3 = virtual channels
+            // 8g + 4hi .. + 3 of the M-tile, i.e. px = g >> 1, co = 8 (g & 1) + 4 hi + r.  One permlane32_swap pair per px hands a lane
+            // 8 consecutive co of fine pixel (2i + py, 2j + px): lanes < 32 co 0-7, lanes >= 32 co 8-15 -- one 16-byte store.
+            // Mask (the LeakyReLU backward of the discriminator's chain): sign bits [fine pixel][2 bytes]; a lane reads the 4 bytes of
+            // its two fine pixels (px = 0, 1) of a fine row and multiplies in fp32 BEFORE the one rounding to bf16.
+#pragma unroll
+            for (int f = 0; f < RPW; ++f) {
+                const int i = row0 + f, j = tx0 + l31;
+                const bool inimg = i < a.H && j < a.W;
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    const size_t frow = ((size_t)b * a.OH + 2 * i + py) * a.OW;
+                    unsigned mw = 0xffffffffu;
+                    if (a.maskbits && inimg) mw = *reinterpret_cast<const unsigned*>(a.maskbits + (frow + 2 * j) * 2);
+                    uint2 o2[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4] = {acc[py][f][4 * g], acc[py][f][4 * g + 1], acc[py][f][4 * g + 2], acc[py][f][4 * g + 3]};
+                        if (a.maskbits) {
+                            const unsigned nib = (mw >> (16 * (g >> 1) + 8 * (g & 1) + 4 * hi)) & 15u;     // byte (px, co >> 3), bits 4hi .. 4hi + 3
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] *= ((nib >> r) & 1u) ? 1.f : SGX_LRELU;
+                        }
+                        o2[g].x = pack_bf16x2(v[0], v[1]);
+                        o2[g].y = pack_bf16x2(v[2], v[3]);
+                    }
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        uint2 lo = o2[2 * px], up = o2[2 * px + 1];
+                        auto rx = __builtin_amdgcn_permlane32_swap(lo.x, up.x, false, false);
+                        auto ry = __builtin_amdgcn_permlane32_swap(lo.y, up.y, false, false);
+                        if (inimg) *reinterpret_cast<uint4*>(a.y + (frow + 2 * j + px) * 16 + 8 * hi) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                    }
+                }
+            }
+            zero_acc();
+        } else
         if (++c_q == spt) {
             c_q = 0;
             // ---- register epilogue (conv2_kernel's, for RPW rows): bias, activation, bf16, v_permlane32_swap pairing -> 16-byte stores
@@ -1004,13 +1124,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
     }
 }
 
-template <int GEO, int NW, int MF, int RPW, int PD, int DIL>
+template <int GEO, int NW, int MF, int RPW, int PD, int DIL, int UB = 0>
 static int launch_conv3(Conv2Args& a, hipStream_t st) {
     using L = C3Lds<GEO, NW, MF, RPW>;
     constexpr int LDS = L::TOTAL;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv3_kernel<GEO, NW, MF, RPW, PD, DIL>;
-    sgx_lds_opt_in<conv3_kernel<GEO, NW, MF, RPW, PD, DIL>>(LDS);
+    auto kern = conv3_kernel<GEO, NW, MF, RPW, PD, DIL, UB>;
+    sgx_lds_opt_in<conv3_kernel<GEO, NW, MF, RPW, PD, DIL, UB>>(LDS);
     const int gh = GEO == C2_D ? a.OH : a.H, gw = GEO == C2_D ? a.OW : a.W;
     a.tiles_x = (gw + 31) / 32; a.tiles_y = (gh + L::TH - 1) / L::TH;
     a.ntiles = a.B * a.tiles_y * a.tiles_x;
@@ -1130,6 +1250,87 @@ static int conv3_variant(int geo, Conv2Args& a, int id, hipStream_t st, int* lau
     return 0;
 }
 
+// ---- transposed 4x4 stride-2 convolution + [1,2,1]x[1,2,1] blur (+ LeakyReLU-backward mask from sign bits) as ONE 3x3 convolution
+// to the four output parity classes (conv3_kernel<UB>): generator conv0_up -> blur (models/CustomLayers.py:143-152,175-177) and the
+// discriminator's backward of "LeakyReLU -> blur -> conv1_down" (models/Blocks.py:140-146).
+// sgx_pack_upblur: t4 = the transposed convolution's 16 taps as the kernels see them, fp32 [ky * 4 + kx][N][K] (sgx_pack_weight's
+// fwd pack of mode U / UF, or the adj pack of mode D, in fp32, blur normalisation 1/16 already in the scale) -> wc, bf16
+// [25][4N][K]: slots 0..8 the composite taps (dy * 3 + dx; row n = (py * 2 + px) * N + co), slots 9..24 the border corrections
+// (9 + dx: first fine row, 12 + dx: last fine row, 15 + dy: first fine column, 18 + dy: last fine column, 21..24: corners TL TR BL BR).
+// 1-D composition (k = [1,2,1] blur taps, w = kernel taps, output Y = 2i + p, input rows i - 1, i, i + 1 <-> d = 0, 1, 2):
+//   p = 0: d0: k0 w2 + k1 w3;  d1: k0 w0 + k1 w1 + k2 w2;  d2: k2 w0        p = 1: d0: k0 w3;  d1: k0 w1 + k1 w2 + k2 w3;  d2: k1 w0 + k2 w1
+__device__ __forceinline__ int upblur_terms(int p, int d, int (&ka)[3], int (&kw)[3]) {
+    if (p == 0) {
+        if (d == 0) { ka[0] = 0; kw[0] = 2; ka[1] = 1; kw[1] = 3; return 2; }
+        if (d == 1) { ka[0] = 0; kw[0] = 0; ka[1] = 1; kw[1] = 1; ka[2] = 2; kw[2] = 2; return 3; }
+        ka[0] = 2; kw[0] = 0; return 1;
+    }
+    if (d == 0) { ka[0] = 0; kw[0] = 3; return 1; }
+    if (d == 1) { ka[0] = 0; kw[0] = 1; ka[1] = 1; kw[1] = 2; ka[2] = 2; kw[2] = 3; return 3; }
+    ka[0] = 1; kw[0] = 0; ka[1] = 2; kw[1] = 1; return 2;
+}
+__global__ __launch_bounds__(256) void pack_upblur_kernel(const float* __restrict__ t4, bf16_t* __restrict__ wc, int N, int K) {
+    const int total = 25 * 4 * N * K;
+    const float kb[3] = {1.f, 2.f, 1.f};
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int k = e % K, n4 = (e / K) % (4 * N), slot = e / (K * 4 * N);
+        const int co = n4 % N, px = (n4 / N) & 1, py = n4 / (2 * N);
+        auto T = [&](int ky, int kx) { return t4[((size_t)(ky * 4 + kx) * N + co) * K + k]; };
+        int ay[3], wy[3], ax[3], wx[3];
+        float v = 0.f;
+        if (slot < 9) {
+            const int dy = slot / 3, dx = slot % 3;
+            const int ny = upblur_terms(py, dy, ay, wy), nx = upblur_terms(px, dx, ax, wx);
+            for (int i = 0; i < ny; ++i)
+                for (int j = 0; j < nx; ++j) v += kb[ay[i]] * kb[ax[j]] * T(wy[i], wx[j]);
+        } else if (slot < 15) {                       // first (9..11) / last (12..14) fine row: kernel row 0 / 3, class py = 0 / 1
+            const bool last = slot >= 12;
+            const int dx = (slot - 9) % 3;
+            if (py == (last ? 1 : 0)) {
+                const int nx = upblur_terms(px, dx, ax, wx);
+                for (int j = 0; j < nx; ++j) v -= kb[last ? 2 : 0] * kb[ax[j]] * T(last ? 3 : 0, wx[j]);
+            }
+        } else if (slot < 21) {                       // first (15..17) / last (18..20) fine column
+            const bool last = slot >= 18;
+            const int dy = (slot - 15) % 3;
+            if (px == (last ? 1 : 0)) {
+                const int ny = upblur_terms(py, dy, ay, wy);
+                for (int i = 0; i < ny; ++i) v -= kb[ay[i]] * kb[last ? 2 : 0] * T(wy[i], last ? 3 : 0);
+            }
+        } else {                                      // corners TL TR BL BR: the cross term both row and column correction removed
+            const int c = slot - 21, cy = c >> 1, cx = c & 1;
+            if (py == cy && px == cx) v = kb[cy ? 2 : 0] * kb[cx ? 2 : 0] * T(cy ? 3 : 0, cx ? 3 : 0);
+        }
+        wc[e] = f2bf(v);
+    }
+}
+extern "C" int sgx_pack_upblur(const float* t4, void* wc, int N, int K, void* stream) {
+    SGX_REQUIRE(t4 && wc && N > 0 && K > 0, SGX_EINVAL, "pack_upblur: bad arguments");
+    const int total = 25 * 4 * N * K;
+    hipLaunchKernelGGL(pack_upblur_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, (hipStream_t)stream, t4,
+                       static_cast<bf16_t*>(wc), N, K);
+    SGX_LAUNCH_CHECK("pack_upblur_kernel");
+    return 0;
+}
+extern "C" int sgx_conv_upblur_ok(int B, int H, int W, int Cin, int Cout, int dtype) {
+    static const int on = [] { const char* e = getenv("SGX_CONV_UPBLUR"); return e ? atoi(e) : 1; }();   // A/B switch
+    return on && dtype == SGX_BF16 && Cin == 32 && Cout == 16 && W % 32 == 0 && B > 0 && H > 0 ? 1 : 0;
+}
+extern "C" int sgx_conv_upblur(const void* x, const void* wc, void* y, const void* maskbits, int B, int H, int W, int Cin, int Cout, int dtype,
+                               void* stream) {
+    SGX_REQUIRE(x && wc && y, SGX_EINVAL, "conv_upblur: null argument");
+    SGX_REQUIRE(dtype == SGX_BF16 && Cin == 32 && Cout == 16 && W % 32 == 0 && B > 0 && H > 0, SGX_EUNSUPPORTED,
+                "conv_upblur: shape B%d %dx%d %d->%d dtype %d has no kernel (sgx_conv_upblur_ok == 0)", B, H, W, Cin, Cout, dtype);
+    SGX_NOTE(2.0 * 36 * Cin * Cout * B * H * W, 2.0 * ((double)B * H * W * (Cin + 4.0 * Cout) + 36.0 * Cin * Cout) + (maskbits ? 0.5 * B * H * W * Cout : 0.0),
+             "convU*blur%s B%d %dx%d %d->%d", maskbits ? "*bits" : "", B, H, W, Cin, Cout);
+    Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(wc), nullptr, static_cast<bf16_t*>(y), nullptr, B, H, W, 2 * H, 2 * W, Cin, 64,
+                SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<const unsigned char*>(maskbits)};
+    a.wcorr = static_cast<const bf16_t*>(wc) + (size_t)9 * 64 * 32;
+    // 8-wave blocks once their 512-pixel tiles fill the chip, else the 4-wave block (256-pixel tiles)
+    const long tiles8 = (long)B * ((H + 15) / 16) * (W / 32);
+    return tiles8 >= sgx_ncu() ? launch_conv3<C2_S, 8, 2, 2, 2, 0, 1>(a, (hipStream_t)stream) : launch_conv3<C2_S, 4, 2, 2, 2, 0, 1>(a, (hipStream_t)stream);
+}
+
 // *launched = 1 if the second-generation kernel ran; 0 leaves the shape to the first-generation kernel.
 int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
                   const void* mask, int variant, hipStream_t st, int* launched) {
@@ -1137,6 +1338,7 @@ int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void
     if (variant >= 30) {                          // conv3_kernel configurations (probes, tests): 30 + id of the table in conv3_variant
         Conv2Args a3{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
                      geo == C2_D ? H / 2 : H, geo == C2_D ? W / 2 : W, Cin, Cout, act, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+        { const char* e = getenv("SGX_CONV3_DBG"); a3.dbg = e ? atoi(e) : 0; }     // (probe path only; read per launch)
         const int rc = conv3_variant(geo, a3, variant - 30, st, launched);
         return rc;
     }

@@ -273,6 +273,33 @@ def clear_pack_cache():
     """Forget every pack (the usage records that ``prepack`` batches by are kept)."""
     for ent in _PACKS.values():
         ent[1], ent[2] = None, {}
+    _UPBLUR_PACKS.clear()
+
+
+# Composite packs of "transposed convolution, then blur" (sgx_conv_upblur): the 9 composite taps to the 4 output parity classes + the
+# 16 border-correction taps, bf16 [25][4N][K], composed by sgx_pack_upblur from the layer's 16 transposed-convolution taps in FP32 (the
+# same sgx_pack_weight pack the plain kernels use, requested in fp32 with the blur's 1/16 in the scale -- one rounding to bf16, of the
+# composite).  Cached per (parameter, use) under the parameter's pack tag, with the event other consumer streams wait for.
+_UPBLUR_PACKS = {}
+
+
+def upblur_pack(weight, mode, scale, ipad, adjoint):
+    key = (id(weight), mode, float(scale), int(ipad), bool(adjoint))
+    tag = _pack_tag(weight)
+    ent = _UPBLUR_PACKS.get(key)
+    if ent is not None and ent[0]() is weight and ent[1] == tag:
+        raw = N.stream()
+        if raw not in ent[3][2] or (not _FAST_FORK and raw != ent[3][1]):
+            _stream_of(raw).wait_event(ent[3][0])
+            ent[3][2].add(raw)
+        return ent[2]
+    fwd32, adj32 = packs(weight, mode, scale / 16.0, ipad, torch.float32)
+    t4 = adj32 if adjoint else fwd32                         # [16][N][K] as the transposed-convolution kernels see the taps
+    taps, Nn, K = t4.shape
+    wc = torch.empty((25, 4 * Nn, K), dtype=torch.bfloat16, device=t4.device)
+    N.check(N.lib().sgx_pack_upblur(N.ptr(t4), N.ptr(wc), Nn, K, N.stream()), "sgx_pack_upblur")
+    _UPBLUR_PACKS[key] = [weakref.ref(weight, lambda _r, k=key: _UPBLUR_PACKS.pop(k, None)), tag, wc, _pack_mark()]
+    return wc
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -398,7 +425,10 @@ class ConvFn(Function):
                 # (the fused kernel reads the mask TENSOR: with the mask as sign bits its blur epilogue, already the limit of that
                 # kernel, gets another ~16 VALU operations per element -- measured 990 us against 342 + 553 for the two passes at
                 # batch 32, 1024^2, profiles/r04_rgbconv_probe_history.txt -- so layers that only have the bits take the two passes)
-                if x_pre is not None and conv_blur_ok(gy, weight.shape[1] if not adjoint else weight.shape[0], mode, not adjoint):
+                cout_b = weight.shape[1] if not adjoint else weight.shape[0]
+                if xb is not None and conv_upblur_ok(gy, cout_b, mode, not adjoint):
+                    gx = _bcall(ConvBlurFn, gy, weight, mode, scale, ipad, not adjoint, None, xb)       # one kernel, the mask from its sign bits
+                elif x_pre is not None and conv_blur_ok(gy, cout_b, mode, not adjoint):
                     gx = _bcall(ConvBlurFn, gy, weight, mode, scale, ipad, not adjoint, x_pre)      # one kernel
                 else:
                     gx = _bcall(BlurMaskFn, _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0), x_pre, xb)
@@ -441,12 +471,28 @@ CONV_BLUR_POLICY = os.environ.get("SGX_CONV_UP_BLUR_POLICY", "auto")
 CONV_BLUR_MIN_PIXELS = 1 << 22          # coarse input pixels B*H*W from which "auto" fuses the 16-channel layer
 
 
+def conv_upblur_ok(x, cout, mode, adjoint):
+    """True if the round-5 kernel (``sgx_conv_upblur``: blur o transposed convolution as ONE 3x3 convolution to the four output parity
+    classes, depth-to-space store, mask from sign bits) takes the convolution (mode, adjoint) applied to NHWC ``x``: 32 -> 16 channels,
+    bf16 -- the 1024x1024 level of both networks, at any batch."""
+    geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
+    if CONV_BLUR_POLICY == "off" or not CONV_UPBLUR or geo != "U" or x.dtype != torch.bfloat16:
+        return False
+    B, H, W, Cin = x.shape
+    return bool(N.lib().sgx_conv_upblur_ok(B, H, W, Cin, int(cout), N.BF16))
+
+
+CONV_UPBLUR = os.environ.get("SGX_CONV_UPBLUR", "1") != "0"     # A/B: 0 = the round-3 kernel (blur in the store epilogue) / the two passes
+
+
 def conv_blur_ok(x, cout, mode, adjoint):
     """True if ``ConvBlurFn`` has a kernel for the convolution (mode, adjoint) applied to NHWC ``x`` with ``cout`` outputs AND the
     policy wants it used."""
     geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
     if CONV_BLUR_POLICY == "off" or geo != "U" or x.dtype != torch.bfloat16:
         return False
+    if conv_upblur_ok(x, cout, mode, adjoint):
+        return True
     B, H, W, Cin = x.shape
     if CONV_BLUR_POLICY == "auto" and not (int(cout) == 16 and B * H * W >= CONV_BLUR_MIN_PIXELS):
         return False
@@ -467,9 +513,22 @@ class ConvBlurFn(Function):
         x = _c(x)
         geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
         assert geo == "U"
+        B, H, W, Cin = x.shape
+        cout_ = weight.shape[1] if adjoint else weight.shape[0]
+        if z is None and conv_upblur_ok(x, cout_, mode, adjoint):
+            # round 5: ONE 3x3 convolution to the four output parity classes (composite weights), depth-to-space store, mask from bits
+            if zbits is not None and (tuple(zbits.shape) != (B, 2 * H, 2 * W, cout_ // 8) or zbits.dtype != torch.uint8):
+                raise N.SgxError("conv+blur: sign bits [B, 2H, 2W, Cout/8] uint8 expected")
+            wc = upblur_pack(weight, mode, scale, ipad, adjoint)
+            y = torch.empty((B, 2 * H, 2 * W, cout_), dtype=x.dtype, device=x.device)
+            N.check(N.lib().sgx_conv_upblur(N.ptr(x), N.ptr(wc), N.ptr(y), N.ptr(None if zbits is None else _c(zbits)), B, H, W, Cin, cout_, N.dt(x),
+                                            N.stream()), "sgx_conv_upblur")
+            ctx.cfg = (mode, scale, ipad, adjoint, 0, False, False, False)
+            ctx.bias_ref = lambda: None
+            ctx.save_for_backward(x, weight, None, None, None, None, None, zbits)
+            return y
         fwd, adj = packs(weight, mode, scale / 16.0, ipad, x.dtype)    # the blur's 1/16 rides in the weight scale (a power of two: exact)
         wq = adj if adjoint else fwd
-        B, H, W, Cin = x.shape
         taps, Cout, K = wq.shape
         if K != Cin:
             raise N.SgxError(f"conv+blur: weight pack expects {K} input channels, activation has {Cin}")

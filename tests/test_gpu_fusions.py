@@ -159,10 +159,62 @@ def test_conv_up_blur_fused_vs_separate_and_oracle(cin, cout, B, H, W, masked):
     assert d1 <= 2.0 * d0 + 1e-3 and d1 < 0.05 * ref.abs().max().item(), (d1, d0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("cin,cout,B,H,W", [(32, 16, 2, 256, 256), (64, 32, 8, 40, 256), (32, 32, 48, 17, 64), (128, 64, 2, 128, 128)])
+# Round 5: blur o transposed convolution as ONE 3x3 convolution to the four output parity classes (sgx_conv_upblur, composite weights
+# from sgx_pack_upblur, depth-to-space store, border correction taps, mask from sign bits).  Every border case: one-row and two-row
+# images (first AND last fine row in one wave), one tile column (first and last column in one tile), ragged rows, several tile
+# columns and rows, the 4- and the 8-wave block; with and without the mask.
+UPBLUR3_CASES = [(2, 1, 32), (1, 2, 32), (3, 16, 32), (2, 17, 64), (1, 40, 96), (2, 33, 128), (5, 64, 64), (2, 256, 256), (1, 130, 512)]
+
+
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("adjoint", [False, True])
+@pytest.mark.parametrize("B,H,W", UPBLUR3_CASES)
+def test_conv_upblur_composite_kernel_vs_oracle(B, H, W, adjoint, masked):
+    """fp64 reference: conv_transpose2d of the bf16-rounded input with the layer's 16 fp32 taps, then the zero-padded [1,2,1]^2/16
+    blur, then the LeakyReLU-backward slope of the mask.  The kernel rounds the COMPOSITE weights and the result to bf16 once each
+    (the separate passes: the taps, the convolution's output and the blur's output).  ``adjoint``: the discriminator's use (the data
+    gradient of a 16 -> 32 stride-2 layer) instead of the generator's (a 32 -> 16 up layer)."""
+    import numpy as np
+    from stylegan.pytorch_amd import functional as F
+    cin, cout = 32, 16
+    w = gu.seeded((cin, cout, 3, 3) if adjoint else (cout, cin, 3, 3), 5).to(DEV)       # [O][I][3][3] of the layer the weight belongs to
+    mode = "D" if adjoint else "U"
+    scale = O.he_w_mul(w.shape[1] * 9, 2 ** 0.5)
+    x = gu.seeded((B, H, W, cin), 7).to(DEV).bfloat16()
+    z = gu.seeded((B, 2 * H, 2 * W, cout), 8).to(DEV).bfloat16()
+    bits = None
+    if masked:
+        zb = (z > 0).cpu().numpy().reshape(B, 2 * H, 2 * W, cout // 8, 8)
+        bits = torch.from_numpy(np.packbits(zb, axis=-1, bitorder="little").reshape(B, 2 * H, 2 * W, cout // 8)).to(DEV)
+    assert F.conv_upblur_ok(x, cout, mode, adjoint)
+    with torch.no_grad():
+        y = F.ConvBlurFn.apply(x, w, mode, scale, int(w.shape[1]), adjoint, None, bits)
+        f32, a32 = F.packs(w, mode, scale, int(w.shape[1]), torch.float32)
+    t4 = (a32 if adjoint else f32).double().cpu()                                         # [ky*4+kx][N = cout][K = cin]
+    wr = t4.view(4, 4, cout, cin).permute(3, 2, 0, 1)                                      # conv_transpose2d weight [Cin][Cout][4][4]
+    ref = TF.conv_transpose2d(x.float().permute(0, 3, 1, 2).double().cpu(), wr, stride=2, padding=1)
+    k = torch.tensor([1.0, 2.0, 1.0], dtype=torch.float64); k = (k[:, None] * k[None, :] / 16.0).expand(cout, 1, 3, 3)
+    ref = TF.conv2d(ref, k, padding=1, groups=cout)
+    if masked:
+        ref = ref * torch.where(z.float().permute(0, 3, 1, 2).double().cpu() > 0, 1.0, 0.2)
+    got = F.nchw_view(y).double().cpu()
+    assert y.shape == (B, 2 * H, 2 * W, cout) and torch.isfinite(got).all()
+    e = rel_err(got, ref)
+    # the border ring separately (first / last two fine rows and columns): a wrong correction tap is an O(1) relative error THERE and
+    # invisible in the whole-tensor norm of a large image
+    ring = torch.zeros_like(ref, dtype=torch.bool)
+    ring[..., :2, :] = True; ring[..., -2:, :] = True; ring[..., :, :2] = True; ring[..., :, -2:] = True
+    e_ring = float((got[ring] - ref[ring]).norm() / ref[ring].norm())
+    d = float((got - ref).abs().max()); scale_v = float(ref.abs().max())
+    print(f"[upblur3 B{B} {H}x{W} adjoint={adjoint} masked={masked}] rel {e:.2e}, border ring rel {e_ring:.2e}, max |d| {d:.2e} of {scale_v:.2e}")
+    assert e <= 3e-3 and e_ring <= 4e-3 and d <= 0.02 * scale_v, (e, e_ring, d, scale_v)
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W", [(64, 32, 8, 40, 256), (32, 32, 48, 17, 64), (128, 64, 2, 128, 128)])
 def test_conv_up_blur_with_the_mask_as_sign_bits(cin, cout, B, H, W):
     """sgx_conv4x4s2_up_blur_bits (round 4): the activation mask read as one sign bit per element -- the same bits as the mask-tensor
-    variant of the kernel produces, for every position (tile seams, borders, ragged tiles)."""
+    variant of the kernel produces, for every position (tile seams, borders, ragged tiles).  (32 -> 16 channels take the round-5
+    kernel when the mask comes as bits: test_conv_upblur_composite_kernel_vs_oracle.)"""
     from stylegan.pytorch_amd import functional as F
     w = gu.seeded((cout, cin, 3, 3), 5).to(DEV)
     scale = O.he_w_mul(cin * 9, 2 ** 0.5)

@@ -38,5 +38,11 @@ for B in [int(v) for v in sys.argv[1:]] or [4, 32]:
             t_bm = timeit(lambda: F.BlurMaskFn.apply(y, z))
             t_f = timeit(lambda: F.ConvBlurFn.apply(x, w, "U", 0.1, cin, False, None))
             t_fm = timeit(lambda: F.ConvBlurFn.apply(x, w, "U", 0.1, cin, False, z))
+            t_fb = t_bb = float("nan")
+            if cout % 8 == 0:
+                bits = (torch.rand(B, 2 * H, 2 * H, cout // 8, device=DEV) * 256).to(torch.uint8)
+                t_bb = timeit(lambda: F.BlurMaskFn.apply(y, None, bits))
+                t_fb = timeit(lambda: F.ConvBlurFn.apply(x, w, "U", 0.1, cin, False, None, bits))
         print(f"B{B} {cin}->{cout} {H}^2->{2 * H}^2: conv {t_c:7.1f} + blur {t_b:7.1f} = {t_c + t_b:7.1f} | fused {t_f:7.1f} ({t_c + t_b - t_f:+7.1f}) || "
-              f"+ blur*mask {t_bm:7.1f} = {t_c + t_bm:7.1f} | fused {t_fm:7.1f} ({t_c + t_bm - t_fm:+7.1f}) us", flush=True)
+              f"+ blur*mask {t_bm:7.1f} = {t_c + t_bm:7.1f} | fused {t_fm:7.1f} ({t_c + t_bm - t_fm:+7.1f}) || + blur*bits {t_bb:7.1f} = {t_c + t_bb:7.1f} | "
+              f"fused {t_fb:7.1f} ({t_c + t_bb - t_fb:+7.1f}) us   [32->16: 'fused' without a mask tensor = the round-5 composite kernel]", flush=True)
