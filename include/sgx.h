@@ -247,11 +247,12 @@ int sgx_conv4x4s2_up_blur(const void* x, const void* w, void* y, const void* mas
  * (blur o transposed-convolution is a 6x6 stride-2 transposed kernel = 3x3 taps per class; the blur's zero padding of the FINE grid is
  * restored at the image border by correction taps).  Replaces conv_transpose2d + BlurLayer (models/CustomLayers.py:143-152,175-177) and, in
  * the discriminator's backward, the adjoint of LeakyReLU -> blur -> conv1_down (models/Blocks.py:140-146) with the mask as sign bits.
- *   sgx_pack_upblur : t4 = the transposed convolution's 16 taps in fp32, [ky*4+kx][N][K] (sgx_pack_weight's fwd pack of mode U/UF or adj
- *                     pack of mode D, dtype f32, the blur's 1/16 in its scale) -> wc bf16 [25][4N][K] (9 composite + 16 correction taps).
+ *   sgx_pack_upblur : the layer's parameter w [O][I][3][3] (mode SGX_PACK_U / _UF: an up layer's own convolution, adjoint = 0; SGX_PACK_D:
+ *                     the data gradient of a down layer, adjoint = 1; scale = w_mul / 16, the blur's normalisation) -> wc bf16 [9][4N][K] + [22][2N][K],
+ *                     (N, K) = (O, I) resp. (I, O): 9 composite taps + 22 border-correction tiles, composed in fp32 and rounded once.
  *   sgx_conv_upblur : y[B][2H][2W][Cout] = blur3x3(conv_transpose(x)) [* slope(bits)], bits [B][2H][2W][Cout/8] or NULL.  bf16, Cin = 32,
  *                     Cout = 16, W % 32 == 0 (sgx_conv_upblur_ok); other shapes: sgx_conv4x4s2_up_blur or the separate passes. */
-int sgx_pack_upblur(const float* t4, void* wc, int N, int K, void* stream);
+int sgx_pack_upblur(const float* w, void* wc, int O, int I, int mode, int adjoint, float scale, void* stream);
 int sgx_conv_upblur_ok(int B, int H, int W, int Cin, int Cout, int dtype);
 int sgx_conv_upblur(const void* x, const void* wc, void* y, const void* maskbits, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
 /* the same with the mask given as SIGN BITS of z, bits[B][2H][2W][Cout/8] as sgx_conv3x3_signbits / sgx_rgbconv_fwd write them */

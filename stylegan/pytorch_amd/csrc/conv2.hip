@@ -73,7 +73,7 @@ struct Conv2Args {
     float fade_alpha, fade_beta;
     const float* fade_ab;                     // ... or the two coefficients in device memory ([alpha, beta]: a captured step graph must not bake them in)
     int part_slots;                           // EPI_STATS: the slot count `part` was sized for (launch_conv2 refuses any other nslots)
-    const bf16_t* wcorr;                      // conv3_kernel<UB>: the 16 border-correction taps [16][64][32] behind the 9 composite taps of the same pack
+    const bf16_t* wcorr;                      // conv3_kernel<UB>: the 22 border-correction tiles [22][32][32] behind the 9 composite taps of the same pack
     int dbg;                                  // conv3_kernel, probe launches only (sgx_conv_variant + SGX_CONV3_DBG): DMA ablations, WRONG results by design
 };
 enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BLUR = 2 };
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
     static_assert(MF == 1 || MF == 2, "one or two 32-channel accumulator rows");
     static_assert(R == 3 || R == 4 || R == 5 || R == 6, "patch rows per group");
     // UB: the transposed 4x4 stride-2 convolution AND the [1,2,1]x[1,2,1] blur behind it as ONE 3x3 stride-1 convolution over the
-    // coarse grid to 4 x 16 "virtual" channels n = (py * 2 + px) * 16 + co (sgx_pack_upblur composes the weights: blur o convT is a
+    // coarse grid to 4 x 16 "virtual" channels n = (px * 2 + py) * 16 + co (sgx_pack_upblur composes the weights: blur o convT is a
     // 6x6 stride-2 transposed kernel = 3x3 taps per output parity class), stored depth-to-space: virtual channel (py, px, co) of
     // coarse pixel (i, j) is channel co of fine pixel (2i + py, 2j + px).  The blur zero-pads the FINE grid, so on the image's first /
     // last fine row and column the composite over-counts the transposed convolution's virtual outputs just outside the image; those
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
             // <= 2 K-steps per tile: step q's weights live in stage q for the whole launch
             // (ablations: 4 / 16 = no weight DMA after the first two stages, 2 = weight pieces read 1 KB of contiguous memory -- what a
             // (K-chunk, tap)-contiguous weight pack would make of them)
-            if (ii < W_INSTR && (spt > 2 || i_n < 2) && !((a.dbg & 20) && i_n >= 2)) {
+            if (ii < W_INSTR && (UB ? i_n == 0 : (spt > 2 || i_n < 2)) && !((a.dbg & 20) && i_n >= 2)) {
                 const bf16_t* w0 = wg + kc * 32 - (GEO == C2_D ? (long)(4 * py + px) * a.Cout * a.Cin : 0);
                 glds16((a.dbg & 2) ? wg + ((size_t)(cb * nchunks + kc) * NPH + ph) * (W_INSTR * 512) + (ii * 64 + lane) * 8 : w0 + wrel[jw], buf + P_BYTES + ii * 1024);
             }
@@ -891,6 +891,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
     zero_acc();
 
     static_for<0, NPI + NWI>([&](auto J) { dma_piece(J, smem); });
+    if constexpr (UB) {
+        // the LDS-resident correction tiles (first / last fine column, corners: 10 tiles of 32 rows x 64 bytes) -> the weight region of
+        // stage 1 (its own copy of the composite taps is not needed: one K-step per tile, the taps are read from stage 0), once
+#pragma unroll
+        for (int jj = 0; jj < (20 + NW - 1) / NW; ++jj) {
+            const int ii = jj * NW + wave;
+            if (ii < 20) {
+                const int s = ii * 64 + lane, row = s >> 2, c = s & 3, n = row & 31;
+                glds16(a.wcorr + (size_t)row * 32 + ((c ^ ((n >> 2) & 3)) << 3), smem + STAGE + P_BYTES + ii * 1024);
+            }
+        }
+    }
     advance_issue();
     int c_t = tile0, c_q = 0;
     for (int step = 0; step < nsteps; ++step) {
@@ -905,7 +917,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) pb[g] = pbase[g] + so;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wb[ks] = wbase[ks] + so;
+        for (int ks = 0; ks < KS; ++ks) wb[ks] = wbase[ks] + (UB ? 0u : so);   // (UB: the composite taps live in stage 0's weight region)
+        unsigned mwp[RPW][2];                        // UB: sign-bit words of the tile this K-step computes (c_t), requested ahead of the MFMAs
+        if constexpr (UB) {
+            int b_, ty_, tx_;
+            tile_coords(c_t, b_, ty_, tx_);
+#pragma unroll
+            for (int f = 0; f < RPW; ++f)
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    const int i = ty_ + RPW * wave + f, j = tx_ + l31;
+                    mwp[f][py] = (a.maskbits && i < a.H && j < a.W)
+                                     ? *reinterpret_cast<const unsigned*>(a.maskbits + ((((size_t)b_ * a.OH + 2 * i + py) * a.OW) + 2 * j) * 2) : 0xffffffffu;
+                }
+        }
         i32x4 brow[2][R], af[NAB][MF];
         auto ld_brow = [&](auto Gi) {
             constexpr int g = decltype(Gi)::value;
@@ -956,16 +981,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
             c_t += tstride;
             const int row0 = ty0 + RPW * wave;                          // this wave's coarse rows row0 .. row0 + RPW - 1
             const bool left = tx0 == 0, right = tx0 + 32 >= a.W;        // (a.W % 32 == 0: the last column is lane 31 of the last tile column)
-            if (left || right || row0 == 0 || row0 + RPW >= a.H) {
-                // A fragment of correction tap t, M-tile m (virtual channels m * 32 .. + 31): row l31, k = ks * 16 + hi * 8 .. + 7 -- read
-                // from global memory (border tiles only; L2 hits)
-                auto corr_a = [&](int t, int m, int ks) {
-                    return *reinterpret_cast<const i32x4*>(a.wcorr + ((size_t)(t * 64 + m * 32 + l31) * 32 + ks * 16 + hi * 8));
-                };
+            const bool rowb = row0 == 0 || row0 + RPW >= a.H;
+            if (left || right || rowb) {
                 // B fragment of patch row pr, column shift dx, k half ks of the stage just consumed (valid until the next barrier)
                 auto patch_b = [&](int pr, int dx, int ks) {
                     const int pc = l31 + dx;
                     return *reinterpret_cast<const i32x4*>(smem + so + ((RPW * wave + pr) * PW + pc) * 64 + (((hi + 2 * ks) ^ ((pc >> 2) & 3)) << 4));
+                };
+                // A fragment of LDS-resident correction tile t (32 rows (py, co) x 32 channels; the weight region of stage 1)
+                auto corr_lds = [&](int t, int ks) {
+                    return *reinterpret_cast<const i32x4*>(smem + STAGE + P_BYTES + (t * 32 + l31) * 64 + (((hi + 2 * ks) ^ ((l31 >> 2) & 3)) << 4));
+                };
+                // ... and of the first / last fine ROW's correction tiles, read from global memory (one wave in the first / last tile row only)
+                auto corr_glb = [&](int t, int ks) {
+                    return *reinterpret_cast<const i32x4*>(a.wcorr + ((size_t)(10 + t) * 32 + l31) * 32 + ks * 16 + hi * 8);
                 };
                 const i32x4 zero4 = {0, 0, 0, 0};
 #pragma unroll
@@ -973,69 +1002,83 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
                     const int r = row0 + f;
                     if (r >= a.H) continue;
                     const bool top = r == 0, bot = r == a.H - 1;
-                    if (!(top || bot || left || right)) continue;
-                    // (rolled loops: this block runs in border tiles only -- keep its registers out of the main loop's budget)
+                    if (left || right) {
+                        // first / last fine column: the column just outside the image contributed k0 (k2) * convT(column -1 (2W)), which only
+                        // input column 0 (W - 1) reaches, through kernel column 0 (3).  Only the border pixel's lane contributes (the others see
+                        // a zero B operand); tiles Cl = 0..2, Cr = 3..5 (negated in the pack) go to the px = 0 / px = 1 accumulators
 #pragma unroll 1
-                    for (int ks = 0; ks < KS; ++ks) {
-                        if (top || bot) {
-                            // first / last fine row: the row above / below the image contributed k0 (k2) * convT(row -1 (2H)), which only
-                            // input row 0 (H - 1) reaches, through kernel row 0 (3): taps Rt / Rb (negated in the pack) on the wave's own row
-#pragma unroll 1
-                            for (int dx = 0; dx < 3; ++dx) {
-                                const i32x4 bf = patch_b(f + 1, dx, ks);
-                                if (top) acc[0][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(0 + dx, 0, ks)), __builtin_bit_cast(bf16x8, bf), acc[0][f], 0, 0, 0);
-                                if (bot) acc[1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(3 + dx, 1, ks)), __builtin_bit_cast(bf16x8, bf), acc[1][f], 0, 0, 0);
-                            }
-                        }
-                        if (left || right) {
-                            // first / last fine column: the same for input column 0 (W - 1) and kernel column 0 (3); only the border pixel's
-                            // lane contributes (the others see a zero B operand); taps Cl / Cr carry zeros in the other px class's rows
+                        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll 1
                             for (int dy = 0; dy < 3; ++dy) {
                                 const i32x4 bfull = patch_b(f + dy, 1, ks);
-                                if (left) {
-                                    const i32x4 bm = l31 == 0 ? bfull : zero4;
+                                if (left) acc[0][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_lds(dy, ks)), __builtin_bit_cast(bf16x8, l31 == 0 ? bfull : zero4), acc[0][f], 0, 0, 0);
+                                if (right) acc[1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_lds(3 + dy, ks)), __builtin_bit_cast(bf16x8, l31 == 31 ? bfull : zero4), acc[1][f], 0, 0, 0);
+                            }
+                            // corners: the row AND the column term both took the (row, column) cross term out: one goes back in (tiles 6..9 = TL TR BL BR)
+                            if (top || bot) {
+                                const i32x4 bc = patch_b(f + 1, 1, ks);
+                                if (top && left) acc[0][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_lds(6, ks)), __builtin_bit_cast(bf16x8, l31 == 0 ? bc : zero4), acc[0][f], 0, 0, 0);
+                                if (top && right) acc[1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_lds(7, ks)), __builtin_bit_cast(bf16x8, l31 == 31 ? bc : zero4), acc[1][f], 0, 0, 0);
+                                if (bot && left) acc[0][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_lds(8, ks)), __builtin_bit_cast(bf16x8, l31 == 0 ? bc : zero4), acc[0][f], 0, 0, 0);
+                                if (bot && right) acc[1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_lds(9, ks)), __builtin_bit_cast(bf16x8, l31 == 31 ? bc : zero4), acc[1][f], 0, 0, 0);
+                            }
+                        }
+                    }
+                    if (top || bot) {
+                        // first / last fine row: the same for input row 0 (H - 1) and kernel row 0 (3), on the wave's own row, all lanes; global
+                        // tiles (dx * 2 + px) for the first row, 6 + (dx * 2 + px) for the last.  The six fragments of a k half are requested together.
+#pragma unroll 1
+                        for (int ks = 0; ks < KS; ++ks) {
+                            if (top) {
+                                i32x4 at[3][2];
+#pragma unroll
+                                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                                    for (int m = 0; m < 2; ++m) at[dx][m] = corr_glb(dx * 2 + m, ks);
+#pragma unroll
+                                for (int dx = 0; dx < 3; ++dx) {
+                                    const i32x4 bf = patch_b(f + 1, dx, ks);
 #pragma unroll
                                     for (int m = 0; m < 2; ++m)
-                                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(6 + dy, m, ks)), __builtin_bit_cast(bf16x8, bm), acc[m][f], 0, 0, 0);
-                                }
-                                if (right) {
-                                    const i32x4 bm = l31 == 31 ? bfull : zero4;
-#pragma unroll
-                                    for (int m = 0; m < 2; ++m)
-                                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(9 + dy, m, ks)), __builtin_bit_cast(bf16x8, bm), acc[m][f], 0, 0, 0);
+                                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, at[dx][m]), __builtin_bit_cast(bf16x8, bf), acc[m][f], 0, 0, 0);
                                 }
                             }
-                            // corners: row AND column term both took the (row, column) cross term out: one goes back in
-                            const i32x4 bc = patch_b(f + 1, 1, ks);
-                            if (top && left) acc[0][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(12, 0, ks)), __builtin_bit_cast(bf16x8, l31 == 0 ? bc : zero4), acc[0][f], 0, 0, 0);
-                            if (top && right) acc[0][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(13, 0, ks)), __builtin_bit_cast(bf16x8, l31 == 31 ? bc : zero4), acc[0][f], 0, 0, 0);
-                            if (bot && left) acc[1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(14, 1, ks)), __builtin_bit_cast(bf16x8, l31 == 0 ? bc : zero4), acc[1][f], 0, 0, 0);
-                            if (bot && right) acc[1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, corr_a(15, 1, ks)), __builtin_bit_cast(bf16x8, l31 == 31 ? bc : zero4), acc[1][f], 0, 0, 0);
+                            if (bot) {
+                                i32x4 ab[3][2];
+#pragma unroll
+                                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                                    for (int m = 0; m < 2; ++m) ab[dx][m] = corr_glb(6 + dx * 2 + m, ks);
+#pragma unroll
+                                for (int dx = 0; dx < 3; ++dx) {
+                                    const i32x4 bf = patch_b(f + 1, dx, ks);
+#pragma unroll
+                                    for (int m = 0; m < 2; ++m)
+                                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ab[dx][m]), __builtin_bit_cast(bf16x8, bf), acc[m][f], 0, 0, 0);
+                                }
+                            }
                         }
                     }
                 }
             }
-            // ---- depth-to-space store.  acc[m = py][f]: lane column l31 = coarse column, registers 4g .. 4g + 3 = virtual channels
-            // 8g + 4hi .. + 3 of the M-tile, i.e. px = g >> 1, co = 8 (g & 1) + 4 hi + r.  One permlane32_swap pair per px hands a lane
+            // ---- depth-to-space store.  acc[m = px][f]: lane column l31 = coarse column j, registers 4g .. 4g + 3 = virtual channels
+            // 8g + 4hi .. + 3 of the M-tile, i.e. py = g >> 1, co = 8 (g & 1) + 4 hi + r.  One permlane32_swap pair per py hands a lane
             // 8 consecutive co of fine pixel (2i + py, 2j + px): lanes < 32 co 0-7, lanes >= 32 co 8-15 -- one 16-byte store.
-            // Mask (the LeakyReLU backward of the discriminator's chain): sign bits [fine pixel][2 bytes]; a lane reads the 4 bytes of
-            // its two fine pixels (px = 0, 1) of a fine row and multiplies in fp32 BEFORE the one rounding to bf16.
+            // Mask (the LeakyReLU backward of the discriminator's chain): sign bits [fine pixel][2 bytes]; the 4 bytes of a lane's two fine
+            // pixels (px = 0, 1) of each fine row were requested before the K-step's MFMAs (mwp); the slope multiplies in fp32 BEFORE
+            // the one rounding to bf16.
 #pragma unroll
             for (int f = 0; f < RPW; ++f) {
                 const int i = row0 + f, j = tx0 + l31;
                 const bool inimg = i < a.H && j < a.W;
 #pragma unroll
-                for (int py = 0; py < 2; ++py) {
-                    const size_t frow = ((size_t)b * a.OH + 2 * i + py) * a.OW;
-                    unsigned mw = 0xffffffffu;
-                    if (a.maskbits && inimg) mw = *reinterpret_cast<const unsigned*>(a.maskbits + (frow + 2 * j) * 2);
+                for (int px = 0; px < 2; ++px) {
                     uint2 o2[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        float v[4] = {acc[py][f][4 * g], acc[py][f][4 * g + 1], acc[py][f][4 * g + 2], acc[py][f][4 * g + 3]};
+                        float v[4] = {acc[px][f][4 * g], acc[px][f][4 * g + 1], acc[px][f][4 * g + 2], acc[px][f][4 * g + 3]};
                         if (a.maskbits) {
-                            const unsigned nib = (mw >> (16 * (g >> 1) + 8 * (g & 1) + 4 * hi)) & 15u;     // byte (px, co >> 3), bits 4hi .. 4hi + 3
+                            const unsigned nib = (mwp[f][g >> 1] >> (16 * px + 8 * (g & 1) + 4 * hi)) & 15u;     // byte (px, co >> 3), bits 4hi .. 4hi + 3
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] *= ((nib >> r) & 1u) ? 1.f : SGX_LRELU;
                         }
@@ -1043,11 +1086,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
                         o2[g].y = pack_bf16x2(v[2], v[3]);
                     }
 #pragma unroll
-                    for (int px = 0; px < 2; ++px) {
-                        uint2 lo = o2[2 * px], up = o2[2 * px + 1];
+                    for (int py = 0; py < 2; ++py) {
+                        uint2 lo = o2[2 * py], up = o2[2 * py + 1];
                         auto rx = __builtin_amdgcn_permlane32_swap(lo.x, up.x, false, false);
                         auto ry = __builtin_amdgcn_permlane32_swap(lo.y, up.y, false, false);
-                        if (inimg) *reinterpret_cast<uint4*>(a.y + (frow + 2 * j + px) * 16 + 8 * hi) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                        if (inimg) *reinterpret_cast<uint4*>(a.y + ((((size_t)b * a.OH + 2 * i + py) * a.OW) + 2 * j + px) * 16 + 8 * hi) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
                     }
                 }
             }
@@ -1253,10 +1296,12 @@ static int conv3_variant(int geo, Conv2Args& a, int id, hipStream_t st, int* lau
 // ---- transposed 4x4 stride-2 convolution + [1,2,1]x[1,2,1] blur (+ LeakyReLU-backward mask from sign bits) as ONE 3x3 convolution
 // to the four output parity classes (conv3_kernel<UB>): generator conv0_up -> blur (models/CustomLayers.py:143-152,175-177) and the
 // discriminator's backward of "LeakyReLU -> blur -> conv1_down" (models/Blocks.py:140-146).
-// sgx_pack_upblur: t4 = the transposed convolution's 16 taps as the kernels see them, fp32 [ky * 4 + kx][N][K] (sgx_pack_weight's
-// fwd pack of mode U / UF, or the adj pack of mode D, in fp32, blur normalisation 1/16 already in the scale) -> wc, bf16
-// [25][4N][K]: slots 0..8 the composite taps (dy * 3 + dx; row n = (py * 2 + px) * N + co), slots 9..24 the border corrections
-// (9 + dx: first fine row, 12 + dx: last fine row, 15 + dy: first fine column, 18 + dy: last fine column, 21..24: corners TL TR BL BR).
+// sgx_pack_upblur: the layer's parameter w [O][I][3][3] (fp32) -> wc, bf16 [9][4N][K] + [22][2N][K] with (N, K) = (O, I) for the forward of
+// an up layer (modes U / UF) and (I, O) for the data gradient of a down layer (mode D, adjoint); the 16 transposed-convolution taps are
+// synthesised in fp32 exactly as sgx_pack_weight does (scale = w_mul / 16: the blur's normalisation), composed in fp32, rounded once:
+// 9 composite taps (dy * 3 + dx; row n = (px * 2 + py) * N + co), then 22 correction tiles of 2N rows (py, co) for ONE px class each:
+// 0..2 first fine column (dy; px = 0), 3..5 last fine column (px = 1), 6..9 corners TL TR BL BR (kept in LDS by the kernel), 10 + dx * 2 + px
+// first fine row, 16 + dx * 2 + px last fine row (read from global memory by the one wave that owns that row).
 // 1-D composition (k = [1,2,1] blur taps, w = kernel taps, output Y = 2i + p, input rows i - 1, i, i + 1 <-> d = 0, 1, 2):
 //   p = 0: d0: k0 w2 + k1 w3;  d1: k0 w0 + k1 w1 + k2 w2;  d2: k2 w0        p = 1: d0: k0 w3;  d1: k0 w1 + k1 w2 + k2 w3;  d2: k1 w0 + k2 w1
 __device__ __forceinline__ int upblur_terms(int p, int d, int (&ka)[3], int (&kw)[3]) {
@@ -1269,13 +1314,37 @@ __device__ __forceinline__ int upblur_terms(int p, int d, int (&ka)[3], int (&kw
     if (d == 1) { ka[0] = 0; kw[0] = 1; ka[1] = 1; kw[1] = 2; ka[2] = 2; kw[2] = 3; return 3; }
     ka[0] = 1; kw[0] = 0; ka[1] = 2; kw[1] = 1; return 2;
 }
-__global__ __launch_bounds__(256) void pack_upblur_kernel(const float* __restrict__ t4, bf16_t* __restrict__ wc, int N, int K) {
-    const int total = 25 * 4 * N * K;
+__global__ __launch_bounds__(256) void pack_upblur_kernel(const float* __restrict__ w, bf16_t* __restrict__ wc, int O, int I, int mode, int adjoint, float scale) {
+    const int N = adjoint ? I : O, K = adjoint ? O : I;
+    const int nmain = 9 * 4 * N * K, total = nmain + 22 * 2 * N * K;
     const float kb[3] = {1.f, 2.f, 1.f};
+    const float sc = scale * (mode == SGX_PACK_D ? 0.25f : 1.f);
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int k = e % K, n4 = (e / K) % (4 * N), slot = e / (K * 4 * N);
-        const int co = n4 % N, px = (n4 / N) & 1, py = n4 / (2 * N);
-        auto T = [&](int ky, int kx) { return t4[((size_t)(ky * 4 + kx) * N + co) * K + k]; };
+        int k, co, px, py, slot;                      // slot 0..8: composite tap dy * 3 + dx; 9 + t: correction tile t (rows (py, co) of ONE px class)
+        if (e < nmain) {
+            k = e % K;
+            const int n4 = (e / K) % (4 * N);
+            slot = e / (K * 4 * N); co = n4 % N; py = (n4 / N) & 1; px = n4 / (2 * N);
+        } else {
+            const int r = e - nmain;
+            k = r % K;
+            const int n2 = (r / K) % (2 * N), t = r / (K * 2 * N);
+            slot = 9 + t; co = n2 % N; py = n2 / N;
+            px = t < 3 ? 0 : (t < 6 ? 1 : (t < 10 ? (t - 6) & 1 : (t - 10) & 1));
+        }
+        const float* wp = w + ((size_t)(adjoint ? k : co) * I + (adjoint ? co : k)) * 9;       // parameter [o][i][3][3]
+        // the transposed convolution's tap (ky, kx) as sgx_pack_weight synthesises it from the 3x3 parameter (modes D / U / UF)
+        auto T = [&](int ky, int kx) {
+            float v = 0.f;
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    const int y = ky - a2, x = kx - b2;
+                    if (y >= 0 && y < 3 && x >= 0 && x < 3) v += wp[mode == SGX_PACK_UF ? (2 - y) * 3 + (2 - x) : y * 3 + x];
+                }
+            return v * sc;
+        };
         int ay[3], wy[3], ax[3], wx[3];
         float v = 0.f;
         if (slot < 9) {
@@ -1283,32 +1352,33 @@ __global__ __launch_bounds__(256) void pack_upblur_kernel(const float* __restric
             const int ny = upblur_terms(py, dy, ay, wy), nx = upblur_terms(px, dx, ax, wx);
             for (int i = 0; i < ny; ++i)
                 for (int j = 0; j < nx; ++j) v += kb[ay[i]] * kb[ax[j]] * T(wy[i], wx[j]);
-        } else if (slot < 15) {                       // first (9..11) / last (12..14) fine row: kernel row 0 / 3, class py = 0 / 1
-            const bool last = slot >= 12;
-            const int dx = (slot - 9) % 3;
-            if (py == (last ? 1 : 0)) {
-                const int nx = upblur_terms(px, dx, ax, wx);
-                for (int j = 0; j < nx; ++j) v -= kb[last ? 2 : 0] * kb[ax[j]] * T(last ? 3 : 0, wx[j]);
-            }
-        } else if (slot < 21) {                       // first (15..17) / last (18..20) fine column
-            const bool last = slot >= 18;
-            const int dy = (slot - 15) % 3;
-            if (px == (last ? 1 : 0)) {
-                const int ny = upblur_terms(py, dy, ay, wy);
+        } else {
+            const int t = slot - 9;
+            if (t < 6) {                                  // first (0..2, px = 0) / last (3..5, px = 1) fine column: kernel column 0 / 3
+                const bool last = t >= 3;
+                const int ny = upblur_terms(py, t % 3, ay, wy);
                 for (int i = 0; i < ny; ++i) v -= kb[ay[i]] * kb[last ? 2 : 0] * T(wy[i], last ? 3 : 0);
+            } else if (t < 10) {                          // corners TL TR BL BR: the cross term that both the row and the column correction removed
+                const int cy = (t - 6) >> 1, cx = (t - 6) & 1;
+                if (py == cy) v = kb[cy ? 2 : 0] * kb[cx ? 2 : 0] * T(cy ? 3 : 0, cx ? 3 : 0);
+            } else {                                      // first (10..15) / last (16..21) fine row, tile (dx * 2 + px): kernel row 0 / 3, class py = 0 / 1
+                const bool last = t >= 16;
+                const int dx = ((t - 10) % 6) >> 1;
+                if (py == (last ? 1 : 0)) {
+                    const int nx = upblur_terms(px, dx, ax, wx);
+                    for (int j = 0; j < nx; ++j) v -= kb[last ? 2 : 0] * kb[ax[j]] * T(last ? 3 : 0, wx[j]);
+                }
             }
-        } else {                                      // corners TL TR BL BR: the cross term both row and column correction removed
-            const int c = slot - 21, cy = c >> 1, cx = c & 1;
-            if (py == cy && px == cx) v = kb[cy ? 2 : 0] * kb[cx ? 2 : 0] * T(cy ? 3 : 0, cx ? 3 : 0);
         }
         wc[e] = f2bf(v);
     }
 }
-extern "C" int sgx_pack_upblur(const float* t4, void* wc, int N, int K, void* stream) {
-    SGX_REQUIRE(t4 && wc && N > 0 && K > 0, SGX_EINVAL, "pack_upblur: bad arguments");
-    const int total = 25 * 4 * N * K;
-    hipLaunchKernelGGL(pack_upblur_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, (hipStream_t)stream, t4,
-                       static_cast<bf16_t*>(wc), N, K);
+extern "C" int sgx_pack_upblur(const float* w, void* wc, int O, int I, int mode, int adjoint, float scale, void* stream) {
+    SGX_REQUIRE(w && wc && O > 0 && I > 0 && (mode == SGX_PACK_D || mode == SGX_PACK_U || mode == SGX_PACK_UF), SGX_EINVAL, "pack_upblur: bad arguments");
+    SGX_REQUIRE((mode == SGX_PACK_D) == (adjoint != 0), SGX_EINVAL, "pack_upblur: the transposed convolution is the forward of an up layer or the adjoint of a down layer");
+    const int total = (9 * 4 + 22 * 2) * O * I;
+    hipLaunchKernelGGL(pack_upblur_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, (hipStream_t)stream, w,
+                       static_cast<bf16_t*>(wc), O, I, mode, adjoint, scale);
     SGX_LAUNCH_CHECK("pack_upblur_kernel");
     return 0;
 }

@@ -277,9 +277,8 @@ def clear_pack_cache():
 
 
 # Composite packs of "transposed convolution, then blur" (sgx_conv_upblur): the 9 composite taps to the 4 output parity classes + the
-# 16 border-correction taps, bf16 [25][4N][K], composed by sgx_pack_upblur from the layer's 16 transposed-convolution taps in FP32 (the
-# same sgx_pack_weight pack the plain kernels use, requested in fp32 with the blur's 1/16 in the scale -- one rounding to bf16, of the
-# composite).  Cached per (parameter, use) under the parameter's pack tag, with the event other consumer streams wait for.
+# 22 border-correction tiles, bf16 [9][4N][K] + [22][2N][K], composed by sgx_pack_upblur straight from the fp32 parameter (the 16 transposed-convolution
+# taps synthesised as sgx_pack_weight does, the blur's 1/16 in the scale -- one rounding to bf16, of the composite).  Cached per (parameter, use) under the parameter's pack tag, with the event other consumer streams wait for.
 _UPBLUR_PACKS = {}
 
 
@@ -293,11 +292,13 @@ def upblur_pack(weight, mode, scale, ipad, adjoint):
             _stream_of(raw).wait_event(ent[3][0])
             ent[3][2].add(raw)
         return ent[2]
-    fwd32, adj32 = packs(weight, mode, scale / 16.0, ipad, torch.float32)
-    t4 = adj32 if adjoint else fwd32                         # [16][N][K] as the transposed-convolution kernels see the taps
-    taps, Nn, K = t4.shape
-    wc = torch.empty((25, 4 * Nn, K), dtype=torch.bfloat16, device=t4.device)
-    N.check(N.lib().sgx_pack_upblur(N.ptr(t4), N.ptr(wc), Nn, K, N.stream()), "sgx_pack_upblur")
+    w = _c(weight.detach())
+    if w.dtype != torch.float32 or int(ipad) != w.shape[1]:
+        raise N.SgxError("conv+blur composite pack: contiguous fp32 parameter without channel padding expected")
+    O, I = w.shape[0], w.shape[1]
+    Nn, K = (I, O) if adjoint else (O, I)
+    wc = torch.empty(((9 * 4 + 22 * 2) * Nn * K,), dtype=torch.bfloat16, device=w.device)      # [9][4N][K] composite taps + [22][2N][K] correction tiles
+    N.check(N.lib().sgx_pack_upblur(N.ptr(w), N.ptr(wc), O, I, MODES[mode], int(bool(adjoint)), float(scale) / 16.0, N.stream()), "sgx_pack_upblur")
     _UPBLUR_PACKS[key] = [weakref.ref(weight, lambda _r, k=key: _UPBLUR_PACKS.pop(k, None)), tag, wc, _pack_mark()]
     return wc
 

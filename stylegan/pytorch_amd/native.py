@@ -84,7 +84,7 @@ SIGNATURES = {
     "sgx_conv4x4s2_up_blur_ok": (I, [I, I, I, I, I, I]),
     "sgx_conv4x4s2_up_blur": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "sgx_conv4x4s2_up_blur_bits": (I, [P, P, P, P, I, I, I, I, I, I, P]),
-    "sgx_pack_upblur": (I, [P, P, I, I, P]),
+    "sgx_pack_upblur": (I, [P, P, I, I, I, I, F, P]),
     "sgx_conv_upblur_ok": (I, [I, I, I, I, I, I]),
     "sgx_conv_upblur": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "sgx_rgbconv_ok": (I, [I, I, I, I, I]),
