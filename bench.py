@@ -521,7 +521,7 @@ def main():
     B, res, depth = a.batch_per_gpu, cfg["resolution"], cfg["depth"]
     if a.sweep:
         assert world == 1 and a.config == "ffhq1024", "--sweep: one GPU, the 1024 model (BASELINE configs[4] on one device)"
-        sg.use_graphs = False
+        sg.use_graphs = a.graphs == "on"          # eager unless asked (--graphs on: hipGraph replay, what StyleGAN.train runs since round 5)
         rows = sweep(sg, a, cfg, dev)
         worst = min(rows, key=lambda r: r["frac_of_mfma_peak"])
         total_img = sum(r["batch"] * a.sweep_steps for r in rows)
@@ -531,7 +531,7 @@ def main():
                           "dtype": a.dtype, "data": "synthetic (full-resolution real batches, down-sampled by the step as the reference does)",
                           "config": {"workload": "ffhq1024 model, depth index 0..8, batch sizes " + str([r["batch"] for r in rows])
                                                  + " (reference config.py:40-41), fade-in over the first half of each depth's timed iterations, "
-                                                   "style mixing on, eager launches"},
+                                                   "style mixing on, " + ("hipGraph replay" if a.graphs == "on" else "eager launches")},
                           "value_note": "images of all depths / time of all depths (equal iteration counts per depth: not the reference's epoch mix)",
                           "worst_depth": {"depth": worst["depth"], "frac_of_mfma_peak": worst["frac_of_mfma_peak"]},
                           "sweep": rows}))

@@ -144,7 +144,21 @@ int sgx_lrelu_bwd_bits(const void* dy, const void* bits, void* dx, size_t n, flo
  * _ok: 1 if the shape has the variant (bf16, second-generation stride-2 kernel), else sgx_conv4x4s2_down + sgx_axpby. */
 int sgx_conv4x4s2_down_fade_ok(int B, int H, int W, int Cin, int Cout, int dtype);
 int sgx_conv4x4s2_down_fade(const void* x, const void* w, const float* bias, const void* resid, float alpha, float beta, const float* ab_dev,
-                            void* y, void* bits, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);    /* ab_dev (nullable): [alpha, beta] in device memory instead (graph replay) */
+                            void* y, void* bits, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* Round 5: the same with the residual branch resid = from_rgb(pimg) (models/GAN.py:423-427: the 1x1 convolution of the DOWN-SAMPLED image)
+ * evaluated in the store: resid[p][c] = bf16((rb[c] * bs1) * bs2 + (r * (ws * wr[c][0]) + g * (ws * wr[c][1])) + b * (ws * wr[c][2])), (r, g, b) =
+ * pimg[p] -- sgx_rgb_in's arithmetic, bit for bit; pimg fp32 [B][H/2][W/2][3], wr = from_rgb.weight [Cout][3], ws = its w_mul (x the
+ * residual's prescale), rb = from_rgb.bias or NULL.  sgx_fade_rgb_bwd is the backward of that tail in ONE pass over g = dL/dy:
+ * gy = (alpha g) slope(bits) (bit for bit sgx_lrelu_bwd_bits), dwr / drb (written, or accumulated per bit 0 / 1 of acc; NULL = skipped) =
+ * beta ws sum_p g pimg resp. beta bs sum_p g, and (gpimg != NULL) gpimg[p][j] = beta ws sum_c g[p][c] wr[c][j]; alpha / beta from the call
+ * or ab_dev[0], ab_dev[1]; ws: sgx_fade_rgb_bwd_ws_bytes.  bf16, C in {32, 64, 128}. */
+int sgx_conv4x4s2_down_fade_rgb(const void* x, const void* w, const float* bias, const float* pimg, const float* wr, float ws, const float* rb,
+                                float bs1, float bs2, float alpha, float beta, const float* ab_dev, void* y, void* bits, int B, int H, int W,
+                                int Cin, int Cout, int dtype, void* stream);
+size_t sgx_fade_rgb_bwd_ws_bytes(size_t npix, int C);
+int sgx_fade_rgb_bwd(const void* g, const void* bits, const float* pimg, const float* wr, float ws, float bs, float alpha, float beta,
+                     const float* ab_dev, void* gy, float* dwr, float* drb, int acc, float* gpimg, void* wsbuf, size_t ws_bytes, size_t npix, int C,
+                     int dtype, void* stream);    /* ab_dev (nullable): [alpha, beta] in device memory instead (graph replay) */
 /* out = alpha*a + beta*b (b may be NULL)    fade-in lerp: models/GAN.py:202,427,586                                 */
 int sgx_axpby(const void* a, const void* b, void* out, float alpha, float beta, size_t n, int dtype, void* stream);
 /* same with the coefficients read from device memory (alpha_dev[0], beta_dev[0]): the fade-in alpha changes every

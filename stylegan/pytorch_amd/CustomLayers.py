@@ -283,6 +283,11 @@ class EqualizedConv2d(nn.Module):
                 resid, alpha, beta = fade
                 if not isinstance(alpha, torch.Tensor):
                     alpha, beta = float(alpha), float(beta)
+                if isinstance(resid, F.RgbResidual):
+                    # the residual branch from_rgb(pooled image) evaluated inside the store (functional.ConvDownFadeRgbFn)
+                    lay = resid.layer
+                    return F.call(F.ConvDownFadeRgbFn, x, self.weight, bias, resid.pimg, lay.weight, lay.bias, float(self.w_mul), int(self.weight.shape[1]),
+                                  alpha, beta, lay.w_mul * float(resid.out_scale), float(lay.b_mul), float(resid.out_scale), x_pre, x_pre_bits)
                 return F.call(F.ConvDownFadeFn, x, self.weight, bias, resid, float(self.w_mul), int(self.weight.shape[1]), alpha, beta, x_pre, x_pre_bits)
             return F.conv(x, self.weight, bias, "D", self.w_mul, act, defer_act=defer_act and act == ACT_LRELU,
                           x_pre=x_pre, x_pre_bits=x_pre_bits)             # bias after the 2x2 mean == bias in the fused store

@@ -422,9 +422,14 @@ class Discriminator(nn.Module):
                 # (1-alpha) of the residual branch rides in from_rgb's weight scale and bias when alpha is a host number (under
                 # graph replay it is device memory): its backward then needs no scaling pass over the activation
                 pre = fuse and not isinstance(alpha, torch.Tensor) and not self.conditional
-                residual = self.from_rgb[self.depth - depth].forward_nhwc(F.call(F.Pool2Fn, img, 0.25), out_dtype=dt,
-                                                                          out_scale=float(1 - alpha) if pre else 1.0)
                 top, top_rgb = self.blocks[self.depth - depth - 1], self.from_rgb[self.depth - depth - 1]
+                res_rgb = self.from_rgb[self.depth - depth]
+                pimg = F.call(F.Pool2Fn, img, 0.25)
+                if fuse and top._act == ACT_LRELU and not self.conditional and F.fade_rgb_ok(res_rgb, top.conv1_down.weight.shape[0], dt):
+                    # round 5: the residual as a recipe -- evaluated inside the store of the newest block's stride-2 convolution (with the lerp)
+                    residual = F.RgbResidual(pimg, res_rgb, float(1 - alpha) if pre else 1.0, dt)
+                else:
+                    residual = res_rgb.forward_nhwc(pimg, out_dtype=dt, out_scale=float(1 - alpha) if pre else 1.0)
                 # the fade-in lerp in the store of the newest block's stride-2 convolution (functional.ConvDownFadeFn) where alpha
                 # is a host number (the residual then already carries its 1 - alpha) and the shape has that kernel
                 fade_arg = None
@@ -438,6 +443,8 @@ class Discriminator(nn.Module):
                 else:
                     out = top.forward_nhwc(top_rgb.forward_nhwc(img, out_dtype=dt), defer_out=fuse, fade=fade_arg)
                 straight, lerped = out if fade_arg is not None else (out, False)
+                if not lerped and isinstance(residual, F.RgbResidual):
+                    residual = residual.materialize()                                    # (no lerp-in-the-store kernel for this shape)
                 x = straight if lerped else F.fade(straight, residual, alpha,            # GAN.py:427
                                                    a_act=fuse and top._act == ACT_LRELU, b_prescaled=pre)
                 x = chain(x, list(self.blocks[(self.depth - depth):]), False)
@@ -914,6 +921,8 @@ class StyleGAN:
         except ImportError:
             torch.save(grid, img_file + ".pt")
 
+    train_graphs = os.environ.get("SGX_TRAIN_GRAPHS", "1") != "0"     # ``train`` replays captured half-iterations (see there)
+
     def train(self, dataset, num_workers, epochs, batch_sizes, fade_in_percentage, logger, output,
               num_samples=36, start_depth=0, feedback_factor=100, checkpoint_factor=1):
         """The reference's training driver (models/GAN.py:682-826), same signature and side effects: per depth a fresh
@@ -929,11 +938,19 @@ class StyleGAN:
         if self.use_ema:
             self.gen_shadow.train()
         was_deferred, self.deferred_losses = self.deferred_losses, True        # the log line of a feedback tick reads them
+        # Round 5: the loop REPLAYS its half-iterations as hipGraphs wherever the step can be captured (``_graphable``: unconditional,
+        # d_repeats 1, 'linear' structure; per depth and batch shape, after two eager calls).  At the top depths the reference's schedule
+        # shrinks the batch to 8 / 4 / 2 where the launch count is largest (567-689 launches per iteration), and the eager loop is bound by
+        # the host's enqueue time there (bench.py --sweep); the replayed step is bound by the GPU.  Same arithmetic as
+        # the eager step with ``alpha_on_device`` (tests/test_gpu_graphs.py).  ``train_graphs = False`` / SGX_TRAIN_GRAPHS=0: eager.
+        was_graphs = getattr(self, "use_graphs", False)                     # (a schedule-only stand-in has no launch state: tests/test_train_schedule.py)
+        self.use_graphs = bool(was_graphs or self.train_graphs)
         try:
             self._train_loop(dataset, num_workers, epochs, batch_sizes, fade_in_percentage, logger, output, num_samples,
                              start_depth, feedback_factor, checkpoint_factor)
         finally:
             self.deferred_losses = was_deferred
+            self.use_graphs = was_graphs
 
     def _train_loop(self, dataset, num_workers, epochs, batch_sizes, fade_in_percentage, logger, output, num_samples,
                     start_depth, feedback_factor, checkpoint_factor):
@@ -948,6 +965,10 @@ class StyleGAN:
         step = 1
         for current_depth in range(start_depth, self.depth):
             current_res = np.power(2, current_depth + 2)
+            # captured steps of the depths already trained are not needed again: give their private memory pools back
+            graphs = getattr(self, "_step_graphs", {})
+            for key in [k for k in graphs if k[1] != current_depth]:
+                del graphs[key]
             logger.info("Currently working on depth: %d", current_depth + 1)
             logger.info("Current resolution: %d x %d" % (current_res, current_res))
             ticker = 1

@@ -72,6 +72,10 @@ struct Conv2Args {
     const bf16_t* fade_resid;
     float fade_alpha, fade_beta;
     const float* fade_ab;                     // ... or the two coefficients in device memory ([alpha, beta]: a captured step graph must not bake them in)
+    // ... or the residual COMPUTED in the store (round 5): fade_resid[pixel][c] = bf16(rb[c] + (r * (ws * W[c][0]) + g * (ws * W[c][1])) +
+    // b * (ws * W[c][2])) with (r, g, b) = fade_pimg[pixel] -- from_rgb of the down-sampled image (models/GAN.py:423-427), the arithmetic of
+    // sgx_rgb_in on a bf16 output, bit for bit -- instead of a [pixel][Cout] tensor written by one pass and read back here
+    const float* fade_pimg; const float* fade_wr; const float* fade_rb; float fade_ws, fade_bs1, fade_bs2;
     int part_slots;                           // EPI_STATS: the slot count `part` was sized for (launch_conv2 refuses any other nslots)
     const bf16_t* wcorr;                      // conv3_kernel<UB>: the 22 border-correction tiles [22][32][32] behind the 9 composite taps of the same pack
     int dbg;                                  // conv3_kernel, probe launches only (sgx_conv_variant + SGX_CONV3_DBG): DMA ablations, WRONG results by design
@@ -98,6 +102,29 @@ template <int GEO, int NW, int MF, int KC = 32> struct C2Lds {
     static constexpr int STAGE = P_BYTES + W_BYTES;
     static constexpr int TOTAL = 2 * STAGE;
 };
+
+// 8 channels (element offset doff = pixel * Cout + c0, c0 % 8 == 0) of the residual branch computed from the pooled image: exactly
+// sgx_rgb_in's arithmetic (pointwise.hip rgb_in_kernel: weights pre-multiplied by the scale, (r w0 + g w1) + b w2, bias added last,
+// no contraction) rounded to bf16 like the tensor that kernel would have stored.  The 32 weight / bias words of a lane are L1 hits.
+__device__ __forceinline__ uint4 fade_resid_from_image(const Conv2Args& a, size_t doff) {
+    const size_t pix = doff / a.Cout;
+    const int c0 = (int)(doff - pix * a.Cout);
+    const float r = a.fade_pimg[pix * 3], g = a.fade_pimg[pix * 3 + 1], b = a.fade_pimg[pix * 3 + 2];
+    unsigned o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = c0 + 2 * q + e;
+            const float w0 = a.fade_ws * a.fade_wr[c * 3], w1 = a.fade_ws * a.fade_wr[c * 3 + 1], w2 = a.fade_ws * a.fade_wr[c * 3 + 2];
+            const float bb = a.fade_rb ? (a.fade_rb[c] * a.fade_bs1) * a.fade_bs2 : 0.f;
+            v[e] = bb + (r * w0 + g * w1 + b * w2);
+        }
+        o[q] = pack_bf16x2(v[0], v[1]);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
 
 // NW waves per block, each owning 2 rows x 32 pixels of the tile grid; MF 32-channel accumulator rows per wave.
 // KC: input channels per K-step (32; 16 = the planar half-width stage).  CO16: 16 real output channels in the 32-channel block.
@@ -598,9 +625,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                                     }
                                     a.signbits[doff >> 3] = (unsigned char)bits;
                                 }
-                                if (GEO == C2_D && a.fade_resid) {
+                                if (GEO == C2_D && (a.fade_resid || a.fade_pimg)) {
                                     const float fade_a = a.fade_ab ? a.fade_ab[0] : a.fade_alpha, fade_b = a.fade_ab ? a.fade_ab[1] : a.fade_beta;
-                                    const uint4 rq = *reinterpret_cast<const uint4*>(a.fade_resid + doff);
+                                    const uint4 rq = a.fade_pimg ? fade_resid_from_image(a, doff) : *reinterpret_cast<const uint4*>(a.fade_resid + doff);
                                     const unsigned yv[4] = {val.x, val.y, val.z, val.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w};
                                     unsigned ov[4];
 #pragma unroll
@@ -1146,9 +1173,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
                                 }
                                 a.signbits[doff >> 3] = (unsigned char)bits;
                             }
-                            if (GEO == C2_D && a.fade_resid) {
+                            if (GEO == C2_D && (a.fade_resid || a.fade_pimg)) {
                                 const float fade_a = a.fade_ab ? a.fade_ab[0] : a.fade_alpha, fade_b = a.fade_ab ? a.fade_ab[1] : a.fade_beta;
-                                const uint4 rq = *reinterpret_cast<const uint4*>(a.fade_resid + doff);
+                                const uint4 rq = a.fade_pimg ? fade_resid_from_image(a, doff) : *reinterpret_cast<const uint4*>(a.fade_resid + doff);
                                 const unsigned yv[4] = {val.x, val.y, val.z, val.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w};
                                 unsigned ov[4];
 #pragma unroll
@@ -1549,17 +1576,35 @@ extern "C" int sgx_conv4x4s2_down_fade_ok(int B, int H, int W, int Cin, int Cout
     static const int on = [] { const char* e = getenv("SGX_FUSE_FADE"); return e ? atoi(e) : 1; }();   // A/B switch
     return on && conv2_pick(C2_D, B, H, W, Cin, Cout, -1).nw ? 1 : 0;
 }
+static int conv_down_fade_launch(const void* x, const void* w, const float* bias, const void* resid, const float* pimg, const float* wr, const float* rb,
+                                 float ws, float bs1, float bs2, float alpha, float beta, const float* ab_dev, void* y, void* bits, int B, int H, int W, int Cin,
+                                 int Cout, int dtype, void* stream);
 extern "C" int sgx_conv4x4s2_down_fade(const void* x, const void* w, const float* bias, const void* resid, float alpha, float beta, const float* ab_dev,
                                        void* y, void* bits, int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    SGX_REQUIRE(resid, SGX_EINVAL, "conv4x4s2_down_fade: null argument");
+    return conv_down_fade_launch(x, w, bias, resid, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, alpha, beta, ab_dev, y, bits, B, H, W, Cin, Cout, dtype, stream);
+}
+// ... with the residual branch from_rgb(pimg) computed in the store: pimg fp32 [B][H/2][W/2][3] (the down-sampled image), wr = from_rgb.weight
+// [Cout][3][1][1], ws = its w_mul (x the prescale of the residual, if any), rb = from_rgb.bias or NULL with its two scales (b_mul, prescale)
+extern "C" int sgx_conv4x4s2_down_fade_rgb(const void* x, const void* w, const float* bias, const float* pimg, const float* wr, float ws, const float* rb,
+                                           float bs1, float bs2, float alpha, float beta, const float* ab_dev, void* y, void* bits, int B, int H, int W,
+                                           int Cin, int Cout, int dtype, void* stream) {
+    SGX_REQUIRE(pimg && wr, SGX_EINVAL, "conv4x4s2_down_fade_rgb: null argument");
+    return conv_down_fade_launch(x, w, bias, nullptr, pimg, wr, rb, ws, bs1, bs2, alpha, beta, ab_dev, y, bits, B, H, W, Cin, Cout, dtype, stream);
+}
+static int conv_down_fade_launch(const void* x, const void* w, const float* bias, const void* resid, const float* pimg, const float* wr, const float* rb,
+                                 float ws, float bs1, float bs2, float alpha, float beta, const float* ab_dev, void* y, void* bits, int B, int H, int W, int Cin,
+                                 int Cout, int dtype, void* stream) {
     SGX_REQUIRE(dtype == SGX_BF16, SGX_EUNSUPPORTED, "conv4x4s2_down_fade: bf16 only");
-    SGX_REQUIRE(x && w && resid && y && bits, SGX_EINVAL, "conv4x4s2_down_fade: null argument");
+    SGX_REQUIRE(x && w && y && bits, SGX_EINVAL, "conv4x4s2_down_fade: null argument");
     const Conv2Pick p = conv2_pick(C2_D, B, H, W, Cin, Cout, -1);
     SGX_REQUIRE(p.nw && Cout % 8 == 0, SGX_EUNSUPPORTED, "conv4x4s2_down_fade: shape B%d %dx%d %d->%d has no variant (sgx_conv4x4s2_down_fade_ok == 0)", B, H, W, Cin, Cout);
     const double opx = (double)B * (H / 2) * (W / 2);
-    SGX_NOTE(2.0 * 16 * Cin * Cout * opx, 2.0 * ((double)B * H * W * Cin + 2.0 * opx * Cout + 16.0 * Cin * Cout) + opx * Cout / 8.0, "convD+fade B%d %dx%d %d->%d", B, H, W, Cin, Cout);
+    SGX_NOTE(2.0 * 16 * Cin * Cout * opx, 2.0 * ((double)B * H * W * Cin + (pimg ? 1.0 : 2.0) * opx * Cout + 16.0 * Cin * Cout) + opx * Cout / 8.0 + (pimg ? 12.0 * opx : 0.0),
+             "convD+fade%s B%d %dx%d %d->%d", pimg ? "(rgb)" : "", B, H, W, Cin, Cout);
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), nullptr, B, H, W, H / 2, W / 2, Cin, Cout,
                 SGX_ACT_LRELU, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, static_cast<unsigned char*>(bits), nullptr,
-                static_cast<const bf16_t*>(resid), alpha, beta, ab_dev};
+                static_cast<const bf16_t*>(resid), alpha, beta, ab_dev, pimg, wr, rb, ws, bs1, bs2};
     hipStream_t st = (hipStream_t)stream;
     const int nw = p.nw;
     if (p.k16) return nw == 8 ? launch_conv2<C2_D, 8, 1, 16, false>(a, st) : launch_conv2<C2_D, 4, 1, 16, false>(a, st);

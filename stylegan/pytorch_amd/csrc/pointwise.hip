@@ -114,6 +114,142 @@ extern "C" int sgx_lrelu_bwd_bits(const void* dy, const void* bits, void* dx, si
     return 0;
 }
 
+// ---------------------------------------------------------------- backward of the fade-in tail with the residual computed in the store
+// Forward (sgx_conv4x4s2_down_fade_rgb): out = a * lrelu(z) + b * (rb' + ws * pimg . W^T), models/GAN.py:423-427.  Given g = dL/dout:
+//   gy[p][c]    = (a * g[p][c]) * slope(bits[p][c])             bit for bit sgx_lrelu_bwd_bits (the stride-2 convolution's upstream gradient)
+//   dW[c][j]   += b * ws * sum_p g[p][c] * pimg[p][j],   drb[c] += b * bs * sum_p g[p][c]          (from_rgb's parameters)
+//   gpimg[p][j] = b * ws * sum_c g[p][c] * W[c][j]                                                  (optional: the image gradient)
+// in ONE pass over g instead of four (lrelu_bwd_bits, rgb_wgrad, colsum, rgb_out).  CV = C / 8 lanes per pixel; a block walks a
+// contiguous pixel range; fp32 partial sums per thread (flushed to fp64 every 64 pixels), fp64 across lanes, waves and blocks in a
+// fixed order: deterministic, no atomics.
+#define FRB_BLOCKS 2048
+template <int CV>
+__global__ __launch_bounds__(256) void fade_rgb_bwd_kernel(const bf16_t* __restrict__ g, const unsigned char* __restrict__ bits, const float* __restrict__ pimg,
+                                                           const float* __restrict__ wr, float ws, float alpha, float beta, const float* __restrict__ ab_dev,
+                                                           bf16_t* __restrict__ gy, float* __restrict__ gpimg, double* __restrict__ part, size_t npix) {
+    constexpr int PPI = 256 / CV;                            // pixels per block iteration
+    __shared__ double sh[4][CV][32];
+    if (ab_dev) { alpha = ab_dev[0]; beta = ab_dev[1]; }
+    const int tid = threadIdx.x, v = tid % CV, pl = tid / CV, lane = tid & 63, wave = tid >> 6;
+    const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+    float wv[8][3];
+    if (gpimg) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wv[j][k] = (beta * ws) * wr[(v * 8 + j) * 3 + k];
+    }
+    double acc[8][4];
+    float q[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[j][k] = 0.0; q[j][k] = 0.f; }
+    int cnt = 0;
+    for (size_t pb = p0; pb < p1; pb += PPI) {               // (block-uniform trip count: the shuffles below run converged)
+        const size_t p = pb + pl;
+        const bool ok = p < p1;
+        float gv[8];
+        float i0 = 0.f, i1 = 0.f, i2 = 0.f;
+        unsigned bb = 0;
+        if (ok) {
+            VecTraits<bf16_t>::load(g + (p * CV + v) * 8, gv);
+            bb = bits[p * CV + v];
+            i0 = pimg[p * 3]; i1 = pimg[p * 3 + 1]; i2 = pimg[p * 3 + 2];
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (alpha * gv[j]) * (((bb >> j) & 1u) ? 1.f : SGX_LRELU);
+            VecTraits<bf16_t>::store(gy + (p * CV + v) * 8, o);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { q[j][0] += gv[j] * i0; q[j][1] += gv[j] * i1; q[j][2] += gv[j] * i2; q[j][3] += gv[j]; }
+        if (++cnt == 64) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { acc[j][k] += (double)q[j][k]; q[j][k] = 0.f; }
+            cnt = 0;
+        }
+        if (gpimg) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s0 += gv[j] * wv[j][0]; s1 += gv[j] * wv[j][1]; s2 += gv[j] * wv[j][2]; }
+#pragma unroll
+            for (int o = 1; o < CV; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            if (ok && v == 0) { gpimg[p * 3] = s0; gpimg[p * 3 + 1] = s1; gpimg[p * 3 + 2] = s2; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double t = acc[j][k] + (double)q[j][k];
+#pragma unroll
+            for (int o = CV; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);          // lanes of one channel vector: lane % CV
+            if (lane < CV) sh[wave][lane][j * 4 + k] = t;
+        }
+    __syncthreads();
+    for (int e = tid; e < CV * 32; e += 256) {
+        const int vv = e / 32, r = e % 32;
+        part[((size_t)blockIdx.x * CV + vv) * 32 + r] = (sh[0][vv][r] + sh[1][vv][r]) + (sh[2][vv][r] + sh[3][vv][r]);
+    }
+}
+// part[blk][C/8][8 channels][4] -> dW[c][j] (j < 3, from_rgb layout [C][3]) and drb[c] (j == 3); acc bit 0 / 1: accumulate into dW / drb
+__global__ __launch_bounds__(256) void fade_rgb_bwd_finish(const double* __restrict__ part, float* __restrict__ dw, float* __restrict__ drb, int nblk, int C,
+                                                           float ws, float bs, float beta, const float* __restrict__ ab_dev, int acc) {
+    __shared__ double sh[64][5];
+    if (ab_dev) beta = ab_dev[1];
+    const int el = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    const int e = blockIdx.x * 4 + el;                       // e = c * 4 + j
+    double s = 0.0;
+    if (e < 4 * C)
+        for (int b = pl; b < nblk; b += 64) s += part[(size_t)b * 4 * C + e];
+    sh[pl][el] = s;
+    __syncthreads();
+    if (pl == 0 && e < 4 * C) {
+        double t = 0.0;
+        for (int k = 0; k < 64; ++k) t += sh[k][el];
+        const int c = e >> 2, j = e & 3;
+        if (j < 3) {
+            if (dw) { const float val = (float)(t * ((double)beta * (double)ws)); dw[c * 3 + j] = (acc & 1) ? dw[c * 3 + j] + val : val; }
+        } else if (drb) {
+            const float val = (float)(t * ((double)beta * (double)bs));
+            drb[c] = (acc & 2) ? drb[c] + val : val;
+        }
+    }
+}
+extern "C" size_t sgx_fade_rgb_bwd_ws_bytes(size_t npix, int C) { (void)npix; return (size_t)FRB_BLOCKS * 4 * C * sizeof(double); }
+extern "C" int sgx_fade_rgb_bwd(const void* g, const void* bits, const float* pimg, const float* wr, float ws, float bs, float alpha, float beta,
+                                const float* ab_dev, void* gy, float* dwr, float* drb, int acc, float* gpimg, void* wsbuf, size_t ws_bytes, size_t npix, int C,
+                                int dtype, void* stream) {
+    SGX_REQUIRE(dtype == SGX_BF16 && (C == 32 || C == 64 || C == 128), SGX_EUNSUPPORTED, "fade_rgb_bwd: bf16, C in {32, 64, 128} (C=%d dtype %d)", C, dtype);
+    SGX_REQUIRE(g && bits && pimg && wr && gy && wsbuf && npix > 0, SGX_EINVAL, "fade_rgb_bwd: null argument");
+    SGX_REQUIRE(ws_bytes >= sgx_fade_rgb_bwd_ws_bytes(npix, C), SGX_EWORKSPACE, "fade_rgb_bwd: workspace");
+    SGX_NOTE(8.0 * npix * C, npix * (4.125 * C + 12.0 + (gpimg ? 12.0 : 0.0)), "fade_rgb_bwd %zux%d", npix, C);
+    hipStream_t st = (hipStream_t)stream;
+    const int ppi = 256 / (C / 8);
+    long nblk = (long)((npix + (size_t)ppi * 8 - 1) / ((size_t)ppi * 8));
+    if (nblk > FRB_BLOCKS) nblk = FRB_BLOCKS;
+    if (nblk < 1) nblk = 1;
+    const bf16_t* gp = static_cast<const bf16_t*>(g);
+    const unsigned char* bp = static_cast<const unsigned char*>(bits);
+    bf16_t* yp = static_cast<bf16_t*>(gy);
+    double* part = static_cast<double*>(wsbuf);
+    if (C == 32) hipLaunchKernelGGL(fade_rgb_bwd_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, st, gp, bp, pimg, wr, ws, alpha, beta, ab_dev, yp, gpimg, part, npix);
+    else if (C == 64) hipLaunchKernelGGL(fade_rgb_bwd_kernel<8>, dim3((unsigned)nblk), dim3(256), 0, st, gp, bp, pimg, wr, ws, alpha, beta, ab_dev, yp, gpimg, part, npix);
+    else hipLaunchKernelGGL(fade_rgb_bwd_kernel<16>, dim3((unsigned)nblk), dim3(256), 0, st, gp, bp, pimg, wr, ws, alpha, beta, ab_dev, yp, gpimg, part, npix);
+    SGX_LAUNCH_CHECK("fade_rgb_bwd_kernel");
+    if (dwr || drb) {
+        hipLaunchKernelGGL(fade_rgb_bwd_finish, dim3((unsigned)((4 * C + 3) / 4)), dim3(256), 0, st, part, dwr, drb, (int)nblk, C, ws, bs, beta, ab_dev, acc);
+        SGX_LAUNCH_CHECK("fade_rgb_bwd_finish");
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------- out = alpha*a + beta*b
 template <typename T>
 __global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, float alpha, float beta,

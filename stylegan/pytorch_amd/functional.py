@@ -988,6 +988,125 @@ class ConvDownFadeFn(Function):
         return out[0], out[1], out[2], g_res, None, None, None, None, None, None
 
 
+FUSE_FADE_RGB = os.environ.get("SGX_FUSE_FADE_RGB", "1") != "0"        # A/B: the residual branch from_rgb(pool(img)) computed in the lerp's store
+
+
+class RgbResidual:
+    """The discriminator's residual branch ``from_rgb(pimg)`` (reference models/GAN.py:423-427) as a RECIPE instead of a tensor: the
+    pooled image, the 1x1 layer's parameters and scales (``out_scale``: the (1 - alpha) prescale when alpha is a host number).
+    ``ConvDownFadeRgbFn`` evaluates it inside the store of the newest block's stride-2 convolution; ``materialize`` runs the layer
+    (``RgbInFn``, the unfused path -- where the lerp is a pass of its own)."""
+
+    def __init__(self, pimg, layer, out_scale, dtype):
+        self.pimg, self.layer, self.out_scale, self.dtype = pimg, layer, float(out_scale), dtype
+
+    def materialize(self):
+        return self.layer.forward_nhwc(self.pimg, out_dtype=self.dtype, out_scale=self.out_scale)
+
+
+def fade_rgb_ok(layer, cout, dtype):
+    """True if ``ConvDownFadeRgbFn`` takes the residual layer: a 3 -> cout 1x1 convolution feeding bf16 activations, cout in {32, 64, 128}."""
+    return (FUSE_FADE and FUSE_FADE_RGB and dtype == torch.bfloat16 and int(cout) in (32, 64, 128) and layer.kernel_size == 1
+            and tuple(layer.weight.shape) == (int(cout), 3, 1, 1))
+
+
+class ConvDownFadeRgbFn(Function):
+    """``ConvDownFadeFn`` with the residual branch evaluated in the store: alpha * lrelu(conv_down(x) + bias) + beta * from_rgb(pimg),
+    from_rgb(pimg)[c] = bf16(rb[c] * bs1 * bs2 + ws * sum_j pimg[j] * wr[c][j]) -- the arithmetic of ``RgbInFn`` on a bf16 output, bit for
+    bit -- so the [B, H/2, W/2, C] residual tensor is neither written nor read (12 bytes of image per pixel instead of 2 x 2C).
+    Backward, first order (the training step): ONE pass over the incoming gradient (``sgx_fade_rgb_bwd``) gives the convolution's
+    upstream gradient alpha * g * slope(bits) (bit for bit ``LReluBwdBitsFn``), from_rgb's weight and bias gradients (accumulated
+    straight into ``.grad`` under ``accumulate_param_grads``) and, where the image needs one, its gradient -- instead of the mask
+    pass + ``RgbWgradFn`` + ``ColSumFn`` + ``RgbOutFn``.  Under ``create_graph`` (the R1 penalty's inner gradient) the backward is
+    the composition of those twice-differentiable ops, as for the unfused branch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pimg, wr, br, scale, ipad, alpha, beta, ws, bs1, bs2, x_pre=None, x_pre_bits=None):
+        x, pimg = _c(x), _c(pimg)
+        fwd, adj = packs(weight, "D", scale, ipad, x.dtype)
+        B, H, W, Cin = x.shape
+        taps, Cout, K = fwd.shape
+        if K != Cin or tuple(pimg.shape) != (B, H // 2, W // 2, 3) or pimg.dtype != torch.float32 or tuple(wr.shape) != (Cout, 3, 1, 1):
+            raise N.SgxError("conv+fade(rgb): pooled fp32 image [B, H/2, W/2, 3] and a [Cout, 3, 1, 1] weight expected")
+        y = torch.empty((B, H // 2, W // 2, Cout), dtype=x.dtype, device=x.device)
+        bits = torch.empty((B, H // 2, W // 2, Cout // 8), dtype=torch.uint8, device=x.device)
+        dev = isinstance(alpha, torch.Tensor)                # [alpha, 1 - alpha] in device memory (graph replay); beta is then ignored
+        if dev and not (alpha.dtype == torch.float32 and alpha.numel() == 2 and alpha.is_contiguous()):
+            raise N.SgxError("conv+fade(rgb): device coefficients must be a contiguous fp32 [alpha, beta] pair")
+        N.check(N.lib().sgx_conv4x4s2_down_fade_rgb(N.ptr(x), N.ptr(fwd), N.ptr(None if bias is None else _c(bias.detach())), N.ptr(pimg),
+                                                    N.ptr(_c(wr.detach())), float(ws), N.ptr(None if br is None else _c(br.detach())), float(bs1), float(bs2),
+                                                    0.0 if dev else float(alpha), 0.0 if dev else float(beta), alpha.data_ptr() if dev else None,
+                                                    N.ptr(y), N.ptr(bits), B, H, W, Cin, Cout, N.dt(x), N.stream()), "sgx_conv4x4s2_down_fade_rgb")
+        ctx.cfg = ("D", scale, ipad, False, 0, bias is not None, False, False)
+        ctx.bias_ref = weakref.ref(bias) if bias is not None else (lambda: None)
+        ctx.br_ref = weakref.ref(br) if br is not None else (lambda: None)
+        ctx.fade = ((None, None) if dev else (float(alpha), float(beta))) + (float(ws), float(bs1) * float(bs2))
+        ctx.save_for_backward(x, weight, None, None, x_pre, x_pre_bits, bits, alpha if dev else None, pimg, wr)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        bits, alpha_dev, pimg, wr = ctx.saved_tensors[6:10]
+        alpha, beta, ws, bs = ctx.fade
+        br = ctx.br_ref()
+        need_img = ctx.needs_input_grad[3]
+        want_w = ctx.needs_input_grad[4] and not _DATA_GRAD_ONLY
+        want_b = br is not None and ctx.needs_input_grad[5] and not _DATA_GRAD_ONLY
+        gpimg = gwr = gbr = None
+        if torch.is_grad_enabled():
+            # the differentiable composition (R1: this backward is itself differentiated)
+            if alpha_dev is not None:
+                g_res = _bcall(ScaleDevFn, g, alpha_dev[1:2])
+                gy = _bcall(LReluBwdBitsFn, g, bits, 0.2, alpha_dev[0:1])
+            else:
+                g_res = g if beta == 1.0 else _bcall(ScaleFn, g, beta)
+                gy = _bcall(LReluBwdBitsFn, g, bits, 0.2, alpha)
+            if need_img:
+                gpimg = _bcall(RgbOutFn, g_res, wr, None, ws)
+            if want_w:
+                gwr = _bcall(RgbWgradFn, pimg, g_res, wr, ws)
+            if want_b:
+                gbr = _bcall(ColSumFn, g_res, bs)
+        else:
+            L = N.lib()
+            C = g.shape[-1]
+            npix = g.numel() // C
+            accum = _ACCUM_PARAM_GRADS and wr.is_leaf and (br is None or br.is_leaf)
+            acc = 0
+            dw = db = None
+            if want_w:
+                if accum and wr.grad is not None:
+                    dw, acc = wr.grad, acc | 1
+                else:
+                    dw = torch.empty(wr.shape, dtype=torch.float32, device=g.device)
+            if want_b:
+                if accum and br.grad is not None:
+                    db, acc = br.grad, acc | 2
+                else:
+                    db = torch.empty(br.shape, dtype=torch.float32, device=g.device)
+            gy = torch.empty_like(g)
+            if need_img:
+                gpimg = torch.empty_like(pimg)
+            wsb = L.sgx_fade_rgb_bwd_ws_bytes(npix, C)
+            wsp = N.workspace(wsb, g.device)
+            dev = alpha_dev is not None
+            N.check(L.sgx_fade_rgb_bwd(N.ptr(g), N.ptr(bits), N.ptr(pimg), N.ptr(_c(wr.detach())), ws, bs, 0.0 if dev else alpha, 0.0 if dev else beta,
+                                       alpha_dev.data_ptr() if dev else None, N.ptr(gy), N.ptr(dw), N.ptr(db), acc, N.ptr(gpimg), N.ptr(wsp), wsb, npix, C,
+                                       N.dt(g), N.stream()), "sgx_fade_rgb_bwd")
+            if accum:
+                for p_, d_ in ((wr, dw), (br, db)):
+                    if d_ is not None:
+                        if p_.grad is None:
+                            p_.grad = d_
+                        if GRAD_NOTE is not None:
+                            GRAD_NOTE(p_)
+            else:
+                gwr, gbr = dw, db
+        out = ConvFn.backward(ctx, gy)                     # (x, weight, bias are inputs 0..2 of both Functions)
+        return (out[0], out[1], out[2], gpimg, gwr, gbr) + (None,) * 9
+
+
 class ColSumFn(Function):
     """[..., C] -> fp32 [C], times ``scale`` (bias gradient)."""
 

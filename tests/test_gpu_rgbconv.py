@@ -234,22 +234,28 @@ def test_discriminator_step_with_the_composed_first_layer(depth, monkeypatch):
     assert med_on <= 1.3 * med_off + 1e-3
 
 
+@pytest.mark.parametrize("rgbres", [False, True])
 @pytest.mark.parametrize("depth,B,composed,dev_alpha", [(5, 16, True, False), (5, 16, False, False), (5, 16, True, True)])     # (batches at which the stride-2 layer runs on the second-generation kernel)
-def test_fade_in_lerp_in_the_store_of_the_stride2_convolution(depth, B, composed, dev_alpha, monkeypatch):
+def test_fade_in_lerp_in_the_store_of_the_stride2_convolution(depth, B, composed, dev_alpha, rgbres, monkeypatch):
     """functional.ConvDownFadeFn (round 4): alpha * lrelu(conv1_down(.)) + (1 - alpha) * from_rgb(pool(img)) with the lerp in the
     convolution's store and the activation kept only as sign bits -- the SAME roundings as the separate passes (the lerp is applied
     to the bf16-rounded activation; the backward multiplies by the same slope), so scores, the R1 image gradient and every parameter
     gradient agree with the unfused path to the order in which autograd sums contributions (reference models/GAN.py:423-427).
-    ``dev_alpha``: [alpha, 1 - alpha] read from device memory by the kernel (what a replayed step graph passes)."""
+    ``dev_alpha``: [alpha, 1 - alpha] read from device memory by the kernel (what a replayed step graph passes).
+    ``rgbres`` (round 5, functional.ConvDownFadeRgbFn): the residual branch itself evaluated in that store from the pooled image
+    (sgx_rgb_in's arithmetic, rounded to bf16 like the tensor it replaces: the forward is bit-identical) and its backward -- mask pass,
+    from_rgb's weight / bias gradient, image gradient -- as one pass over the incoming gradient (sgx_fade_rgb_bwd)."""
     from stylegan.pytorch_amd import functional as F
     alpha = torch.tensor([0.3, 0.7], dtype=torch.float32, device=DEV) if dev_alpha else 0.3
     R = 4 << depth
     real = gu.seeded((B, 3, R, R), 61); fake = gu.seeded((B, 3, R, R), 62)
     dis, dp = build_dis()
     monkeypatch.setattr(F, "RGBCONV", composed)
+    monkeypatch.setattr(F, "FUSE_FADE_RGB", rgbres)
     calls = []
-    orig = F.ConvDownFadeFn.forward
-    monkeypatch.setattr(F.ConvDownFadeFn, "forward", staticmethod(lambda ctx, *a: (calls.append(1), orig(ctx, *a))[1]))
+    Fn = F.ConvDownFadeRgbFn if rgbres else F.ConvDownFadeFn
+    orig = Fn.forward
+    monkeypatch.setattr(Fn, "forward", staticmethod(lambda ctx, *a: (calls.append(1), orig(ctx, *a))[1]))
     loss_on, g_on, gi_on = d_loss_grads(dis, real.to(DEV), fake.to(DEV), depth, alpha)
     assert len(calls) == 3, calls
     monkeypatch.setattr(F, "FUSE_FADE", False)
