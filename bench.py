@@ -108,15 +108,19 @@ def sweep(sg, a, cfg, dev):
         def step(i, alpha):
             sg.optimize_discriminator(lats[i % 2], reals[i % 2], depth, alpha)
             sg.optimize_generator(lats[i % 2], reals[i % 2], depth, alpha)
-        for i in range(2):                                   # untimed: first use of this depth's kernels, packs, gradient buffers
+        replay = bool(sg.use_graphs)
+        for i in range(1 if replay else 2):                  # untimed: first use of this depth's kernels, packs, gradient buffers
             step(i, alphas[0])
         torch.cuda.synchronize()
-        native.prof_start(1)                                 # one surveyed iteration: launches per step, kernel time
-        step(0, alphas[0])
+        native.prof_start(1)                                 # one surveyed iteration: launches per step, kernel time (replay: the second
+        step(0, alphas[0])                                   # of the two eager calls before the capture -- events cannot be captured)
         torch.cuda.synchronize()
         native.prof_start(0)
         recs = native.prof_records()
         torch.cuda.synchronize()
+        if replay:
+            step(1, alphas[0])                               # untimed: the capture of both half-iterations and their first replay
+            torch.cuda.synchronize()
         prof = None
         if os.environ.get("SGX_SWEEP_PROFILE"):              # where the host spends the timed loop (stderr)
             import cProfile

@@ -105,23 +105,24 @@ template <int GEO, int NW, int MF, int KC = 32> struct C2Lds {
 
 // 8 channels (element offset doff = pixel * Cout + c0, c0 % 8 == 0) of the residual branch computed from the pooled image: exactly
 // sgx_rgb_in's arithmetic (pointwise.hip rgb_in_kernel: weights pre-multiplied by the scale, (r w0 + g w1) + b w2, bias added last,
-// no contraction) rounded to bf16 like the tensor that kernel would have stored.  The 32 weight / bias words of a lane are L1 hits.
-__device__ __forceinline__ uint4 fade_resid_from_image(const Conv2Args& a, size_t doff) {
+// no contraction) rounded to bf16 like the tensor that kernel would have stored.  fw: the block's table [BCO][4] = (ws w[c][0..2], bias)
+// in LDS (fade_table_fill), c_local = the first of the 8 channels inside the block's channel range.
+__device__ __forceinline__ void fade_table_fill(const Conv2Args& a, float* fw, int co0, int nch, int tid) {
+    if (tid < nch) {
+        const int c = co0 + tid;
+        const float w0 = a.fade_ws * a.fade_wr[c * 3], w1 = a.fade_ws * a.fade_wr[c * 3 + 1], w2 = a.fade_ws * a.fade_wr[c * 3 + 2];
+        const float bb = a.fade_rb ? (a.fade_rb[c] * a.fade_bs1) * a.fade_bs2 : 0.f;
+        reinterpret_cast<float4*>(fw)[tid] = make_float4(w0, w1, w2, bb);
+    }
+}
+__device__ __forceinline__ uint4 fade_resid_from_image(const Conv2Args& a, const float* fw, size_t doff, int c_local) {
     const size_t pix = doff / a.Cout;
-    const int c0 = (int)(doff - pix * a.Cout);
     const float r = a.fade_pimg[pix * 3], g = a.fade_pimg[pix * 3 + 1], b = a.fade_pimg[pix * 3 + 2];
     unsigned o[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float v[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int c = c0 + 2 * q + e;
-            const float w0 = a.fade_ws * a.fade_wr[c * 3], w1 = a.fade_ws * a.fade_wr[c * 3 + 1], w2 = a.fade_ws * a.fade_wr[c * 3 + 2];
-            const float bb = a.fade_rb ? (a.fade_rb[c] * a.fade_bs1) * a.fade_bs2 : 0.f;
-            v[e] = bb + (r * w0 + g * w1 + b * w2);
-        }
-        o[q] = pack_bf16x2(v[0], v[1]);
+        const float4 t0 = reinterpret_cast<const float4*>(fw)[c_local + 2 * q], t1 = reinterpret_cast<const float4*>(fw)[c_local + 2 * q + 1];
+        o[q] = pack_bf16x2(t0.w + (r * t0.x + g * t0.y + b * t0.z), t1.w + (r * t1.x + g * t1.y + b * t1.z));
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
     constexpr int TSY = EPI == EPI_BLUR ? TH - 1 : TH, TSX = EPI == EPI_BLUR ? 31 : 32;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     float* const ecoef = reinterpret_cast<float*>(smem + L::TOTAL);     // EPI_STATS: [2][BCO] epilogue bias / noise weight of this channel block
+                                                                        // C2_D with the residual computed in the store: [BCO][4] (fade_table_fill)
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -178,6 +180,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
         }
     }
     if (my_tiles <= 0) return;
+    if constexpr (GEO == C2_D && EPI == EPI_NONE) {
+        if (a.fade_pimg) fade_table_fill(a, ecoef, cb * BCO, BCO, threadIdx.x);      // (read in the epilogue, behind the main loop's barriers)
+    }
     const int nchunks = a.Cin / KC;
     const int spt = nchunks * NPH;                        // K-steps per tile
     const int nsteps = my_tiles * spt;
@@ -627,7 +632,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                                 }
                                 if (GEO == C2_D && (a.fade_resid || a.fade_pimg)) {
                                     const float fade_a = a.fade_ab ? a.fade_ab[0] : a.fade_alpha, fade_b = a.fade_ab ? a.fade_ab[1] : a.fade_beta;
-                                    const uint4 rq = a.fade_pimg ? fade_resid_from_image(a, doff) : *reinterpret_cast<const uint4*>(a.fade_resid + doff);
+                                    const uint4 rq = a.fade_pimg ? fade_resid_from_image(a, ecoef, doff, m * 32 + 16 * k + 8 * hi) : *reinterpret_cast<const uint4*>(a.fade_resid + doff);
                                     const unsigned yv[4] = {val.x, val.y, val.z, val.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w};
                                     unsigned ov[4];
 #pragma unroll
@@ -1173,9 +1178,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
                                 }
                                 a.signbits[doff >> 3] = (unsigned char)bits;
                             }
-                            if (GEO == C2_D && (a.fade_resid || a.fade_pimg)) {
+                            if (GEO == C2_D && a.fade_resid) {
                                 const float fade_a = a.fade_ab ? a.fade_ab[0] : a.fade_alpha, fade_b = a.fade_ab ? a.fade_ab[1] : a.fade_beta;
-                                const uint4 rq = a.fade_pimg ? fade_resid_from_image(a, doff) : *reinterpret_cast<const uint4*>(a.fade_resid + doff);
+                                const uint4 rq = *reinterpret_cast<const uint4*>(a.fade_resid + doff);
                                 const unsigned yv[4] = {val.x, val.y, val.z, val.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w};
                                 unsigned ov[4];
 #pragma unroll
@@ -1220,7 +1225,7 @@ static int launch_conv3(Conv2Args& a, hipStream_t st) {
 template <int GEO, int NW, int MF, int KC = 32, bool CO16 = false, int EPI = EPI_NONE>
 static int launch_conv2(Conv2Args& a, hipStream_t st) {
     using L = C2Lds<GEO, NW, MF, KC>;
-    constexpr int LDS = L::TOTAL + (EPI != EPI_NONE ? 1024 : 0);
+    constexpr int LDS = L::TOTAL + ((EPI != EPI_NONE || GEO == C2_D) ? 1024 : 0);      // + the epilogue's coefficient table (statistics; residual in the store)
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kern = conv2_kernel<GEO, NW, MF, KC, CO16, EPI>;
     sgx_lds_opt_in<conv2_kernel<GEO, NW, MF, KC, CO16, EPI>>(LDS);

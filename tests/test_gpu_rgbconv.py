@@ -262,7 +262,12 @@ def test_fade_in_lerp_in_the_store_of_the_stride2_convolution(depth, B, composed
     loss_off, g_off, gi_off = d_loss_grads(dis, real.to(DEV), fake.to(DEV), depth, alpha)
     assert len(calls) == 3
     assert abs(loss_on - loss_off) <= 1e-6 * abs(loss_off), (loss_on, loss_off)
-    assert rel_err(gi_on, gi_off) <= 1e-5
+    # With alpha in device memory the UNFUSED residual branch rounds (1 - alpha) * g to bf16 before from_rgb's backward reads it
+    # (ScaleDevFn writes a bf16 tensor); the one-pass backward multiplies in fp32: the image gradient and the residual layer's own
+    # gradients then differ by that rounding (2^-9 per element: measured 1.7e-3 rel-L2), everything else stays at summation order.
+    loose = 4e-3 if (rgbres and dev_alpha) else 1e-5
+    assert rel_err(gi_on, gi_off) <= loose
     assert sorted(g_on) == sorted(g_off)
+    res_layer = f"from_rgb.{dis.depth - depth}."
     for k in g_on:
-        assert rel_err(g_on[k], g_off[k]) <= 1e-5, (k, rel_err(g_on[k], g_off[k]))
+        assert rel_err(g_on[k], g_off[k]) <= (loose if k.startswith(res_layer) else 1e-5), (k, rel_err(g_on[k], g_off[k]))
