@@ -1106,9 +1106,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
             // pixels (px = 0, 1) of each fine row were requested before the K-step's MFMAs (mwp); the slope multiplies in fp32 BEFORE
             // the one rounding to bf16.
             if (a.maskbits) {
-                // the sign-bit words were requested before this K-step's DMA instructions: at most NPI of those (this wave's) are younger
+                // the sign-bit words were requested before this K-step's DMA instructions; loads retire in order, so they have landed once no
+                // more are outstanding than the DMA instructions this wave issued BEHIND them: at least P_INSTR / NW when a next stage was
+                // staged, none on the block's last K-step (waiting for a larger count there would not wait at all)
                 static_assert(RPW == 2, "mask words: two rows per wave");
-                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(mwp[0][0]), "+v"(mwp[0][1]), "+v"(mwp[1][0]), "+v"(mwp[1][1]) : "n"(NPI < 1 ? 0 : NPI - 1));
+                if (more) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(mwp[0][0]), "+v"(mwp[0][1]), "+v"(mwp[1][0]), "+v"(mwp[1][1]) : "n"(P_INSTR / NW));
+                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(mwp[0][0]), "+v"(mwp[0][1]), "+v"(mwp[1][0]), "+v"(mwp[1][1]));
             }
 #pragma unroll
             for (int f = 0; f < RPW; ++f) {
