@@ -937,6 +937,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
     }
     advance_issue();
     int c_t = tile0, c_q = 0;
+    unsigned mwp[RPW][2];                            // UB: sign-bit words of the tile being computed (c_t), see mwn in the loop
+    if constexpr (UB) {
+        int b_, ty_, tx_;
+        tile_coords(tile0, b_, ty_, tx_);
+#pragma unroll
+        for (int f = 0; f < RPW; ++f)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int i = ty_ + RPW * wave + f, j = tx_ + l31;
+                mwp[f][py] = (a.maskbits && i < a.H && j < a.W)
+                                 ? *reinterpret_cast<const unsigned*>(a.maskbits + ((((size_t)b_ * a.OH + 2 * i + py) * a.OW) + 2 * j) * 2) : 0xffffffffu;
+            }
+    }
     for (int step = 0; step < nsteps; ++step) {
         const unsigned so = (step & 1) * STAGE;
         char* const nxt = smem + (STAGE - so);
@@ -950,24 +963,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
         for (int g = 0; g < NG; ++g) pb[g] = pbase[g] + so;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) wb[ks] = wbase[ks] + (UB ? 0u : so);   // (UB: the composite taps live in stage 0's weight region)
-        unsigned mwp[RPW][2];                        // UB: sign-bit words of the tile this K-step computes (c_t), requested ahead of the MFMAs
+        // UB: the sign-bit words of the NEXT tile (the one whose patch is being staged: the issue cursor's) are requested now; they are
+        // consumed one K-step later, behind the barrier that also waits for that stage -- never a wait of their own in the epilogue.
+        // (Measured and dropped: requesting the current tile's words here and waiting for them in the epilogue with a counted vmcnt --
+        // LDS-DMA loads and ordinary loads do not retire in one order: the words were stale in every run, tools/repro_check.py.)
+        unsigned mwn[RPW][2];
         if constexpr (UB) {
-            // inline-asm loads: hipcc would wait vmcnt(0) -- i.e. for the NEXT stage's LDS-DMA, issued right behind these -- before their
-            // first use in the epilogue; the epilogue waits for them with a counted vmcnt instead (loads retire in order: at most the
-            // wave's own DMA instructions of this K-step may still be outstanding)
-            if (a.maskbits) {
-                int b_, ty_, tx_;
-                tile_coords(c_t, b_, ty_, tx_);
 #pragma unroll
-                for (int f = 0; f < RPW; ++f)
+            for (int f = 0; f < RPW; ++f)
 #pragma unroll
-                    for (int py = 0; py < 2; ++py) {
-                        const int i = ty_ + RPW * wave + f, j = tx_ + l31;
-                        const bool in = i < a.H && j < a.W;                         // (out-of-image lanes read the first word: ignored, never stored)
-                        const unsigned char* mp = a.maskbits + (in ? ((((size_t)b_ * a.OH + 2 * i + py) * a.OW) + 2 * j) * 2 : (size_t)0);
-                        asm volatile("global_load_dword %0, %1, off" : "=v"(mwp[f][py]) : "v"(mp));
-                    }
-            }
+                for (int py = 0; py < 2; ++py) {
+                    const int i = ity0 + RPW * wave + f, j = itx0 + l31;
+                    mwn[f][py] = (a.maskbits && more && i < a.H && j < a.W)
+                                     ? *reinterpret_cast<const unsigned*>(a.maskbits + ((((size_t)ib * a.OH + 2 * i + py) * a.OW) + 2 * j) * 2) : 0xffffffffu;
+                }
         }
         i32x4 brow[2][R], af[NAB][MF];
         auto ld_brow = [&](auto Gi) {
@@ -1105,14 +1114,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
             // Mask (the LeakyReLU backward of the discriminator's chain): sign bits [fine pixel][2 bytes]; the 4 bytes of a lane's two fine
             // pixels (px = 0, 1) of each fine row were requested before the K-step's MFMAs (mwp); the slope multiplies in fp32 BEFORE
             // the one rounding to bf16.
-            if (a.maskbits) {
-                // the sign-bit words were requested before this K-step's DMA instructions; loads retire in order, so they have landed once no
-                // more are outstanding than the DMA instructions this wave issued BEHIND them: at least P_INSTR / NW when a next stage was
-                // staged, none on the block's last K-step (waiting for a larger count there would not wait at all)
-                static_assert(RPW == 2, "mask words: two rows per wave");
-                if (more) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(mwp[0][0]), "+v"(mwp[0][1]), "+v"(mwp[1][0]), "+v"(mwp[1][1]) : "n"(P_INSTR / NW));
-                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(mwp[0][0]), "+v"(mwp[0][1]), "+v"(mwp[1][0]), "+v"(mwp[1][1]));
-            }
 #pragma unroll
             for (int f = 0; f < RPW; ++f) {
                 const int i = row0 + f, j = tx0 + l31;
@@ -1140,6 +1141,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
                     }
                 }
             }
+#pragma unroll
+            for (int f = 0; f < RPW; ++f)
+#pragma unroll
+                for (int py = 0; py < 2; ++py) mwp[f][py] = mwn[f][py];
             zero_acc();
         } else
         if (++c_q == spt) {
