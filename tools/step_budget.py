@@ -13,9 +13,9 @@ import csv
 import re
 import sys
 
-FAMILIES = [("conv", r"conv2?_kernel"), ("wgrad", r"wgrad|prereduce|colsum|rgb_wgrad"), ("epilogue", r"gepi"),
-            ("blur", r"blur"), ("rgb/fade/act", r"rgb_|axpby|lrelu|up2|pool2|bias_act"), ("optimizer", r"adam|ema|sumsq|scale_dev|clip"),
-            ("pack", r"pack_weight"), ("linear/mapping", r"gemm|style_|pixelnorm|linear|mbstd")]
+FAMILIES = [("conv", r"conv[23]?_kernel"), ("wgrad", r"wgrad|prereduce|colsum|rgb_wgrad"), ("epilogue", r"gepi"),
+            ("blur", r"blur"), ("rgb/fade/act", r"rgb_|axpby|lrelu|up2|pool2|bias_act|fade_"), ("optimizer", r"adam|ema|sumsq|scale_dev|clip"),
+            ("pack", r"pack_weight|pack_upblur|rgbconv_pack"), ("linear/mapping", r"gemm|style_|pixelnorm|linear|mbstd")]
 
 
 def family(kernel):
