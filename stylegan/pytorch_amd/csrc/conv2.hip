@@ -115,9 +115,7 @@ __device__ __forceinline__ void fade_table_fill(const Conv2Args& a, float* fw, i
         reinterpret_cast<float4*>(fw)[tid] = make_float4(w0, w1, w2, bb);
     }
 }
-__device__ __forceinline__ uint4 fade_resid_from_image(const Conv2Args& a, const float* fw, size_t doff, int c_local) {
-    const size_t pix = doff / a.Cout;
-    const float r = a.fade_pimg[pix * 3], g = a.fade_pimg[pix * 3 + 1], b = a.fade_pimg[pix * 3 + 2];
+__device__ __forceinline__ uint4 fade_resid_from_image(const float* fw, float r, float g, float b, int c_local) {
     unsigned o[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -349,6 +347,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                         const int px = (i * 64 + lane) / VPR, oy = ty_ + 2 * wave + f, ox = tx_ + px;
                         nzv[f][i] = (oy < a.OH && ox < a.OW) ? a.enoise[((size_t)b_ * a.OH + oy) * a.OW + ox] : 0.f;
                     }
+            }
+        }
+        // residual in the store (C2_D): the pooled-image pixels of the two rows this lane stores, requested before the MFMAs of the tile's
+        // last K-step (like the noise values above) -- read in the epilogue they would cost one exposed load latency per store
+        float pim[2][3];
+        if constexpr (GEO == C2_D && EPI == EPI_NONE) {
+            const int it_ = step / spt;
+            if (a.fade_pimg && step - it_ * spt == spt - 1) {
+                int b_, ty_, tx_;
+                tile_coords(tile0 + it_ * tstride, b_, ty_, tx_);
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const int oy = ty_ + 2 * wave + f, ox = tx_ + l31;
+                    const bool in = oy < a.OH && ox < a.OW;
+                    const float* pp = a.fade_pimg + (in ? (((size_t)b_ * a.OH + oy) * a.OW + ox) * 3 : (size_t)0);
+                    pim[f][0] = pp[0]; pim[f][1] = pp[1]; pim[f][2] = pp[2];
+                }
             }
         }
         if constexpr (GEO == C2_U) {
@@ -611,6 +626,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                             o2[g].x = pack_bf16x2(v[0], v[1]);
                             o2[g].y = pack_bf16x2(v[2], v[3]);
                         }
+                        unsigned sbw = 0;                // this lane's sign bytes of the 32-channel row: byte (k) at bit 16 k
 #pragma unroll
                         for (int k = 0; k < (CO16 ? 1 : 2); ++k) {
                             uint2 lo = o2[2 * k], up = o2[2 * k + 1];
@@ -628,11 +644,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                                         bits |= ((short)(wv[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q);
                                         bits |= ((short)(wv[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
                                     }
-                                    a.signbits[doff >> 3] = (unsigned char)bits;
+                                    sbw |= bits << (16 * k);
                                 }
                                 if (GEO == C2_D && (a.fade_resid || a.fade_pimg)) {
                                     const float fade_a = a.fade_ab ? a.fade_ab[0] : a.fade_alpha, fade_b = a.fade_ab ? a.fade_ab[1] : a.fade_beta;
-                                    const uint4 rq = a.fade_pimg ? fade_resid_from_image(a, ecoef, doff, m * 32 + 16 * k + 8 * hi) : *reinterpret_cast<const uint4*>(a.fade_resid + doff);
+                                    const uint4 rq = a.fade_pimg ? fade_resid_from_image(ecoef, pim[f][0], pim[f][1], pim[f][2], m * 32 + 16 * k + 8 * hi)
+                                                                 : *reinterpret_cast<const uint4*>(a.fade_resid + doff);
                                     const unsigned yv[4] = {val.x, val.y, val.z, val.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w};
                                     unsigned ov[4];
 #pragma unroll
@@ -642,6 +659,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                                     val = make_uint4(ov[0], ov[1], ov[2], ov[3]);
                                 }
                                 *reinterpret_cast<uint4*>(a.y + doff) = val;
+                            }
+                        }
+                        if ((GEO == C2_S || GEO == C2_D) && a.signbits) {
+                            // the four sign bytes of a pixel's 32-channel row (bytes 2k + hi) leave as ONE aligned word from the lower half-wave
+                            // (128 contiguous bytes per 32 pixels) instead of four scattered byte stores: the upper half-wave's two bytes come over
+                            // with one v_permlane32_swap (16 channels: two bytes, one 16-bit store)
+                            auto sw = __builtin_amdgcn_permlane32_swap(sbw, sbw, false, false);
+                            if (inimg && hi == 0) {
+                                const unsigned word = sw[0] | (sw[1] << 8);
+                                const size_t bidx = (pix + m * 32) >> 3;
+                                if constexpr (CO16) *reinterpret_cast<unsigned short*>(a.signbits + bidx) = (unsigned short)word;
+                                else *reinterpret_cast<unsigned*>(a.signbits + bidx) = word;
                             }
                         }
                     }
@@ -1178,6 +1207,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
                         o2[g].x = pack_bf16x2(v[0], v[1]);
                         o2[g].y = pack_bf16x2(v[2], v[3]);
                     }
+                    unsigned sbw = 0;
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         uint2 lo = o2[2 * k], up = o2[2 * k + 1];
@@ -1195,7 +1225,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
                                     bits |= ((short)(wv[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q);
                                     bits |= ((short)(wv[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
                                 }
-                                a.signbits[doff >> 3] = (unsigned char)bits;
+                                sbw |= bits << (16 * k);
                             }
                             if (GEO == C2_D && a.fade_resid) {
                                 const float fade_a = a.fade_ab ? a.fade_ab[0] : a.fade_alpha, fade_b = a.fade_ab ? a.fade_ab[1] : a.fade_beta;
@@ -1210,6 +1240,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
                             }
                             *reinterpret_cast<uint4*>(a.y + doff) = val;
                         }
+                    }
+                    if (a.signbits) {                 // (one aligned word per pixel and 32 channels: conv2_kernel's epilogue)
+                        auto sw = __builtin_amdgcn_permlane32_swap(sbw, sbw, false, false);
+                        if (inimg && hi == 0) *reinterpret_cast<unsigned*>(a.signbits + ((pix + m * 32) >> 3)) = sw[0] | (sw[1] << 8);
                     }
                 }
             }
