@@ -57,6 +57,10 @@ HOT = [
     ("rgbconv_fwdblur_kernel<1>(float const*, unsigned short const*, float const*, unsigned short*, unsigned char*, int, int, int, int, int, int, int, int)", 6),                                        # from_rgb + conv0 + LeakyReLU + blur, 3 -> 16 at 1024^2
     ("rgbconv_dgrad_kernel<1>(unsigned short const*, unsigned short const*, float*, int, int, int, int, int)", 6),                                          # its image gradient
     ("rgbconv_wgrad_kernel<1>(float const*, unsigned short const*, float*, int, int, int, int, int, int, int)", 4),                                          # its (composed) weight gradient: 3 resident blocks per CU
+    # round 5: blur o transposed convolution as one 3x3 convolution to four parity classes (8-wave block: two waves per SIMD; the border
+    # block's loops are rolled so that its fragments stay out of the main loop's register budget: unrolled it spilled 68 bytes per lane)
+    ("conv3_kernel<0, 8, 2, 2, 2, 0, 1>(Conv2Args)", 2),
+    ("conv3_kernel<0, 4, 2, 2, 2, 0, 1>(Conv2Args)", 1),                     # (the 4-wave block for small launches: one wave per SIMD, 153 KB of LDS)
 ]
 
 
