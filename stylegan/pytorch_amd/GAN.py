@@ -921,7 +921,11 @@ class StyleGAN:
         except ImportError:
             torch.save(grid, img_file + ".pt")
 
-    train_graphs = os.environ.get("SGX_TRAIN_GRAPHS", "1") != "0"     # ``train`` replays captured half-iterations (see there)
+    # ``train`` replays captured half-iterations (see there): "auto" (default) decides per depth from three timed eager iterations --
+    # replay where the host's enqueue time is the step time (the 4x4 / 8x8 depths at batch 128 and the top depths at batch 8 / 4 / 2:
+    # +25 % / +24 % and +25 % / +54 % / +74 % img/s in profiles/r05_bench_sweep_*.json), eager launches where the GPU is the limit (replay
+    # measured 7-19 % SLOWER at depth 2 and 4: a captured half-iteration re-packs every weight it uses); True / False (SGX_TRAIN_GRAPHS=1 / 0)
+    train_graphs = {"0": False, "1": True}.get(os.environ.get("SGX_TRAIN_GRAPHS", "auto"), "auto")
 
     def train(self, dataset, num_workers, epochs, batch_sizes, fade_in_percentage, logger, output,
               num_samples=36, start_depth=0, feedback_factor=100, checkpoint_factor=1):
@@ -942,9 +946,10 @@ class StyleGAN:
         # d_repeats 1, 'linear' structure; per depth and batch shape, after two eager calls).  At the top depths the reference's schedule
         # shrinks the batch to 8 / 4 / 2 where the launch count is largest (567-689 launches per iteration), and the eager loop is bound by
         # the host's enqueue time there (bench.py --sweep); the replayed step is bound by the GPU.  Same arithmetic as
-        # the eager step with ``alpha_on_device`` (tests/test_gpu_graphs.py).  ``train_graphs = False`` / SGX_TRAIN_GRAPHS=0: eager.
+        # the eager step with ``alpha_on_device`` (tests/test_gpu_graphs.py).  ``train_graphs``: "auto" (per depth, measured), True, False.
         was_graphs = getattr(self, "use_graphs", False)                     # (a schedule-only stand-in has no launch state: tests/test_train_schedule.py)
-        self.use_graphs = bool(was_graphs or self.train_graphs)
+        self.use_graphs = bool(was_graphs or self.train_graphs is True)
+        self._train_forced_graphs = self.use_graphs                          # the caller (or SGX_TRAIN_GRAPHS=1) asked for replay: no per-depth probe
         try:
             self._train_loop(dataset, num_workers, epochs, batch_sizes, fade_in_percentage, logger, output, num_samples,
                              start_depth, feedback_factor, checkpoint_factor)
@@ -969,6 +974,12 @@ class StyleGAN:
             graphs = getattr(self, "_step_graphs", {})
             for key in [k for k in graphs if k[1] != current_depth]:
                 del graphs[key]
+            # "auto": this depth starts with eager launches; iterations 2..4 are timed (host enqueue time against wall time incl. the GPU)
+            probe = None
+            if self.train_graphs == "auto" and getattr(self, "device", None) is not None and self.device.type == "cuda" \
+                    and not getattr(self, "_train_forced_graphs", False):
+                self.use_graphs = False
+                probe = {"n": 0, "t0": 0.0}
             logger.info("Currently working on depth: %d", current_depth + 1)
             logger.info("Current resolution: %d x %d" % (current_res, current_res))
             ticker = 1
@@ -988,8 +999,21 @@ class StyleGAN:
                         images, labels = batch, None
                     images = images.to(self.device)
                     gan_input = torch.randn(images.shape[0], self.latent_size).to(self.device)
+                    if probe is not None and probe["n"] == 1:
+                        torch.cuda.synchronize(); probe["t0"] = time.perf_counter()
                     dis_loss = self.optimize_discriminator(gan_input, images, current_depth, alpha, labels)
                     gen_loss = self.optimize_generator(gan_input, images, current_depth, alpha, labels)
+                    if probe is not None:
+                        probe["n"] += 1
+                        if probe["n"] == 4:
+                            t_enq = time.perf_counter() - probe["t0"]
+                            torch.cuda.synchronize()
+                            t_all = time.perf_counter() - probe["t0"]
+                            self.use_graphs = bool(t_enq >= 0.85 * t_all)          # the host is the limit: replay from here on
+                            logger.info("Depth %d: %s launches (host enqueue %.1f ms of %.1f ms per iteration)" % (
+                                current_depth + 1, "hipGraph replay of the captured half-iterations" if self.use_graphs else "eager",
+                                t_enq / 3 * 1e3, t_all / 3 * 1e3))
+                            probe = None
                     if self.is_feedback_batch(i, total_batches, feedback_factor):
                         elapsed = str(datetime.timedelta(seconds=time.time() - t_begin)).split('.')[0]
                         logger.info("Elapsed: [%s] Step: %d  Batch: %d  D_Loss: %f  G_Loss: %f"
