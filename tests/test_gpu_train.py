@@ -55,6 +55,11 @@ def test_sample_yaml_trains_first_two_depths(tmp_path):
         # hundreds to ~1.2e3 depending on the initial weights -- measured 1170.9 with the generator state another test order left)
         assert d == d and g == g and abs(d) < 1e4 and abs(g) < 1e4, l
     assert lines[-1].startswith("Training completed")
+    # round 5: the loop decided per depth, from iterations 2..4, between eager launches and hipGraph replay (StyleGAN.train_graphs "auto");
+    # depth 1 (index) ran its last four iterations in the mode it chose -- replay included where this box's host is the limit
+    mode_lines = [l for l in lines if "launches (host enqueue" in l]
+    assert len(mode_lines) == 2 and mode_lines[0].startswith("Depth 1:") and mode_lines[1].startswith("Depth 2:"), mode_lines
+    assert style_gan.use_graphs is False                                            # the caller's setting is restored
     assert sorted(os.listdir(os.path.join(out, "samples")))[0].startswith("gen_0_1_1")
     models = os.listdir(os.path.join(out, "models"))
     # checkpoint epochs: depth 0 -> 1, 2 (first and last); depth 1 -> 1, 4: five files each
