@@ -1197,6 +1197,15 @@ class _StepGraph:
         self._adam_steps_before_capture = [(st, float(st["step"])) for st in opt.state.values() if "step" in st]
         native.reserve_capture_staging(1 << 20)                # descriptor tables are staged in pre-allocated pinned memory
         F.clear_pack_cache()                                   # the graph packs every weight it uses itself
+        # No destructor may run while the launches are being recorded: a garbage-collected StyleGAN of an earlier depth / test takes
+        # its captured graphs, events and streams down with it (hipGraphExecDestroy, hipEventDestroy ...), and such a call from this
+        # thread in the middle of a stream capture invalidates it ("operation failed due to a previous error during capture" --
+        # seen once in six runs of the data-parallel graph test, after which RCCL's watchdog aborted the process on an event of the dead
+        # capture).  Collect first, then keep the collector off until the capture has ended.
+        import gc
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
         torch.cuda.synchronize()
         opt._capture_log = []
         self.graph = torch.cuda.CUDAGraph()
@@ -1215,6 +1224,8 @@ class _StepGraph:
                     self._body("update")
         finally:
             self.adam_entries, opt._capture_log = opt._capture_log, None
+            if gc_was:
+                gc.enable()
         # the gradient tensors the graph writes (static addresses): re-attached after every replay so that .grad shows
         # this iteration's gradients even if an eager call in between replaced them
         self.grads = [(p, p.grad) for p in net.parameters() if p.grad is not None]
