@@ -15,7 +15,10 @@ launch alone on the GPU, the number `rocprofv3 --kernel-trace --stats -- python 
 reproduces (profiles/).  `b32` (default invocation, N=1): a second measured block at batch 32 on the one GPU -- the
 configuration BASELINE.json's north-star target is stated on -- with its own throughput and `roofline`.  `cpu_baseline`
 times the CPU oracle (a port of the reference step, oracle/stylegan_oracle.py) -- or the reference itself where its
-sources exist -- on this host's cores on a bounded sample (rank 0, N=1 only).
+sources exist -- on this host's cores on a bounded sample (rank 0, N=1 only).  Two short extra blocks follow the
+measured ones in the default invocation (N=1, batch 4; `--no-extras` skips them): `sweep_top_depths` = BASELINE
+configs[4]'s depth indices 6,7,8 at the reference's batch sizes with hipGraph replay (the mode `StyleGAN.train` runs),
+and `ffhq128_fp32_b64` = BASELINE configs[1] as its own bench line from a child process.
 """
 import argparse
 import json
@@ -62,6 +65,9 @@ def parse():
     ap.add_argument("--layer-table", default=None, help="write a per-layer conv/wgrad timing table (TSV) to this path (+ .b32.tsv for the batch-32 block)")
     ap.add_argument("--no-b32", action="store_true", help="skip the second measured block (batch 32 on one GPU)")
     ap.add_argument("--b32-steps", type=int, default=8)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the two short extra blocks of the default invocation: BASELINE configs[4]'s top depths (6,7,8) replayed, "
+                         "and BASELINE configs[1] (ffhq128, fp32, batch 64) in a child process")
     ap.add_argument("--sweep", action="store_true",
                     help="BASELINE configs[4]: the progressive-growing sweep, depth index 0..8 of the 1024 model with the reference's per-depth "
                          "batch sizes (config.py:40-41), the fade-in ramp of models/GAN.py:748-753 and style mixing on; per-depth img/s")
@@ -147,6 +153,55 @@ def sweep(sg, a, cfg, dev):
         del reals, lats
         torch.cuda.empty_cache()
     return rows
+
+
+def extra_sweep_top_depths(sg, a, cfg, dev):
+    """Default invocation, N=1: BASELINE configs[4]'s three top depths (index 6,7,8 = 256^2, 512^2, 1024^2 at the reference's batch sizes
+    8, 4, 2) with hipGraph replay -- what `StyleGAN.train` runs since round 5 -- 6 timed iterations each, after the headline blocks
+    (never inside their timed regions).  A failure here is recorded, it does not take the line down."""
+    import copy
+    b = copy.copy(a)
+    b.sweep_depths, b.sweep_steps, b.sweep_batch_scale = "6,7,8", 6, 1.0
+    was = sg.use_graphs
+    try:
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        sg._step_graphs.clear()
+        sg.use_graphs = True
+        t0 = time.perf_counter()
+        rows = sweep(sg, b, cfg, dev)
+        return {"config": {"workload": "ffhq1024 model, depth index 6,7,8 at the reference's batch sizes 8,4,2 (config.py:40-41), fade-in over the "
+                                       "first half of the timed iterations, style mixing on, hipGraph replay"},
+                "steps": b.sweep_steps, "rows": rows, "wall_s": round(time.perf_counter() - t0, 1)}
+    except Exception as e:                                   # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        sg.use_graphs = was
+        sg._step_graphs.clear()
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+
+
+def extra_ffhq128_fp32_b64(timeout_s=150.0):
+    """Default invocation, N=1: BASELINE configs[1] (FFHQ-128 model, depth index 5, fp32, batch 64) as its own bench line from a child
+    process (own model, own dtype), embedded without its evidence text."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", "ffhq128", "--dtype", "fp32", "--batch-per-gpu", "64",
+           "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras"]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"child rc {r.returncode}: {r.stderr.strip()[-300:]}"}
+        j = json.loads(line[-1])
+        keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "host_enqueue_ms_per_step", "hip_graphs",
+                "useful_tflops", "executed_tflops", "executed_frac_of_mfma_peak", "roofline")
+        out = {k: j[k] for k in keep if k in j}
+        out["wall_s"] = round(time.perf_counter() - t0, 1)
+        return out
+    except subprocess.TimeoutExpired:
+        return {"error": f"child exceeded {timeout_s:.0f} s"}
+    except Exception as e:                                   # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def cpu_baseline_subprocess(config, timeout_s):
@@ -581,6 +636,9 @@ def main():
         if b32 is not None:
             b32["config"] = {"workload": f"{a.config}: same model, batch 32 on one GPU (the north-star target configuration)"}
             out["b32"] = b32
+        if headline and world == 1 and not a.no_extras and B == 4:
+            out["sweep_top_depths"] = extra_sweep_top_depths(sg, a, cfg, dev)
+            out["ffhq128_fp32_b64"] = extra_ffhq128_fp32_b64()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(a.config, a.cpu_baseline_timeout)
         print(json.dumps(out))

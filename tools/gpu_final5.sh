@@ -29,7 +29,7 @@ if [ "$2" = "test" ]; then
 fi
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
 echo "== bench default (b4 + b32 blocks, cpu baseline)"; timeout 900 python bench.py --layer-table $O/layers_b4.tsv 2>$O/bench_default.err | tail -1 > $O/bench_default.json; stamp_json $O/bench_default.json; cut -c1-260 $O/bench_default.json
-echo "== bench b4 single stream"; timeout 400 python bench.py --no-b32 --no-cpu-baseline --graphs off --streams 00 --layer-table $O/layers_b4_single.tsv 2>/dev/null | tail -1 > $O/bench_b4_single.json; stamp_json $O/bench_b4_single.json; cut -c1-200 $O/bench_b4_single.json
+echo "== bench b4 single stream"; timeout 400 python bench.py --no-b32 --no-extras --no-cpu-baseline --graphs off --streams 00 --layer-table $O/layers_b4_single.tsv 2>/dev/null | tail -1 > $O/bench_b4_single.json; stamp_json $O/bench_b4_single.json; cut -c1-200 $O/bench_b4_single.json
 echo "== bench b32 single stream"; timeout 400 python bench.py --batch-per-gpu 32 --steps 8 --warmup 2 --no-cpu-baseline --graphs off --streams 00 --layer-table $O/layers_b32_single.tsv 2>/dev/null | tail -1 > $O/bench_b32_single.json; stamp_json $O/bench_b32_single.json; cut -c1-200 $O/bench_b32_single.json
 python tools/step_budget.py $O/layers_b4_single.tsv > $O/step_budget_b4.txt 2>&1; python tools/step_budget.py $O/layers_b32_single.tsv > $O/step_budget_b32.txt 2>&1
 for f in $O/layers_*.tsv $O/step_budget_*.txt; do stamp_txt $f; done
@@ -37,7 +37,7 @@ if [ "$3" = "ab" ]; then
   echo "== A/B on this box: the round-5 fusions off (SGX_CONV_UPBLUR=0 SGX_FUSE_FADE_RGB=0 SGX_TRAIN_GRAPHS unaffected) vs on, default bench line, interleaved"
   for i in 1 2; do for v in off on; do
     if [ $v = off ]; then export SGX_CONV_UPBLUR=0 SGX_FUSE_FADE_RGB=0; else unset SGX_CONV_UPBLUR SGX_FUSE_FADE_RGB; fi
-    timeout 400 python bench.py --no-cpu-baseline --steps 30 2>/dev/null | tail -1 | python -c "
+    timeout 400 python bench.py --no-cpu-baseline --no-extras --steps 30 2>/dev/null | tail -1 | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
 print('round-5 fusions $v: b4', round(d['value'], 1), 'img/s', round(d['ms_per_step'], 3), 'ms graphs', d.get('hip_graphs'), '| b32', round(d['b32']['value'], 1), 'img/s', round(d['b32']['ms_per_step'], 2), 'ms')"
@@ -48,7 +48,7 @@ fi
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"
 for B in 4 32; do
-  BA="--batch-per-gpu $B --no-b32 --no-cpu-baseline --no-kernel-timing --graphs off --streams 00"
+  BA="--batch-per-gpu $B --no-b32 --no-extras --no-cpu-baseline --no-kernel-timing --graphs off --streams 00"
   echo "== rocprofv3 stats, batch $B"
   timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b$B -o st -- python $R/bench.py --steps 3 --warmup 1 $BA > $O/prof_bench_b$B.log 2>&1
   tail -1 $O/prof_bench_b$B.log | cut -c1-160
