@@ -1199,13 +1199,16 @@ class _StepGraph:
         F.clear_pack_cache()                                   # the graph packs every weight it uses itself
         # No destructor may run while the launches are being recorded: a garbage-collected StyleGAN of an earlier depth / test takes
         # its captured graphs, events and streams down with it (hipGraphExecDestroy, hipEventDestroy ...), and such a call from this
-        # thread in the middle of a stream capture invalidates it ("operation failed due to a previous error during capture" --
-        # seen once in six runs of the data-parallel graph test, after which RCCL's watchdog aborted the process on an event of the dead
-        # capture).  Collect first, then keep the collector off until the capture has ended.
+        # thread in the middle of a stream capture invalidates it ("operation failed due to a previous error during capture"); with a
+        # process group alive RCCL's watchdog thread then throws hipErrorCapturedEvent and the process aborts before any eager retry
+        # can help (profiles/r05_capture_gc_guard.txt: 6 of 11 runs of tests/test_gpu_graphs.py aborted without this guard, 0 of 10
+        # with it).  Collect first, then keep the collector off until the capture has ended.
         import gc
-        gc.collect()
-        gc_was = gc.isenabled()
-        gc.disable()
+        gc_was = False
+        if os.environ.get("SGX_CAPTURE_GC_GUARD", "1") != "0":  # (0: A/B of the guard itself)
+            gc.collect()
+            gc_was = gc.isenabled()
+            gc.disable()
         torch.cuda.synchronize()
         opt._capture_log = []
         self.graph = torch.cuda.CUDAGraph()
