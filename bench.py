@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--layer-table", default=None, help="write a per-layer conv/wgrad timing table (TSV) to this path (+ .b32.tsv for the batch-32 block)")
     ap.add_argument("--no-b32", action="store_true", help="skip the second measured block (batch 32 on one GPU)")
     ap.add_argument("--b32-steps", type=int, default=8)
+    ap.add_argument("--rccl-group-of-one", action="store_true",
+                    help="N=1 only: run the data-parallel code path over an RCCL process group of size 1 (bucketed all-reduce launched for real, "
+                         "replay split into [graph | all-reduce | graph]) -- measures what that path costs per step on one GPU; not a scaling run")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the two short extra blocks of the default invocation: BASELINE configs[4]'s top depths (6,7,8) replayed, "
                          "and BASELINE configs[1] (ffhq128, fp32, batch 64) in a child process")
@@ -583,6 +586,11 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         from stylegan.pytorch_amd.dist import DataParallelGroup
         dp = DataParallelGroup()
+    elif a.rccl_group_of_one:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29655", rank=0, world_size=1, device_id=dev)
+        from stylegan.pytorch_amd.dist import DataParallelGroup
+        dp = DataParallelGroup(force_collectives=True)
 
     sg = make_stylegan(a, cfg, dev, dp)
     B, res, depth = a.batch_per_gpu, cfg["resolution"], cfg["depth"]
@@ -633,6 +641,9 @@ def main():
                 out[k] = v
         if "roofline" in blk:
             out["roofline"] = blk["roofline"]
+        if a.rccl_group_of_one:
+            out["rccl_group_of_one"] = ("data-parallel code path over an RCCL group of size 1: bucketed all-reduce launched for real (no peer to exchange "
+                                        "with), replay split into [graph | all-reduce | graph]; NOT a scaling measurement")
         if b32 is not None:
             b32["config"] = {"workload": f"{a.config}: same model, batch 32 on one GPU (the north-star target configuration)"}
             out["b32"] = b32
@@ -642,7 +653,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(a.config, a.cpu_baseline_timeout)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or a.rccl_group_of_one:
         torch.distributed.destroy_process_group()
 
 
