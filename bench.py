@@ -295,6 +295,15 @@ def cpu_baseline(cfg, batch=CPU_BATCH):
                       f"(oracle/stylegan_oracle.py; the reference's sources are not on this box), {cores} threads, {dt:.1f} s"}
 
 
+def flush_c_stdio():
+    """fflush(NULL): push out what C libraries (RCCL's banner) hold in stdio buffers now, not at exit."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                        # noqa: BLE001 -- cosmetic
+        pass
+
+
 def make_stylegan(a, cfg, dev, dp):
     from stylegan.pytorch_amd.GAN import StyleGAN
     act_dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -592,6 +601,7 @@ def main():
         from stylegan.pytorch_amd.dist import DataParallelGroup
         dp = DataParallelGroup(force_collectives=True)
 
+    flush_c_stdio()
     sg = make_stylegan(a, cfg, dev, dp)
     B, res, depth = a.batch_per_gpu, cfg["resolution"], cfg["depth"]
     if a.sweep:
@@ -652,9 +662,21 @@ def main():
             out["ffhq128_fp32_b64"] = extra_ffhq128_fp32_b64()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(a.config, a.cpu_baseline_timeout)
-        print(json.dumps(out))
+        line = json.dumps(out)
+    # The JSON line must be the LAST line of the job's stdout.  RCCL prints its version banner through C stdio, which is fully buffered
+    # when stdout is a pipe: left alone it comes out when the process exits, AFTER Python's own output (seen with --rccl-group-of-one:
+    # `tail -1` was "Librccl path : ...").  So: tear the group down, flush C stdio on every rank, let the other ranks' processes end,
+    # and only then print.
     if world > 1 or a.rccl_group_of_one:
+        if world > 1:
+            torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:
+        if world > 1:
+            time.sleep(1.0)
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
