@@ -1053,6 +1053,10 @@ class StyleGAN:
 
 
 
+# data parallel under hipGraph replay: the update after the all-reduce as eager launches (1) or as a second captured graph (0)
+DP_EAGER_UPDATE = os.environ.get("SGX_DP_EAGER_UPDATE", "1") != "0"
+
+
 class _StepGraph:
     """One half-iteration (kind 'd' or 'g') at one depth and one batch shape as a replayable hipGraph.
 
@@ -1078,6 +1082,7 @@ class _StepGraph:
         self.latents2 = self.latents2_host = None
         self.adam_entries = []
         self.graph_update = None
+        self.split = False                                     # data parallel: [graph: grads] -> eager all-reduce -> update (graph or eager)
         self.done = torch.cuda.Event()
 
     def _mixing(self):
@@ -1143,6 +1148,7 @@ class _StepGraph:
                         print(f"stylegan.pytorch_amd: hipGraph capture of the {self.kind}-step failed ({type(e).__name__}: {e}); "
                               "continuing eagerly", file=sys.stderr)
                         self.graph = self.graph_update = None
+                        self.split = False
                         sg.use_graphs = False
                         torch.cuda.synchronize()
                         native.lib().sgx_clear_error()                             # the failed capture leaves a sticky error
@@ -1156,18 +1162,21 @@ class _StepGraph:
                 else:
                     FusedAdam.graph_advance(self.adam_entries)
                 self.graph.replay()
-                if self.graph_update is not None:                                  # data parallel: grads | all-reduce | update
+                if self.split:                                                     # data parallel: grads | all-reduce | update
                     for p, g in self.grads:
                         if p.grad is not g:
                             p.grad = g
                     (sg._d_reduce if self.kind == "d" else sg._g_reduce)()
                     self.loss_global = sg.dp.all_reduce_scalar(self.loss)           # partial losses -> the global loss
-                    self.graph_update.replay()
+                    if self.graph_update is not None:
+                        self.graph_update.replay()
+                    else:
+                        self._body("update")                                       # 2-4 launches: cheaper than a second graph launch
                 F.bump_weight_generation(self._changed_params())                   # eager users must re-pack these
                 for p, g in self.grads:
                     if p.grad is not g:
                         p.grad = g
-                loss = self.loss_global if self.graph_update is not None else self.loss
+                loss = self.loss_global if self.split else self.loss
             out = DeferredLoss(loss, stream=loss_stream)
             self.done.record()
         self.calls += 1
@@ -1217,8 +1226,13 @@ class _StepGraph:
         try:
             with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="relaxed"):
                 self.loss = self._body("grads" if split else "all")
-            if split:
-                # RCCL stays outside the graphs: [graph: losses + backward] -> eager bucketed all-reduce -> [graph:
+            self.split = split
+            if split and DP_EAGER_UPDATE:
+                # RCCL stays outside the graph: [graph: losses + backward] -> eager bucketed all-reduce -> eager clip / Adam / EMA
+                # (a handful of launches; a second graph per half-iteration costs its launch latency twice per step).
+                pass
+            elif split:
+                # SGX_DP_EAGER_UPDATE=0: [graph: losses + backward] -> eager bucketed all-reduce -> [graph:
                 # clip / Adam / EMA].  The second capture needs this iteration's gradient tensors to exist (they are
                 # allocated by the first graph's capture and only hold values after a replay), so nothing is replayed
                 # in between: a capture records launches, it does not run them.

@@ -150,11 +150,15 @@ def test_graph_and_eager_calls_interleave():
         assert k in SKIP or close(sg.gen.state_dict()[k], v, 1e-1), k
 
 
-def test_data_parallel_graphs_split_around_the_all_reduce():
-    """With a process group the half-iteration is [graph: losses + backward] -> eager all-reduce -> [graph: update].
-    One rank (RCCL group of size 1) on this box: same results as the single-process eager run."""
+@pytest.mark.parametrize("eager_update", [True, False], ids=["eager-update", "update-graph"])
+def test_data_parallel_graphs_split_around_the_all_reduce(monkeypatch, eager_update):
+    """With a process group the half-iteration is [graph: losses + backward] -> eager all-reduce -> update (eager launches, the default
+    since round 5, or a second graph: SGX_DP_EAGER_UPDATE=0).  One rank (RCCL group of size 1) on this box: same results as the
+    single-process eager run."""
     import torch.distributed as dist
+    from stylegan.pytorch_amd import GAN as G
     from stylegan.pytorch_amd.dist import DataParallelGroup
+    monkeypatch.setattr(G, "DP_EAGER_UPDATE", eager_update)
     if not dist.is_initialized():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29611", rank=0, world_size=1, device_id=torch.device(DEV))
     try:
@@ -165,7 +169,7 @@ def test_data_parallel_graphs_split_around_the_all_reduce():
         # force_collectives: the bucketed RCCL all-reduce (side stream, flat buckets, multi-tensor copy-back) really runs
         lg, sgr, sg = run(True, torch.float32, 5, psi=-1.0, dp=DataParallelGroup(force_collectives=True, bucket_mb=1.0))
         graphs = list(sg._step_graphs.values())
-        assert len(graphs) == 2 and all(g.graph is not None and g.graph_update is not None for g in graphs)
+        assert len(graphs) == 2 and all(g.graph is not None and g.split and (g.graph_update is None) == eager_update for g in graphs)
         # eager with a process group: all-reduce + update run on their own stream, overlapped with the next half-iteration
         la, sa, sga = run(False, torch.float32, 5, psi=-1.0, dev_alpha=True, dp=DataParallelGroup(force_collectives=True, bucket_mb=1.0))
         assert "_update_stream" in sga.__dict__
