@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--b32-steps", type=int, default=8)
     ap.add_argument("--rccl-group-of-one", action="store_true",
                     help="N=1 only: run the data-parallel code path over an RCCL process group of size 1 (bucketed all-reduce launched for real, "
-                         "replay split into [graph | all-reduce | graph]) -- measures what that path costs per step on one GPU; not a scaling run")
+                         "replay split into [graph | all-reduce | update]) -- measures what that path costs per step on one GPU; not a scaling run")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the two short extra blocks of the default invocation: BASELINE configs[4]'s top depths (6,7,8) replayed, "
                          "and BASELINE configs[1] (ffhq128, fp32, batch 64) in a child process")
@@ -653,7 +653,7 @@ def main():
             out["roofline"] = blk["roofline"]
         if a.rccl_group_of_one:
             out["rccl_group_of_one"] = ("data-parallel code path over an RCCL group of size 1: bucketed all-reduce launched for real (no peer to exchange "
-                                        "with), replay split into [graph | all-reduce | graph]; NOT a scaling measurement")
+                                        "with), replay split into [graph | all-reduce | update]; NOT a scaling measurement")
         if b32 is not None:
             b32["config"] = {"workload": f"{a.config}: same model, batch 32 on one GPU (the north-star target configuration)"}
             out["b32"] = b32
