@@ -8,7 +8,8 @@ Workload (BASELINE.json `metric` / configs[2..3]): FFHQ-1024 model (8 mapping la
 depth index 8 (1024x1024), batch 4 per GPU, alpha 0.5 (fade-in active: both branches live), bf16 activations with
 fp32 accumulation / parameters.  Random-init weights, synthetic N(0,1) latents and images.
 
-Prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of the dominant kernel (the
+The LAST stdout line is ONE compact JSON object (< 4 KB: the contract's keys, `roofline`, `cpu_baseline`, a scalar `b32` block);
+the full record with every table goes to gpurun_out/bench_detail.json (`--detail-file`).  `roofline` is measured live with HIP events around every launch of the dominant kernel (the
 instantiation with the largest total time in a surveyed single-stream step), on the launch stream, by the library's own
 per-launch profiler (sgx_prof_*), in a single-stream eager re-run of the timed steps right after the timed region: each
 launch alone on the GPU, the number `rocprofv3 --kernel-trace --stats -- python bench.py --graphs off --streams 00`
@@ -71,6 +72,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the two short extra blocks of the default invocation: BASELINE configs[4]'s top depths (6,7,8) replayed, "
                          "and BASELINE configs[1] (ffhq128, fp32, batch 64) in a child process")
+    ap.add_argument("--detail-file", default="gpurun_out/bench_detail.json",
+                    help="where the full record (per-layer tables, calibration, sweep rows, the configs[1] block) is written, relative to the repo root")
+    ap.add_argument("--no-detail-file", action="store_true")
     ap.add_argument("--sweep", action="store_true",
                     help="BASELINE configs[4]: the progressive-growing sweep, depth index 0..8 of the 1024 model with the reference's per-depth "
                          "batch sizes (config.py:40-41), the fade-in ramp of models/GAN.py:748-753 and style mixing on; per-depth img/s")
@@ -188,7 +192,7 @@ def extra_ffhq128_fp32_b64(timeout_s=150.0):
     process (own model, own dtype), embedded without its evidence text."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--config", "ffhq128", "--dtype", "fp32", "--batch-per-gpu", "64",
-           "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras"]
+           "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--no-detail-file"]
     t0 = time.perf_counter()
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
@@ -558,6 +562,96 @@ def measure(sg, a, cfg, dev, B, steps, warmup, rank, world, want_graphs, stream_
     return out
 
 
+LINE_LIMIT = 4096        # the driver keeps ~8 KB of stdout: the LAST line must sit wholly inside it (round 5's 21 KB line did not parse)
+ROOF_KEEP = ("bound", "kernel", "launches", "avg_us", "achieved", "peak", "unit", "frac", "traffic",
+             "algorithmic_bytes_per_launch", "flops_per_launch")
+
+
+def _r(v, nd=4):
+    return round(v, nd) if isinstance(v, float) else v
+
+
+def _short_kernel(name):
+    return name.split("(")[0].replace("void ", "") if isinstance(name, str) else name
+
+
+def compact_roofline(roof):
+    if not roof:
+        return None
+    out = {k: _r(roof.get(k)) for k in ROOF_KEEP}
+    out["kernel"] = _short_kernel(out["kernel"])
+    return out
+
+
+def compact_block(blk):
+    """The scalars of one measured block (no tables)."""
+    keep = ("value", "unit", "steps", "warmup", "ms_per_step", "batch_per_gpu", "global_batch", "host_enqueue_ms_per_step", "hip_graphs",
+            "useful_tflops", "mfma_frac_of_step", "executed_tflops", "executed_frac_of_mfma_peak")
+    out = {k: _r(blk[k]) for k in keep if k in blk}
+    roof = blk.get("roofline")
+    if roof:
+        for k in ("library_launches_per_step", "library_kernels_ms_per_step", "algorithmic_gbytes_per_step"):
+            if k in roof:
+                out[k] = roof[k]
+        out["roofline"] = compact_roofline(roof)
+    return out
+
+
+def compact_line(full, detail_path=None):
+    """The ONE JSON line the driver parses: the contract's keys + `roofline` + `cpu_baseline` + a scalar `b32` block, under LINE_LIMIT
+    characters.  Everything else (per-layer tables, calibration, the sweep rows, the whole configs[1] block, notes) lives in the detail
+    file named by `detail`."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+           "config")
+    out = {k: _r(full[k]) for k in top if k in full}
+    for k, v in compact_block(full).items():
+        out.setdefault(k, v)
+    cb = full.get("cpu_baseline")
+    if cb is not None:
+        out["cpu_baseline"] = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
+        if cb.get("value") is None and "error" in cb:
+            out["cpu_baseline"]["error"] = str(cb["error"])[:160]
+    if full.get("b32"):
+        b = compact_block(full["b32"])
+        b["config"] = full["b32"].get("config")
+        out["b32"] = b
+    sw = full.get("sweep_top_depths")
+    if sw:
+        out["sweep_top_depths"] = ({"error": str(sw["error"])[:120]} if "error" in sw else
+                                   [{"depth": r["depth"], "batch": r["batch"], "img_per_s": r["img_per_s"]} for r in sw.get("rows", [])])
+    f128 = full.get("ffhq128_fp32_b64")
+    if f128:
+        out["ffhq128_fp32_b64"] = ({"error": str(f128["error"])[:120]} if "error" in f128 else
+                                   {"value": _r(f128.get("value")), "unit": "img/s", "ms_per_step": _r(f128.get("ms_per_step")),
+                                    "roofline_frac": _r((f128.get("roofline") or {}).get("frac"))})
+    if "rccl_group_of_one" in full:
+        out["rccl_group_of_one"] = True
+    if detail_path:
+        out["detail"] = detail_path
+    line = json.dumps(out)
+    for k in ("ffhq128_fp32_b64", "sweep_top_depths", "detail"):          # never let an optional field push the line over
+        if len(line) < LINE_LIMIT:
+            break
+        out.pop(k, None)
+        line = json.dumps(out)
+    if len(line) >= LINE_LIMIT and "cpu_baseline" in out:
+        out["cpu_baseline"].pop("sample", None)
+        line = json.dumps(out)
+    assert len(line) < LINE_LIMIT, len(line)
+    return line
+
+
+def write_detail(full, path):
+    """The full record (every table) beside the line: a file, never stdout."""
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(full, fh, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
+
+
 def main():
     a = parse()
     cfg = CONFIGS[a.config]
@@ -662,7 +756,8 @@ def main():
             out["ffhq128_fp32_b64"] = extra_ffhq128_fp32_b64()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(a.config, a.cpu_baseline_timeout)
-        line = json.dumps(out)
+        detail = None if a.no_detail_file else write_detail(out, os.path.join(ROOT, a.detail_file))
+        line = compact_line(out, detail)
     # The JSON line must be the LAST line of the job's stdout.  RCCL prints its version banner through C stdio, which is fully buffered
     # when stdout is a pipe: left alone it comes out when the process exits, AFTER Python's own output (seen with --rccl-group-of-one:
     # `tail -1` was "Librccl path : ...").  So: tear the group down, flush C stdio on every rank, let the other ranks' processes end,

@@ -54,3 +54,51 @@ def test_a_failing_child_is_recorded_not_raised(monkeypatch):
         raise subprocess.TimeoutExpired(cmd, kw["timeout"])
     monkeypatch.setattr(subprocess, "run", timeout)
     assert "exceeded" in bench.extra_ffhq128_fp32_b64(timeout_s=1.0)["error"]
+
+
+def _full_record():
+    """The complete record of a default invocation (round 5's 21 KB line, kept as the first line of profiles/r05_bench_default_head.json):
+    the input `compact_line` must shrink."""
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default_head.json")) as fh:
+        return json.loads(fh.readline())
+
+
+def test_the_last_stdout_line_stays_driver_readable():
+    """Round 5's record went unparsed: the line had grown to 21 KB and the driver keeps ~8 KB of stdout.  The line is now built by
+    `compact_line`: < 4 KB, one JSON object, with the contract's keys, `roofline` and `cpu_baseline`."""
+    full = _full_record()
+    assert len(json.dumps(full)) > 3 * bench.LINE_LIMIT                     # the stub really is the oversized record
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    assert "\n" not in line and len(line) < 4096 == bench.LINE_LIMIT
+    j = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config"):
+        assert k in j, k
+    assert j["value"] == round(full["value"], 4) and j["config"]["workload"].startswith("ffhq1024")
+    roof = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in roof, k
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert "layers" not in roof and "top_layers" not in roof
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["kind"] in ("port", "reference") and j["cpu_baseline"]["cores"] >= 1
+    assert j["b32"]["value"] > 0 and j["b32"]["roofline"]["frac"] > 0 and "layers" not in j["b32"]["roofline"]
+    assert j["detail"] == "gpurun_out/bench_detail.json"
+
+
+def test_optional_blocks_are_dropped_before_the_line_grows_past_the_limit():
+    full = _full_record()
+    full["sweep_top_depths"]["rows"] = full["sweep_top_depths"]["rows"] * 40          # an absurdly long optional block
+    j = json.loads(bench.compact_line(full, "d.json"))
+    assert "sweep_top_depths" not in j and "roofline" in j and "cpu_baseline" in j and "b32" in j
+    full = _full_record()
+    full["cpu_baseline"] = {"value": None, "error": "x" * 5000}
+    line = bench.compact_line(full, None)
+    assert len(line) < bench.LINE_LIMIT and json.loads(line)["cpu_baseline"]["value"] is None
+
+
+def test_the_detail_file_holds_the_full_record(tmp_path):
+    full = _full_record()
+    rel = bench.write_detail(full, str(tmp_path / "sub" / "detail.json"))
+    assert rel is not None
+    with open(tmp_path / "sub" / "detail.json") as fh:
+        assert json.load(fh) == full
