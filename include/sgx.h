@@ -159,6 +159,11 @@ size_t sgx_fade_rgb_bwd_ws_bytes(size_t npix, int C);
 int sgx_fade_rgb_bwd(const void* g, const void* bits, const float* pimg, const float* wr, float ws, float bs, float alpha, float beta,
                      const float* ab_dev, void* gy, float* dwr, float* drb, int acc, float* gpimg, void* wsbuf, size_t ws_bytes, size_t npix, int C,
                      int dtype, void* stream);    /* ab_dev (nullable): [alpha, beta] in device memory instead (graph replay) */
+/* Round 6: the parameter-gradient half on its own -- after a sgx_fade_rgb_bwd call with dwr = drb = NULL (which leaves the block partials in
+ * wsbuf), on any stream ordered behind it: the step accumulates EVERY .grad on one side stream (two backward branches of the D step run on
+ * different streams and both reach from_rgb of the residual branch). */
+int sgx_fade_rgb_bwd_finish(const void* wsbuf, size_t ws_bytes, size_t npix, int C, float ws, float bs, float beta, const float* ab_dev,
+                            float* dwr, float* drb, int acc, void* stream);
 /* out = alpha*a + beta*b (b may be NULL)    fade-in lerp: models/GAN.py:202,427,586                                 */
 int sgx_axpby(const void* a, const void* b, void* out, float alpha, float beta, size_t n, int dtype, void* stream);
 /* same with the coefficients read from device memory (alpha_dev[0], beta_dev[0]): the fade-in alpha changes every

@@ -979,7 +979,7 @@ class StyleGAN:
             if self.train_graphs == "auto" and getattr(self, "device", None) is not None and self.device.type == "cuda" \
                     and not getattr(self, "_train_forced_graphs", False):
                 self.use_graphs = False
-                probe = {"n": 0, "t0": 0.0}
+                probe = {"seen": 0, "n": 0, "enq": 0.0, "all": 0.0}
             logger.info("Currently working on depth: %d", current_depth + 1)
             logger.info("Current resolution: %d x %d" % (current_res, current_res))
             ticker = 1
@@ -999,16 +999,35 @@ class StyleGAN:
                         images, labels = batch, None
                     images = images.to(self.device)
                     gan_input = torch.randn(images.shape[0], self.latent_size).to(self.device)
-                    if probe is not None and probe["n"] == 1:
-                        torch.cuda.synchronize(); probe["t0"] = time.perf_counter()
-                    dis_loss = self.optimize_discriminator(gan_input, images, current_depth, alpha, labels)
-                    gen_loss = self.optimize_generator(gan_input, images, current_depth, alpha, labels)
+                    # the probe times ONLY the two optimize_* calls of a full-size, non-feedback iteration (the loader, the H2D copy,
+                    # the feedback tick's loss read and sample grid are host work that replay does not remove): per probed iteration the
+                    # host enqueue time of the two calls, then their wall time including the GPU
+                    probing = (probe is not None and probe["seen"] >= 1 and images.shape[0] == batch_sizes[current_depth]
+                               and not self.is_feedback_batch(i, total_batches, feedback_factor))
+                    if probing:
+                        torch.cuda.synchronize(); t_probe = time.perf_counter()
+                    # a ragged last batch of an epoch runs eagerly: its own captured graph would hold a private pool for one use per epoch
+                    ragged = self.use_graphs and images.shape[0] != batch_sizes[current_depth]
+                    if ragged:
+                        self.use_graphs = False
+                    try:
+                        dis_loss = self.optimize_discriminator(gan_input, images, current_depth, alpha, labels)
+                        gen_loss = self.optimize_generator(gan_input, images, current_depth, alpha, labels)
+                    finally:
+                        if ragged:
+                            self.use_graphs = True
                     if probe is not None:
-                        probe["n"] += 1
-                        if probe["n"] == 4:
-                            t_enq = time.perf_counter() - probe["t0"]
-                            torch.cuda.synchronize()
-                            t_all = time.perf_counter() - probe["t0"]
+                        probe["seen"] += 1
+                    if probing:
+                        t_enq = time.perf_counter() - t_probe
+                        torch.cuda.synchronize()
+                        probe["enq"] += t_enq; probe["all"] += time.perf_counter() - t_probe; probe["n"] += 1
+                        if probe["n"] == 3:
+                            t_enq, t_all = probe["enq"], probe["all"]
+                            if self.dp is not None:
+                                # ONE decision for all ranks (the slowest rank's times): a rank replaying [graph | all-reduce | update]
+                                # next to a rank on the eager bucket schedule would issue different collectives
+                                t_enq, t_all = self.dp.host_max([t_enq, t_all])
                             self.use_graphs = bool(t_enq >= 0.85 * t_all)          # the host is the limit: replay from here on
                             logger.info("Depth %d: %s launches (host enqueue %.1f ms of %.1f ms per iteration)" % (
                                 current_depth + 1, "hipGraph replay of the captured half-iterations" if self.use_graphs else "eager",
@@ -1141,17 +1160,25 @@ class _StepGraph:
                 loss_stream = sg.__dict__.pop("_loss_stream", None)
             else:
                 if self.graph is None:
+                    err = None
                     try:
                         self._capture()
                     except Exception as e:                                         # noqa: BLE001 -- stay correct, go eager
+                        err = e
+                        torch.cuda.synchronize()
+                        native.lib().sgx_clear_error()                             # the failed capture leaves a sticky error
+                    # data parallel: ONE outcome for all ranks -- a rank that replays [graph | all-reduce | update] next to a rank that
+                    # fell back to the eager bucket schedule would issue different collectives (hang or mismatched reductions)
+                    ok = err is None if sg.dp is None else sg.dp.all_ok(err is None)
+                    if not ok:
                         import sys
-                        print(f"stylegan.pytorch_amd: hipGraph capture of the {self.kind}-step failed ({type(e).__name__}: {e}); "
+                        why = f"{type(err).__name__}: {err}" if err is not None else "it failed on another rank"
+                        print(f"stylegan.pytorch_amd: hipGraph capture of the {self.kind}-step failed ({why}); "
                               "continuing eagerly", file=sys.stderr)
                         self.graph = self.graph_update = None
                         self.split = False
                         sg.use_graphs = False
                         torch.cuda.synchronize()
-                        native.lib().sgx_clear_error()                             # the failed capture leaves a sticky error
                         self._undo_failed_capture()
                         loss = self._body()
                         out = DeferredLoss(loss, stream=sg.__dict__.pop("_loss_stream", None))
@@ -1214,16 +1241,16 @@ class _StepGraph:
         # with it).  Collect first, then keep the collector off until the capture has ended.
         import gc
         gc_was = False
-        if os.environ.get("SGX_CAPTURE_GC_GUARD", "1") != "0":  # (0: A/B of the guard itself)
-            gc.collect()
-            gc_was = gc.isenabled()
-            gc.disable()
-        torch.cuda.synchronize()
-        opt._capture_log = []
-        self.graph = torch.cuda.CUDAGraph()
         split = sg.dp is not None
         net = sg.dis if self.kind == "d" else sg.gen
         try:
+            if os.environ.get("SGX_CAPTURE_GC_GUARD", "1") != "0":  # (0: A/B of the guard itself)
+                gc.collect()
+                gc_was = gc.isenabled()
+                gc.disable()                                   # (inside the try: whatever raises below, `finally` turns it back on)
+            torch.cuda.synchronize()
+            opt._capture_log = []
+            self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="relaxed"):
                 self.loss = self._body("grads" if split else "all")
             self.split = split
@@ -1240,7 +1267,7 @@ class _StepGraph:
                 with torch.cuda.graph(self.graph_update, stream=self.stream, capture_error_mode="relaxed"):
                     self._body("update")
         finally:
-            self.adam_entries, opt._capture_log = opt._capture_log, None
+            self.adam_entries, opt._capture_log = (getattr(opt, "_capture_log", None) or []), None
             if gc_was:
                 gc.enable()
         # the gradient tensors the graph writes (static addresses): re-attached after every replay so that .grad shows

@@ -498,8 +498,13 @@ static int launch_conv(ConvArgs& a, int ngroups, hipStream_t st) {
     auto kern = conv_kernel<T, KC, GEO, TH, TW, BP, CT>;
     sgx_lds_opt_in<conv_kernel<T, KC, GEO, TH, TW, BP, CT>>(LDS);
     a.ntiles = ngroups * a.tiles_y * a.tiles_x;
+    // the ablation switches give WRONG results by design: only a probe build (make PROBE=1 -> -DSGX_PROBE_BUILD) reads them
+#ifdef SGX_PROBE_BUILD
     static const int dbg = [] { const char* e = getenv("SGX_CONV_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
+#else
+    a.dbg = 0;
+#endif
     // persistent grid: exactly as many blocks as are resident at once (register- and LDS-limited; asked of the runtime
     // for this instantiation), never more than tiles.  More blocks than that would run as a second, under-occupied round.
     static const int resident = [] {

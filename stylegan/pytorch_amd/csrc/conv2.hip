@@ -1493,7 +1493,9 @@ int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void
     if (variant >= 30) {                          // conv3_kernel configurations (probes, tests): 30 + id of the table in conv3_variant
         Conv2Args a3{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
                      geo == C2_D ? H / 2 : H, geo == C2_D ? W / 2 : W, Cin, Cout, act, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
-        { const char* e = getenv("SGX_CONV3_DBG"); a3.dbg = e ? atoi(e) : 0; }     // (probe path only; read per launch)
+#ifdef SGX_PROBE_BUILD                            // DMA ablations (WRONG results by design): probe builds only (make PROBE=1)
+        { const char* e = getenv("SGX_CONV3_DBG"); a3.dbg = e ? atoi(e) : 0; }
+#endif
         const int rc = conv3_variant(geo, a3, variant - 30, st, launched);
         return rc;
     }

@@ -249,6 +249,24 @@ extern "C" int sgx_fade_rgb_bwd(const void* g, const void* bits, const float* pi
     }
     return 0;
 }
+// The parameter-gradient half of sgx_fade_rgb_bwd on its own: sums the block partials a call with dwr = drb = NULL left in `wsbuf` and
+// writes / accumulates from_rgb's gradients.  The caller orders it behind that call and may run it on another stream -- the one every
+// other accumulation into .grad of the step runs on, so that two backward branches never read-modify-write the same gradient unordered.
+extern "C" int sgx_fade_rgb_bwd_finish(const void* wsbuf, size_t ws_bytes, size_t npix, int C, float ws, float bs, float beta, const float* ab_dev,
+                                       float* dwr, float* drb, int acc, void* stream) {
+    SGX_REQUIRE(C == 32 || C == 64 || C == 128, SGX_EUNSUPPORTED, "fade_rgb_bwd_finish: C in {32, 64, 128} (C=%d)", C);
+    SGX_REQUIRE(wsbuf && npix > 0 && (dwr || drb), SGX_EINVAL, "fade_rgb_bwd_finish: null argument");
+    SGX_REQUIRE(ws_bytes >= sgx_fade_rgb_bwd_ws_bytes(npix, C), SGX_EWORKSPACE, "fade_rgb_bwd_finish: workspace");
+    const int ppi = 256 / (C / 8);
+    long nblk = (long)((npix + (size_t)ppi * 8 - 1) / ((size_t)ppi * 8));      // as sgx_fade_rgb_bwd
+    if (nblk > FRB_BLOCKS) nblk = FRB_BLOCKS;
+    if (nblk < 1) nblk = 1;
+    SGX_NOTE(0.0, (double)nblk * 4 * C * sizeof(double), "fade_rgb_bwd_finish C%d", C);
+    hipLaunchKernelGGL(fade_rgb_bwd_finish, dim3((unsigned)((4 * C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, static_cast<const double*>(wsbuf), dwr, drb,
+                       (int)nblk, C, ws, bs, beta, ab_dev, acc);
+    SGX_LAUNCH_CHECK("fade_rgb_bwd_finish");
+    return 0;
+}
 
 // ---------------------------------------------------------------- out = alpha*a + beta*b
 template <typename T>
@@ -547,8 +565,8 @@ __global__ __launch_bounds__(256) void blur3x3s_kernel(const T* __restrict__ x, 
 // SGX_BLUR_SHFL: 0 = the three-load kernel everywhere, 1..4 = the one-load kernel at that prefetch depth; unset: the depth measured best
 // per mode (tools/blur_probe.py, profiles/r04_blur_probe.txt)
 static int blur_shfl_pf(int mode) {
-    const char* e = getenv("SGX_BLUR_SHFL");
-    if (e) return atoi(e);
+    static const int env = [] { const char* e = getenv("SGX_BLUR_SHFL"); return e ? atoi(e) : -1; }();     // read once per process
+    if (env >= 0) return env;
     return (mode == 1 || mode == 5) ? 1 : 3;                 // (the modes with a pre-op are the register-heavier ones: more waves beat a deeper ring)
 }
 template <typename T, int PF>

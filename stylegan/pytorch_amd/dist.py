@@ -355,6 +355,23 @@ class DataParallelGroup:
             self._all_reduce(out)
         return out
 
+    def host_max(self, values):
+        """Element-wise MAX of a list of host floats over the ranks (a HOST decision every rank must take identically: launch mode
+        of a depth, "did every rank's capture succeed").  Synchronous; called a handful of times per depth, never per iteration."""
+        vals = [float(v) for v in values]
+        if self.world_size == 1 and not self.force_collectives:
+            return vals
+        if dist.get_backend(self.group) == "gloo" or not torch.cuda.is_available():
+            t = torch.tensor(vals, dtype=torch.float64)
+        else:
+            t = torch.tensor(vals, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return [float(v) for v in t.cpu()]
+
+    def all_ok(self, ok: bool) -> bool:
+        """True iff ``ok`` on EVERY rank."""
+        return self.host_max([0.0 if ok else 1.0])[0] == 0.0
+
     def _mean_over_ranks(self, t):
         out = t.detach().clone()
         if self.world_size > 1 or self.force_collectives:

@@ -152,6 +152,29 @@ def _param_grads(mode, adjoint, x, gy, weight, scale, want_bias, into):
     return dW, db
 
 
+def _fork_to(side, cur_raw, launch, reads=(), fresh=()):
+    """Run ``launch()`` on the stream ``side`` ordered behind everything enqueued on the current stream (raw handle ``cur_raw``), as
+    ``_param_grads`` does: ``reads`` = tensors of the current stream that the side stream touches, ``fresh`` = a list ``launch`` fills with
+    tensors it allocated (under the side stream) that the current stream will use."""
+    if not _FAST_FORK or _set_stream is None:
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            launch()
+    else:
+        cur = _stream_of(cur_raw)
+        N.check(N.lib().sgx_stream_wait_stream(side.cuda_stream, cur_raw), "sgx_stream_wait_stream")
+        _set_stream(stream_id=side.stream_id, device_index=side.device_index, device_type=side.device_type)
+        try:
+            launch()
+        finally:
+            _set_stream(stream_id=cur.stream_id, device_index=cur.device_index, device_type=cur.device_type)
+    for t in reads:
+        t.record_stream(side)
+    for t in fresh:
+        t.record_stream(cur)
+
+
 @contextlib.contextmanager
 def accumulate_param_grads():
     """Inside: the backward of a convolution writes / accumulates the gradients of its LEAF weight and bias straight into
@@ -429,7 +452,7 @@ class ConvFn(Function):
                 cout_b = weight.shape[1] if not adjoint else weight.shape[0]
                 if xb is not None and conv_upblur_ok(gy, cout_b, mode, not adjoint):
                     gx = _bcall(ConvBlurFn, gy, weight, mode, scale, ipad, not adjoint, None, xb)       # one kernel, the mask from its sign bits
-                elif x_pre is not None and conv_blur_ok(gy, cout_b, mode, not adjoint):
+                elif x_pre is not None and conv_blur_ok(gy, cout_b, mode, not adjoint, has_mask_tensor=True):
                     gx = _bcall(ConvBlurFn, gy, weight, mode, scale, ipad, not adjoint, x_pre)      # one kernel
                 else:
                     gx = _bcall(BlurMaskFn, _bcall(ConvFn, gy, weight, None, mode, scale, ipad, not adjoint, 0), x_pre, xb)
@@ -486,13 +509,14 @@ def conv_upblur_ok(x, cout, mode, adjoint):
 CONV_UPBLUR = os.environ.get("SGX_CONV_UPBLUR", "1") != "0"     # A/B: 0 = the round-3 kernel (blur in the store epilogue) / the two passes
 
 
-def conv_blur_ok(x, cout, mode, adjoint):
+def conv_blur_ok(x, cout, mode, adjoint, has_mask_tensor=False):
     """True if ``ConvBlurFn`` has a kernel for the convolution (mode, adjoint) applied to NHWC ``x`` with ``cout`` outputs AND the
-    policy wants it used."""
+    policy wants it used.  ``has_mask_tensor``: the caller will pass the mask as a TENSOR (``z``): the round-5 composite kernel takes
+    no mask or sign bits only, so that call is served by the round-3 kernel under its own policy and shape check."""
     geo = ADJ_GEO[mode] if adjoint else FWD_GEO[mode]
     if CONV_BLUR_POLICY == "off" or geo != "U" or x.dtype != torch.bfloat16:
         return False
-    if conv_upblur_ok(x, cout, mode, adjoint):
+    if not has_mask_tensor and conv_upblur_ok(x, cout, mode, adjoint):
         return True
     B, H, W, Cin = x.shape
     if CONV_BLUR_POLICY == "auto" and not (int(cout) == 16 and B * H * W >= CONV_BLUR_MIN_PIXELS):
@@ -1075,25 +1099,44 @@ class ConvDownFadeRgbFn(Function):
             accum = _ACCUM_PARAM_GRADS and wr.is_leaf and (br is None or br.is_leaf)
             acc = 0
             dw = db = None
-            if want_w:
-                if accum and wr.grad is not None:
-                    dw, acc = wr.grad, acc | 1
-                else:
-                    dw = torch.empty(wr.shape, dtype=torch.float32, device=g.device)
-            if want_b:
-                if accum and br.grad is not None:
-                    db, acc = br.grad, acc | 2
-                else:
-                    db = torch.empty(br.shape, dtype=torch.float32, device=g.device)
-            gy = torch.empty_like(g)
+            if want_w and accum and wr.grad is not None:
+                dw, acc = wr.grad, acc | 1
+            if want_b and accum and br.grad is not None:
+                db, acc = br.grad, acc | 2
+            gy = torch.empty_like(g)                         # (fresh dw / db are allocated under the stream that writes them, below)
             if need_img:
                 gpimg = torch.empty_like(pimg)
             wsb = L.sgx_fade_rgb_bwd_ws_bytes(npix, C)
             wsp = N.workspace(wsb, g.device)
             dev = alpha_dev is not None
+            side = _PARAM_GRAD_STREAM if (accum and (want_w or want_b)) else None
+            cur_raw = N.stream()
+            if side is not None and side.cuda_stream == cur_raw:
+                side = None
+            if side is None:
+                if want_w and dw is None:
+                    dw = torch.empty(wr.shape, dtype=torch.float32, device=g.device)
+                if want_b and db is None:
+                    db = torch.empty(br.shape, dtype=torch.float32, device=g.device)
+            # with a side stream: this pass leaves the block partials in wsp, and the .grad write / accumulate runs where every other
+            # accumulation into .grad of the step runs (D(fake)'s backward is on the auxiliary stream, D(real)'s on the main one, and both
+            # reach this from_rgb: unordered read-modify-writes of one gradient otherwise)
             N.check(L.sgx_fade_rgb_bwd(N.ptr(g), N.ptr(bits), N.ptr(pimg), N.ptr(_c(wr.detach())), ws, bs, 0.0 if dev else alpha, 0.0 if dev else beta,
-                                       alpha_dev.data_ptr() if dev else None, N.ptr(gy), N.ptr(dw), N.ptr(db), acc, N.ptr(gpimg), N.ptr(wsp), wsb, npix, C,
-                                       N.dt(g), N.stream()), "sgx_fade_rgb_bwd")
+                                       alpha_dev.data_ptr() if dev else None, N.ptr(gy), None if side is not None else N.ptr(dw),
+                                       None if side is not None else N.ptr(db), acc, N.ptr(gpimg), N.ptr(wsp), wsb, npix, C,
+                                       N.dt(g), cur_raw), "sgx_fade_rgb_bwd")
+            if side is not None:
+                fresh = []
+
+                def finish():
+                    nonlocal dw, db
+                    if want_w and dw is None:
+                        dw = torch.empty(wr.shape, dtype=torch.float32, device=g.device); fresh.append(dw)
+                    if want_b and db is None:
+                        db = torch.empty(br.shape, dtype=torch.float32, device=g.device); fresh.append(db)
+                    N.check(L.sgx_fade_rgb_bwd_finish(N.ptr(wsp), wsb, npix, C, ws, bs, 0.0 if dev else beta, alpha_dev.data_ptr() if dev else None,
+                                                      N.ptr(dw), N.ptr(db), acc, N.stream()), "sgx_fade_rgb_bwd_finish")
+                _fork_to(side, cur_raw, finish, reads=(wsp,) + ((alpha_dev,) if dev else ()), fresh=fresh)
             if accum:
                 for p_, d_ in ((wr, dw), (br, db)):
                     if d_ is not None:

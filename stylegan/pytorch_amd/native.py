@@ -58,6 +58,7 @@ SIGNATURES = {
     "sgx_conv4x4s2_down_fade_rgb": (I, [P, P, P, P, P, F, P, F, F, F, F, P, P, P, I, I, I, I, I, I, P]),
     "sgx_fade_rgb_bwd_ws_bytes": (Z, [Z, I]),
     "sgx_fade_rgb_bwd": (I, [P, P, P, P, F, F, F, F, P, P, P, P, I, P, P, Z, Z, I, I, P]),
+    "sgx_fade_rgb_bwd_finish": (I, [P, Z, Z, I, F, F, F, P, P, P, I, P]),
     "sgx_axpby": (I, [P, P, P, F, F, Z, I, P]),
     "sgx_axpby_dev": (I, [P, P, P, P, P, Z, I, P]),
     "sgx_blur3x3": (I, [P, P, I, I, I, I, I, P]),

@@ -103,6 +103,10 @@ def _worker(rank, port, out_q):
             assert torch.allclose(p.grad, w, rtol=1e-12, atol=0), "bucket all-reduce"
         loss_part = torch.tensor(1.5 + rank, dtype=torch.float64)
         assert float(group.all_reduce_scalar(loss_part)) == 4.0 and float(loss_part) == 1.5 + rank    # a new tensor; the input is untouched
+        # host decisions every rank must take identically (round 6: launch mode of a depth from the slowest rank's timings; "did every
+        # rank's hipGraph capture succeed" -- a rank replaying [graph | all-reduce | update] next to an eager rank would hang the group)
+        assert group.host_max([1.0 + rank, 5.0 - rank]) == [2.0, 5.0]
+        assert group.all_ok(True) is True and group.all_ok(rank == 0) is False and group.all_ok(False) is False
         avg = torch.full((4,), float(rank + 1))
         group.broadcast(avg, src=0)
         # numpy payloads are pickled by value (torch tensors would travel as shared-memory handles of a dying process)

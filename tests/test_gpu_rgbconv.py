@@ -271,3 +271,48 @@ def test_fade_in_lerp_in_the_store_of_the_stride2_convolution(depth, B, composed
     res_layer = f"from_rgb.{dis.depth - depth}."
     for k in g_on:
         assert rel_err(g_on[k], g_off[k]) <= (loose if k.startswith(res_layer) else 1e-5), (k, rel_err(g_on[k], g_off[k]))
+
+
+def test_residual_from_rgb_gradients_with_two_backward_branches(monkeypatch):
+    """Round 6: in the default D step (LogisticGAN, auxiliary stream on) D(fake)'s backward runs on the auxiliary stream
+    and D(real)'s on the main one, and BOTH reach ``ConvDownFadeRgbFn`` of the newest block, whose one-pass backward accumulates
+    from_rgb's weight / bias gradient straight into ``.grad``.  Those accumulations must run on the one parameter-gradient stream like
+    every other (``sgx_fade_rgb_bwd_finish`` behind the pass, on ``functional._PARAM_GRAD_STREAM``): compared, over repeated steps, with
+    the single-stream run of the same kernels (summation order of the three contributions only) and with the unfused residual branch."""
+    import random
+
+    from stylegan.pytorch_amd import functional as F
+    from test_gpu_graphs import make
+    from gpu_util import mid_noises, pin_noise
+    B, depth, alpha = 16, 5, 0.3
+    calls = []
+    orig = F.ConvDownFadeRgbFn.forward
+    monkeypatch.setattr(F.ConvDownFadeRgbFn, "forward", staticmethod(lambda ctx, *a: (calls.append(1), orig(ctx, *a))[1]))
+
+    def grads(aux, side, fused=True, reps=3):
+        monkeypatch.setattr(F, "FUSE_FADE_RGB", fused)
+        sg = make(False, torch.bfloat16, psi=-1.0)
+        sg.aux_stream, sg.param_stream = aux, side
+        pin_noise(sg.gen, mid_noises(B))
+        res = f"from_rgb.{sg.dis.depth - depth}."
+        out = []
+        for i in range(reps):
+            torch.manual_seed(7); random.seed(7)
+            z = gu.seeded((B, 512), 300).to(DEV); real = gu.seeded((B, 3, 128, 128), 301).to(DEV)
+            sg._d_grads(z, real, depth, alpha)
+            torch.cuda.synchronize()
+            out.append({k: p.grad.detach().clone() for k, p in sg.dis.named_parameters() if p.grad is not None and k.startswith(res)})
+            assert sorted(out[-1]) == [res + "bias", res + "weight"]
+        return out
+
+    single = grads(False, False)
+    n0 = len(calls)
+    assert n0 == 3 * 2                      # D(real) + D(fake) per step (the R1 pass differentiates D(real)'s graph)
+    for aux, side in ((True, True), (True, False)):
+        multi = grads(aux, side)
+        for g1 in multi:
+            for k, v in single[0].items():
+                assert rel_err(g1[k], v) <= 1e-5, (aux, side, k, rel_err(g1[k], v))
+    unfused = grads(True, True, fused=False, reps=1)[0]
+    for k, v in single[0].items():
+        assert rel_err(unfused[k], v) <= 1e-5, (k, rel_err(unfused[k], v))
