@@ -999,11 +999,10 @@ class StyleGAN:
                         images, labels = batch, None
                     images = images.to(self.device)
                     gan_input = torch.randn(images.shape[0], self.latent_size).to(self.device)
-                    # the probe times ONLY the two optimize_* calls of a full-size, non-feedback iteration (the loader, the H2D copy,
-                    # the feedback tick's loss read and sample grid are host work that replay does not remove): per probed iteration the
-                    # host enqueue time of the two calls, then their wall time including the GPU
-                    probing = (probe is not None and probe["seen"] >= 1 and images.shape[0] == batch_sizes[current_depth]
-                               and not self.is_feedback_batch(i, total_batches, feedback_factor))
+                    # the probe times ONLY the two optimize_* calls of a full-size iteration (the loader, the H2D copy, the feedback tick's
+                    # loss read -- the losses are deferred inside train() -- and sample grid lie outside the window: host work that replay
+                    # does not remove): per probed iteration the host enqueue time of the two calls, then their wall time including the GPU
+                    probing = probe is not None and probe["seen"] >= 1 and images.shape[0] == batch_sizes[current_depth]
                     if probing:
                         torch.cuda.synchronize(); t_probe = time.perf_counter()
                     # a ragged last batch of an epoch runs eagerly: its own captured graph would hold a private pool for one use per epoch

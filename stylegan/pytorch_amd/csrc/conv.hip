@@ -691,8 +691,8 @@ extern "C" int sgx_conv_variant(int geo, const void* x, const void* w, const flo
         if (geo == GDOWN) return dispatch_conv<GDOWN>(a, dtype, (hipStream_t)stream);
         return dispatch_conv<GUP>(a, dtype, (hipStream_t)stream);
     }
-    SGX_REQUIRE(dtype == SGX_BF16 && (variant == 4 || variant == 8 || (variant >= 30 && variant <= 36)), SGX_EINVAL,
-                "conv_variant: variant %d needs bf16 and 4 or 8 waves (or 30..36: a conv3_kernel configuration)", variant);
+    SGX_REQUIRE(dtype == SGX_BF16 && (variant == 4 || variant == 8 || (variant >= 20 && variant <= 29) || (variant >= 30 && variant <= 36)), SGX_EINVAL,
+                "conv_variant: variant %d needs bf16 and 4 or 8 waves (or 20..29: a wide-block configuration, 30..36: a conv3_kernel configuration)", variant);
     int launched = 0;
     const int rc = sgx_conv2_try(geo, x, w, bias, y, B, H, W, Cin, Cout, act, nullptr, variant, (hipStream_t)stream, &launched);
     SGX_REQUIRE(rc || launched, SGX_EUNSUPPORTED, "conv_variant: shape not covered by the second-generation kernel");

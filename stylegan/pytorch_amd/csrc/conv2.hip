@@ -93,7 +93,9 @@ template <int GEO, int NW, int MF, int KC = 32> struct C2Lds {
     static constexpr int SPR = KC / 8;                                              // 16-byte slots per row
     static constexpr int WROWS = G2<GEO>::NTW * BCO;
     static constexpr int OROW = BCO * 2 + 16;
-    static constexpr int SCRATCH = NW * (GEO == C2_U ? 64 : 32) * OROW;            // epilogue: per-wave pixel-major rows
+    // epilogue scratch: per-wave pixel-major rows (the LDS-transposed stores: transposed geometry, statistics); the 128-channel block
+    // (MF = 4) only has the register epilogue
+    static constexpr int SCRATCH = MF > 2 ? 0 : NW * (GEO == C2_U ? 64 : 32) * OROW;
     static constexpr int P_INSTR = (PROWS * SPR + 63) / 64;
     static constexpr int P_RAW = P_INSTR * 1024;
     static constexpr int P_BYTES = ((P_RAW > SCRATCH ? P_RAW : SCRATCH) + 1023) / 1024 * 1024;
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
     static_assert(GEO != C2_U || MF == 1, "four parity classes of accumulators: one 32-channel row per wave");
     static_assert(EPI != EPI_STATS || GEO == C2_S, "the statistics epilogue is built for the 3x3 geometry");
     static_assert(EPI != EPI_BLUR || GEO == C2_U, "the blur epilogue is built for the transposed geometry");
+    static_assert(MF <= 2 || (EPI == EPI_NONE && GEO != C2_U), "the 128-channel block: register epilogue only");
     // EPI_BLUR: y = blur3x3(conv(x)) [* slope(mask)] -- the [1,2,1]x[1,2,1]/16 blur that follows the transposed convolution in
     // both networks (generator: conv0_up -> blur, models/CustomLayers.py:176-177; discriminator backward: the adjoint of
     // "LeakyReLU -> blur -> conv1_down", models/Blocks.py:140-145) applied to the accumulators before they are stored: the
@@ -1498,6 +1501,13 @@ int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void
 #endif
         const int rc = conv3_variant(geo, a3, variant - 30, st, launched);
         return rc;
+    }
+    if (variant == 20 || variant == 21) {        // probe: 128 output channels per block on 16-channel K-steps (one staged patch feeds 4 accumulator rows)
+        if (geo != C2_S || Cin % 16 || Cout % 128 || W % 32) return 0;
+        Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
+                    H, W, Cin, Cout, act, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+        *launched = 1;
+        return variant == 20 ? launch_conv2<C2_S, 8, 4, 16>(a, st) : launch_conv2<C2_S, 4, 4, 16>(a, st);
     }
     const Conv2Pick p = conv2_pick(geo, B, H, W, Cin, Cout, variant);
     if (!p.nw) return 0;

@@ -370,6 +370,227 @@ __global__ __launch_bounds__(256) void gepi_apply(const T* __restrict__ x, const
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small layers (round 6): the whole epilogue of one (image, 16-channel group) in ONE block, one launch per direction.
+// At 4x4 .. 64x64 a layer's tensor is a few hundred KB to 8 MB (L2 resident) and the two-pass structure above costs two
+// (forward) / three (backward) launches of 8-20 us each that are bound by launch latency and by the round trip of the
+// per-chunk partials through memory -- 40 of the 126 epilogue launches of a batch-4 step.  Here a block owns ALL pixels of
+// its 16 channels of image b: the statistics are block-local (fp32 per lane over <= IT values, fp64 across lanes and waves in
+// a fixed order: deterministic), and the block goes straight on to the apply pass from the SAME registers: every lane keeps
+// its <= IT pixels (IT x 16 bytes) from the first pass, nothing is read twice.  thread = (pixel row r, 16-byte channel vector
+// v); NT threads: 256 up to 16x16, 1024 above (a 64x64 layer is 8 pixels per lane; the first version walked 32 pixels per lane
+// twice through L2 with 256 threads and lost to the two-pass kernels' 512 blocks: 48 -> 96 us at batch 32, 64x64).
+#define GS_CG 16                                                   // channels per block
+// Fixed-order block sum of the per-thread partial vectors (q0, q1)[VE]: lanes of a wave with the same channel vector by xor
+// shuffles (fp64), the waves' results through LDS -> tot[v * 2 * VE + j] for j < VE (q0) and VE + j (q1).  NV * 2 * VE = 32 outputs.
+template <int VE, int NT>
+__device__ __forceinline__ void gs_block_sum(const float (&q0)[VE], const float (&q1)[VE], double* sh, double* tot) {
+    constexpr int NV = GS_CG / VE, W2 = 2 * VE, NO = NV * W2, NWV = NT / 64;
+    static_assert(NO == 32, "32 outputs per block");
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+#pragma unroll
+    for (int j = 0; j < W2; ++j) {                                 // one value at a time: two live registers, not 4 * VE
+        double d = (double)(j < VE ? q0[j < VE ? j : 0] : q1[j < VE ? 0 : j - VE]);
+#pragma unroll
+        for (int o = 32; o >= NV; o >>= 1) d += __shfl_xor(d, o, 64);
+        if (lane < NV) sh[(wv * NV + lane) * W2 + j] = d;
+    }
+    __syncthreads();
+    if (t < NO) {
+        const int v = t / W2, j = t % W2;
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) a += sh[(w * NV + v) * W2 + j];
+        tot[t] = a;
+    }
+    __syncthreads();
+}
+
+template <typename T, int NT, int IT>
+__global__ __launch_bounds__(NT) void gepi_small_fwd(const T* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ noise,
+                                                     const float* __restrict__ nw, const float* __restrict__ style, T* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, int HW, int C, int act, int norm) {
+    constexpr int VE = VecTraits<T>::VE, NV = GS_CG / VE, R = NT / NV, W2 = 2 * VE;
+    __shared__ double sh[(NT / 64) * NV * W2 + 32];               // per-wave partials, [32] totals
+    __shared__ float sstat[2 * GS_CG];                            // mean / rstd of the block's channels
+    double* const tot = sh + (NT / 64) * NV * W2;
+    const int b = blockIdx.y, t = threadIdx.x, v = t % NV, r = t / NV;
+    const int cv = C / VE, vg = blockIdx.x * NV + v, c0 = vg * VE;
+    float kb[VE], kw[VE], s0[VE], s1[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { kb[j] = 0.f; s0[j] = 0.f; s1[j] = 0.f; }
+    if (bias) load_coef<VE>(bias + c0, kb);
+    load_coef<VE>(nw + c0, kw);
+    const T* xb = x + ((size_t)b * HW * cv + vg) * VE;
+    const float* nzb = noise + (size_t)b * HW;
+    uint4 xq[IT];
+    float nz[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {                                 // all of the lane's loads in flight at once
+        const int p = r + i * R;
+        const bool ok = p < HW;
+        xq[i] = ok ? *reinterpret_cast<const uint4*>(xb + (size_t)p * cv * VE) : make_uint4(0u, 0u, 0u, 0u);
+        nz[i] = ok ? nzb[p] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        if (r + i * R < HW) {
+            float xv[VE];
+            unpack16<T>(xq[i], xv);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {
+                const float a = act_apply(xv[j] + kb[j] + kw[j] * nz[i], act);
+                s0[j] += a; s1[j] += a * a;
+            }
+        }
+    }
+    gs_block_sum<VE, NT>(s0, s1, sh, tot);
+    if (t < GS_CG) {
+        float m = 0.f, rs = 1.f;
+        if (norm) {                                                // as gepi_fin_stats
+            const int vv = t / VE, j = t % VE;
+            const double mm = tot[vv * W2 + j] / HW;
+            double var = tot[vv * W2 + VE + j] / HW - mm * mm;
+            if (var < 0.0) var = 0.0;
+            m = (float)mm; rs = (float)(1.0 / sqrt(var + (double)GEPI_EPS));
+        }
+        sstat[t] = m; sstat[GS_CG + t] = rs;
+        mean_out[(size_t)b * C + blockIdx.x * GS_CG + t] = m;
+        rstd_out[(size_t)b * C + blockIdx.x * GS_CG + t] = rs;
+    }
+    __syncthreads();
+    float km[VE], kr[VE], ks[VE], k1[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { km[j] = sstat[v * VE + j]; kr[j] = sstat[GS_CG + v * VE + j]; }
+    load_coef<VE>(style + (size_t)b * 2 * C + c0, ks);
+    load_coef<VE>(style + (size_t)b * 2 * C + C + c0, k1);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) ks[j] += 1.f;
+    T* yb = y + ((size_t)b * HW * cv + vg) * VE;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int p = r + i * R;
+        if (p < HW) {
+            float xv[VE];
+            unpack16<T>(xq[i], xv);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {                         // the arithmetic of gepi_apply
+                const float a = act_apply(xv[j] + kb[j] + kw[j] * nz[i], act);
+                const float xh = (a - km[j]) * kr[j];
+                xv[j] = xh * ks[j] + k1[j];
+            }
+            VecTraits<T>::store(yb + (size_t)p * cv * VE, xv);
+        }
+    }
+}
+
+// backward of the same: reduction (sum dy, sum dy*xh) -> the statistics-gradient coefficients and d style, then dx and the block's
+// (image's) share of d noise-weight / d bias: part[b][C][2] = (sum dp*noise, sum dp), summed over images by gepi_fin_bwd2
+template <typename T, int NT, int IT>
+__global__ __launch_bounds__(NT) void gepi_small_bwd(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                     const float* __restrict__ bias, const float* __restrict__ noise, const float* __restrict__ nw,
+                                                     const float* __restrict__ style, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     float* __restrict__ dstyle, double* __restrict__ part, int HW, int C, int act, int norm) {
+    constexpr int VE = VecTraits<T>::VE, NV = GS_CG / VE, R = NT / NV, W2 = 2 * VE;
+    __shared__ double sh[(NT / 64) * NV * W2 + 32];
+    __shared__ float scoef[2 * GS_CG];                            // [16] k1, [16] k2
+    double* const tot = sh + (NT / 64) * NV * W2;
+    const int b = blockIdx.y, t = threadIdx.x, v = t % NV, r = t / NV;
+    const int cv = C / VE, vg = blockIdx.x * NV + v, c0 = vg * VE;
+    float kb[VE], kw[VE], km[VE], kr[VE], ks[VE], s0[VE], s1[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { kb[j] = 0.f; s0[j] = 0.f; s1[j] = 0.f; }
+    if (bias) load_coef<VE>(bias + c0, kb);
+    load_coef<VE>(nw + c0, kw);
+    load_coef<VE>(mean + (size_t)b * C + c0, km);
+    load_coef<VE>(rstd + (size_t)b * C + c0, kr);
+    load_coef<VE>(style + (size_t)b * 2 * C + c0, ks);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) ks[j] += 1.f;
+    const size_t base = ((size_t)b * HW * cv + vg) * VE;
+    const float* nzb = noise + (size_t)b * HW;
+    uint4 xq[IT], gq[IT];
+    float nz[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int p = r + i * R;
+        const bool ok = p < HW;
+        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+        xq[i] = ok ? *reinterpret_cast<const uint4*>(x + base + (size_t)p * cv * VE) : z4;
+        gq[i] = ok ? *reinterpret_cast<const uint4*>(dy + base + (size_t)p * cv * VE) : z4;
+        nz[i] = ok ? nzb[p] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        if (r + i * R < HW) {
+            float xv[VE], gv[VE];
+            unpack16<T>(xq[i], xv); unpack16<T>(gq[i], gv);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {                         // gepi_pass<T, 1>
+                const float xh = (act_apply(xv[j] + kb[j] + kw[j] * nz[i], act) - km[j]) * kr[j];
+                s0[j] += gv[j]; s1[j] += gv[j] * xh;
+            }
+        }
+    }
+    gs_block_sum<VE, NT>(s0, s1, sh, tot);
+    if (t < GS_CG) {                                               // gepi_fin_bwd1
+        const int vv = t / VE, j = t % VE, c = blockIdx.x * GS_CG + t;
+        const double sdy = tot[vv * W2 + j], sdx = tot[vv * W2 + VE + j];
+        if (dstyle) {
+            dstyle[(size_t)b * 2 * C + c] = (float)sdx;            // d/d style[:,0] = sum dy*xh
+            dstyle[(size_t)b * 2 * C + C + c] = (float)sdy;        // d/d style[:,1] = sum dy
+        }
+        const double sc = (double)style[(size_t)b * 2 * C + c] + 1.0;
+        scoef[t] = norm ? (float)(sc * sdy / HW) : 0.f;
+        scoef[GS_CG + t] = norm ? (float)(sc * sdx / HW) : 0.f;
+    }
+    __syncthreads();
+    float k1[VE], k2[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { k1[j] = scoef[v * VE + j]; k2[j] = scoef[GS_CG + v * VE + j]; s0[j] = 0.f; s1[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int p = r + i * R;
+        if (p < HW) {
+            float xv[VE], gv[VE], ov[VE];
+            unpack16<T>(xq[i], xv); unpack16<T>(gq[i], gv);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {                         // gepi_pass<T, 2>
+                const float pp = xv[j] + kb[j] + kw[j] * nz[i];
+                const float xh = (act_apply(pp, act) - km[j]) * kr[j];
+                const float da = kr[j] * (gv[j] * ks[j] - k1[j] - xh * k2[j]);
+                const float dp = act ? da * lrelu_slope(pp) : da;
+                ov[j] = dp;
+                s0[j] += dp * nz[i]; s1[j] += dp;
+            }
+            VecTraits<T>::store(dx + base + (size_t)p * cv * VE, ov);
+        }
+    }
+    gs_block_sum<VE, NT>(s0, s1, sh, tot);
+    if (t < GS_CG) {
+        const int vv = t / VE, j = t % VE;
+        double* o = part + ((size_t)b * C + blockIdx.x * GS_CG + t) * 2;
+        o[0] = tot[vv * W2 + j]; o[1] = tot[vv * W2 + VE + j];
+    }
+}
+// block shape by layer size: 2 pixels per lane, R = NT / NV rows -- 256 threads up to 16x16 (bf16), 1024 up to 32x32; a 64x64 layer would
+// be 8 pixels per lane (16 fp32): 128+ registers of cached vectors at 1024 threads spill, so it stays with the two-pass kernels
+template <typename T> struct GsPlan {
+    static constexpr int NV = GS_CG / VecTraits<T>::VE;
+    static constexpr int MAX_HW = 2 * (1024 / NV);                 // bf16: 1024, fp32: 512
+    static int pick(int HW) { return HW <= 2 * (256 / NV) ? 0 : 1; }
+};
+// which layers take the one-launch kernels (SGX_GEPI_SMALL=0: A/B against the two-pass structure)
+template <typename T> static bool gepi_small_ok(int B, int HW, int C) {
+    static const int on = [] { const char* e = getenv("SGX_GEPI_SMALL"); return e ? atoi(e) : 1; }();
+    // measured (tools/gepi_probe.py, kernel time forward / backward, two-pass -> one launch): batch 4: 4x4..16x16 18-21 / 30-34 -> 8-9 / 19-20 us,
+    // 32x32 26 / 39 -> 16 / 36; batch 32: 16x16 26 / 39 -> 19 / 37, but 32x32 39 / 59 -> 60 / 125: a block reads 32 of every 128-byte line, and
+    // once the layer (33 MB) no longer sits in L2 the other three quarters are fetched again by the blocks of the other channel groups
+    const long bytes = (long)B * HW * C * (long)sizeof(T);
+    return on && C % GS_CG == 0 && (long)B * (C / GS_CG) >= 64 && (HW <= GsPlan<T>::MAX_HW / 4 || (HW <= GsPlan<T>::MAX_HW && bytes <= (8L << 20)));
+}
+
 template <typename T>
 static int gepi_fwd_t(const void* x, const float* bias, const float* noise, const float* nw, const float* style, void* y,
                       float* mean, float* rstd, void* ws, const double* pre_part, int pre_npart, int B, int HW, int C, int flags,
@@ -388,6 +609,16 @@ static int gepi_fwd_t(const void* x, const float* bias, const float* noise, cons
         hipLaunchKernelGGL(gepi_apply<T>, dim3(g.nchunk, B), dim3(256), 0, st, (const T*)x, bias, noise, nw, style, mean, rstd,
                            (T*)y, HW, C, g.cvt, g.rows, g.chunk, act, (const double*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr);
         SGX_LAUNCH_CHECK("gepi_apply");
+        return 0;
+    }
+    if (gepi_small_ok<T>(B, HW, C)) {                   // (with or without the normalisation: one launch)
+        SGX_NOTE(0.0, 2.0 * nb, "gepi_fwd1 B%d HW%d C%d", B, HW, C);
+        const dim3 grid(C / GS_CG, B);
+        switch (GsPlan<T>::pick(HW)) {
+            case 0: hipLaunchKernelGGL((gepi_small_fwd<T, 256, 2>), grid, dim3(256), 0, st, (const T*)x, bias, noise, nw, style, (T*)y, mean, rstd, HW, C, act, norm); break;
+            default: hipLaunchKernelGGL((gepi_small_fwd<T, 1024, 2>), grid, dim3(1024), 0, st, (const T*)x, bias, noise, nw, style, (T*)y, mean, rstd, HW, C, act, norm);
+        }
+        SGX_LAUNCH_CHECK("gepi_small_fwd");
         return 0;
     }
     if (norm) {
@@ -428,6 +659,18 @@ static int gepi_bwd_t(const void* dy, const void* x, const float* bias, const fl
     float* coef = reinterpret_cast<float*>(partB + (size_t)B * g.nchunk * C * 2);
     const size_t shb = 256 * 2 * VE * sizeof(double);
     const double nb = (double)sizeof(T) * B * HW * C;
+    if (gepi_small_ok<T>(B, HW, C)) {
+        SGX_NOTE(0.0, 3.0 * nb, "gepi_bwd B%d HW%d C%d", B, HW, C);
+        const dim3 grid(C / GS_CG, B);
+        switch (GsPlan<T>::pick(HW)) {
+            case 0: hipLaunchKernelGGL((gepi_small_bwd<T, 256, 2>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, (T*)dx, bias, noise, nw, style, mean, rstd, dstyle, partB, HW, C, act, norm); break;
+            default: hipLaunchKernelGGL((gepi_small_bwd<T, 1024, 2>), grid, dim3(1024), 0, st, (const T*)x, (const T*)dy, (T*)dx, bias, noise, nw, style, mean, rstd, dstyle, partB, HW, C, act, norm);
+        }
+        SGX_LAUNCH_CHECK("gepi_small_bwd");
+        hipLaunchKernelGGL(gepi_fin_bwd2, dim3((C + 3) / 4), dim3(256), 0, st, partB, dnw, dbias, B, C, 1);
+        SGX_LAUNCH_CHECK("gepi_fin_bwd2");
+        return 0;
+    }
     SGX_NOTE(0.0, 2.0 * nb, "gepi_bwd1 B%d HW%d C%d", B, HW, C);
     hipLaunchKernelGGL((gepi_pass<T, 1>), dim3(g.nchunk, B), dim3(256), shb, st, (const T*)x, (const T*)dy, (T*)nullptr, bias,
                        noise, nw, style, mean, rstd, (const float*)nullptr, partA, HW, C, g.cvt, g.rows, g.chunk, act,

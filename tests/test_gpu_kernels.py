@@ -220,7 +220,9 @@ def test_second_order_block():
             assert_close(p.grad, p64[k].grad, 1e-4, "R1 grad " + k)
 
 
-@pytest.mark.parametrize("B,C,H", [(2, 16, 32), (3, 32, 8), (4, 64, 4), (1, 16, 128), (2, 512, 4)])
+# (the last five shapes: >= 64 (image, 16-channel group) blocks at <= 64x64 -- the round-6 one-launch kernels gepi_small_fwd / _bwd)
+@pytest.mark.parametrize("B,C,H", [(2, 16, 32), (3, 32, 8), (4, 64, 4), (1, 16, 128), (2, 512, 4), (4, 256, 64), (8, 128, 32), (4, 512, 16), (4, 512, 32),
+                                   (16, 64, 8), (5, 256, 12)])
 def test_layer_epilogue(B, C, H):
     from stylegan.pytorch_amd.CustomLayers import LayerEpilogue
     epi = LayerEpilogue(C, 512, True, True, False, True, True, torch.nn.LeakyReLU(0.2)).to(DEV)
@@ -243,6 +245,39 @@ def test_layer_epilogue(B, C, H):
     assert_close(dg.grad, d64.grad, 2e-4, "d dlatent")
     for k, p in names.items():
         assert_close(p.grad, p64[k].grad, 2e-4, k)
+
+
+@pytest.mark.parametrize("B,C,H,flags", [(4, 256, 64, 3), (8, 512, 8, 3), (4, 512, 4, 3), (4, 256, 32, 1), (4, 256, 32, 2), (32, 128, 16, 3)])
+def test_layer_epilogue_bf16_one_launch_kernels(B, C, H, flags):
+    """The small-layer epilogue (round 6: statistics + apply in ONE launch per direction, a block per (image, 16 channels)) in bf16
+    storage, straight through ``GEpilogueFn`` -- against the fp64 oracle evaluated on the SAME bf16-rounded input (so the only
+    differences are the kernel's fp32 arithmetic and the bf16 rounding of its outputs: 2^-9 relative per element), every stage flag
+    combination (activation / instance norm), conv bias folded in (reference models/CustomLayers.py:219-248)."""
+    from stylegan.pytorch_amd import functional as F
+    from stylegan.pytorch_amd import native as N
+    x = gu.seeded((B, H, H, C), 41).bfloat16()
+    noise = gu.seeded((B, 1, H, H), 42); nw = 0.5 * gu.seeded((C,), 43); bias = 0.3 * gu.seeded((C,), 44); style = 0.5 * gu.seeded((B, 2 * C), 45)
+    xd = x.to(DEV).requires_grad_(True)
+    prm = [t.to(DEV).requires_grad_(True) for t in (bias, nw, style)]
+    y = F.GEpilogueFn.apply(xd, prm[0], noise.to(DEV), prm[1], prm[2], flags)
+    assert y.dtype == torch.bfloat16
+    x64 = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    p64 = [t.double().requires_grad_(True) for t in (bias, nw, style)]
+    a = x64 + p64[0].view(1, -1, 1, 1) + p64[1].view(1, -1, 1, 1) * noise.double()
+    if flags & N.EPI_ACT:
+        a = TF.leaky_relu(a, 0.2)
+    if flags & N.EPI_NORM:
+        a = O.instance_norm(a)
+    s = p64[2].view(B, 2, C, 1, 1)
+    y64 = a * (s[:, 0] + 1.0) + s[:, 1]
+    assert_close(y.float().permute(0, 3, 1, 2), y64, 3e-3, "y")
+    g = gu.seeded((B, H, H, C), 46).bfloat16()
+    y.backward(g.to(DEV)); y64.backward(g.double().permute(0, 3, 1, 2))
+    assert_close(xd.grad.float().permute(0, 3, 1, 2), x64.grad, 3e-3, "dx")
+    for t, t64, what in zip(prm, p64, ("d bias", "d noise weight", "d style")):
+        if what == "d bias" and flags == N.EPI_NORM:
+            continue                                     # (no activation before the instance norm: the bias gradient is analytically zero)
+        assert_close(t.grad, t64.grad, 1e-3, what, floor=1e-4)
 
 
 def test_pointwise_ops():
