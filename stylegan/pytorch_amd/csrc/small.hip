@@ -397,7 +397,12 @@ __global__ __launch_bounds__(256) void style_bwd_data_kernel(const float* __rest
     const int N = (int)r[2], layer = (int)r[7];
     const float w_mul = __uint_as_float((unsigned)r[5]);
     const float* gyg = gy + (size_t)r[3];
-    for (int i = threadIdx.x; i < B * N; i += 256) sh[i] = gyg[i];
+    // gy_g transposed to [n][MB] (rows of images, zero beyond B): the MB values of one n are consecutive, so a lane fetches them with
+    // MB / 4 broadcast ds_read_b128 instead of MB ds_read_b32 -- the loop is LDS-issue bound (batch 32: 293 us with the [b][n] image)
+    for (int i = threadIdx.x; i < MB * N; i += 256) {
+        const int n = i / MB, b = i % MB;
+        sh[i] = b < B ? gyg[(size_t)b * N + n] : 0.f;
+    }
     __syncthreads();
     const int kk = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
     float acc[MB];
@@ -411,16 +416,23 @@ __global__ __launch_bounds__(256) void style_bwd_data_kernel(const float* __rest
 #pragma unroll
             for (int u = 0; u < 16; ++u) w[u] = W[(size_t)(n + 4 * u) * D + kk];
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
+            for (int u = 0; u < 16; ++u) {
+                const float4* row = reinterpret_cast<const float4*>(sh + (size_t)(n + 4 * u) * MB);
 #pragma unroll
-                for (int b = 0; b < MB; ++b)
-                    if (b < B) acc[b] += sh[b * N + n + 4 * u] * w[u];
+                for (int q = 0; q < MB / 4; ++q) {
+                    const float4 g4 = row[q];
+                    acc[4 * q] += g4.x * w[u]; acc[4 * q + 1] += g4.y * w[u]; acc[4 * q + 2] += g4.z * w[u]; acc[4 * q + 3] += g4.w * w[u];
+                }
+            }
         }
         for (; n < N; n += 4) {
             const float w = W[(size_t)n * D + kk];
+            const float4* row = reinterpret_cast<const float4*>(sh + (size_t)n * MB);
 #pragma unroll
-            for (int b = 0; b < MB; ++b)
-                if (b < B) acc[b] += sh[b * N + n] * w;
+            for (int q = 0; q < MB / 4; ++q) {
+                const float4 g4 = row[q];
+                acc[4 * q] += g4.x * w; acc[4 * q + 1] += g4.y * w; acc[4 * q + 2] += g4.z * w; acc[4 * q + 3] += g4.w * w;
+            }
         }
     }
     __syncthreads();
@@ -493,7 +505,8 @@ extern "C" int sgx_style_fwd(const float* lm, const void* table, float* y, int G
 }
 extern "C" int sgx_style_bwd_data(const float* gy, const void* table, float* glm, int G, int B, int D, int max_n, void* stream) {
     int rc = style_check(G, B, D); if (rc) return rc;
-    const size_t a = (size_t)B * max_n, b = (size_t)4 * B * 64;
+    const int mb = B <= 4 ? 4 : (B <= 8 ? 8 : (B <= 16 ? 16 : 32));
+    const size_t a = (size_t)mb * max_n, b = (size_t)4 * B * 64;  // the transposed gy image [max_n][MB], then the wave partials
     SGX_NOTE(0.0, 0.0, "style_bwd_data G%d B%d", G, B);
     if (B <= 4) hipLaunchKernelGGL(style_bwd_data_kernel<4>, dim3(D / 64, G), dim3(256), (a > b ? a : b) * sizeof(float), (hipStream_t)stream, gy, (const long long*)table, glm, G, B, D);
     else if (B <= 8) hipLaunchKernelGGL(style_bwd_data_kernel<8>, dim3(D / 64, G), dim3(256), (a > b ? a : b) * sizeof(float), (hipStream_t)stream, gy, (const long long*)table, glm, G, B, D);

@@ -316,3 +316,57 @@ def test_residual_from_rgb_gradients_with_two_backward_branches(monkeypatch):
     unfused = grads(True, True, fused=False, reps=1)[0]
     for k, v in single[0].items():
         assert rel_err(unfused[k], v) <= 1e-5, (k, rel_err(unfused[k], v))
+
+
+@pytest.mark.parametrize("B,R,C,dev_alpha,with_img", [(2, 512, 32, False, True), (2, 256, 64, True, True), (3, 128, 128, False, False), (1, 64, 32, True, True)])
+def test_fade_rgb_backward_kernel_vs_oracle(B, R, C, dev_alpha, with_img):
+    """``sgx_fade_rgb_bwd`` DIRECTLY against the oracle (round 5 compared it with the unfused path only): the tail of the newest
+    discriminator block, y = alpha * lrelu(z) + (1 - alpha) * from_rgb(pool(img)) (reference models/GAN.py:423-427, from_rgb =
+    EqualizedConv2d 1x1 with gain sqrt 2, models/GAN.py:377), differentiated by autograd on the oracle's own layers in fp64, at the
+    shapes of depth index 8 / 7 / 6 (R x R x C = 512^2 x 32, 256^2 x 64, 128^2 x 128).  Inputs are bf16-exact, so what is compared is
+    the kernel's arithmetic: gy is bf16 (2^-9 per element), the three parameter / image gradients are fp32 sums (fp64 across threads)."""
+    import math
+    from stylegan.pytorch_amd import native as N
+    L = N.lib()
+    alpha = 0.3
+    z = gu.seeded((B, C, R, R), 71, torch.float64)                          # the pre-activation (only its sign reaches the kernel)
+    g = gu.seeded((B, R, R, C), 72).bfloat16()                              # dL/dy, NHWC
+    pimg = gu.seeded((B, 3, R, R), 73)                                      # the pooled image
+    wr = gu.seeded((C, 3, 1, 1), 74); br = 0.1 * gu.seeded((C,), 75)
+    # oracle
+    p64 = [t.double().requires_grad_(True) for t in (z, pimg, wr, br)]
+    y = alpha * O.leaky_relu(p64[0]) + (1.0 - alpha) * O.eq_conv2d(p64[1], p64[2], p64[3], gain=math.sqrt(2.0))
+    y.backward(g.double().permute(0, 3, 1, 2))
+    # kernel
+    bits = torch.zeros((B, R, R, C // 8), dtype=torch.uint8)
+    zb = (z.permute(0, 2, 3, 1) > 0).reshape(B, R, R, C // 8, 8).to(torch.uint8)
+    for j in range(8):
+        bits |= zb[..., j] << j
+    ws, bs = math.sqrt(2.0) / math.sqrt(3.0), 1.0                           # from_rgb's w_mul (gain sqrt 2, fan-in 3) and b_mul
+    gd, bitsd = g.to(DEV), bits.to(DEV)
+    pimgd = pimg.permute(0, 2, 3, 1).contiguous().to(DEV); wrd = wr.to(DEV)
+    gy = torch.empty_like(gd)
+    dw = torch.empty((C, 3), dtype=torch.float32, device=DEV); db = torch.empty((C,), dtype=torch.float32, device=DEV)
+    gpimg = torch.empty_like(pimgd) if with_img else None
+    npix = B * R * R
+    wsb = L.sgx_fade_rgb_bwd_ws_bytes(npix, C)
+    wsp = N.workspace(wsb, gd.device)
+    ab = torch.tensor([alpha, 1.0 - alpha], dtype=torch.float32, device=DEV) if dev_alpha else None
+    N.check(L.sgx_fade_rgb_bwd(N.ptr(gd), N.ptr(bitsd), N.ptr(pimgd), N.ptr(wrd), ws, bs, 0.0 if dev_alpha else alpha, 0.0 if dev_alpha else 1.0 - alpha,
+                               N.ptr(ab), N.ptr(gy), N.ptr(dw), N.ptr(db), 0, N.ptr(gpimg), N.ptr(wsp), wsb, npix, C, N.BF16, N.stream()), "sgx_fade_rgb_bwd")
+    torch.cuda.synchronize()
+    assert rel_err(gy.float().permute(0, 3, 1, 2), p64[0].grad) <= 3e-3                      # bf16 output
+    assert rel_err(dw.view(C, 3, 1, 1), p64[2].grad) <= 1e-4, rel_err(dw.view(C, 3, 1, 1), p64[2].grad)
+    assert rel_err(db, p64[3].grad) <= 1e-4
+    if with_img:
+        assert rel_err(gpimg.permute(0, 3, 1, 2), p64[1].grad) <= 1e-5
+    # the two-call form (the pass leaves the block partials, sgx_fade_rgb_bwd_finish accumulates on any stream ordered behind it)
+    dw2 = torch.full_like(dw, 2.0); db2 = torch.full_like(db, -1.0)
+    gy2 = torch.empty_like(gd)
+    N.check(L.sgx_fade_rgb_bwd(N.ptr(gd), N.ptr(bitsd), N.ptr(pimgd), N.ptr(wrd), ws, bs, 0.0 if dev_alpha else alpha, 0.0 if dev_alpha else 1.0 - alpha,
+                               N.ptr(ab), N.ptr(gy2), None, None, 0, None, N.ptr(wsp), wsb, npix, C, N.BF16, N.stream()), "sgx_fade_rgb_bwd")
+    N.check(L.sgx_fade_rgb_bwd_finish(N.ptr(wsp), wsb, npix, C, ws, bs, 0.0 if dev_alpha else 1.0 - alpha, N.ptr(ab), N.ptr(dw2), N.ptr(db2), 3,
+                                      N.stream()), "sgx_fade_rgb_bwd_finish")
+    torch.cuda.synchronize()
+    assert torch.equal(gy2, gy)
+    assert torch.equal(dw2, dw + 2.0) and torch.equal(db2, db - 1.0)                         # accumulate bits 0 and 1
