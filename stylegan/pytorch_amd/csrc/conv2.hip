@@ -1348,11 +1348,33 @@ static Conv2Pick conv2_pick(int geo, int B, int H, int W, int Cin, int Cout, int
     }
     const int bco = (geo == C2_S && Cout % 64 == 0) ? 64 : 32;       // (3x3 with 32 output channels: the MF = 1 block)
     if (Cin % 32 != 0 || Cout % bco != 0 || gw % 32 != 0 || Cout / bco > 32 || gh < 1 || (geo == C2_D && ((H | W) & 1))) return none;
-    const bool mf2 = geo != C2_U && Cout % 64 == 0;
+    bool mf2 = geo != C2_U && Cout % 64 == 0;
     if (variant < 0 && geo == C2_D && !mf2) return none;   // 32-channel stride-2 blocks: measured no better than the first generation
+    static const int force_nw = [] { const char* e = getenv("SGX_CONV2_NW"); return e ? atoi(e) : 0; }();
+    if (geo == C2_S && mf2 && variant < 0 && !force_nw) {
+        // small grids (batch 4 at 32^2..64^2): the 32-channel block doubles the block count.  Measured alone (round 6, tools/conv2_probe.py
+        // variants 22 / 23, bit-identical outputs): batch 4, 64^2 256->256: (8 waves, 64 ch) 128 blocks 33.0 us, (4, 64) 256 blocks 29.3,
+        // (8, 32) 256 blocks 24.0, (4, 32) 512 blocks 31.9; 32^2 512->512: first generation 36.4, (4, 64) 48.0, (8, 32) 37.3, (4, 32) 256
+        // blocks 31.1; batch 8, 32^2: (4, 64) 52.4, (8, 32) 44.5, (4, 32) 58.2 -- the first shape in this order that fills the chip
+        static const int small = [] { const char* e = getenv("SGX_CONV2_SMALL"); return e ? atoi(e) : 1; }();     // A/B: 0 = the round-2 rule
+        const long t8 = (long)B * ((gh + 15) / 16) * (gw / 32), t4 = (long)B * ((gh + 7) / 8) * (gw / 32);
+        const int c64 = Cout / 64, c32 = Cout / 32, ncu = conv2_ncu();
+        if (small && t8 * c64 < ncu) {
+            if (t8 * c32 >= ncu) return Conv2Pick{8, false, false};
+            if (t4 * c64 >= ncu) return Conv2Pick{4, true, false};
+            if (t4 * c32 >= ncu) return Conv2Pick{4, false, false};
+            return none;
+        }
+    }
+    if (geo == C2_D && mf2 && variant < 0 && !force_nw) {
+        // the same for the stride-2 geometry, where only (8 waves, 32 channels) ever beat the round-2 choice: batch 4, 128^2 128->256:
+        // (4, 64) 33.6 us, first generation 33.4, (8, 32) 28.5 (the other small-grid shapes: (8, 64) or the first generation stay best)
+        static const int small = [] { const char* e = getenv("SGX_CONV2_SMALL"); return e ? atoi(e) : 1; }();
+        const long t8 = (long)B * ((gh + 15) / 16) * (gw / 32);
+        if (small && t8 * (Cout / 64) < conv2_ncu() && t8 * (Cout / 32) >= conv2_ncu()) return Conv2Pick{8, false, false};
+    }
     const int cbs = Cout / (mf2 ? 64 : 32);
     const long blocks8 = (long)B * ((gh + 15) / 16) * (gw / 32) * cbs, blocks4 = (long)B * ((gh + 7) / 8) * (gw / 32) * cbs;
-    static const int force_nw = [] { const char* e = getenv("SGX_CONV2_NW"); return e ? atoi(e) : 0; }();
     // measured (profiles/r02_conv2_probe.txt): the 8-wave block wins once its 512-pixel tiles fill the chip, the 4-wave
     // block (256-pixel tiles) down to one block per CU, below that the first-generation kernel's 64-pixel tiles do
     if (variant < 0 && !force_nw && blocks4 < conv2_ncu()) return none;
@@ -1508,6 +1530,14 @@ int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void
                     H, W, Cin, Cout, act, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
         *launched = 1;
         return variant == 20 ? launch_conv2<C2_S, 8, 4, 16>(a, st) : launch_conv2<C2_S, 4, 4, 16>(a, st);
+    }
+    if (variant == 22 || variant == 23) {        // probe: 32 output channels per block (MF = 1) whatever Cout: twice the blocks of the 64-channel tile
+        if ((geo != C2_S && geo != C2_D) || Cin % 32 || Cout % 32 || (geo == C2_D ? W / 2 : W) % 32) return 0;
+        Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(w), bias, static_cast<bf16_t*>(y), static_cast<const bf16_t*>(mask), B, H, W,
+                    geo == C2_D ? H / 2 : H, geo == C2_D ? W / 2 : W, Cin, Cout, act, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+        *launched = 1;
+        if (geo == C2_D) return variant == 22 ? launch_conv2<C2_D, 4, 1>(a, st) : launch_conv2<C2_D, 8, 1>(a, st);
+        return variant == 22 ? launch_conv2<C2_S, 4, 1>(a, st) : launch_conv2<C2_S, 8, 1>(a, st);
     }
     const Conv2Pick p = conv2_pick(geo, B, H, W, Cin, Cout, variant);
     if (!p.nw) return 0;
