@@ -430,8 +430,10 @@ __global__ __launch_bounds__(NT) void gepi_small_fwd(const T* __restrict__ x, co
     for (int i = 0; i < IT; ++i) {                                 // all of the lane's loads in flight at once
         const int p = r + i * R;
         const bool ok = p < HW;
-        xq[i] = ok ? *reinterpret_cast<const uint4*>(xb + (size_t)p * cv * VE) : make_uint4(0u, 0u, 0u, 0u);
-        nz[i] = ok ? nzb[p] : 0.f;
+        const uint4 xl = *reinterpret_cast<const uint4*>(xb + (size_t)(ok ? p : 0) * cv * VE);     // (clamped address, value select: see the backward)
+        const float nl = nzb[ok ? p : 0];
+        xq[i] = make_uint4(ok ? xl.x : 0u, ok ? xl.y : 0u, ok ? xl.z : 0u, ok ? xl.w : 0u);
+        nz[i] = ok ? nl : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
@@ -516,10 +518,14 @@ __global__ __launch_bounds__(NT) void gepi_small_bwd(const T* __restrict__ x, co
     for (int i = 0; i < IT; ++i) {
         const int p = r + i * R;
         const bool ok = p < HW;
-        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-        xq[i] = ok ? *reinterpret_cast<const uint4*>(x + base + (size_t)p * cv * VE) : z4;
-        gq[i] = ok ? *reinterpret_cast<const uint4*>(dy + base + (size_t)p * cv * VE) : z4;
-        nz[i] = ok ? nzb[p] : 0.f;
+        // (clamped address + select of the VALUE: a ?: between a load and an addressable zero vector compiles to a flat load from a
+        // scratch copy of the zeros -- seen in the ISA of the first version, 32 bytes of scratch per lane)
+        const size_t po = (size_t)(ok ? p : 0) * cv * VE;
+        const uint4 xl = *reinterpret_cast<const uint4*>(x + base + po), gl = *reinterpret_cast<const uint4*>(dy + base + po);
+        const float nl = nzb[ok ? p : 0];
+        xq[i] = make_uint4(ok ? xl.x : 0u, ok ? xl.y : 0u, ok ? xl.z : 0u, ok ? xl.w : 0u);
+        gq[i] = make_uint4(ok ? gl.x : 0u, ok ? gl.y : 0u, ok ? gl.z : 0u, ok ? gl.w : 0u);
+        nz[i] = ok ? nl : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
@@ -574,11 +580,11 @@ __global__ __launch_bounds__(NT) void gepi_small_bwd(const T* __restrict__ x, co
         o[0] = tot[vv * W2 + j]; o[1] = tot[vv * W2 + VE + j];
     }
 }
-// block shape by layer size: 2 pixels per lane, R = NT / NV rows -- 256 threads up to 16x16 (bf16), 1024 up to 32x32; a 64x64 layer would
-// be 8 pixels per lane (16 fp32): 128+ registers of cached vectors at 1024 threads spill, so it stays with the two-pass kernels
+// block shape by layer size: 256 threads x 2 pixels per lane up to 16x16 (bf16), 512 threads x 4 up to 32x32 (1024 threads x 2 caps the
+// kernel at 128 registers: the bf16 backward spilled 40 bytes); a 64x64 layer would be 16 cached vectors per lane and stays two-pass
 template <typename T> struct GsPlan {
     static constexpr int NV = GS_CG / VecTraits<T>::VE;
-    static constexpr int MAX_HW = 2 * (1024 / NV);                 // bf16: 1024, fp32: 512
+    static constexpr int MAX_HW = 4 * (512 / NV);                  // bf16: 1024, fp32: 512
     static int pick(int HW) { return HW <= 2 * (256 / NV) ? 0 : 1; }
 };
 // which layers take the one-launch kernels (SGX_GEPI_SMALL=0: A/B against the two-pass structure)
@@ -616,7 +622,7 @@ static int gepi_fwd_t(const void* x, const float* bias, const float* noise, cons
         const dim3 grid(C / GS_CG, B);
         switch (GsPlan<T>::pick(HW)) {
             case 0: hipLaunchKernelGGL((gepi_small_fwd<T, 256, 2>), grid, dim3(256), 0, st, (const T*)x, bias, noise, nw, style, (T*)y, mean, rstd, HW, C, act, norm); break;
-            default: hipLaunchKernelGGL((gepi_small_fwd<T, 1024, 2>), grid, dim3(1024), 0, st, (const T*)x, bias, noise, nw, style, (T*)y, mean, rstd, HW, C, act, norm);
+            default: hipLaunchKernelGGL((gepi_small_fwd<T, 512, 4>), grid, dim3(512), 0, st, (const T*)x, bias, noise, nw, style, (T*)y, mean, rstd, HW, C, act, norm);
         }
         SGX_LAUNCH_CHECK("gepi_small_fwd");
         return 0;
@@ -664,7 +670,7 @@ static int gepi_bwd_t(const void* dy, const void* x, const float* bias, const fl
         const dim3 grid(C / GS_CG, B);
         switch (GsPlan<T>::pick(HW)) {
             case 0: hipLaunchKernelGGL((gepi_small_bwd<T, 256, 2>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, (T*)dx, bias, noise, nw, style, mean, rstd, dstyle, partB, HW, C, act, norm); break;
-            default: hipLaunchKernelGGL((gepi_small_bwd<T, 1024, 2>), grid, dim3(1024), 0, st, (const T*)x, (const T*)dy, (T*)dx, bias, noise, nw, style, mean, rstd, dstyle, partB, HW, C, act, norm);
+            default: hipLaunchKernelGGL((gepi_small_bwd<T, 512, 4>), grid, dim3(512), 0, st, (const T*)x, (const T*)dy, (T*)dx, bias, noise, nw, style, mean, rstd, dstyle, partB, HW, C, act, norm);
         }
         SGX_LAUNCH_CHECK("gepi_small_bwd");
         hipLaunchKernelGGL(gepi_fin_bwd2, dim3((C + 3) / 4), dim3(256), 0, st, partB, dnw, dbias, B, C, 1);
