@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-5 evidence in one GPU-box session.   usage: tools/gpu_final5.sh <tag> [test]
+# Round-6 evidence in one GPU-box session.   usage: tools/gpu_final6.sh <tag> [test]
 #   smoke; the default bench line (headline batch 4 + the batch-32 block + cpu_baseline) and its layer tables; single-stream bench lines at
 #   batch 4 and 32 (per-kernel times without stream overlap) + step budgets; and for BOTH batch sizes: rocprofv3 --kernel-trace --stats,
 #   one SQ counter pass, two HBM traffic passes of the single-stream step.  `test`: the whole -m gpu suite first.
 # Every JSON / text artefact gets the box id and the commit the snapshot was made from (tools/.evidence_commit, written by the caller).
-tag=${1:-final5}
+tag=${1:-final6}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R
 BOX="$(hostname) gpu-uid $(cat /sys/class/drm/card*/device/unique_id 2>/dev/null | head -1)"
@@ -28,22 +28,22 @@ if [ "$2" = "test" ]; then
   grep -aE "passed|failed" $O/pytest.log | tail -2; stamp_txt $O/pytest.log
 fi
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
-echo "== bench default (b4 + b32 blocks, cpu baseline)"; timeout 900 python bench.py --layer-table $O/layers_b4.tsv 2>$O/bench_default.err | tail -1 > $O/bench_default.json; stamp_json $O/bench_default.json; cut -c1-260 $O/bench_default.json
+echo "== bench default (b4 + b32 blocks, cpu baseline)"; timeout 900 python bench.py --layer-table $O/layers_b4.tsv 2>$O/bench_default.err | tail -1 > $O/bench_default.json; stamp_json $O/bench_default.json; cp gpurun_out/bench_detail.json $O/bench_default_detail.json 2>/dev/null; wc -c < $O/bench_default.json; cut -c1-260 $O/bench_default.json
 echo "== bench b4 single stream"; timeout 400 python bench.py --no-b32 --no-extras --no-cpu-baseline --graphs off --streams 00 --layer-table $O/layers_b4_single.tsv 2>/dev/null | tail -1 > $O/bench_b4_single.json; stamp_json $O/bench_b4_single.json; cut -c1-200 $O/bench_b4_single.json
 echo "== bench b32 single stream"; timeout 400 python bench.py --batch-per-gpu 32 --steps 8 --warmup 2 --no-cpu-baseline --graphs off --streams 00 --layer-table $O/layers_b32_single.tsv 2>/dev/null | tail -1 > $O/bench_b32_single.json; stamp_json $O/bench_b32_single.json; cut -c1-200 $O/bench_b32_single.json
 python tools/step_budget.py $O/layers_b4_single.tsv > $O/step_budget_b4.txt 2>&1; python tools/step_budget.py $O/layers_b32_single.tsv > $O/step_budget_b32.txt 2>&1
 for f in $O/layers_*.tsv $O/step_budget_*.txt; do stamp_txt $f; done
 if [ "$3" = "ab" ]; then
-  echo "== A/B on this box: the round-5 fusions off (SGX_CONV_UPBLUR=0 SGX_FUSE_FADE_RGB=0 SGX_TRAIN_GRAPHS unaffected) vs on, default bench line, interleaved"
+  echo "== A/B on this box: the round-6 changes off (SGX_GEPI_SMALL=0 SGX_CONV2_SMALL=0) vs on, default bench line, interleaved"
   for i in 1 2; do for v in off on; do
-    if [ $v = off ]; then export SGX_CONV_UPBLUR=0 SGX_FUSE_FADE_RGB=0; else unset SGX_CONV_UPBLUR SGX_FUSE_FADE_RGB; fi
+    if [ $v = off ]; then export SGX_GEPI_SMALL=0 SGX_CONV2_SMALL=0; else unset SGX_GEPI_SMALL SGX_CONV2_SMALL; fi
     timeout 400 python bench.py --no-cpu-baseline --no-extras --steps 30 2>/dev/null | tail -1 | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
-print('round-5 fusions $v: b4', round(d['value'], 1), 'img/s', round(d['ms_per_step'], 3), 'ms graphs', d.get('hip_graphs'), '| b32', round(d['b32']['value'], 1), 'img/s', round(d['b32']['ms_per_step'], 2), 'ms')"
-  done; done | tee $O/ab_round5_fusions.txt
-  unset SGX_CONV_UPBLUR SGX_FUSE_FADE_RGB
-  stamp_txt $O/ab_round5_fusions.txt
+print('round-6 changes $v: b4', round(d['value'], 1), 'img/s', round(d['ms_per_step'], 3), 'ms graphs', d.get('hip_graphs'), 'launches', d.get('library_launches_per_step'), '| b32', round(d['b32']['value'], 1), 'img/s', round(d['b32']['ms_per_step'], 2), 'ms')"
+  done; done | tee $O/ab_round6.txt
+  unset SGX_GEPI_SMALL SGX_CONV2_SMALL
+  stamp_txt $O/ab_round6.txt
 fi
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"
