@@ -40,7 +40,10 @@ def test_sample_yaml_trains_first_two_depths(tmp_path):
                          d_repeats=opt.d_repeats, use_ema=opt.use_ema, ema_decay=opt.ema_decay, device=torch.device(DEV))
     epochs = list(opt.sched.epochs[:2]) + [0] * (len(opt.sched.epochs) - 2)        # sample.yaml's [2, 4, ...]: depths 0 and 1 only
     torch.manual_seed(0)
-    style_gan.train(dataset=dataset, num_workers=opt.num_works, epochs=epochs, batch_sizes=opt.sched.batch_sizes,
+    # num_workers 0 (train.py passes opt.num_works = 4): the loader's worker processes are outside the path under test, and forking four
+    # of them per epoch from a pytest process that has run 500 GPU tests took 280 of the suite's 646 s (25 s when this file runs alone)
+    assert opt.num_works == 4
+    style_gan.train(dataset=dataset, num_workers=0, epochs=epochs, batch_sizes=opt.sched.batch_sizes,
                     fade_in_percentage=opt.sched.fade_in_percentage, logger=log, output=opt.output_dir,
                     num_samples=opt.num_samples, start_depth=0, feedback_factor=opt.feedback_factor,
                     checkpoint_factor=opt.checkpoint_factor)
