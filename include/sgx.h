@@ -194,6 +194,9 @@ int sgx_images_u8_to_nhwc(const void* src, void* dst, const int* flip, int B, in
 int sgx_pool2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream);
 /* y = scale * nearest_up2(x)    Upscale2d CustomLayers.py:27-36; F.interpolate(scale_factor=2) models/GAN.py:173     */
 int sgx_up2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream);
+/* Round 6: y = a + scale * nearest-up(x), a and y shaped [B][2H][2W][C] -- the adjoint of the 2x2 pool AND the sum with the other gradient of
+ * a tensor that feeds both a full-resolution branch and a pooled one (the discriminator's image: models/GAN.py:423-427), one pass.     */
+int sgx_up2_add(const void* x, const void* a, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream);
 /* out[c] = scale * sum_p x[p][c]  (fp32 out)        bias gradient                                                    */
 size_t sgx_colsum_ws_bytes(size_t npix, int C);
 int sgx_colsum(const void* x, float* out, float scale, void* ws, size_t ws_bytes, size_t npix, int C, int dtype,

@@ -424,7 +424,11 @@ class Discriminator(nn.Module):
                 pre = fuse and not isinstance(alpha, torch.Tensor) and not self.conditional
                 top, top_rgb = self.blocks[self.depth - depth - 1], self.from_rgb[self.depth - depth - 1]
                 res_rgb = self.from_rgb[self.depth - depth]
-                pimg = F.call(F.Pool2Fn, img, 0.25)
+                # (the image feeds the newest block AND, pooled, the residual branch: PoolForkFn joins its two gradients in one pass)
+                if F.POOL_FORK:
+                    img, pimg = F.call(F.PoolForkFn, img, 0.25)
+                else:
+                    pimg = F.call(F.Pool2Fn, img, 0.25)
                 if fuse and top._act == ACT_LRELU and not self.conditional and F.fade_rgb_ok(res_rgb, top.conv1_down.weight.shape[0], dt):
                     # round 5: the residual as a recipe -- evaluated inside the store of the newest block's stride-2 convolution (with the lerp)
                     residual = F.RgbResidual(pimg, res_rgb, float(1 - alpha) if pre else 1.0, dt)

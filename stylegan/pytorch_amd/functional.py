@@ -1458,6 +1458,51 @@ class Up2Fn(Function):
         return _bcall(Pool2Fn, g, ctx.scale), None
 
 
+class UpAddFn(Function):
+    """a + scale * nearest-up(x) in one pass (``sgx_up2_add``); adjoint = (g, scale * 2x2 block sum of g)."""
+
+    @staticmethod
+    def forward(ctx, a, x, scale):
+        a, x = _c(a), _c(x)
+        B, H, W, C = x.shape
+        if tuple(a.shape) != (B, 2 * H, 2 * W, C) or a.dtype != x.dtype:
+            raise N.SgxError("UpAddFn: a must be [B, 2H, 2W, C] of x's dtype")
+        y = torch.empty_like(a)
+        N.check(N.lib().sgx_up2_add(N.ptr(x), N.ptr(a), N.ptr(y), B, H, W, C, float(scale), N.dt(x), N.stream()), "sgx_up2_add")
+        ctx.scale = float(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, _bcall(Pool2Fn, g, ctx.scale), None
+
+
+POOL_FORK = os.environ.get("SGX_POOL_FORK", "1") != "0"      # A/B: 0 = Pool2Fn and autograd's own sum of the two image gradients
+
+
+class PoolForkFn(Function):
+    """x -> (x, scale * pool2(x)) for a tensor that feeds BOTH a full-resolution branch and a pooled one -- the discriminator's image under
+    fade-in: the newest block on the image, the residual from_rgb on its 2x2 average (reference models/GAN.py:423-427).  Forward = ``Pool2Fn``;
+    the point is the backward: autograd would run the pool's adjoint (nearest-up: one pass writing a full-resolution fp32 image) and then sum
+    it with the other branch's gradient in a pass of its own (read 2, write 1); here the two meet in ONE pass, ``g_x + scale * up(g_y)``
+    (``UpAddFn``: twice differentiable, so the R1 double backward goes through it unchanged)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        y = Pool2Fn.forward(_NoGradCtx(), x, scale)
+        ctx.scale = float(scale)
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, gx, gy):
+        if gy is None:
+            return gx, None
+        if gx is None:
+            return _bcall(Up2Fn, gy, ctx.scale), None
+        return _bcall(UpAddFn, gx, gy, ctx.scale), None
+
+
 # ---------------------------------------------------------------------------------------------------
 # 1x1 RGB convolutions.  Images are fp32 [B,H,W,3]; the weight is the raw parameter ([C,3,1,1] from_rgb or
 # [3,C,1,1] to_rgb), read in place: element (j, c) at w[j*sj + c*sc], times wscale (= w_mul).

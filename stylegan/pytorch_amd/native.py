@@ -66,6 +66,7 @@ SIGNATURES = {
     "sgx_blur_kxk": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "sgx_pool2": (I, [P, P, I, I, I, I, F, I, P]),
     "sgx_up2": (I, [P, P, I, I, I, I, F, I, P]),
+    "sgx_up2_add": (I, [P, P, P, I, I, I, I, F, I, P]),
     "sgx_colsum_ws_bytes": (Z, [Z, I]),
     "sgx_colsum": (I, [P, P, F, P, Z, Z, I, I, P]),
     "sgx_rgb_in": (I, [P, P, I, I, F, P, P, Z, I, I, P]),

@@ -300,6 +300,41 @@ def test_pointwise_ops():
     assert_close(F.ScaleFn.apply(odd.to(DEV), -2.0), -2.0 * odd, 1e-7, "scale tail")
 
 
+@pytest.mark.parametrize("B,H,W,C,dtype", [(2, 8, 10, 3, torch.float32), (1, 4, 4, 5, torch.float32), (2, 6, 8, 16, torch.bfloat16), (3, 64, 64, 3, torch.float32)])
+def test_pool_fork_joins_the_two_gradients_in_one_pass(B, H, W, C, dtype):
+    """functional.PoolForkFn / UpAddFn (round 6): x -> (x, pool2(x)) for the discriminator's image, which feeds the newest block at full
+    resolution and the residual from_rgb through a 2x2 average (reference models/GAN.py:423-427).  Against torch's own autograd on the CPU in
+    fp64: first order (the join g_x + up(g_y) / 4 is one kernel) and second order (the R1 penalty differentiates that join)."""
+    from stylegan.pytorch_amd import functional as F
+    x = gu.seeded((B, H, W, C), 81)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xd = x.to(DEV).to(dtype).requires_grad_(True)
+    xa, p = F.PoolForkFn.apply(xd, 0.25)
+    assert xa.shape == xd.shape and p.shape == (B, H // 2, W // 2, C)
+    x64 = x.double().requires_grad_(True)
+    p64 = TF.avg_pool2d(x64.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    tol = 1e-6 if dtype == torch.float32 else 6e-3
+    assert_close(p.float(), p64, tol, "pool")
+    w1 = gu.seeded((B, H, W, C), 82); w2 = gu.seeded((B, H // 2, W // 2, C), 83)
+    # first order, both / one branch only
+    (g,) = torch.autograd.grad((xa.float() * w1.to(DEV)).sum() + (p.float() * w2.to(DEV)).sum(), xd, retain_graph=True)
+    (g64,) = torch.autograd.grad((x64 * w1.double()).sum() + (p64 * w2.double()).sum(), x64, retain_graph=True)
+    assert_close(g.float(), g64, tol, "joined gradient")
+    (g,) = torch.autograd.grad((p.float() * w2.to(DEV)).sum(), xd, retain_graph=True)
+    (g64,) = torch.autograd.grad((p64 * w2.double()).sum(), x64, retain_graph=True)
+    assert_close(g.float(), g64, tol, "pooled branch only")
+    if dtype != torch.float32:
+        return
+    # second order: the gradient of |d loss / d x|^2 (R1's structure)
+    (gx,) = torch.autograd.grad((xa * xa * w1.to(DEV)).sum() + (p * p * w2.to(DEV)).sum(), xd, create_graph=True)
+    (gx64,) = torch.autograd.grad((x64 * x64 * w1.double()).sum() + (p64 * p64 * w2.double()).sum(), x64, create_graph=True)
+    assert_close(gx, gx64, 1e-5, "inner gradient")
+    (gg,) = torch.autograd.grad((gx * gx).sum(), xd)
+    (gg64,) = torch.autograd.grad((gx64 * gx64).sum(), x64)
+    assert_close(gg, gg64, 1e-5, "gradient of the squared gradient")
+
+
 def test_rgb_convs():
     from stylegan.pytorch_amd.CustomLayers import EqualizedConv2d
     for C in (16, 32, 128, 512):
