@@ -212,6 +212,10 @@ int sgx_rgb_in(const float* img, const float* w, int sj, int sc, float wscale, c
                int C, int dtype, void* stream);
 int sgx_rgb_out(const void* x, const float* w, int sj, int sc, float wscale, const float* bias, float* img, size_t npix,
                 int C, int dtype, void* stream);
+/* Round 6: y = add + sgx_rgb_in(img) (no bias; add and y shaped [npix][C] of `dtype`): to_rgb's data gradient joined with the gradient the
+ * forked activation got from its other consumer (models/GAN.py:199-202 under fade-in), one pass, one rounding.                          */
+int sgx_rgb_in_add(const float* img, const float* w, int sj, int sc, float wscale, const void* add, void* y, size_t npix, int C, int dtype,
+                   void* stream);
 size_t sgx_rgb_wgrad_ws_bytes(size_t npix, int C);
 /* real images at the current depth with the fade-in blend (models/GAN.py:575-586): out = alpha * x + beta *
  * nearest_up2(avgpool2(x)) on fp32 [B][H][W][3] in one pass; ab_dev as in sgx_rgb_out_fade. */

@@ -244,7 +244,12 @@ class GSynthesis(nn.Module):
                     x = block.forward_nhwc(x, dl[2 * (i + 1):2 * (i + 2)])
                 # reference GAN.py:199 applies to_rgb AFTER the nearest upsample; a 1x1 conv commutes with
                 # replication, so convert at the low resolution (4x fewer bytes) and upsample the RGB image.
-                low = self.to_rgb[depth - 1].forward_nhwc(x)                                      # RGB at the previous resolution
+                prev = self.to_rgb[depth - 1]
+                if F.RGB_FORK and prev.weight.shape[0] == 3 and prev.weight.shape[1] == x.shape[3]:
+                    # x feeds the newest block AND this to_rgb: RgbOutForkFn joins its two gradients in to_rgb's data-gradient pass
+                    x, low = F.call(F.RgbOutForkFn, x, prev.weight, prev.scaled_bias(), prev.w_mul)
+                else:
+                    low = prev.forward_nhwc(x)                                                    # RGB at the previous resolution
                 rgb = self.to_rgb[depth]
                 last = self.blocks[depth - 1]
                 if (F.FUSE_EPI_RGB and FUSE_RGB_FADE and last.epi2._fusable and rgb.weight.shape[0] == 3 and low.dtype == torch.float32

@@ -1088,7 +1088,7 @@ extern "C" int sgx_colsum(const void* x, float* out, float scale, void* ws, size
 // ---------------------------------------------------------------- 1x1 RGB convolutions (3 <-> C), images fp32 [p][3]
 template <typename T>
 __global__ void rgb_in_kernel(const float* __restrict__ img, const float* __restrict__ w, int sj, int sc, float wscale,
-                              const float* __restrict__ bias, T* __restrict__ y, size_t npix, int C) {
+                              const float* __restrict__ bias, T* __restrict__ y, size_t npix, int C, const T* __restrict__ add) {
     constexpr int VE = VecTraits<T>::VE;
     const int cv = C / VE;                                   // power of two <= 64, divides the grid stride
     const size_t nvec = npix * cv;
@@ -1106,6 +1106,12 @@ __global__ void rgb_in_kernel(const float* __restrict__ img, const float* __rest
         float v[VE];
 #pragma unroll
         for (int j = 0; j < VE; ++j) v[j] = bb[j] + (r * wr[j] + g * wg[j] + b * wb[j]);
+        if (add) {                                           // (sgx_rgb_in_add: the other gradient of a forked tensor joins here)
+            float av[VE];
+            VecTraits<T>::load(add + i * VE, av);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) v[j] += av[j];
+        }
         VecTraits<T>::store(y + i * VE, v);
     }
 }
@@ -1120,12 +1126,30 @@ extern "C" int sgx_rgb_in(const float* img, const float* w, int sj, int sc, floa
     SGX_NOTE(6.0 * npix * C, npix * (12.0 + (dtype == SGX_F32 ? 4.0 : 2.0) * C), "rgb_in %zux%d", npix, C);
     if (dtype == SGX_F32) {
         SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "rgb_in: C %% 4");
-        hipLaunchKernelGGL(rgb_in_kernel<float>, dim3(rgb_in_grid(npix * C / 4, C / 4)), dim3(256), 0, st, img, w, sj, sc, wscale, bias, (float*)y, npix, C);
+        hipLaunchKernelGGL(rgb_in_kernel<float>, dim3(rgb_in_grid(npix * C / 4, C / 4)), dim3(256), 0, st, img, w, sj, sc, wscale, bias, (float*)y, npix, C, (const float*)nullptr);
     } else {
         SGX_REQUIRE(C % 8 == 0, SGX_EUNSUPPORTED, "rgb_in: C %% 8");
-        hipLaunchKernelGGL(rgb_in_kernel<bf16_t>, dim3(rgb_in_grid(npix * C / 8, C / 8)), dim3(256), 0, st, img, w, sj, sc, wscale, bias, (bf16_t*)y, npix, C);
+        hipLaunchKernelGGL(rgb_in_kernel<bf16_t>, dim3(rgb_in_grid(npix * C / 8, C / 8)), dim3(256), 0, st, img, w, sj, sc, wscale, bias, (bf16_t*)y, npix, C, (const bf16_t*)nullptr);
     }
     SGX_LAUNCH_CHECK("rgb_in");
+    return 0;
+}
+
+// y = add + sgx_rgb_in(img) (no bias): to_rgb's data gradient written ON TOP of the gradient the forked activation received from its other
+// consumer (generator under fade-in: a block's output feeds the next block and the previous resolution's to_rgb, models/GAN.py:199-202) --
+// one rounding and one pass instead of sgx_rgb_in + an add pass (read 2, write 1)
+extern "C" int sgx_rgb_in_add(const float* img, const float* w, int sj, int sc, float wscale, const void* add, void* y, size_t npix, int C, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SGX_REQUIRE(img && w && add && y && npix > 0, SGX_EINVAL, "rgb_in_add: null argument");
+    SGX_NOTE(6.0 * npix * C, npix * (12.0 + 2.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * C), "rgb_in+add %zux%d", npix, C);
+    if (dtype == SGX_F32) {
+        SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "rgb_in_add: C %% 4");
+        hipLaunchKernelGGL(rgb_in_kernel<float>, dim3(rgb_in_grid(npix * C / 4, C / 4)), dim3(256), 0, st, img, w, sj, sc, wscale, (const float*)nullptr, (float*)y, npix, C, (const float*)add);
+    } else {
+        SGX_REQUIRE(dtype == SGX_BF16 && C % 8 == 0, SGX_EUNSUPPORTED, "rgb_in_add: bf16 with C %% 8");
+        hipLaunchKernelGGL(rgb_in_kernel<bf16_t>, dim3(rgb_in_grid(npix * C / 8, C / 8)), dim3(256), 0, st, img, w, sj, sc, wscale, (const float*)nullptr, (bf16_t*)y, npix, C, (const bf16_t*)add);
+    }
+    SGX_LAUNCH_CHECK("rgb_in_add");
     return 0;
 }
 

@@ -1580,6 +1580,51 @@ class RgbOutFn(Function):
         return gx, gw, gb, None
 
 
+RGB_FORK = os.environ.get("SGX_RGB_FORK", "1") != "0"        # A/B: 0 = RgbOutFn and autograd's own sum of the activation's two gradients
+
+
+class RgbOutForkFn(Function):
+    """x -> (x, to_rgb(x)) for an activation with TWO consumers: the generator under fade-in hands a block's output to the next block AND to
+    the previous resolution's to_rgb (reference models/GAN.py:199-202).  Forward = ``RgbOutFn``.  Backward: to_rgb's data gradient is written
+    ON TOP of the gradient that came back from the other consumer (``sgx_rgb_in_add``: one pass, one rounding) instead of ``sgx_rgb_in``
+    followed by autograd's add pass (read 2, write 1 of the activation).  The generator is never under a double backward; should this
+    backward itself be differentiated it falls back to the differentiable composition."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, wscale):
+        img = RgbOutFn.forward(ctx, x, weight, bias, wscale)         # (saves x, weight; sets has_bias, wscale)
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), img
+
+    @staticmethod
+    def backward(ctx, gx, g):
+        if g is None:
+            return gx, None, None, None
+        x, weight = ctx.saved_tensors
+        g = _c(g)
+        out = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if gx is None:
+                out = _bcall(RgbInFn, g, weight, None, ctx.wscale, x.dtype)
+            elif torch.is_grad_enabled():
+                out = gx + _bcall(RgbInFn, g, weight, None, ctx.wscale, x.dtype)
+            else:
+                gx, w = _c(gx), _c(weight.detach())
+                sj, sc, C = rgb_layout(w)
+                B, H, W, _ = g.shape
+                out = torch.empty_like(gx)
+                N.check(N.lib().sgx_rgb_in_add(N.ptr(g), N.ptr(w), sj, sc, ctx.wscale, N.ptr(gx), N.ptr(out), B * H * W, C, N.dt(gx), N.stream()),
+                        "sgx_rgb_in_add")
+        else:
+            out = gx
+        if not _DATA_GRAD_ONLY:
+            if ctx.needs_input_grad[1]:
+                gw = _bcall(RgbWgradFn, g, x, weight, ctx.wscale)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = _bcall(ColSumFn, g, 1.0)
+        return out, gw, gb, None
+
+
 class RgbOutFadeFn(Function):
     """img = alpha * to_rgb(x) + (1 - alpha) * nearest_up2(low): the generator's output (1x1 convolution, upsample of the
     previous resolution's RGB image and fade-in lerp, reference models/GAN.py:199-202) in ONE pass over x.  ``alpha``: python

@@ -70,6 +70,7 @@ SIGNATURES = {
     "sgx_colsum_ws_bytes": (Z, [Z, I]),
     "sgx_colsum": (I, [P, P, F, P, Z, Z, I, I, P]),
     "sgx_rgb_in": (I, [P, P, I, I, F, P, P, Z, I, I, P]),
+    "sgx_rgb_in_add": (I, [P, P, I, I, F, P, P, Z, I, I, P]),
     "sgx_rgb_out": (I, [P, P, I, I, F, P, P, Z, I, I, P]),
     "sgx_downsample_fade_rgb": (I, [P, P, I, I, I, F, F, P, P]),
     "sgx_rgb_out_fade": (I, [P, P, I, I, F, P, P, F, F, P, P, I, I, I, I, I, P]),

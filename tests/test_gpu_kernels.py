@@ -335,6 +335,35 @@ def test_pool_fork_joins_the_two_gradients_in_one_pass(B, H, W, C, dtype):
     assert_close(gg, gg64, 1e-5, "gradient of the squared gradient")
 
 
+@pytest.mark.parametrize("dtype,C", [(torch.float32, 16), (torch.bfloat16, 32), (torch.bfloat16, 16)])
+def test_to_rgb_fork_joins_the_activation_gradients(dtype, C):
+    """functional.RgbOutForkFn (round 6): x -> (x, to_rgb(x)) for the generator activation that feeds the next block AND the previous
+    resolution's to_rgb under fade-in (reference models/GAN.py:199-202): to_rgb's data gradient lands on top of the other consumer's
+    gradient in one pass (sgx_rgb_in_add).  Against the closed form in fp64."""
+    from stylegan.pytorch_amd import functional as F
+    B, H, W = 2, 16, 24
+    x = gu.seeded((B, H, W, C), 91).to(dtype).float()
+    w = gu.seeded((3, C, 1, 1), 92); b = 0.1 * gu.seeded((3,), 93); ws = 0.37
+    q = gu.seeded((B, H, W, C), 94).to(dtype).float(); r = gu.seeded((B, H, W, 3), 95)
+    xd = x.to(DEV).to(dtype).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    xa, img = F.RgbOutForkFn.apply(xd, wd, bd, ws)
+    img64 = b.double() + ws * torch.einsum("bhwc,jc->bhwj", x.double(), w.double()[:, :, 0, 0])
+    assert_close(img, img64, 1e-5 if dtype == torch.float32 else 1e-5, "to_rgb")
+    # the other consumer's gradient arrives as a tensor of the activation's dtype (a data-gradient kernel wrote it)
+    loss = (img * r.to(DEV)).sum() + (xa * q.to(DEV).to(dtype)).sum().float()
+    loss.backward()
+    gx64 = q.double() + ws * torch.einsum("bhwj,jc->bhwc", r.double(), w.double()[:, :, 0, 0])
+    assert_close(xd.grad.float(), gx64, 1e-6 if dtype == torch.float32 else 4e-3, "joined gradient")
+    assert_close(wd.grad, ws * torch.einsum("bhwj,bhwc->jc", r.double(), x.double()).view(3, C, 1, 1), 1e-5, "d weight")
+    assert_close(bd.grad, r.double().sum(dim=(0, 1, 2)), 1e-5, "d bias")
+    # only one of the two consumers has a gradient
+    xd.grad = None
+    xa, img = F.RgbOutForkFn.apply(xd, wd, bd, ws)
+    (img * r.to(DEV)).sum().backward()
+    assert_close(xd.grad.float(), gx64 - q.double(), 1e-6 if dtype == torch.float32 else 4e-3, "to_rgb branch only")
+
+
 def test_rgb_convs():
     from stylegan.pytorch_amd.CustomLayers import EqualizedConv2d
     for C in (16, 32, 128, 512):

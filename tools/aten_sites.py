@@ -45,11 +45,26 @@ def main():
             "aten::flatten", "aten::_reshape_alias", "aten::lift_fresh", "aten::is_same_size", "aten::stride", "aten::size", "aten::record_stream",
             "aten::new_empty", "aten::new_empty_strided", "aten::contiguous", "aten::resize_", "aten::set_", "aten::is_pinned", "aten::_local_scalar_dense"}
 
+    # engine-level adds (a tensor with two gradient contributions) have no Python frame: tag them with the custom Function whose backward
+    # finished last -- the producer of the SECOND contribution -- by wrapping every Function.backward of the package
+    from stylegan.pytorch_amd import functional as Fm
+    last = {"fn": "?"}
+    for nm in dir(Fm):
+        cls = getattr(Fm, nm)
+        if isinstance(cls, type) and issubclass(cls, torch.autograd.Function) and cls is not torch.autograd.Function and "backward" in cls.__dict__:
+            orig = cls.__dict__["backward"].__func__
+
+            def wrapped(ctx, *g, _orig=orig, _nm=nm):
+                out = _orig(ctx, *g)
+                last["fn"] = _nm
+                return out
+            cls.backward = staticmethod(wrapped)
+
     class Log(TorchDispatchMode):
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
             name = func.name().split(".")[0]
             if name not in SKIP:
-                site = "(no package frame: autograd engine -- gradient accumulation, materialised zero gradients)"
+                site = "(autograd engine: gradient accumulation / materialised zeros) after " + last["fn"] + ".backward"
                 for fr in reversed(traceback.extract_stack()):
                     if "stylegan/pytorch_amd" in fr.filename:
                         site = f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.name}"
