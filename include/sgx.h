@@ -164,6 +164,12 @@ int sgx_fade_rgb_bwd(const void* g, const void* bits, const float* pimg, const f
  * different streams and both reach from_rgb of the residual branch). */
 int sgx_fade_rgb_bwd_finish(const void* wsbuf, size_t ws_bytes, size_t npix, int C, float ws, float bs, float beta, const float* ab_dev,
                             float* dwr, float* drb, int acc, void* stream);
+/* Round 6: the adjoint of sgx_fade_rgb_bwd's data half (gy, gpimg as functions of g) -- what the R1 double backward needs of this tail -- in one
+ * pass: out = bf16(t1 + t2), t1 = bf16((alpha ggy) slope(bits)) (sgx_lrelu_bwd_bits on ggy), t2 = bf16(sgx_rgb_in(ggp; wr, ws)) [ab_dev: then
+ * bf16(beta t2)]: the roundings of the three passes it replaces are kept, the result is theirs bit for bit.  ggy or ggp may be NULL.  A host
+ * beta rides in ws (pass 1).  bf16, C in {32, 64, 128}. */
+int sgx_fade_rgb_bwd2(const void* ggy, const float* ggp, const void* bits, const float* wr, float ws, float alpha, float beta, const float* ab_dev,
+                      void* out, size_t npix, int C, int dtype, void* stream);
 /* out = alpha*a + beta*b (b may be NULL)    fade-in lerp: models/GAN.py:202,427,586                                 */
 int sgx_axpby(const void* a, const void* b, void* out, float alpha, float beta, size_t n, int dtype, void* stream);
 /* same with the coefficients read from device memory (alpha_dev[0], beta_dev[0]): the fade-in alpha changes every

@@ -268,6 +268,62 @@ extern "C" int sgx_fade_rgb_bwd_finish(const void* wsbuf, size_t ws_bytes, size_
     return 0;
 }
 
+// The adjoint of sgx_fade_rgb_bwd's data half -- what the R1 double backward needs of the newest block's tail -- in ONE pass:
+//   out[p][c] = bf16( t1 + t2 ),  t1 = bf16((alpha ggy[p][c]) slope(bits[p][c]))            (bit for bit sgx_lrelu_bwd_bits on ggy)
+//                                 t2 = bf16(sum_j ggp[p][j] (ws W[c][j]))                       (bit for bit sgx_rgb_in on ggp, no bias)
+//                                      [ab_dev: then bf16(beta t2), the unfused path's scaling pass]
+// i.e. the three passes of the differentiable composition (mask pass, from_rgb of the image-gradient's gradient, autograd's add) with their
+// roundings kept, so every bit of the result is theirs.  Either operand may be NULL (its term is zero).  thread = 8 channels of a pixel.
+__global__ __launch_bounds__(256) void fade_rgb_bwd2_kernel(const bf16_t* __restrict__ ggy, const float* __restrict__ ggp, const unsigned char* __restrict__ bits,
+                                                            const float* __restrict__ wr, float ws, float alpha, float beta, const float* __restrict__ ab_dev,
+                                                            bf16_t* __restrict__ out, size_t npix, int C) {
+    const int cv = C / 8;                                    // power of two <= 16: divides the grid stride
+    const size_t nvec = npix * cv;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = (int)(i0 % cv) * 8;
+    if (ab_dev) { alpha = ab_dev[0]; beta = ab_dev[1]; }
+    float w0[8], w1[8], w2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { w0[j] = ws * wr[(c0 + j) * 3]; w1[j] = ws * wr[(c0 + j) * 3 + 1]; w2[j] = ws * wr[(c0 + j) * 3 + 2]; }
+    for (size_t i = i0; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cv;
+        float t1[8], t2[8], o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { t1[j] = 0.f; t2[j] = 0.f; }
+        if (ggy) {
+            float g[8];
+            VecTraits<bf16_t>::load(ggy + i * 8, g);
+            const unsigned bb = bits[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t1[j] = bf2f(f2bf((alpha * g[j]) * (((bb >> j) & 1u) ? 1.f : SGX_LRELU)));
+        }
+        if (ggp) {
+            const float r = ggp[p * 3], g = ggp[p * 3 + 1], b = ggp[p * 3 + 2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                t2[j] = bf2f(f2bf(0.f + (r * w0[j] + g * w1[j] + b * w2[j])));
+                if (ab_dev) t2[j] = bf2f(f2bf(beta * t2[j]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = t1[j] + t2[j];
+        VecTraits<bf16_t>::store(out + i * 8, o);
+    }
+}
+extern "C" int sgx_fade_rgb_bwd2(const void* ggy, const float* ggp, const void* bits, const float* wr, float ws, float alpha, float beta, const float* ab_dev,
+                                 void* out, size_t npix, int C, int dtype, void* stream) {
+    SGX_REQUIRE(dtype == SGX_BF16 && (C == 32 || C == 64 || C == 128), SGX_EUNSUPPORTED, "fade_rgb_bwd2: bf16, C in {32, 64, 128} (C=%d dtype %d)", C, dtype);
+    SGX_REQUIRE((ggy || ggp) && wr && out && npix > 0 && (!ggy || bits), SGX_EINVAL, "fade_rgb_bwd2: null argument");
+    SGX_REQUIRE(ab_dev || beta == 1.0f, SGX_EUNSUPPORTED, "fade_rgb_bwd2: a host beta other than 1 rides in ws (as the forward's)");
+    SGX_NOTE(6.0 * npix * C, npix * ((ggy ? 4.125 : 2.0) * C + (ggp ? 12.0 : 0.0)), "fade_rgb_bwd2 %zux%d", npix, C);
+    const int cv = C / 8;
+    unsigned grid = grid_for(npix * cv);
+    hipLaunchKernelGGL(fade_rgb_bwd2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, static_cast<const bf16_t*>(ggy), ggp,
+                       static_cast<const unsigned char*>(bits), wr, ws, alpha, beta, ab_dev, static_cast<bf16_t*>(out), npix, C);
+    SGX_LAUNCH_CHECK("fade_rgb_bwd2_kernel");
+    return 0;
+}
+
 // ---------------------------------------------------------------- out = alpha*a + beta*b
 template <typename T>
 __global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, float alpha, float beta,

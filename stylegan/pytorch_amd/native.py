@@ -59,6 +59,7 @@ SIGNATURES = {
     "sgx_fade_rgb_bwd_ws_bytes": (Z, [Z, I]),
     "sgx_fade_rgb_bwd": (I, [P, P, P, P, F, F, F, F, P, P, P, P, I, P, P, Z, Z, I, I, P]),
     "sgx_fade_rgb_bwd_finish": (I, [P, Z, Z, I, F, F, F, P, P, P, I, P]),
+    "sgx_fade_rgb_bwd2": (I, [P, P, P, P, F, F, F, P, P, Z, I, I, P]),
     "sgx_axpby": (I, [P, P, P, F, F, Z, I, P]),
     "sgx_axpby_dev": (I, [P, P, P, P, P, Z, I, P]),
     "sgx_blur3x3": (I, [P, P, I, I, I, I, I, P]),

@@ -370,3 +370,36 @@ def test_fade_rgb_backward_kernel_vs_oracle(B, R, C, dev_alpha, with_img):
     torch.cuda.synchronize()
     assert torch.equal(gy2, gy)
     assert torch.equal(dw2, dw + 2.0) and torch.equal(db2, db - 1.0)                         # accumulate bits 0 and 1
+
+
+@pytest.mark.parametrize("C,dev_alpha", [(32, False), (64, True), (128, False)])
+def test_adjoint_of_the_fade_backward_is_bit_identical_to_the_three_passes(C, dev_alpha):
+    """``sgx_fade_rgb_bwd2`` (round 6: what the R1 double backward needs of the newest block's tail, one pass) keeps the roundings of the three
+    passes it replaces -- ``LReluBwdBitsFn`` on the gradient's gradient, ``RgbInFn`` (from_rgb) of the image gradient's gradient [and the
+    device-beta scaling pass], autograd's bf16 add -- so its output is theirs BIT FOR BIT; each operand alone too."""
+    from stylegan.pytorch_amd import functional as F
+    from stylegan.pytorch_amd import native as N
+    L = N.lib()
+    B, R, alpha, ws = 2, 48, 0.3, 0.41
+    ggy = gu.seeded((B, R, R, C), 101).bfloat16().to(DEV)
+    ggp = gu.seeded((B, R, R, 3), 102).to(DEV)
+    bits = (gu.seeded((B, R, R, C // 8), 103) * 1000).abs().to(torch.int64).remainder(256).to(torch.uint8).to(DEV)
+    wr = gu.seeded((C, 3, 1, 1), 104).to(DEV)
+    ab = torch.tensor([alpha, 1.0 - alpha], dtype=torch.float32, device=DEV) if dev_alpha else None
+    with torch.no_grad():
+        t1 = F.LReluBwdBitsFn.apply(ggy, bits, 0.2, ab[0:1] if dev_alpha else alpha)
+        t2 = F.RgbInFn.apply(ggp, wr, None, ws, torch.bfloat16)
+        if dev_alpha:
+            t2 = F.ScaleDevFn.apply(t2, ab[1:2])
+        want = t1 + t2
+    npix = B * R * R
+
+    def run(a, b):
+        out = torch.empty_like(ggy)
+        N.check(L.sgx_fade_rgb_bwd2(N.ptr(a), N.ptr(b), N.ptr(bits), N.ptr(wr), ws, 0.0 if dev_alpha else alpha, 1.0, N.ptr(ab), N.ptr(out), npix, C,
+                                    N.BF16, N.stream()), "sgx_fade_rgb_bwd2")
+        torch.cuda.synchronize()
+        return out
+    assert torch.equal(run(ggy, ggp).view(torch.int16), want.view(torch.int16))
+    assert torch.equal(run(ggy, None).view(torch.int16), t1.view(torch.int16))
+    assert torch.equal(run(None, ggp).view(torch.int16), t2.view(torch.int16))
