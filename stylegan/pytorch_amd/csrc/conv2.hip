@@ -78,6 +78,7 @@ struct Conv2Args {
     const float* fade_pimg; const float* fade_wr; const float* fade_rb; float fade_ws, fade_bs1, fade_bs2;
     int part_slots;                           // EPI_STATS: the slot count `part` was sized for (launch_conv2 refuses any other nslots)
     const bf16_t* wcorr;                      // conv3_kernel<UB>: the 22 border-correction tiles [22][32][32] behind the 9 composite taps of the same pack
+    int ureg;                                 // C2_U without the blur epilogue: 0 = the LDS-transposed store (default), 1 = the register epilogue (A/B: SGX_CONVU_REGSTORE=1, measured 0.5 % slower)
     int dbg;                                  // conv3_kernel, probe launches only (sgx_conv_variant + SGX_CONV3_DBG): DMA ablations, WRONG results by design
 };
 enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BLUR = 2 };
@@ -570,8 +571,43 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                     }
                 }
             } else if constexpr (GEO == C2_U) {
+              if (a.ureg) {
+                // ---- register epilogue (round 6), the one of the S / D geometries: one v_permlane32_swap per dword and pair of channel groups
+                // hands every lane 8 CONSECUTIVE channels of its fine pixel (2 l31 + px); the two half-waves fill the pixel's 32-byte sectors
+                // together, the four stores (px, k) of a lane pair complete the 128-byte line of two neighbouring fine pixels.  No LDS
+                // transposition (whose 8-byte writes at a row stride of 160 bytes were a 4-way bank conflict: 31 % of this kernel's LDS
+                // cycles, profiles/r05_pmc_mfma_bf16_b32.json), no barrier before the store.
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+#pragma unroll
+                    for (int py = 0; py < 2; ++py) {
+                        const int oy = 2 * (ty0 + 2 * wave + f) + py;
+#pragma unroll
+                        for (int px = 0; px < 2; ++px) {
+                            const int ox = 2 * (tx0 + l31) + px;
+                            const bool inimg = oy < a.OH && ox < a.OW;
+                            const size_t pix = (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + 8 * hi;
+                            const f32x16& v = acc[py * 2 + px][f];
+#pragma unroll
+                            for (int k = 0; k < (CO16 ? 1 : 2); ++k) {
+                                const unsigned lx = pack_bf16x2(v[8 * k], v[8 * k + 1]), ly = pack_bf16x2(v[8 * k + 2], v[8 * k + 3]);
+                                const unsigned ux = pack_bf16x2(v[8 * k + 4], v[8 * k + 5]), uy = pack_bf16x2(v[8 * k + 6], v[8 * k + 7]);
+                                auto rx = __builtin_amdgcn_permlane32_swap(lx, ux, false, false);
+                                auto ry = __builtin_amdgcn_permlane32_swap(ly, uy, false, false);
+                                if (inimg) *reinterpret_cast<uint4*>(a.y + pix + 16 * k) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                            }
+                        }
+                    }
+                }
+              } else {
                 __syncthreads();                 // every wave is done reading this stage's patch
                 char* scr = cur + wave * (64 * OROW);
+                // LDS-transposed store.  Round 6: a lane's four 8-byte pieces of scratch row 2 l31 + px (80 bytes: the row pitch is 40 dwords
+                // per l31, i.e. 8 (l31 & 3) mod 32 banks -- the 16 lanes of a ds_write_b64 group landed on FOUR bank pairs, a 4-way conflict and
+                // 31 % of this kernel's LDS cycles, profiles/r05_pmc_mfma_bf16_b32.json) are XOR-swizzled inside the row by the two lane
+                // bits the pitch loses: 16-byte chunk g ^ bit 2 of l31, 8-byte half hi ^ bit 3 of l31 -- 16 lanes, 16 distinct bank pairs; the
+                // read-back undoes it (chunk v ^ bit, halves swapped by a select)
+                const int wsw = ((((l31 >> 2) & 1) << 4) | (((l31 >> 3) & 1) << 3));           // byte XOR inside the row
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
 #pragma unroll
@@ -584,20 +620,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                                 uint2 o;
                                 o.x = pack_bf16x2(v[4 * g], v[4 * g + 1]);
                                 o.y = pack_bf16x2(v[4 * g + 2], v[4 * g + 3]);
-                                *reinterpret_cast<uint2*>(scr + (2 * l31 + px) * OROW + (8 * g + 4 * hi) * 2) = o;
+                                *reinterpret_cast<uint2*>(scr + (2 * l31 + px) * OROW + (((8 * g + 4 * hi) * 2) ^ wsw)) = o;
                             }
                         }
                         const int oy = 2 * (ty0 + 2 * wave + f) + py;
 #pragma unroll
                         for (int i = 0; i < 64 * VPR / 64; ++i) {
                             const int idx = i * 64 + lane, fpx = idx / VPR, v = idx % VPR;
-                            const uint4 val = *reinterpret_cast<const uint4*>(scr + fpx * OROW + v * 16);
+                            const int sl = fpx >> 1;                                           // the l31 that wrote this row
+                            const uint4 raw = *reinterpret_cast<const uint4*>(scr + fpx * OROW + ((v ^ ((sl >> 2) & 1)) * 16));
+                            const bool swp = (sl >> 3) & 1;
+                            const uint4 val = make_uint4(swp ? raw.z : raw.x, swp ? raw.w : raw.y, swp ? raw.x : raw.z, swp ? raw.y : raw.w);
                             const int ox = 2 * tx0 + fpx;
                             if (oy < a.OH && ox < a.OW)
                                 *reinterpret_cast<uint4*>(a.y + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8) = val;
                         }
                     }
                 }
+              }
             } else if constexpr (EPI == EPI_NONE) {
                 // ---- register epilogue (round 3): a lane holds its pixel's channels 8g+4hi .. +3 (g = 0..3 per 32-channel row), the
                 // other half-wave the 4 channels in between.  One v_permlane32_swap per dword and pair of groups hands every lane 8
@@ -1293,6 +1333,12 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
     }
     a.ntiles = a.B * a.tiles_y * a.tiles_x;
     a.ncb = CO16 ? 1 : a.Cout / L::BCO;
+    if constexpr (GEO == C2_U && EPI == EPI_NONE) {
+        // A/B switch; measured on one box (round 6, default bench line, two interleaved rounds): register store 291.2 / 291.4 img/s at batch 4 and
+        // 523.0 / 521.4 at batch 32, LDS-transposed store 292.8 / 293.9 and 525.0 / 525.4 -- whole 64-byte pixels per store instruction win
+        static const int ureg = [] { const char* e = getenv("SGX_CONVU_REGSTORE"); return e ? atoi(e) : 0; }();
+        a.ureg = ureg;
+    }
     // resident blocks per CU: one for the round-2 instantiations (their LDS stages fill the CU); the half-width stages of the
     // 16-channel layers leave room for two (LDS <= 80 KB per block, <= 128 registers), so that one block's store epilogue
     // overlaps the other's loads

@@ -22,18 +22,23 @@ static GepiGeom gepi_geom(int B, int HW, int C, int ve) {
     int cv = C / ve;
     g.cvt = cv < 256 ? cv : 256;
     g.rows = 256 / g.cvt;
-    int rpt = GEPI_ROWS_PER_THREAD;
+    static const int rpt_max = [] { const char* e = getenv("SGX_GEPI_RPT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : GEPI_ROWS_PER_THREAD; }();
+    int rpt = rpt_max;
     while (rpt > 8 && (long)B * ((HW + g.rows * rpt - 1) / (g.rows * rpt)) < GEPI_MIN_BLOCKS) rpt >>= 1;
     g.chunk = g.rows * rpt;
     g.nchunk = (HW + g.chunk - 1) / g.chunk;
     return g;
 }
 
-extern "C" size_t sgx_gepi_ws_bytes(int B, int HW, int C) {
+static size_t gepi_ws_head(int B, int HW, int C) {
     GepiGeom g4 = gepi_geom(B, HW, C, 4), g8 = gepi_geom(B, HW, C, 8);
     int nchunk = g4.nchunk > g8.nchunk ? g4.nchunk : g8.nchunk;
-    return (size_t)2 * B * nchunk * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float) + 256;
+    return ((size_t)2 * B * nchunk * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float) + 255) / 256 * 256;
 }
+extern "C" size_t sgx_gepi_ws_bytes(int B, int HW, int C) {
+    return gepi_ws_head(B, HW, C) + (size_t)B * 6 * C * sizeof(float) + 256;     // + [B][6][C] floats: the apply pass's coefficient tables
+}
+static float* gepi_ctab(void* ws, int B, int HW, int C) { return reinterpret_cast<float*>(static_cast<char*>(ws) + gepi_ws_head(B, HW, C)); }
 
 // sum over 16 consecutive lanes (the finalizers give every output 16 lanes that stride over the chunk partials)
 __device__ __forceinline__ double sum16(double v) {
@@ -164,6 +169,7 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
         if (tr < rows) {
             // loads in flight per lane: 8 rows for the read-only statistics pass (2 blocks per CU: it is latency-bound, 2.6 ->
             // 3.2 TB/s); 4 for the two-tensor passes (8 costs them the second wave per SIMD: 284 VGPRs, measured 2x slower)
+            // (round 6, tools/gepi_probe.py with 1 / 2 / 4 / 8 in flight for both read-only passes: no difference beyond noise)
             constexpr int UNR = MODE == 0 ? 8 : 4;
 #pragma unroll UNR
             for (int p = p0 + tr; p < p1; p += rows) {
@@ -240,15 +246,26 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
 }
 
 // forward finalize: mean / rstd per (b,c); 16 lanes per output
+// ``tab`` (optional): the apply pass's per-(image, channel) coefficients packed as [B][6][C] floats -- bias, noise weight, mean, rstd, style
+// scale + 1, style shift -- so that a short-lived block of gepi_apply1 fetches its whole table with ONE coalesced load per thread
 __global__ void gepi_fin_stats(const double* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd, int B, int C,
-                               int nchunk, int HW, int norm) {
+                               int nchunk, int HW, int norm, float* __restrict__ tab = nullptr, const float* __restrict__ bias = nullptr,
+                               const float* __restrict__ nw = nullptr, const float* __restrict__ style = nullptr) {
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
     const bool ok = i < B * C;
+    const int b = ok ? i / C : 0, c = ok ? i % C : 0;
+    auto put = [&](float m, float r) {
+        mean[i] = m; rstd[i] = r;
+        if (tab) {
+            float* t = tab + (size_t)b * 6 * C + c;
+            t[0] = bias ? bias[c] : 0.f; t[C] = nw[c]; t[2 * C] = m; t[3 * C] = r;
+            t[4 * C] = style[(size_t)b * 2 * C + c] + 1.f; t[5 * C] = style[(size_t)b * 2 * C + C + c];
+        }
+    };
     if (!norm) {                                                   // no instance norm: xh = a
-        if (ok && !l) { mean[i] = 0.f; rstd[i] = 1.f; }
+        if (ok && !l) put(0.f, 1.f);
         return;
     }
-    const int b = ok ? i / C : 0, c = ok ? i % C : 0;
     double s = 0.0, ss = 0.0;
     if (ok)
         for (int k = l; k < nchunk; k += 16) {
@@ -260,8 +277,7 @@ __global__ void gepi_fin_stats(const double* __restrict__ part, float* __restric
     const double m = s / HW;
     double var = ss / HW - m * m;
     if (var < 0.0) var = 0.0;
-    mean[i] = (float)m;
-    rstd[i] = (float)(1.0 / sqrt(var + (double)GEPI_EPS));
+    put((float)m, (float)(1.0 / sqrt(var + (double)GEPI_EPS)));
 }
 
 // backward finalize 1: dstyle and the two per-(b,c) coefficients of the apply pass
@@ -370,6 +386,56 @@ __global__ __launch_bounds__(256) void gepi_apply(const T* __restrict__ x, const
     }
 }
 
+
+// ---- the apply pass as SHORT-LIVED blocks (round 6).  tools/stream_probe.hip on the MI355X: a read + write stream of 537 MB runs at 5.1 TB/s
+// in this file's long-loop block shape (64 pixel rows per thread), at 5.0 as a capped grid-stride loop -- and at 6.1-6.2 TB/s when every
+// thread moves ONE 16-byte vector and exits (aten's elementwise kernels sit at 6.3 the same way); more work per thread only loses (x2 5.9, x4
+// 5.7, x8 5.4).  What kept the loop here was the 6 x VE per-(image, channel) coefficients a thread needs: loaded per thread from global for one
+// vector they cost 2.7 TB/s.  So: the block's coefficient table (6 x C floats) goes through LDS once per block, requested AFTER the thread's
+// own data and noise loads so that the three latencies overlap, and every thread then does the arithmetic of gepi_apply on one vector --
+// same operations in the same order: bit-identical output (probe: 6.05 TB/s for this shape).  mean / rstd come from gepi_fin_stats.
+template <typename T>
+__global__ __launch_bounds__(256) void gepi_apply1(const T* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ ctab,
+                                                   T* __restrict__ y, int HW, int C, int act) {
+    constexpr int VE = VecTraits<T>::VE;
+    extern __shared__ float tab[];                                 // [6][C]: bias, noise weight, mean, rstd, style scale + 1, style shift (gepi_fin_stats)
+    const int b = blockIdx.y, cv = C / VE;
+    const size_t nvi = (size_t)HW * cv;                            // vectors per image
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < nvi;
+    const size_t p = live ? i / cv : 0;
+    const int c0 = (int)(i - p * cv) * VE;
+    const size_t off = ((size_t)b * nvi + (live ? i : 0)) * VE;
+    uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+    float nz = 0.f;
+    if (live) {
+        raw = *reinterpret_cast<const uint4*>(x + off);
+        nz = noise[(size_t)b * HW + p];
+    }
+    const float4* src = reinterpret_cast<const float4*>(ctab + (size_t)b * 6 * C);
+    for (int j = threadIdx.x; j < 6 * C / 4; j += 256) reinterpret_cast<float4*>(tab)[j] = src[j];
+    __syncthreads();
+    if (!live) return;
+    float kb[VE], kw[VE], km[VE], kr[VE], ks[VE], k1[VE], xv[VE];
+    load_coef<VE>(tab + c0, kb); load_coef<VE>(tab + C + c0, kw); load_coef<VE>(tab + 2 * C + c0, km);
+    load_coef<VE>(tab + 3 * C + c0, kr); load_coef<VE>(tab + 4 * C + c0, ks); load_coef<VE>(tab + 5 * C + c0, k1);
+    unpack16<T>(raw, xv);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+        const float a = act_apply(xv[j] + kb[j] + kw[j] * nz, act);
+        const float xh = (a - km[j]) * kr[j];
+        xv[j] = xh * ks[j] + k1[j];
+    }
+    *reinterpret_cast<uint4*>(y + off) = pack16<T>(xv);
+}
+// the launch of the apply pass: short-lived blocks (SGX_GEPI_APPLY1, default 1) or the long-loop kernel with the statistics finalize folded in
+// Measured alone (tools/gepi_probe.py, statistics + apply, batch 32): 1024^2 x 16: 664 -> 599 us, 512^2 x 32: 345 -> 310, 256^2 x 64: 175 -> 170,
+// 128^2 x 128: no change; batch 4 (tensors of <= 134 MB): +2..3 us for the separate finalize launch and nothing back.  So: tensors of >= 192 MB.
+static bool gepi_apply1_on(int C, double tensor_bytes) {
+    static const int on = [] { const char* e = getenv("SGX_GEPI_APPLY1"); return e ? atoi(e) : 1; }();      // 2 = whatever the size
+    // (a block's table is 24 C bytes next to 4 KB of data: the 256 / 512-channel layers keep the loop)
+    return on != 0 && C <= 128 && (on == 2 || tensor_bytes >= 192e6);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Small layers (round 6): the whole epilogue of one (image, 16-channel group) in ONE block, one launch per direction.
@@ -605,11 +671,22 @@ static int gepi_fwd_t(const void* x, const float* bias, const float* noise, cons
     constexpr int VE = VecTraits<T>::VE;
     GepiGeom g = gepi_geom(B, HW, C, VE);
     double* part = static_cast<double*>(ws);
+    float* ctab = gepi_ctab(ws, B, HW, C);                         // gepi_apply1's coefficient tables, behind the partials of both directions
     const double nb = (double)sizeof(T) * B * HW * C;
     if (norm && pre_part) {
         // the statistics pass already happened in the kernel that PRODUCED x (sgx_blur3x3_stats / the convolution's store
         // epilogue): pre_npart partial (sum a, sum a^2) pairs per (image, channel), same layout as gepi_pass<T, 0> writes
-        hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 15) / 16), dim3(256), 0, st, pre_part, mean, rstd, B, C, pre_npart, HW, norm);
+        if (gepi_apply1_on(C, nb)) {
+            hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 15) / 16), dim3(256), 0, st, pre_part, mean, rstd, B, C, pre_npart, HW, norm, ctab, bias, nw, style);
+            SGX_LAUNCH_CHECK("gepi_fin_stats");
+            SGX_NOTE(0.0, 2.0 * nb, "gepi_apply B%d HW%d C%d", B, HW, C);
+            hipLaunchKernelGGL(gepi_apply1<T>, dim3((unsigned)(((size_t)HW * (C / VE) + 255) / 256), B), dim3(256), 6 * C * sizeof(float), st, (const T*)x, noise,
+                               (const float*)ctab, (T*)y, HW, C, act);
+            SGX_LAUNCH_CHECK("gepi_apply1");
+            return 0;
+        }
+        hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 15) / 16), dim3(256), 0, st, pre_part, mean, rstd, B, C, pre_npart, HW, norm, (float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
         SGX_LAUNCH_CHECK("gepi_fin_stats");
         SGX_NOTE(0.0, 2.0 * nb, "gepi_apply B%d HW%d C%d", B, HW, C);
         hipLaunchKernelGGL(gepi_apply<T>, dim3(g.nchunk, B), dim3(256), 0, st, (const T*)x, bias, noise, nw, style, mean, rstd,
@@ -637,6 +714,15 @@ static int gepi_fwd_t(const void* x, const float* bias, const float* noise, cons
     // the statistics' finalize (mean / rstd from the per-chunk partials) rides in the apply pass: every block sums the partials of
     // its image itself (SGX_GEPI_FOLD=0: the separate gepi_fin_stats launch, A/B)
     static const int fold = [] { const char* e = getenv("SGX_GEPI_FOLD"); return e ? atoi(e) : 1; }();
+    if (gepi_apply1_on(C, nb)) {
+        hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 15) / 16), dim3(256), 0, st, (const double*)part, mean, rstd, B, C, g.nchunk, HW, norm, ctab, bias, nw, style);
+        SGX_LAUNCH_CHECK("gepi_fin_stats");
+        SGX_NOTE(0.0, 2.0 * nb, "gepi_apply B%d HW%d C%d", B, HW, C);
+        hipLaunchKernelGGL(gepi_apply1<T>, dim3((unsigned)(((size_t)HW * (C / VE) + 255) / 256), B), dim3(256), 6 * C * sizeof(float), st, (const T*)x, noise,
+                           (const float*)ctab, (T*)y, HW, C, act);
+        SGX_LAUNCH_CHECK("gepi_apply1");
+        return 0;
+    }
     if (fold) {
         SGX_NOTE(0.0, 2.0 * nb, "gepi_apply B%d HW%d C%d", B, HW, C);
         hipLaunchKernelGGL(gepi_apply<T>, dim3(g.nchunk, B), dim3(256), 512 * sizeof(double) + 2 * C * sizeof(float), st, (const T*)x, bias, noise,
@@ -644,7 +730,8 @@ static int gepi_fwd_t(const void* x, const float* bias, const float* noise, cons
         SGX_LAUNCH_CHECK("gepi_apply");
         return 0;
     }
-    hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 15) / 16), dim3(256), 0, st, part, mean, rstd, B, C, g.nchunk, HW, norm);
+    hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 15) / 16), dim3(256), 0, st, (const double*)part, mean, rstd, B, C, g.nchunk, HW, norm, (float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
     SGX_LAUNCH_CHECK("gepi_fin_stats");
     SGX_NOTE(0.0, 2.0 * nb, "gepi_apply B%d HW%d C%d", B, HW, C);
     hipLaunchKernelGGL(gepi_apply<T>, dim3(g.nchunk, B), dim3(256), 0, st, (const T*)x, bias, noise, nw, style, mean, rstd,
@@ -743,7 +830,7 @@ static int gepi_stats_t(const void* x, const float* bias, const float* noise, co
         SGX_LAUNCH_CHECK("gepi_stats");
     }
     hipLaunchKernelGGL(gepi_fin_stats, dim3((B * C + 15) / 16), dim3(256), 0, st, pre_part ? pre_part : (const double*)part, mean, rstd, B, C,
-                       pre_part ? pre_npart : g.nchunk, HW, norm);
+                       pre_part ? pre_npart : g.nchunk, HW, norm, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
     SGX_LAUNCH_CHECK("gepi_fin_stats");
     return 0;
 }

@@ -5,7 +5,20 @@
 
 static inline unsigned grid_for(size_t nvec, int block = 256) {
     size_t g = (nvec + block - 1) / block;
-    if (g > 2048 * 4) g = 2048 * 4;
+    static const size_t cap = [] { const char* e = getenv("SGX_GRID_CAP"); const long v = e ? atol(e) : 8192; return (size_t)(v > 0 ? v : 0x7fffffffL); }();
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+// The grid of a pass whose threads have NO per-thread setup worth amortising (pure elementwise kernels, the blur's strips): one trip of the
+// kernel's grid-stride loop per thread.  Round 6, tools/stream_probe.hip + the step's layer tables with SGX_GRID_CAP=0: a read + write stream
+// runs at 6.1-6.2 TB/s as short-lived blocks against 5.0-5.1 under the 8192-block cap above (lrelu_bwd_bits 214 -> 184 us, lrelu_bwd 148 ->
+// 126, up2+add 164 -> 146, the blurs -2..4 %); kernels that hoist weights per thread (rgb_in / rgb_out / fade_rgb_bwd2) lose and keep the cap.
+// SGX_GRID_ALL_CAP (A/B): the cap of these launches, default none.
+static inline unsigned grid_all(size_t nvec, int block = 256) {
+    size_t g = (nvec + block - 1) / block;
+    static const size_t cap = [] { const char* e = getenv("SGX_GRID_ALL_CAP"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 0x7fffffffL); }();
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (unsigned)g;
 }
@@ -47,11 +60,11 @@ extern "C" int sgx_bias_act(const void* x, const float* bias, float bscale, void
     if (dtype == SGX_F32) {
         SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "bias_act: C %% 4");
         size_t nvec = npix * C / 4;
-        hipLaunchKernelGGL(bias_act_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, st, (const float*)x, bias, bscale, (float*)y, nvec, C, act);
+        hipLaunchKernelGGL(bias_act_kernel<float>, dim3(grid_all(nvec)), dim3(256), 0, st, (const float*)x, bias, bscale, (float*)y, nvec, C, act);
     } else {
         SGX_REQUIRE(C % 8 == 0, SGX_EUNSUPPORTED, "bias_act: C %% 8");
         size_t nvec = npix * C / 8;
-        hipLaunchKernelGGL(bias_act_kernel<bf16_t>, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)x, bias, bscale, (bf16_t*)y, nvec, C, act);
+        hipLaunchKernelGGL(bias_act_kernel<bf16_t>, dim3(grid_all(nvec)), dim3(256), 0, st, (const bf16_t*)x, bias, bscale, (bf16_t*)y, nvec, C, act);
     }
     SGX_LAUNCH_CHECK("bias_act");
     return 0;
@@ -80,10 +93,10 @@ extern "C" int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, 
     SGX_NOTE(0.0, 3.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * n, "lrelu_bwd %zu", n);
     if (dtype == SGX_F32) {
         SGX_REQUIRE(n % 4 == 0, SGX_EUNSUPPORTED, "lrelu_bwd: n %% 4");
-        hipLaunchKernelGGL(lrelu_bwd_kernel<float>, dim3(grid_for(n / 4)), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)dx, n / 4, slope, scale, scale_dev);
+        hipLaunchKernelGGL(lrelu_bwd_kernel<float>, dim3(grid_all(n / 4)), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)dx, n / 4, slope, scale, scale_dev);
     } else {
         SGX_REQUIRE(n % 8 == 0, SGX_EUNSUPPORTED, "lrelu_bwd: n %% 8");
-        hipLaunchKernelGGL(lrelu_bwd_kernel<bf16_t>, dim3(grid_for(n / 8)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n / 8, slope, scale, scale_dev);
+        hipLaunchKernelGGL(lrelu_bwd_kernel<bf16_t>, dim3(grid_all(n / 8)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n / 8, slope, scale, scale_dev);
     }
     SGX_LAUNCH_CHECK("lrelu_bwd");
     return 0;
@@ -108,7 +121,7 @@ extern "C" int sgx_lrelu_bwd_bits(const void* dy, const void* bits, void* dx, si
     SGX_REQUIRE(dtype == SGX_BF16 && n % 8 == 0, SGX_EUNSUPPORTED, "lrelu_bwd_bits: bf16, n %% 8 == 0");
     SGX_REQUIRE(dy && bits && dx, SGX_EINVAL, "lrelu_bwd_bits: null argument");
     SGX_NOTE(0.0, 4.125 * n, "lrelu_bwd_bits %zu", n);
-    hipLaunchKernelGGL(lrelu_bwd_bits_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const unsigned char*)bits, (bf16_t*)dx,
+    hipLaunchKernelGGL(lrelu_bwd_bits_kernel, dim3(grid_all(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const unsigned char*)bits, (bf16_t*)dx,
                        n / 8, slope, scale, scale_dev);
     SGX_LAUNCH_CHECK("lrelu_bwd_bits");
     return 0;
@@ -359,10 +372,10 @@ static int axpby_launch(const void* a, const void* b, void* out, float alpha, fl
     if (n == 0) return 0;
     if (dtype == SGX_F32) {
         size_t nvec = (n + 3) / 4;
-        hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, alpha, beta, alpha_dev, beta_dev, nvec, n);
+        hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid_all(nvec)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, alpha, beta, alpha_dev, beta_dev, nvec, n);
     } else {
         size_t nvec = (n + 7) / 8;
-        hipLaunchKernelGGL(axpby_kernel<bf16_t>, dim3(grid_for(nvec)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, alpha, beta, alpha_dev, beta_dev, nvec, n);
+        hipLaunchKernelGGL(axpby_kernel<bf16_t>, dim3(grid_all(nvec)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, alpha, beta, alpha_dev, beta_dev, nvec, n);
     }
     SGX_LAUNCH_CHECK("axpby");
     return 0;
@@ -625,10 +638,10 @@ static int blur_shfl_pf(int mode) {
     if (env >= 0) return env;
     return (mode == 1 || mode == 5) ? 1 : 3;                 // (the modes with a pre-op are the register-heavier ones: more waves beat a deeper ring)
 }
-template <typename T, int PF>
+template <typename T, int PF, int ROWS = BLUR_ROWS>
 static void blur_launch_shfl(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, hipStream_t st) {
-    constexpr int VE = VecTraits<T>::VE, ROWS = BLUR_ROWS;
-    const dim3 grid(grid_for((size_t)B * ((H + ROWS - 1) / ROWS) * W * C / VE)), block(256);
+    constexpr int VE = VecTraits<T>::VE;
+    const dim3 grid(grid_all((size_t)B * ((H + ROWS - 1) / ROWS) * W * C / VE)), block(256);
     const T* xp = (const T*)x; const T* zp = (const T*)z; T* yp = (T*)y;
     switch (mode) {
         case 0: hipLaunchKernelGGL((blur3x3s_kernel<T, 0, ROWS, PF>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
@@ -641,7 +654,7 @@ static void blur_launch_shfl(const void* x, const void* z, void* y, int B, int H
 template <typename T, int ROWS>
 static void blur_launch_rows(const void* x, const void* z, void* y, int B, int H, int W, int C, int mode, hipStream_t st) {
     constexpr int VE = VecTraits<T>::VE;
-    const dim3 grid(grid_for((size_t)B * ((H + ROWS - 1) / ROWS) * W * C / VE)), block(256);
+    const dim3 grid(grid_all((size_t)B * ((H + ROWS - 1) / ROWS) * W * C / VE)), block(256);
     const T* xp = (const T*)x; const T* zp = (const T*)z; T* yp = (T*)y;
     switch (mode) {
         case 0: hipLaunchKernelGGL((blur3x3_kernel<T, 0, ROWS>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
@@ -661,6 +674,8 @@ static void blur_launch(const void* x, const void* z, void* y, int B, int H, int
     const int cv = C / VecTraits<T>::VE, pf = blur_shfl_pf(mode);
     if (lanes8 < (size_t)256 * 512) blur_launch_rows<T, 2>(x, z, y, B, H, W, C, mode, st);
     else if (pf > 0 && mode != 3 && cv <= 16 && (cv & (cv - 1)) == 0 && ((size_t)W * cv) % 64 == 0 && lanes8 < ((size_t)1 << 31)) {
+        // (strip heights 2 / 4 / 16 of this kernel measured in round 6, tools/blur_rows_probe.py: 8 rows stays best -- 5.1-5.2 TB/s of algorithmic bytes
+        // is 5.8 with the 10 / 8 rows it reads; the short-lived-block form of the elementwise passes has nothing to give a stencil)
         if (pf == 1) blur_launch_shfl<T, 1>(x, z, y, B, H, W, C, mode, st);
         else if (pf == 2) blur_launch_shfl<T, 2>(x, z, y, B, H, W, C, mode, st);
         else if (pf == 3) blur_launch_shfl<T, 3>(x, z, y, B, H, W, C, mode, st);
@@ -993,7 +1008,7 @@ extern "C" int sgx_up2_add(const void* x, const void* a, void* y, int B, int H, 
     SGX_NOTE(0.0, 9.0 * es * B * H * W * C, "up2+add B%d %dx%d C%d", B, H, W, C);
     const size_t nout = (size_t)B * H * W * 4 * C;
     if (dtype == SGX_F32 && C == 3 && (2 * W * 3) % 4 == 0)
-        hipLaunchKernelGGL(up2_add_rgb_kernel, dim3(grid_for(nout / 4)), dim3(256), 0, st, (const float*)x, (const float*)a, (float*)y, B, H, W, scale);
+        hipLaunchKernelGGL(up2_add_rgb_kernel, dim3(grid_all(nout / 4)), dim3(256), 0, st, (const float*)x, (const float*)a, (float*)y, B, H, W, scale);
     else if (dtype == SGX_F32)
         hipLaunchKernelGGL(up2_add_kernel<float>, dim3(grid_for(nout)), dim3(256), 0, st, (const float*)x, (const float*)a, (float*)y, B, H, W, C, scale);
     else
@@ -1006,11 +1021,11 @@ extern "C" int sgx_up2(const void* x, void* y, int B, int H, int W, int C, float
     SGX_NOTE(0.0, 5.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * C, "up2 B%d %dx%d C%d", B, H, W, C);
     const size_t nout = (size_t)B * H * W * 4 * C;
     if (dtype == SGX_F32) {
-        if (C % 4 == 0) hipLaunchKernelGGL((up2_kernel<float, true>), dim3(grid_for(nout / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
-        else if (C == 3 && (2 * W * 3) % 4 == 0) hipLaunchKernelGGL(up2_rgb_kernel, dim3(grid_for(nout / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, scale);
+        if (C % 4 == 0) hipLaunchKernelGGL((up2_kernel<float, true>), dim3(grid_all(nout / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
+        else if (C == 3 && (2 * W * 3) % 4 == 0) hipLaunchKernelGGL(up2_rgb_kernel, dim3(grid_all(nout / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, scale);
         else hipLaunchKernelGGL((up2_kernel<float, false>), dim3(grid_for(nout)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
     } else {
-        if (C % 8 == 0) hipLaunchKernelGGL((up2_kernel<bf16_t, true>), dim3(grid_for(nout / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, scale);
+        if (C % 8 == 0) hipLaunchKernelGGL((up2_kernel<bf16_t, true>), dim3(grid_all(nout / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, scale);
         else hipLaunchKernelGGL((up2_kernel<bf16_t, false>), dim3(grid_for(nout)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, scale);
     }
     SGX_LAUNCH_CHECK("up2");

@@ -184,19 +184,21 @@ __global__ __launch_bounds__(512, 2) void wgrad2_s_kernel(Wg2Args a) {
 
     // ---- sum the two column-segment waves of each channel pair through LDS (the stages are dead), 16 floats per lane a round
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem) + (pair * 64 + lane) * 16;
+    // (lane-contiguous float4 slots: the [lane][16 floats] layout this replaced put 8 / 16 lanes of a ds_write_b128 / ds_read_b128 group on 2 / 4
+    // banks' worth of addresses -- all of this kernel's 15 % LDS bank conflicts, profiles/r06_pmc_mfma_bf16_b32.json)
+    float4* red = reinterpret_cast<float4*>(smem) + pair * 256 + lane;
 #pragma unroll
     for (int t = 0; t < 10; ++t) {
         f32x16& v = t < 9 ? acc[t] : bacc;
         if (seg == 1) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(red)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            for (int q = 0; q < 4; ++q) red[q * 64] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
         }
         __syncthreads();
         if (seg == 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 o = reinterpret_cast<const float4*>(red)[q];
+                const float4 o = red[q * 64];
                 v[4 * q] += o.x; v[4 * q + 1] += o.y; v[4 * q + 2] += o.z; v[4 * q + 3] += o.w;
             }
         }

@@ -334,3 +334,77 @@ def test_bf16_storage_vs_fp64_truth(name, golden_dir):
     assert e_full <= 2 * m[0] and e_score <= 2 * m[1] and e_d <= 2 * m[2] and e_g <= 2 * m[3], (e_full, e_score, e_d, e_g, m)
     for p in list(sg.gen.parameters()) + list(sg.dis.parameters()):
         assert torch.isfinite(p).all()
+
+
+# ---- the benchmarked batch sizes through a size-independent property (round 6).  The oracle runs the real widths at batch 2 / 4 (above);
+# BASELINE's configs[1] is batch 64 and the north-star block batch 32.  Nothing in the step couples samples except the minibatch-stddev
+# layer, whose groups are the strided quadruples {m, M+m, 2M+m, 3M+m} (M = B/4, models/CustomLayers.py:288-305), and every loss term is a
+# batch MEAN (models/Losses.py:146-169, R1 included): so the parameter gradients of one batch-B step are the mean of the gradients of its
+# M stddev groups run as M independent batch-4 steps -- the configuration the oracle DOES pin -- once the one batch SUM of the step, the R1
+# penalty (models/Losses.py:210), is given the weight M * r1_gamma in the group steps.  Style mixing (a per-batch random draw) and the
+# truncation's moving average (sample 0 of the batch) are switched off: they are host-side, batch-shaped state, not kernels.
+LINEARITY = {
+    # name: (config, batch, activation dtype, rel-L2 bar per gradient tensor, floor of that bar as a fraction of the network's largest
+    #        gradient tensor, bar on the MEDIAN over tensors, bar on the losses)
+    "ffhq128_fp32_b64": ("128", 64, torch.float32, 2e-4, 1e-5, 1e-4, 2e-5),          # fp32: only the summation order over the batch differs
+    "ffhq1024_bf16_b32": ("1024", 32, torch.bfloat16, 2e-2, 1e-4, 1e-2, 2e-3),       # bf16 storage: other tile shapes round other partial sums
+}
+
+
+@pytest.mark.parametrize("tag", list(LINEARITY))
+def test_benchmarked_batch_is_the_mean_of_its_stddev_groups(tag):
+    from stylegan.pytorch_amd import functional as F
+    name, B, act_dtype, tol, floor, mtol, ltol = LINEARITY[tag]
+    cfg = dict(CFG[name], batch=B, psi=-1.0)
+    depth, R, M = cfg["depth"], cfg["resolution"], B // 4
+    sg, gp, dp = make_stylegan(cfg, act_dtype=act_dtype)
+    sg.gen.style_mixing_prob = None
+    nz = noises(cfg)
+    z = gu.seeded((B, 512), 21); real = gu.seeded((B, 3, R, R), 22)
+
+    dis_loss = sg.loss.dis_loss
+
+    def step(idx, r1_gamma=10.0):
+        """D gradients, then G gradients, of the samples ``idx`` on the SAME (initial) parameters."""
+        sg.loss.dis_loss = lambda *a, **k: dis_loss(*a, **dict(k, r1_gamma=r1_gamma))
+        load_into(sg.gen, gp); load_into(sg.dis, dp); F.bump_weight_generation()
+        pin_noise(sg.gen, [n[idx] for n in nz])
+        zz, rr = z[idx].to(DEV), real[idx].to(DEV)
+        torch.manual_seed(77); random.seed(77)
+        dl = float(sg.optimize_discriminator(zz, rr, depth, ALPHA))
+        dg = {k: p.grad.detach().double().cpu() for k, p in sg.dis.named_parameters() if p.grad is not None}
+        load_into(sg.dis, dp); F.bump_weight_generation()
+        torch.manual_seed(78); random.seed(78)
+        gl = float(sg.optimize_generator(zz, rr, depth, ALPHA))
+        gg = {k: p.grad.detach().double().cpu() for k, p in sg.gen.named_parameters() if p.grad is not None}
+        return dl, gl, dg, gg
+
+    dl, gl, dg, gg = step(torch.arange(B))
+    acc = None
+    for m in range(M):
+        part = step(torch.arange(4) * M + m, r1_gamma=10.0 * M)
+        if acc is None:
+            acc = [part[0], part[1], part[2], part[3]]
+        else:
+            acc[0] += part[0]; acc[1] += part[1]
+            for a, p in ((acc[2], part[2]), (acc[3], part[3])):
+                for k in a:
+                    a[k] += p[k]
+    assert abs(dl - acc[0] / M) <= ltol * abs(dl) and abs(gl - acc[1] / M) <= ltol * abs(gl), (dl, acc[0] / M, gl, acc[1] / M)
+    worst, bad = [], []
+    for net, full, parts in (("d", dg, acc[2]), ("g", gg, acc[3])):
+        assert sorted(full) == sorted(parts)
+        scale = max(torch.linalg.vector_norm(v).item() for v in full.values())
+        for k, v in full.items():
+            want = parts[k] / M
+            err = torch.linalg.vector_norm(v - want).item()
+            den = torch.linalg.vector_norm(want).item()
+            worst.append((err / (den + 1e-30), net + ":" + k))
+            if err > tol * den + floor * scale:
+                bad.append(f"{tag} {net} grad {k}: rel-L2 {err / (den + 1e-30):.3e} > {tol:.0e} (|g| {den:.3e}, largest tensor of the network {scale:.3e})")
+    worst.sort(reverse=True)
+    med = float(np.median([e for e, _ in worst]))
+    print(f"[{tag}] batch {B} vs the mean of its {M} stddev groups: losses {dl:.6f}/{acc[0] / M:.6f} {gl:.6f}/{acc[1] / M:.6f}; "
+          f"gradient rel-L2 median {med:.1e}, worst " + ", ".join(f"{k} {e:.1e}" for e, k in worst[:6]))
+    assert not bad, "\n".join(bad)
+    assert med <= mtol, (med, mtol)

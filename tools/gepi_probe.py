@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from stylegan.pytorch_amd import functional as F  # noqa: E402
 from stylegan.pytorch_amd import native as N  # noqa: E402
 
-SHAPES = [(4, 512), (8, 512), (16, 512), (32, 512), (64, 256), (128, 128), (256, 64)]
+SHAPES = [(4, 512), (8, 512), (16, 512), (32, 512), (64, 256), (128, 128), (256, 64), (512, 32), (1024, 16)]
 
 
 def timed(fn, reps):
@@ -29,11 +29,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, nargs="+", default=[4, 32])
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--min-h", type=int, default=0)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    print("SGX_GEPI_SMALL =", os.environ.get("SGX_GEPI_SMALL", "(unset: 1)"))
+    print("SGX_GEPI_SMALL =", os.environ.get("SGX_GEPI_SMALL", "(unset: 1)"), " SGX_GEPI_RPT =", os.environ.get("SGX_GEPI_RPT", "(unset: 64)"),
+          " SGX_GEPI_FOLD =", os.environ.get("SGX_GEPI_FOLD", "(unset: 1)"))
     for B in a.batch:
         for H, C in SHAPES:
+            if H < a.min_h:
+                continue
             x = torch.randn(B, H, H, C, device=dev).bfloat16().requires_grad_(True)
             noise = torch.randn(B, 1, H, H, device=dev); nw = torch.randn(C, device=dev, requires_grad=True)
             bias = torch.randn(C, device=dev, requires_grad=True); style = torch.randn(B, 2 * C, device=dev, requires_grad=True)
