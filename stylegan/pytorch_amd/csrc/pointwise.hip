@@ -792,6 +792,35 @@ __global__ void pool2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, 
         }
     }
 }
+// fp32 RGB images (C = 3, W % 8 == 0): the scalar variant above moves 4 bytes per lane (4.4 TB/s on the five 1024^2 image pools of a batch-32
+// step).  Here a lane owns FOUR output pixels: 2 x 6 float4 loads (eight input pixels of two rows), 3 float4 stores; the sums in the scalar
+// variant's order (bit-identical).  One trip per thread (grid_all).
+__global__ __launch_bounds__(256) void pool2_rgb_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, float scale) {
+    const int OH = H / 2, OW = W / 2, q4 = OW / 4;
+    const size_t n = (size_t)B * OH * q4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % q4);
+        const size_t row = i / q4;                                 // b * OH + oh
+        const int oh = (int)(row % OH);
+        const size_t b = row / OH;
+        const float4* r0 = reinterpret_cast<const float4*>(x + ((b * H + 2 * oh) * W + 8 * q) * 3);
+        const float4* r1 = reinterpret_cast<const float4*>(x + ((b * H + 2 * oh + 1) * W + 8 * q) * 3);
+        float a[24], c[24], o[12];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float4 t = r0[k], u = r1[k];
+            a[4 * k] = t.x; a[4 * k + 1] = t.y; a[4 * k + 2] = t.z; a[4 * k + 3] = t.w;
+            c[4 * k] = u.x; c[4 * k + 1] = u.y; c[4 * k + 2] = u.z; c[4 * k + 3] = u.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) o[3 * j + ch] = scale * ((a[6 * j + ch] + a[6 * j + 3 + ch]) + (c[6 * j + ch] + c[6 * j + 3 + ch]));
+        float4* dst = reinterpret_cast<float4*>(y + (row * OW + 4 * q) * 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    }
+}
 extern "C" int sgx_pool2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SGX_NOTE(0.0, 1.25 * (dtype == SGX_F32 ? 4.0 : 2.0) * B * H * W * C, "pool2 B%d %dx%d C%d", B, H, W, C);
@@ -799,6 +828,8 @@ extern "C" int sgx_pool2(const void* x, void* y, int B, int H, int W, int C, flo
     const size_t nout = (size_t)B * (H / 2) * (W / 2) * C;
     if (dtype == SGX_F32) {
         if (C % 4 == 0) hipLaunchKernelGGL((pool2_kernel<float, true>), dim3(grid_for(nout / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
+        else if (C == 3 && W % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
+            hipLaunchKernelGGL(pool2_rgb_kernel, dim3(grid_all(nout / 12)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, scale);
         else hipLaunchKernelGGL((pool2_kernel<float, false>), dim3(grid_for(nout)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
     } else {
         if (C % 8 == 0) hipLaunchKernelGGL((pool2_kernel<bf16_t, true>), dim3(grid_for(nout / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, scale);
@@ -964,6 +995,28 @@ __global__ void up2_rgb_kernel(const float* __restrict__ x, float* __restrict__ 
         *reinterpret_cast<float4*>(y + row * OW * 3 + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
+// the same with whole 16-byte accesses (W % 4 == 0): a lane owns four input pixels = 3 float4 loads and writes their eight output pixels to
+// BOTH output rows = 12 float4 stores (the kernel above gathers four scalars per stored vector: 3.7 TB/s)
+__global__ __launch_bounds__(256) void up2_rgb4_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, float scale) {
+    const int q4 = W / 4, OW = 2 * W;
+    const size_t n = (size_t)B * H * q4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % q4);
+        const size_t row = i / q4;                                 // b * H + h
+        const float4* src = reinterpret_cast<const float4*>(x + (row * W + 4 * q) * 3);
+        float a[12], o[24];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const float4 t = src[k]; a[4 * k] = t.x; a[4 * k + 1] = t.y; a[4 * k + 2] = t.z; a[4 * k + 3] = t.w; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { const float v = scale * a[3 * j + ch]; o[6 * j + ch] = v; o[6 * j + 3 + ch] = v; }
+        float4* d0 = reinterpret_cast<float4*>(y + ((2 * row) * OW + 8 * q) * 3);
+        float4* d1 = reinterpret_cast<float4*>(y + ((2 * row + 1) * OW + 8 * q) * 3);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const float4 t = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]); d0[k] = t; d1[k] = t; }
+    }
+}
 // y = a + scale * nearest-up(x) for fp32 RGB images (C = 3): the JOIN of the two gradients of an image that feeds both the full-resolution
 // branch and, through a 2x2 average pool, the residual branch of the discriminator (models/GAN.py:423-427) -- the pool's adjoint and the sum
 // of the two contributions in one pass (27 bytes per pixel instead of 15 + 36 for up2 + add).  Four consecutive floats of an output row per lane.
@@ -1022,6 +1075,8 @@ extern "C" int sgx_up2(const void* x, void* y, int B, int H, int W, int C, float
     const size_t nout = (size_t)B * H * W * 4 * C;
     if (dtype == SGX_F32) {
         if (C % 4 == 0) hipLaunchKernelGGL((up2_kernel<float, true>), dim3(grid_all(nout / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
+        else if (C == 3 && W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
+            hipLaunchKernelGGL(up2_rgb4_kernel, dim3(grid_all((size_t)B * H * (W / 4))), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, scale);
         else if (C == 3 && (2 * W * 3) % 4 == 0) hipLaunchKernelGGL(up2_rgb_kernel, dim3(grid_all(nout / 4)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, scale);
         else hipLaunchKernelGGL((up2_kernel<float, false>), dim3(grid_for(nout)), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C, scale);
     } else {

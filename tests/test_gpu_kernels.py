@@ -290,9 +290,16 @@ def test_pointwise_ops():
     assert_close(F.nchw_view(F.BlurFn.apply(xd)), O.blur3(xn.double()), 1e-6, "blur")
     assert_close(F.nchw_view(F.Pool2Fn.apply(xd, 0.25)), TF.avg_pool2d(xn, 2), 1e-6, "avgpool")
     assert_close(F.nchw_view(F.Up2Fn.apply(xd, 1.0)), O.upscale2d(xn), 0, "up2")
-    img = gu.seeded((2, 16, 16, 3), 22).to(DEV)                       # RGB images: C = 3 scalar path
-    assert_close(F.nchw_view(F.Pool2Fn.apply(img, 0.25)), TF.avg_pool2d(img.cpu().permute(0, 3, 1, 2), 2), 1e-6, "avgpool rgb")
-    assert_close(F.nchw_view(F.Up2Fn.apply(img, 1.0)), O.upscale2d(img.cpu().permute(0, 3, 1, 2)), 0, "up2 rgb")
+    # RGB images (C = 3): widths that take the 16-byte kernels (pool: W % 8 == 0, up: W % 4 == 0; round 6) and widths that fall back to the
+    # scalar ones.  The up-sampling is a copy: exact; the pool sums in one fixed order in every variant: the variants agree bit for bit
+    for k, shp in enumerate([(2, 16, 16, 3), (3, 24, 40, 3), (1, 6, 12, 3), (2, 10, 6, 3), (2, 64, 72, 3)]):
+        img = gu.seeded(shp, 22 + 100 * k).to(DEV)
+        inchw = img.cpu().permute(0, 3, 1, 2)
+        pooled = F.Pool2Fn.apply(img, 0.25)
+        assert_close(F.nchw_view(pooled), TF.avg_pool2d(inchw, 2), 1e-6, f"avgpool rgb {shp}")
+        want = 0.25 * ((img[:, 0::2, 0::2] + img[:, 0::2, 1::2]) + (img[:, 1::2, 0::2] + img[:, 1::2, 1::2]))
+        assert torch.equal(pooled, want), f"avgpool rgb {shp}: summation order"
+        assert_close(F.nchw_view(F.Up2Fn.apply(img, 1.0)), O.upscale2d(inchw), 0, f"up2 rgb {shp}")
     b = 0.1 * gu.seeded((32,), 23)
     assert_close(F.BiasActFn.apply(xd, b.to(DEV), 1.0, 1), TF.leaky_relu(x + b, 0.2), 1e-6, "bias+lrelu")
     assert_close(F.ColSumFn.apply(xd, 1.0), x.double().sum(dim=(0, 1, 2)), 1e-6, "colsum")
