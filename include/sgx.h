@@ -83,6 +83,15 @@ int sgx_conv4x4s2_up(const void* x, const void* w, void* y, int B, int H, int W,
  *   The three entry points above choose by themselves.                                                               */
 int sgx_conv_variant(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
                      int act, int dtype, int variant, void* stream);
+/* Round 6: split-K for the bf16 launches that leave most of the chip idle (the 512-channel layers at 4x4 .. 32x32 of a small batch: 32-128
+ * blocks, each streaming its whole weight slice at one CU's load rate).  sgx_conv_splitk_ws_bytes: 0 = the shape does not split (call
+ * sgx_conv3x3 / sgx_conv4x4s2_down / sgx_conv4x4s2_up), else the bytes of fp32 partials [ksplit][output pixel][Cout] sgx_conv_splitk needs.
+ * sgx_conv_splitk: geo 0 / 1 / 2 = those three entry points' convolutions (models/CustomLayers.py:137-180; bias, act, mask as there; mask geo 0
+ * only), the reduction over input channels split over ksplit blocks, the partials summed in a fixed order by a second launch. */
+size_t sgx_conv_splitk_ws_bytes(int geo, int B, int H, int W, int Cin, int Cout, int dtype);
+int sgx_conv_splitk(int geo, const void* x, const void* w, const float* bias, void* y, const void* mask, int B, int H, int W, int Cin, int Cout,
+                    int act, int dtype, void* ws, size_t ws_bytes, void* stream);
+
 /* Host-only query: the launch configuration a convolution of this shape resolves to (geo 0: 3x3, 1: 4x4s2 down,
  * 2: 4x4s2 up; H,W = input size).  cfg5 = {KC, TH, TW, pixels per block, output-channel sub-tiles}: the template
  * arguments of conv_kernel<T, KC, geo, TH, TW, BP, CT> as rocprofv3 prints them.                                    */

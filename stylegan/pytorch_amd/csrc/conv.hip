@@ -26,7 +26,8 @@ int sgx_wgrad2_plan(int geo, int B, int H, int W, int Ck, int Cn, int* nct_n, in
 int sgx_wgrad2_launch(int geo, const void* kside, const void* nside, float* ws, size_t ws_bytes, int B, int H, int W, int Ck, int Cn,
                       int want_bias, hipStream_t st, int* nsplit_out);
 int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
-                  const void* mask, int variant, hipStream_t st, int* launched);        // conv2.hip   // GUPA: GUP with all four parity classes in one block (bf16)
+                  const void* mask, int variant, hipStream_t st, int* launched);        // conv2.hip
+int sgx_conv2_takes(int geo, int B, int H, int W, int Cin, int Cout);                   // conv2.hip   // GUPA: GUP with all four parity classes in one block (bf16)
 
 // LDS operand tiles are arrays of rows (one pixel, or one (tap, output channel) weight row) holding KC channels.
 // rowb_*: row pitch in bytes; load(): the lane's MFMA fragment (k = kk-step, q = lane>>4); lstore(): one 16-byte chunk.
@@ -107,6 +108,11 @@ struct ConvArgs {
     const void* mask;   // 3x3 only: y *= slope(mask) in the store (mask: a tensor shaped like y; the activation-backward of the layer below)
     int dbg;   // ablation switches (SGX_CONV_DBG, profiling only): 1 no MFMA, 2 no global loads, 4 no LDS stores, 8 no output stores
     int bands;          // XCD-aware tile order (grid x a multiple of 8): see conv_kernel
+    // Split-K (round 6, bf16, the 512-channel layers at 4^2..32^2 of a small batch): ksplit > 1 = blockIdx.z / NCLS selects one of ksplit equal
+    // ranges of the K-chunks; the block writes its RAW fp32 accumulators to kws[split][output pixel][Cout] and conv_splitk_finish sums the
+    // splits in a fixed order and applies bias / activation / mask.  Why: these launches are 32-128 blocks that each stream their whole
+    // 0.26-0.6 MB weight slice at ONE CU's load rate (~25 GB/s): 15-36 us for 0.5-5 GFLOP, whatever the K-chunk depth.
+    int ksplit; float* kws;
 };
 
 template <int GEO> struct Geo;
@@ -140,7 +146,7 @@ template <typename T>
 constexpr bool conv_bands_ok(int GEO, int TH, int TW, int BP) {
     return sizeof(T) == 2 && (GEO == G3X3 || GEO == GUPA) && TH == 16 && TW == 16 && BP == 256;
 }
-template <typename T, int KC, int GEO, int TH, int TW, int BP, int CT>
+template <typename T, int KC, int GEO, int TH, int TW, int BP, int CT, bool SK = false>
 // Register budget: two waves per SIMD (<= 256 VGPR+AGPR) except for the 64-channel x 256-pixel tile, whose prefetch
 // registers would spill at that bound -- and a spilled descriptor reload (scratch_load + s_waitcnt vmcnt) serialises
 // the whole global prefetch behind it (seen in the ISA), which is far worse than one wave per SIMD.
@@ -171,7 +177,15 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
     // the first K-chunk of the NEXT tile is prefetched into registers while the current tile's MFMAs run.
     const int co0 = blockIdx.y * BCO;
     int py = 0, px = 0;
-    if (GEO == GUP) { py = blockIdx.z >> 1; px = blockIdx.z & 1; }
+    constexpr int NCLS_Z = Geo<GEO>::NCLS;
+    if (GEO == GUP) { py = (SK ? (int)(blockIdx.z % NCLS_Z) : (int)blockIdx.z) >> 1; px = blockIdx.z & 1; }
+    // split-K (the SK instantiations only: the others are instruction for instruction what they were): this block's range of K-chunks
+    int split = 0, k_lo = 0, k_hi = a.Cin;
+    if constexpr (SK) {
+        const int nkc = a.Cin / KC;
+        split = (int)blockIdx.z / NCLS_Z;
+        k_lo = (split * nkc / a.ksplit) * KC; k_hi = ((split + 1) * nkc / a.ksplit) * KC;
+    }
     // Per-thread staging descriptors, computed ONCE: the index arithmetic of the global->LDS copy (which element of
     // the halo patch / weight tile this thread moves) does not depend on the tile or the K-chunk.  (Measured: doing
     // it per chunk cost 3-8 VALU instructions per MFMA and made the kernel issue-bound.)
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
     // staging (GUPA: the whole fine tile) reaches into the weight region of the LDS, then it is re-staged per tile
     constexpr bool OUT_CLOBBERS_W = (UPA && 4 * BP * (BCO * 2 + 16) > IN_BYTES) ||
                                     (!UPA && sizeof(T) == 2 && CT >= 2 && BP * (BCO * 2 + 16) > IN_BYTES);
-    const bool w_static = (a.Cin == KC) && !OUT_CLOBBERS_W;
+    const bool w_static = (a.Cin == KC) && !OUT_CLOBBERS_W;      // (never with split-K: >= 2 chunks)
     auto gload = [&](int k0, bool with_w) {
         const T* src0 = xg + in_base + k0;
 #pragma unroll
@@ -291,24 +305,24 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
         if (tile >= a.ntiles) return;
     }
     set_tile(tile);
-    gload(0, true);
+    gload(k_lo, true);
     bool first = true;
     for (;;) {
     const int c_img0 = img0, c_ty0 = ty0, c_tx0 = tx0;   // ... and of the tile being COMPUTED
-    for (int k0 = 0; k0 < a.Cin; k0 += KC) {
+    for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
         if (!first) __syncthreads();                  // every wave is done reading the previous stage
         const bool ww = first || !w_static;
         if (!(a.dbg & 4) || first) lstore(ww);
         first = false;
         __syncthreads();
         if constexpr (BANDS) {
-        if (a.dbg & 2) { if (k0 + KC >= a.Cin && next_tile >= 0) set_tile(next_tile); }
-        else if (k0 + KC < a.Cin) gload(k0 + KC, true);    // in flight during the MFMAs below
-        else if (next_tile >= 0) { set_tile(next_tile); gload(0, !w_static); }
+        if (a.dbg & 2) { if (k0 + KC >= k_hi && next_tile >= 0) set_tile(next_tile); }
+        else if (k0 + KC < k_hi) gload(k0 + KC, true);    // in flight during the MFMAs below
+        else if (next_tile >= 0) { set_tile(next_tile); gload(k_lo, !w_static); }
         } else {
-        if (a.dbg & 2) { if (k0 + KC >= a.Cin && tile + (int)gridDim.x < a.ntiles) set_tile(tile + gridDim.x); }
-        else if (k0 + KC < a.Cin) gload(k0 + KC, true);    // in flight during the MFMAs below
-        else if (tile + (int)gridDim.x < a.ntiles) { set_tile(tile + gridDim.x); gload(0, !w_static); }
+        if (a.dbg & 2) { if (k0 + KC >= k_hi && tile + (int)gridDim.x < a.ntiles) set_tile(tile + gridDim.x); }
+        else if (k0 + KC < k_hi) gload(k0 + KC, true);    // in flight during the MFMAs below
+        else if (tile + (int)gridDim.x < a.ntiles) { set_tile(tile + gridDim.x); gload(k_lo, !w_static); }
         }
         if constexpr (UPA) {
             // position-major: each of the 9 patch positions (dy, dx) is read once and feeds every class that has a tap
@@ -361,6 +375,28 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
     // bf16 with >= 32 output channels per block: a lane's natural store is 8 bytes and a wave instruction writes 32-byte
     // pieces (measured: 14 of 43 us on the 256^2 64->64 layer).  Transpose the tile through LDS instead and write whole
     // BCO*2-byte channel rows with 16 bytes per lane.
+    if constexpr (SK) {
+        // split-K: the raw fp32 accumulators of this K range, kws[split][output pixel][Cout]; a lane's 4 consecutive channels = one 16-byte store
+        float* const dst0 = a.kws + (size_t)split * ((size_t)a.B * a.OH * a.OW) * a.Cout + co0 + q * 4;
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            const int m = (wave * SPW + s) * 16 + l15;
+            const int il = m / (TH * TW), r = (m / TW) % TH, c = m % TW;
+            const int b = c_img0 + il, oyc = c_ty0 + r, oxc = c_tx0 + c;
+            if (b >= a.B || oyc >= a.OHc || oxc >= a.OWc) continue;
+#pragma unroll
+            for (int cls = 0; cls < NCL; ++cls) {
+                const int oy = UPA ? 2 * oyc + (cls >> 1) : ((GEO == GUP) ? 2 * oyc + py : oyc);
+                const int ox = UPA ? 2 * oxc + (cls & 1) : ((GEO == GUP) ? 2 * oxc + px : oxc);
+                float* d = dst0 + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const f32x4 v = acc[cls * CT + ct][s];
+                    *reinterpret_cast<float4*>(d + ct * 16) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    } else
     if constexpr (UPA) {
         // the block owns the complete (2 TH) x (2 TW) fine tile: stage it in LDS pixel-major and write whole rows
         static_assert(sizeof(T) == 2, "GUPA is the bf16 path");
@@ -482,7 +518,7 @@ __global__ __launch_bounds__(256, conv_min_waves(sizeof(T), CT, BP, GEO, KC)) vo
     }
 }
 
-template <typename T, int KC, int GEO, int TH, int TW, int BP, int CT>
+template <typename T, int KC, int GEO, int TH, int TW, int BP, int CT, bool SK = false>
 static int launch_conv(ConvArgs& a, int ngroups, hipStream_t st) {
     constexpr int FK = (sizeof(T) == 2 && KC > 32) ? 32 : KC, NPL = KC / FK;
     using F = Frag<T, FK>;
@@ -495,8 +531,8 @@ static int launch_conv(ConvArgs& a, int ngroups, hipStream_t st) {
                                      : ((sizeof(T) == 2 && CT >= 2) ? BP * (CT * 32 + 16) : 0);   // LDS-transposed bf16 epilogue tile
     constexpr int LDS = OPER > OUTB ? OPER : OUTB;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv_kernel<T, KC, GEO, TH, TW, BP, CT>;
-    sgx_lds_opt_in<conv_kernel<T, KC, GEO, TH, TW, BP, CT>>(LDS);
+    auto kern = conv_kernel<T, KC, GEO, TH, TW, BP, CT, SK>;
+    sgx_lds_opt_in<conv_kernel<T, KC, GEO, TH, TW, BP, CT, SK>>(LDS);
     a.ntiles = ngroups * a.tiles_y * a.tiles_x;
     // the ablation switches give WRONG results by design: only a probe build (make PROBE=1 -> -DSGX_PROBE_BUILD) reads them
 #ifdef SGX_PROBE_BUILD
@@ -509,7 +545,7 @@ static int launch_conv(ConvArgs& a, int ngroups, hipStream_t st) {
     // for this instantiation), never more than tiles.  More blocks than that would run as a second, under-occupied round.
     static const int resident = [] {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(conv_kernel<T, KC, GEO, TH, TW, BP, CT>), 256, LDS) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(conv_kernel<T, KC, GEO, TH, TW, BP, CT, SK>), 256, LDS) != hipSuccess || nb < 1) nb = 1;
         const char* e = getenv("SGX_CONV_PERCU");
         if (e && atoi(e) > 0 && atoi(e) < nb) nb = atoi(e);
         return nb;
@@ -526,7 +562,13 @@ static int launch_conv(ConvArgs& a, int ngroups, hipStream_t st) {
         gx = gx / 8 * 8;
         a.bands = 1;
     }
-    dim3 grid((unsigned)gx, (unsigned)(a.Cout / (CT * 16)), Geo<GEO>::NCLS);
+    int ksp = 1;
+    if constexpr (SK) {
+        ksp = a.ksplit;
+        SGX_REQUIRE(ksp > 1 && a.kws && a.Cin / KC >= ksp, SGX_EINVAL, "conv: %d K-chunks do not split %d ways", a.Cin / KC, ksp);
+        gx = a.ntiles; a.bands = 0;                     // (small launches by construction: one tile per block)
+    }
+    dim3 grid((unsigned)gx, (unsigned)(a.Cout / (CT * 16)), Geo<GEO>::NCLS * ksp);
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, a);
     SGX_LAUNCH_CHECK("conv_kernel");
     return 0;
@@ -575,19 +617,21 @@ static bool conv_deep_k(int geo, int B, int ohc, int owc, int Cin, int Cout) {
     return c.bp == 64 && (c.ct == 1 || c.ct == 2);
 }
 
-template <typename T, int KC, int GEO, int BP, int CT>
+template <typename T, int KC, int GEO, int BP, int CT, bool SK = false>
 static int dispatch_tile(ConvArgs& a, const ConvCfg& c, hipStream_t st) {
     a.tiles_y = (a.OHc + c.th - 1) / c.th; a.tiles_x = (a.OWc + c.tw - 1) / c.tw;
     const int ngroups = (a.B + c.ni - 1) / c.ni;
-    if (c.tw == 16) return launch_conv<T, KC, GEO, BP / 16, 16, BP, CT>(a, ngroups, st);
-    if (c.tw == 8) return launch_conv<T, KC, GEO, 8, 8, BP, CT>(a, ngroups, st);
-    return launch_conv<T, KC, GEO, 4, 4, BP, CT>(a, ngroups, st);
+    if (c.tw == 16) return launch_conv<T, KC, GEO, BP / 16, 16, BP, CT, SK>(a, ngroups, st);
+    if (c.tw == 8) return launch_conv<T, KC, GEO, 8, 8, BP, CT, SK>(a, ngroups, st);
+    return launch_conv<T, KC, GEO, 4, 4, BP, CT, SK>(a, ngroups, st);
 }
 
-template <typename T, int KC, int GEO>
+// (SK: the split-K instantiations exist for the 64- and 128-pixel tiles with 16 / 32 output channels only -- conv_splitk_plan asks for nothing else)
+template <typename T, int KC, int GEO, bool SK = false>
 static int dispatch_cfg(ConvArgs& a, hipStream_t st) {
     const ConvCfg c = pick_cfg(GEO, a.B, a.OHc, a.OWc, a.Cout);
     SGX_REQUIRE(c.bp != 0, SGX_EUNSUPPORTED, "conv: no launch configuration for Cout=%d", a.Cout);
+    if constexpr (!SK) {
     if constexpr (GEO != GDOWN) {
         if constexpr (GEO != GUPA) {
             if (c.bp == 256 && c.ct == 4) return dispatch_tile<T, KC, GEO, 256, 4>(a, c, st);
@@ -596,36 +640,136 @@ static int dispatch_cfg(ConvArgs& a, hipStream_t st) {
         if (c.bp == 256 && c.ct == 2) return dispatch_tile<T, KC, GEO, 256, 2>(a, c, st);
         if (c.bp == 256 && c.ct == 1) return dispatch_tile<T, KC, GEO, 256, 1>(a, c, st);
     }
-    if (c.bp == 128 && c.ct == 2) return dispatch_tile<T, KC, GEO, 128, 2>(a, c, st);
-    if (c.bp == 128 && c.ct == 1) return dispatch_tile<T, KC, GEO, 128, 1>(a, c, st);
-    if (c.bp == 64 && c.ct == 2) return dispatch_tile<T, KC, GEO, 64, 2>(a, c, st);
-    return dispatch_tile<T, KC, GEO, 64, 1>(a, c, st);
+    } else {
+        SGX_REQUIRE(c.bp <= 128 && c.ct <= 2, SGX_EUNSUPPORTED, "conv split-K: %d-pixel x %d-channel tile", c.bp, 16 * c.ct);
+    }
+    if (c.bp == 128 && c.ct == 2) return dispatch_tile<T, KC, GEO, 128, 2, SK>(a, c, st);
+    if (c.bp == 128 && c.ct == 1) return dispatch_tile<T, KC, GEO, 128, 1, SK>(a, c, st);
+    if (c.bp == 64 && c.ct == 2) return dispatch_tile<T, KC, GEO, 64, 2, SK>(a, c, st);
+    return dispatch_tile<T, KC, GEO, 64, 1, SK>(a, c, st);
 }
 
-template <int GEO>
+template <int GEO, bool SK = false>
 static int dispatch_conv(ConvArgs& a, int dtype, hipStream_t st) {
     SGX_REQUIRE(a.Cout % 16 == 0 && a.Cin % 16 == 0, SGX_EUNSUPPORTED, "conv: channels must be multiples of 16 (Cin=%d Cout=%d)", a.Cin, a.Cout);
     SGX_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0, SGX_EINVAL, "conv: bad shape");
-    if (dtype == SGX_F32) return dispatch_cfg<float, 16, GEO>(a, st);
+    if constexpr (!SK) {
+        if (dtype == SGX_F32) return dispatch_cfg<float, 16, GEO>(a, st);
+    }
     if (dtype == SGX_BF16) {
         if constexpr (GEO != GDOWN) {                          // (the stride-2 patch x 4 planes does not fit the LDS)
             if (conv_deep_k(GEO, a.B, a.OHc, a.OWc, a.Cin, a.Cout)) {
                 const ConvCfg c = pick_cfg(GEO, a.B, a.OHc, a.OWc, a.Cout);
-                if (c.ct == 2) return dispatch_tile<bf16_t, 128, GEO, 64, 2>(a, c, st);
-                return dispatch_tile<bf16_t, 128, GEO, 64, 1>(a, c, st);
+                if constexpr (!SK) {
+                    if (c.ct == 2) return dispatch_tile<bf16_t, 128, GEO, 64, 2>(a, c, st);
+                } else {                                       // (its split-K form spills 300-440 bytes per lane: not built, never planned)
+                    SGX_REQUIRE(c.ct == 1, SGX_EUNSUPPORTED, "conv split-K: deep K-chunks with 32 output channels per block");
+                }
+                return dispatch_tile<bf16_t, 128, GEO, 64, 1, SK>(a, c, st);
             }
         }
         if constexpr (GEO == GUP) {
             static const int fuse = [] { const char* e = getenv("SGX_CONV_UPA"); return e ? atoi(e) : 1; }();   // A/B switch
             if (fuse) {
-                if (a.Cin % 32 == 0) return dispatch_cfg<bf16_t, 32, GUPA>(a, st);
-                return dispatch_cfg<bf16_t, 16, GUPA>(a, st);
+                if (a.Cin % 32 == 0) return dispatch_cfg<bf16_t, 32, GUPA, SK>(a, st);
+                return dispatch_cfg<bf16_t, 16, GUPA, SK>(a, st);
             }
         }
-        if (a.Cin % 32 == 0) return dispatch_cfg<bf16_t, 32, GEO>(a, st);
-        return dispatch_cfg<bf16_t, 16, GEO>(a, st);
+        if (a.Cin % 32 == 0) return dispatch_cfg<bf16_t, 32, GEO, SK>(a, st);
+        return dispatch_cfg<bf16_t, 16, GEO, SK>(a, st);
     }
     SGX_REQUIRE(false, SGX_EINVAL, "conv: bad dtype %d", dtype);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- split-K (round 6)
+// y[p][c] = mask(bf16(act(sum_s kws[s][p][c] + bias[c]))): the splits in a FIXED order (deterministic), then exactly the epilogue of conv_kernel
+// (bias, activation, one rounding to bf16, the output mask on the rounded value).  8 channels per lane.
+__global__ __launch_bounds__(256) void conv_splitk_finish(const float* __restrict__ kws, int ksplit, size_t npix, int Cout, const float* __restrict__ bias,
+                                                          int act, const bf16_t* __restrict__ mask, bf16_t* __restrict__ y) {
+    const size_t nvec = npix * Cout / 8, stride = npix * Cout;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    const int c0 = (int)((i * 8) % Cout);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int s = 0; s < ksplit; ++s) {
+        const float4 a0 = *reinterpret_cast<const float4*>(kws + s * stride + i * 8), a1 = *reinterpret_cast<const float4*>(kws + s * stride + i * 8 + 4);
+        v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+    }
+    if (bias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += bias[c0 + j];
+    }
+    if (act == SGX_ACT_LRELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = lrelu(v[j]);
+    }
+    uint4 o = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    if (mask) o = lrelu_mask_bf16x8(o, *reinterpret_cast<const uint4*>(mask + i * 8));
+    *reinterpret_cast<uint4*>(y + i * 8) = o;
+}
+// How many ways a bf16 launch splits its reduction (0 = not at all): only launches that stay with this file's kernel, only when their grid
+// leaves most of the chip idle, a divisor of the K-chunk count, as many blocks as ~2 per CU, at most 8 (the finish pass reads ksplit partials).
+static int conv_splitk_plan(int geo, int B, int H, int W, int Cin, int Cout, int dtype) {
+    static const int on = [] { const char* e = getenv("SGX_CONV_SPLITK"); return e ? atoi(e) : 1; }();      // A/B switch (0 = off; n > 1 = at most n ways)
+    if (!on || dtype != SGX_BF16 || geo < 0 || geo > 2 || Cin % 16 || Cout % 16) return 0;
+    // Measured alone on the MI355X (tools/splitk_probe.py, batch 4, 512 channels; both launches of the split form): stride-2 16^2 -> 8^2 23.1 ->
+    // 17.0 us, 8^2 -> 4^2 21.2 -> 11.4 us; 3x3 at 4^2 / 8^2 11.3 -> 9.7 / 11.7 -> 10.8 us; transposed 4^2 -> 8^2 8.2 -> 9.1 us (worse).  The 3x3 and
+    // transposed launches already run deep (128-channel) K-chunks -- 4 of them; the stride-2 geometry cannot (its patch x 4 planes does not
+    // fit the LDS) and walks 16 chunks of 32 channels, each behind a global-load latency: that is the one split-K shortens enough to pay for
+    // the finishing launch.  SGX_CONV_SPLITK=-1 lifts the restriction (probes, tests of the other geometries).
+    if (geo != GDOWN && on >= 0) return 0;
+    if (sgx_conv2_takes(geo, B, H, W, Cin, Cout)) return 0;
+    const int ohc = geo == GDOWN ? H / 2 : H, owc = geo == GDOWN ? W / 2 : W;
+    // the instantiation dispatch_conv picks for this shape: deep K-chunks first, else (transposed) the all-class kernel
+    const bool deep = geo != GDOWN && conv_deep_k(geo, B, ohc, owc, Cin, Cout);
+    const ConvCfg c = pick_cfg((geo == GUP && !deep) ? GUPA : geo, B, ohc, owc, Cout);
+    if (!c.bp || c.bp > 128 || c.ct > 2 || (deep && c.ct != 1)) return 0;       // (the tiles the split-K instantiations exist for)
+    const int kc = deep ? 128 : (Cin % 32 == 0 ? 32 : 16);
+    const int nk = Cin / kc;
+    const long blocks = (long)((B + c.ni - 1) / c.ni) * ((ohc + c.th - 1) / c.th) * ((owc + c.tw - 1) / c.tw) * (Cout / (16 * c.ct)) * ((geo == GUP && deep) ? 4 : 1);
+    const int ncu = sgx_ncu();
+    if (nk < 4 || blocks > ncu) return 0;                                         // (at most one block per CU without the split)
+    int want = (int)((2L * ncu + blocks - 1) / blocks);
+    const int cap = on > 1 ? on : 8;
+    if (want > cap) want = cap;
+    if (want > nk / 2) want = nk / 2;                                             // (>= 2 chunks per block: the register prefetch still overlaps one)
+    return want >= 2 ? want : 0;                                                  // (uneven ranges are fine: split s owns chunks [s nk / ks, (s + 1) nk / ks))
+}
+extern "C" size_t sgx_conv_splitk_ws_bytes(int geo, int B, int H, int W, int Cin, int Cout, int dtype) {
+    const int ks = conv_splitk_plan(geo, B, H, W, Cin, Cout, dtype);
+    if (!ks) return 0;
+    const size_t opix = geo == GDOWN ? (size_t)B * (H / 2) * (W / 2) : (geo == GUP ? (size_t)B * 4 * H * W : (size_t)B * H * W);
+    return (size_t)ks * opix * Cout * sizeof(float);
+}
+// sgx_conv3x3 / sgx_conv4x4s2_down / sgx_conv4x4s2_up (geo 0 / 1 / 2) of a shape for which sgx_conv_splitk_ws_bytes is not 0, with the
+// reduction split over blocks: the partials go through `ws`, a second (tiny) launch finishes.  `mask`: geo 0 only.
+extern "C" int sgx_conv_splitk(int geo, const void* x, const void* w, const float* bias, void* y, const void* mask, int B, int H, int W, int Cin, int Cout,
+                               int act, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    const int ks = conv_splitk_plan(geo, B, H, W, Cin, Cout, dtype);
+    SGX_REQUIRE(ks > 1, SGX_EUNSUPPORTED, "conv_splitk: this shape does not split (geo %d B%d %dx%d %d->%d)", geo, B, H, W, Cin, Cout);
+    SGX_REQUIRE(x && w && y && ws && ws_bytes >= sgx_conv_splitk_ws_bytes(geo, B, H, W, Cin, Cout, dtype), SGX_EWORKSPACE, "conv_splitk: workspace");
+    SGX_REQUIRE(geo == G3X3 || !mask, SGX_EINVAL, "conv_splitk: the output mask belongs to the 3x3 geometry");
+    SGX_REQUIRE(geo != GDOWN || (H % 2 == 0 && W % 2 == 0), SGX_EINVAL, "conv_splitk: odd input size");
+    hipStream_t st = (hipStream_t)stream;
+    const int OH = geo == GDOWN ? H / 2 : (geo == GUP ? 2 * H : H), OW = geo == GDOWN ? W / 2 : (geo == GUP ? 2 * W : W);
+    ConvArgs a{x, w, nullptr, y, B, H, W, OH, OW, geo == GUP ? H : OH, geo == GUP ? W : OW, Cin, Cout, SGX_ACT_NONE, 0, 0, 0, nullptr};
+    a.ksplit = ks; a.kws = static_cast<float*>(ws);
+    const double taps = geo == G3X3 ? 9.0 : 16.0, opix = (double)B * OH * OW, macs = geo == GUP ? taps / 4.0 : taps;
+    SGX_NOTE(2.0 * macs * Cin * Cout * opix, 2.0 * ((double)B * H * W * Cin + opix * Cout + taps * Cin * Cout) + 4.0 * ks * opix * Cout, "conv%c/k%d B%d %dx%d %d->%d",
+             geo == G3X3 ? 'S' : (geo == GDOWN ? 'D' : 'U'), ks, B, H, W, Cin, Cout);
+    int rc;
+    if (geo == G3X3) rc = dispatch_conv<G3X3, true>(a, dtype, st);
+    else if (geo == GDOWN) rc = dispatch_conv<GDOWN, true>(a, dtype, st);
+    else rc = dispatch_conv<GUP, true>(a, dtype, st);
+    if (rc) return rc;
+    const size_t npix = (size_t)B * OH * OW, nvec = npix * Cout / 8;
+    SGX_NOTE(0.0, 4.0 * ks * npix * Cout + 2.0 * npix * Cout, "conv_splitk_finish %zux%d", npix, Cout);
+    hipLaunchKernelGGL(conv_splitk_finish, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, (const float*)ws, ks, npix, Cout, bias, act,
+                       static_cast<const bf16_t*>(mask), static_cast<bf16_t*>(y));
+    SGX_LAUNCH_CHECK("conv_splitk_finish");
+    return 0;
 }
 
 extern "C" int sgx_conv_config(int geo, int B, int H, int W, int Cin, int Cout, int dtype, int* cfg5) {

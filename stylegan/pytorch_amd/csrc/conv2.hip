@@ -1558,6 +1558,8 @@ extern "C" int sgx_conv_upblur(const void* x, const void* wc, void* y, const voi
 }
 
 // *launched = 1 if the second-generation kernel ran; 0 leaves the shape to the first-generation kernel.
+// would sgx_conv2_try (variant -1) take this bf16 shape?  (the split-K plan of conv.hip only covers launches that stay with the first generation)
+int sgx_conv2_takes(int geo, int B, int H, int W, int Cin, int Cout) { return conv2_pick(geo, B, H, W, Cin, Cout, -1).nw != 0; }
 int sgx_conv2_try(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int act,
                   const void* mask, int variant, hipStream_t st, int* launched) {
     *launched = 0;

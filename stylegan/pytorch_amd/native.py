@@ -41,6 +41,8 @@ SIGNATURES = {
     "sgx_wgrad_ws_bytes": (Z, [I, I, I, I, I, I]),
     "sgx_images_u8_to_nhwc": (I, [P, P, P, I, I, I, I, I, P]),
     "sgx_selftest_tr16": (I, [P, P]),
+    "sgx_conv_splitk_ws_bytes": (Z, [I, I, I, I, I, I, I]),
+    "sgx_conv_splitk": (I, [I, P, P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
     "sgx_conv_config": (I, [I, I, I, I, I, I, I, P]),
     "sgx_prof_start": (I, [I, I]),
     "sgx_prof_count": (I, []),
