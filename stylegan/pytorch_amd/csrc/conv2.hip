@@ -866,7 +866,7 @@ template <int NG, int NDY, int MF, int R, int PD> struct C3Seq {
 };
 
 template <int GEO, int NW, int MF, int RPW, int PD, int DIL, int UB = 0>
-__global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
+__global__ __launch_bounds__(NW * 64, UB == 2 ? 2 * NW / 4 : NW / 4) void conv3_kernel(Conv2Args a) {      // (UB == 2: two blocks per CU)
     using G = G2<GEO>;
     using L = C3Lds<GEO, NW, MF, RPW>;
     static_assert(GEO == C2_S || GEO == C2_D, "3x3 and stride-2 geometries");
@@ -995,7 +995,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
     zero_acc();
 
     static_for<0, NPI + NWI>([&](auto J) { dma_piece(J, smem); });
-    if constexpr (UB) {
+    // UB == 2 (round 6): the COMPACT image -- [patch 0][composite taps][patch 1], 80 KB with the 4-wave block's 10 x 34 patch -- for TWO blocks
+    // per CU: they share nothing and drift apart, so one block's depth-to-space store runs under the other's MFMAs (the 8-wave block's
+    // waves all store at once behind one barrier: 3.4 TB/s, 0.27 of the MFMA pipe).  The ten LDS-resident correction tiles are read from
+    // global memory instead (L2 hits; one tile column in sixteen needs them at 512^2).
+    if constexpr (UB == 1) {
         // the LDS-resident correction tiles (first / last fine column, corners: 10 tiles of 32 rows x 64 bytes) -> the weight region of
         // stage 1 (its own copy of the composite taps is not needed: one K-step per tile, the taps are read from stage 0), once
 #pragma unroll
@@ -1109,7 +1113,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
                 };
                 // A fragment of LDS-resident correction tile t (32 rows (py, co) x 32 channels; the weight region of stage 1)
                 auto corr_lds = [&](int t, int ks) {
-                    return *reinterpret_cast<const i32x4*>(smem + STAGE + P_BYTES + (t * 32 + l31) * 64 + (((hi + 2 * ks) ^ ((l31 >> 2) & 3)) << 4));
+                    if constexpr (UB == 2) return *reinterpret_cast<const i32x4*>(a.wcorr + ((size_t)t * 32 + l31) * 32 + ks * 16 + hi * 8);
+                    else return *reinterpret_cast<const i32x4*>(smem + STAGE + P_BYTES + (t * 32 + l31) * 64 + (((hi + 2 * ks) ^ ((l31 >> 2) & 3)) << 4));
                 };
                 // ... and of the first / last fine ROW's correction tiles, read from global memory (one wave in the first / last tile row only)
                 auto corr_glb = [&](int t, int ks) {
@@ -1298,15 +1303,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3_kernel(Conv2Args a) {
 template <int GEO, int NW, int MF, int RPW, int PD, int DIL, int UB = 0>
 static int launch_conv3(Conv2Args& a, hipStream_t st) {
     using L = C3Lds<GEO, NW, MF, RPW>;
-    constexpr int LDS = L::TOTAL;
-    static_assert(LDS <= 160 * 1024, "LDS budget");
+    constexpr int LDS = UB == 2 ? L::TOTAL - L::W_BYTES : L::TOTAL;      // (UB == 2: no second weight region)
+    constexpr int BPC = UB == 2 ? (160 * 1024) / LDS : 1;                // resident blocks per CU the launch is sized for
+    static_assert(LDS <= 160 * 1024 && BPC >= 1 && (UB != 2 || BPC == 2), "LDS budget");
     auto kern = conv3_kernel<GEO, NW, MF, RPW, PD, DIL, UB>;
     sgx_lds_opt_in<conv3_kernel<GEO, NW, MF, RPW, PD, DIL, UB>>(LDS);
     const int gh = GEO == C2_D ? a.OH : a.H, gw = GEO == C2_D ? a.OW : a.W;
     a.tiles_x = (gw + 31) / 32; a.tiles_y = (gh + L::TH - 1) / L::TH;
     a.ntiles = a.B * a.tiles_y * a.tiles_x;
     a.ncb = a.Cout / L::BCO;
-    int per = sgx_ncu() / (8 * a.ncb);
+    int per = sgx_ncu() * BPC / (8 * a.ncb);
     const int need = (a.ntiles + 7) / 8;
     if (per > need) per = need;
     if (per < 1) per = 1;
@@ -1552,8 +1558,11 @@ extern "C" int sgx_conv_upblur(const void* x, const void* wc, void* y, const voi
     Conv2Args a{static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(wc), nullptr, static_cast<bf16_t*>(y), nullptr, B, H, W, 2 * H, 2 * W, Cin, 64,
                 SGX_ACT_NONE, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<const unsigned char*>(maskbits)};
     a.wcorr = static_cast<const bf16_t*>(wc) + (size_t)9 * 64 * 32;
-    // 8-wave blocks once their 512-pixel tiles fill the chip, else the 4-wave block (256-pixel tiles)
-    const long tiles8 = (long)B * ((H + 15) / 16) * (W / 32);
+    // 8-wave blocks once their 512-pixel tiles fill the chip, else the 4-wave block (256-pixel tiles); SGX_UPBLUR_BPC=2: two compact 4-wave
+    // blocks per CU (round 6)
+    static const int bpc2 = [] { const char* e = getenv("SGX_UPBLUR_BPC"); return e ? atoi(e) : 1; }();
+    const long tiles8 = (long)B * ((H + 15) / 16) * (W / 32), tiles4 = (long)B * ((H + 7) / 8) * (W / 32);
+    if (bpc2 == 2 && tiles4 >= 2L * sgx_ncu()) return launch_conv3<C2_S, 4, 2, 2, 2, 0, 2>(a, (hipStream_t)stream);
     return tiles8 >= sgx_ncu() ? launch_conv3<C2_S, 8, 2, 2, 2, 0, 1>(a, (hipStream_t)stream) : launch_conv3<C2_S, 4, 2, 2, 2, 0, 1>(a, (hipStream_t)stream);
 }
 

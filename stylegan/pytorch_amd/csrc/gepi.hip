@@ -7,6 +7,7 @@
 // Layout per block: image b, pixel chunk; thread = (pixel row tr, channel vector tc); channel vectors are 16 bytes.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define GEPI_EPS 1e-5f
 #define GEPI_ROWS_PER_THREAD 64
@@ -35,10 +36,14 @@ static size_t gepi_ws_head(int B, int HW, int C) {
     int nchunk = g4.nchunk > g8.nchunk ? g4.nchunk : g8.nchunk;
     return ((size_t)2 * B * nchunk * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float) + 255) / 256 * 256;
 }
+// behind the head: [B][7][C] floats (the short-lived apply passes' coefficient tables), then the per-block partials of gepi_bwd2s
+static size_t gepi_ws_tab(int B, int C) { return ((size_t)B * 7 * C * sizeof(float) + 255) / 256 * 256; }
 extern "C" size_t sgx_gepi_ws_bytes(int B, int HW, int C) {
-    return gepi_ws_head(B, HW, C) + (size_t)B * 6 * C * sizeof(float) + 256;     // + [B][6][C] floats: the apply pass's coefficient tables
+    const size_t nblk = ((size_t)HW * (C / 4) + 1023) / 1024;                     // (the fp32 vector width gives the larger count)
+    return gepi_ws_head(B, HW, C) + gepi_ws_tab(B, C) + (size_t)B * nblk * C * 2 * sizeof(double) + 256;
 }
 static float* gepi_ctab(void* ws, int B, int HW, int C) { return reinterpret_cast<float*>(static_cast<char*>(ws) + gepi_ws_head(B, HW, C)); }
+static double* gepi_part2s(void* ws, int B, int HW, int C) { return reinterpret_cast<double*>(static_cast<char*>(ws) + gepi_ws_head(B, HW, C) + gepi_ws_tab(B, C)); }
 
 // sum over 16 consecutive lanes (the finalizers give every output 16 lanes that stride over the chunk partials)
 __device__ __forceinline__ double sum16(double v) {
@@ -281,8 +286,12 @@ __global__ void gepi_fin_stats(const double* __restrict__ part, float* __restric
 }
 
 // backward finalize 1: dstyle and the two per-(b,c) coefficients of the apply pass
+// ``tab`` (optional): the short-lived backward apply pass's per-(image, channel) coefficients packed as [B][7][C] floats -- bias, noise weight, mean,
+// rstd, style scale + 1, and the two statistics-gradient coefficients -- one coalesced load per thread of a block (gepi_bwd2s)
 __global__ void gepi_fin_bwd1(const double* __restrict__ part, const float* __restrict__ style, float* __restrict__ dstyle,
-                              float* __restrict__ coef, int B, int C, int nchunk, int HW, int norm) {
+                              float* __restrict__ coef, int B, int C, int nchunk, int HW, int norm, float* __restrict__ tab = nullptr,
+                              const float* __restrict__ bias = nullptr, const float* __restrict__ nw = nullptr, const float* __restrict__ mean = nullptr,
+                              const float* __restrict__ rstd = nullptr) {
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15;
     const bool ok = i < B * C;
     const int b = ok ? i / C : 0, c = ok ? i % C : 0;
@@ -297,8 +306,14 @@ __global__ void gepi_fin_bwd1(const double* __restrict__ part, const float* __re
     dstyle[(size_t)b * 2 * C + c] = (float)s0;              // d/d style[:,0] = sum dy*xh
     dstyle[(size_t)b * 2 * C + C + c] = (float)s1;          // d/d style[:,1] = sum dy
     const double sc = (double)style[(size_t)b * 2 * C + c] + 1.0;
-    coef[(size_t)i * 2] = norm ? (float)(sc * s1 / HW) : 0.f;      // the statistics' own gradient terms (instance norm only)
-    coef[(size_t)i * 2 + 1] = norm ? (float)(sc * s0 / HW) : 0.f;
+    const float k1 = norm ? (float)(sc * s1 / HW) : 0.f, k2 = norm ? (float)(sc * s0 / HW) : 0.f;   // the statistics' own gradient terms (instance norm only)
+    coef[(size_t)i * 2] = k1;
+    coef[(size_t)i * 2 + 1] = k2;
+    if (tab) {
+        float* t = tab + (size_t)b * 7 * C + c;
+        t[0] = bias ? bias[c] : 0.f; t[C] = nw[c]; t[2 * C] = mean[i]; t[3 * C] = rstd[i];
+        t[4 * C] = style[(size_t)b * 2 * C + c] + 1.f; t[5 * C] = k1; t[6 * C] = k2;
+    }
 }
 
 // backward finalize 2: d noise-weight and d bias per channel (sum over images and chunks); one wave per channel (batch 32 at
@@ -400,12 +415,12 @@ __global__ __launch_bounds__(256) void gepi_apply1(const T* __restrict__ x, cons
     constexpr int VE = VecTraits<T>::VE;
     extern __shared__ float tab[];                                 // [6][C]: bias, noise weight, mean, rstd, style scale + 1, style shift (gepi_fin_stats)
     const int b = blockIdx.y, cv = C / VE;
-    const size_t nvi = (size_t)HW * cv;                            // vectors per image
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned nvi = (unsigned)HW * (unsigned)cv;              // vectors per image (< 2^31: 32-bit index arithmetic, one 32-bit divide)
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
     const bool live = i < nvi;
-    const size_t p = live ? i / cv : 0;
-    const int c0 = (int)(i - p * cv) * VE;
-    const size_t off = ((size_t)b * nvi + (live ? i : 0)) * VE;
+    const unsigned p = live ? i / (unsigned)cv : 0u;
+    const int c0 = (int)(i - p * (unsigned)cv) * VE;
+    const size_t off = ((size_t)b * nvi + (live ? i : 0u)) * VE;
     uint4 raw = make_uint4(0u, 0u, 0u, 0u);
     float nz = 0.f;
     if (live) {
@@ -428,6 +443,122 @@ __global__ __launch_bounds__(256) void gepi_apply1(const T* __restrict__ x, cons
     }
     *reinterpret_cast<uint4*>(y + off) = pack16<T>(xv);
 }
+// ---- the backward apply pass as short-lived blocks (round 6; as gepi_apply1): two inputs, one output -- 4.0 TB/s through a capped grid-stride
+// loop, 6.0 as blocks that move a vector or four per thread and exit (tools/stream_probe.hip T0).  A thread owns U = 4 vectors of ONE channel vector
+// (pixels 256 / cv apart), so the per-channel sums of d noise-weight / d bias are 2 x VE fp32 partials per thread; lanes of a wave with the same
+// channel vector are summed by xor shuffles, the four waves through LDS (fp64), one partial per (block, channel) for gepi_fin_bwd2 -- a fixed
+// order, no atomics.  dx: the arithmetic of gepi_pass<T, 2> on the coefficients gepi_fin_bwd1 computed: bit-identical.
+template <typename T>
+__global__ __launch_bounds__(256) void gepi_bwd2s(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, const float* __restrict__ noise,
+                                                  const float* __restrict__ ctab, double* __restrict__ part, int HW, int C, int act) {
+    constexpr int VE = VecTraits<T>::VE, U = 4;
+    extern __shared__ float tab[];                                 // [7][C] coefficients, then [4 waves][cv][2 * VE] doubles
+    const int b = blockIdx.y, cv = C / VE, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lcv = 31 - __builtin_clz((unsigned)cv);              // cv is a power of two (gepi_bwd2s_on): shifts, no division (a 64-bit divide per
+                                                                   // vector made the first version of this kernel 45 % SLOWER than the loop it replaces)
+    const unsigned nvi = (unsigned)HW * (unsigned)cv;              // vectors per image (< 2^31: gepi_check)
+    const unsigned i0 = blockIdx.x * (256u * U) + threadIdx.x;
+    const int c0 = (int)(i0 & (unsigned)(cv - 1)) * VE;            // (256 % cv == 0: the same channel vector for every u)
+    const T* xb = x + (size_t)b * nvi * VE; const T* gb = dy + (size_t)b * nvi * VE; T* db = dx + (size_t)b * nvi * VE;
+    const float* nzb = noise + (size_t)b * HW;
+    uint4 rx[U], rg[U];
+    float nz[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned i = i0 + u * 256u;
+        rx[u] = make_uint4(0u, 0u, 0u, 0u); rg[u] = rx[u]; nz[u] = 0.f;
+        if (i < nvi) {
+            rx[u] = *reinterpret_cast<const uint4*>(xb + (size_t)i * VE);
+            rg[u] = *reinterpret_cast<const uint4*>(gb + (size_t)i * VE);
+            nz[u] = nzb[i >> lcv];
+        }
+    }
+    const float4* src = reinterpret_cast<const float4*>(ctab + (size_t)b * 7 * C);
+    for (int j = threadIdx.x; j < 7 * C / 4; j += 256) reinterpret_cast<float4*>(tab)[j] = src[j];
+    __syncthreads();
+    float kb[VE], kw[VE], km[VE], kr[VE], ks[VE], k1[VE], k2[VE], s0[VE], s1[VE];
+    load_coef<VE>(tab + c0, kb); load_coef<VE>(tab + C + c0, kw); load_coef<VE>(tab + 2 * C + c0, km); load_coef<VE>(tab + 3 * C + c0, kr);
+    load_coef<VE>(tab + 4 * C + c0, ks); load_coef<VE>(tab + 5 * C + c0, k1); load_coef<VE>(tab + 6 * C + c0, k2);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned i = i0 + u * 256u;
+        if (i < nvi) {
+            float xv[VE], gv[VE], ov[VE];
+            unpack16<T>(rx[u], xv); unpack16<T>(rg[u], gv);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {
+                const float pp = xv[j] + kb[j] + kw[j] * nz[u];
+                const float xh = (act_apply(pp, act) - km[j]) * kr[j];
+                const float da = kr[j] * (gv[j] * ks[j] - k1[j] - xh * k2[j]);
+                const float dp = act ? da * lrelu_slope(pp) : da;
+                ov[j] = dp;
+                s0[j] += dp * nz[u]; s1[j] += dp;
+            }
+            *reinterpret_cast<uint4*>(db + (size_t)i * VE) = pack16<T>(ov);
+        }
+    }
+    // lanes of a 16-lane ROW with the same channel vector (lane % cv; cv a power of two <= 16): DPP row rotations -- one v_add per step and value
+    // (the first version summed over the whole wave with 80 ds_bpermute shuffles per thread and was 75 % slower than the loop it replaces)
+    auto ror_add = [](float v, auto N) {
+        constexpr int n = decltype(N)::value;
+        return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + n, 0xf, 0xf, false));
+    };
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+        if (cv <= 8) { s0[j] = ror_add(s0[j], std::integral_constant<int, 8>{}); s1[j] = ror_add(s1[j], std::integral_constant<int, 8>{}); }
+        if (cv <= 4) { s0[j] = ror_add(s0[j], std::integral_constant<int, 4>{}); s1[j] = ror_add(s1[j], std::integral_constant<int, 4>{}); }
+        if (cv <= 2) { s0[j] = ror_add(s0[j], std::integral_constant<int, 2>{}); s1[j] = ror_add(s1[j], std::integral_constant<int, 2>{}); }
+        if (cv <= 1) { s0[j] = ror_add(s0[j], std::integral_constant<int, 1>{}); s1[j] = ror_add(s1[j], std::integral_constant<int, 1>{}); }
+    }
+    // the 16 rows of the block (4 waves x 4 rows) through LDS in fp64, summed in a fixed order by one thread per (channel vector, value)
+    double* wtot = reinterpret_cast<double*>(tab + 7 * C + (7 * C & 1));       // [16 rows][cv][2 * VE] (8-byte aligned: 7 C is even for C % 8 == 0; kept general)
+    const int row = wave * 4 + (lane >> 4), l15 = lane & 15;
+    if (l15 < cv) {
+#pragma unroll
+        for (int j = 0; j < VE; ++j) { wtot[(row * cv + l15) * 2 * VE + j] = (double)s0[j]; wtot[(row * cv + l15) * 2 * VE + VE + j] = (double)s1[j]; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cv * 2 * VE) {
+        const int v = threadIdx.x / (2 * VE), k = threadIdx.x % (2 * VE);
+        double a = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += wtot[(r * cv + v) * 2 * VE + k];
+        part[(((size_t)b * gridDim.x + blockIdx.x) * C + (size_t)v * VE + (k % VE)) * 2 + (k / VE)] = a;
+    }
+}
+// gepi_bwd2s leaves one partial row of 2 C doubles per BLOCK (65 536 rows at 1024^2 x 16, batch 32): gepi_fin_bwd2 walks a channel's rows with one
+// wave -- 16 waves on the whole chip, 500 us for 17 MB.  This pre-reduction sums contiguous ranges of rows with every lane loading its own
+// value of consecutive rows (coalesced): out[j][w] = sum of rows [j K / NB, (j + 1) K / NB), NB <= 256 rows left for gepi_fin_bwd2.
+__global__ __launch_bounds__(256) void gepi_rows_prereduce(const double* __restrict__ part, double* __restrict__ out, int K, int Wd) {
+    extern __shared__ double shr[];                                // [256]
+    const int NB = gridDim.x, j = blockIdx.x;
+    const int k0 = (int)((long)j * K / NB), k1 = (int)((long)(j + 1) * K / NB);
+    const int lanes = 256 / Wd * Wd;                               // threads in use: whole rows per sweep (Wd <= 256)
+    const int w = threadIdx.x % Wd, r = threadIdx.x / Wd, rows = 256 / Wd;
+    double a = 0.0;
+    if ((int)threadIdx.x < lanes)
+        for (int k = k0 + r; k < k1; k += rows) a += part[(size_t)k * Wd + w];
+    shr[threadIdx.x] = (int)threadIdx.x < lanes ? a : 0.0;
+    __syncthreads();
+    if ((int)threadIdx.x < Wd) {
+        double t = 0.0;
+        for (int q = 0; q < rows; ++q) t += shr[q * Wd + threadIdx.x];
+        out[(size_t)j * Wd + threadIdx.x] = t;
+    }
+}
+// Measured alone (tools/gepi_probe.py, both backward passes + finalisers, batch 32): 1024^2 x 16 1043..1083 -> 1002 us, 512^2 x 32 531 -> 526,
+// 256^2 x 64 284 -> 319 (worse): the noise load, the coefficient table, the in-block sums and the extra pre-reduction launch eat most of what the
+// two-input stream gains in the probe (267 vs 348 us for 1.6 GB).  So: tensors of >= 800 MB only (the 1024^2 layer from batch 24 up).
+static bool gepi_bwd2s_on(int C, int VE, double tensor_bytes) {
+    static const int on = [] { const char* e = getenv("SGX_GEPI_BWD2S"); return e ? atoi(e) : 1; }();       // A/B switch; 2 = whatever the size
+    const int cv = C / VE;
+    return on != 0 && C <= 128 && cv >= 1 && cv <= 16 && (cv & (cv - 1)) == 0 && (on == 2 || tensor_bytes >= 800e6);
+}
+// partials of the short-lived backward apply pass: blocks per image
+static int gepi_bwd2s_blocks(int HW, int C, int VE) { return (int)(((size_t)HW * (C / VE) + 1023) / 1024); }
+
 // the launch of the apply pass: short-lived blocks (SGX_GEPI_APPLY1, default 1) or the long-loop kernel with the statistics finalize folded in
 // Measured alone (tools/gepi_probe.py, statistics + apply, batch 32): 1024^2 x 16: 664 -> 599 us, 512^2 x 32: 345 -> 310, 256^2 x 64: 175 -> 170,
 // 128^2 x 128: no change; batch 4 (tensors of <= 134 MB): +2..3 us for the separate finalize launch and nothing back.  So: tensors of >= 192 MB.
@@ -770,6 +901,29 @@ static int gepi_bwd_t(const void* dy, const void* x, const float* bias, const fl
                        (const double*)nullptr, 0, 0, (float*)nullptr);
     SGX_LAUNCH_CHECK("gepi_bwd1");
     static const int fold = [] { const char* e = getenv("SGX_GEPI_FOLD"); return e ? atoi(e) : 1; }();
+    if (gepi_bwd2s_on(C, VE, nb)) {
+        float* ctab = gepi_ctab(ws, B, HW, C);
+        double* part2 = gepi_part2s(ws, B, HW, C);
+        const int nblk = gepi_bwd2s_blocks(HW, C, VE), cv = C / VE;
+        hipLaunchKernelGGL(gepi_fin_bwd1, dim3((B * C + 15) / 16), dim3(256), 0, st, (const double*)partA, style, dstyle, coef, B, C, g.nchunk, HW, norm, ctab, bias, nw,
+                           mean, rstd);
+        SGX_LAUNCH_CHECK("gepi_fin_bwd1");
+        SGX_NOTE(0.0, 3.0 * nb, "gepi_bwd2 B%d HW%d C%d", B, HW, C);
+        const size_t shs = (size_t)(7 * C + 2) * sizeof(float) + (size_t)16 * cv * 2 * VE * sizeof(double);
+        hipLaunchKernelGGL(gepi_bwd2s<T>, dim3((unsigned)nblk, B), dim3(256), shs, st, (const T*)x, (const T*)dy, (T*)dx, noise, (const float*)ctab, part2, HW, C, act);
+        SGX_LAUNCH_CHECK("gepi_bwd2s");
+        // B * nblk partial rows -> <= 256 (into the head's partB region, sized for B * nchunk >= 256 rows at these tensor sizes) -> the two gradients
+        const int K = B * nblk, NB = K < 256 ? K : 256;
+        if ((size_t)NB <= (size_t)B * g.nchunk && 2 * C <= 256) {
+            hipLaunchKernelGGL(gepi_rows_prereduce, dim3(NB), dim3(256), 256 * sizeof(double), st, (const double*)part2, partB, K, 2 * C);
+            SGX_LAUNCH_CHECK("gepi_rows_prereduce");
+            hipLaunchKernelGGL(gepi_fin_bwd2, dim3((C + 3) / 4), dim3(256), 0, st, (const double*)partB, dnw, dbias, 1, C, NB);
+        } else {
+            hipLaunchKernelGGL(gepi_fin_bwd2, dim3((C + 3) / 4), dim3(256), 0, st, (const double*)part2, dnw, dbias, B, C, nblk);
+        }
+        SGX_LAUNCH_CHECK("gepi_fin_bwd2");
+        return 0;
+    }
     if (fold) {          // gepi_fin_bwd1's work (dstyle, the statistics-gradient coefficients) in the prologue of the apply pass
         SGX_NOTE(0.0, 3.0 * nb, "gepi_bwd2 B%d HW%d C%d", B, HW, C);
         hipLaunchKernelGGL((gepi_pass<T, 2>), dim3(g.nchunk, B), dim3(256), shb + 2 * C * sizeof(float), st, (const T*)x, (const T*)dy, (T*)dx, bias,
@@ -777,7 +931,8 @@ static int gepi_bwd_t(const void* dy, const void* x, const float* bias, const fl
                            (const double*)partA, g.nchunk, norm, dstyle);
         SGX_LAUNCH_CHECK("gepi_bwd2");
     } else {
-        hipLaunchKernelGGL(gepi_fin_bwd1, dim3((B * C + 15) / 16), dim3(256), 0, st, partA, style, dstyle, coef, B, C, g.nchunk, HW, norm);
+        hipLaunchKernelGGL(gepi_fin_bwd1, dim3((B * C + 15) / 16), dim3(256), 0, st, (const double*)partA, style, dstyle, coef, B, C, g.nchunk, HW, norm, (float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
         SGX_LAUNCH_CHECK("gepi_fin_bwd1");
         SGX_NOTE(0.0, 3.0 * nb, "gepi_bwd2 B%d HW%d C%d", B, HW, C);
         hipLaunchKernelGGL((gepi_pass<T, 2>), dim3(g.nchunk, B), dim3(256), shb, st, (const T*)x, (const T*)dy, (T*)dx, bias, noise,
