@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-6 evidence in one GPU-box session.   usage: tools/gpu_final6.sh <tag> [test]
+# Round-6 evidence in one GPU-box session.   usage: tools/gpu_final6.sh <tag> [test|notest] [ab]
 #   smoke; the default bench line (headline batch 4 + the batch-32 block + cpu_baseline) and its layer tables; single-stream bench lines at
 #   batch 4 and 32 (per-kernel times without stream overlap) + step budgets; and for BOTH batch sizes: rocprofv3 --kernel-trace --stats,
 #   one SQ counter pass, two HBM traffic passes of the single-stream step.  `test`: the whole -m gpu suite first.
@@ -34,16 +34,24 @@ echo "== bench b32 single stream"; timeout 400 python bench.py --batch-per-gpu 3
 python tools/step_budget.py $O/layers_b4_single.tsv > $O/step_budget_b4.txt 2>&1; python tools/step_budget.py $O/layers_b32_single.tsv > $O/step_budget_b32.txt 2>&1
 for f in $O/layers_*.tsv $O/step_budget_*.txt; do stamp_txt $f; done
 if [ "$3" = "ab" ]; then
-  echo "== A/B on this box: the round-6 changes off (SGX_GEPI_SMALL=0 SGX_CONV2_SMALL=0) vs on, default bench line, interleaved"
-  for i in 1 2; do for v in off on; do
-    if [ $v = off ]; then export SGX_GEPI_SMALL=0 SGX_CONV2_SMALL=0; else unset SGX_GEPI_SMALL SGX_CONV2_SMALL; fi
-    timeout 400 python bench.py --no-cpu-baseline --no-extras --steps 30 2>/dev/null | tail -1 | python -c "
+  OFF1="SGX_GEPI_SMALL=0 SGX_CONV2_SMALL=0"
+  OFF2="SGX_GEPI_APPLY1=0 SGX_GEPI_BWD2S=0 SGX_GRID_ALL_CAP=8192 SGX_CONV_SPLITK=0 SGX_FUSE_FADE_BWD2=0 SGX_POOL_FORK=0 SGX_RGB_FORK=0"
+  echo "== A/B on this box, default bench line, interleaved: [all off] = the round's switches off ($OFF1 $OFF2); [session 1] = only the second session's off ($OFF2); [on] = defaults"
+  for i in 1 2; do for v in alloff session1 on; do
+    if [ $v = alloff ]; then e="$OFF1 $OFF2"; elif [ $v = session1 ]; then e="$OFF2"; else e="SGX_AB_DUMMY=1"; fi
+    env $e timeout 400 python bench.py --no-cpu-baseline --no-extras --steps 30 2>/dev/null | tail -1 | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
-print('round-6 changes $v: b4', round(d['value'], 1), 'img/s', round(d['ms_per_step'], 3), 'ms graphs', d.get('hip_graphs'), 'launches', d.get('library_launches_per_step'), '| b32', round(d['b32']['value'], 1), 'img/s', round(d['b32']['ms_per_step'], 2), 'ms')"
+print('[$v] b4', round(d['value'], 1), 'img/s', round(d['ms_per_step'], 3), 'ms graphs', d.get('hip_graphs'), 'launches', d.get('library_launches_per_step'), '| b32', round(d['b32']['value'], 1), 'img/s', round(d['b32']['ms_per_step'], 2), 'ms')"
   done; done | tee $O/ab_round6.txt
-  unset SGX_GEPI_SMALL SGX_CONV2_SMALL
   stamp_txt $O/ab_round6.txt
+  echo "== the split-K tests of all three geometries (SGX_CONV_SPLITK=-1)"
+  SGX_CONV_SPLITK=-1 timeout 300 python -m pytest tests/test_gpu_kernels.py -q -k split_k 2>&1 | tail -2 | tee $O/splitk_all_geometries.txt
+  echo "== probes of the second session"
+  timeout 120 tools/stream_probe > $O/stream_probe.txt 2>&1; stamp_txt $O/stream_probe.txt; head -12 $O/stream_probe.txt
+  timeout 200 python tools/overlap_probe.py 2>/dev/null > $O/overlap_probe.txt; stamp_txt $O/overlap_probe.txt; cat $O/overlap_probe.txt
+  timeout 200 python tools/splitk_probe.py --batch 4 8 2>/dev/null > $O/splitk_probe.txt; SGX_CONV_SPLITK=-1 timeout 200 python tools/splitk_probe.py --batch 4 2>/dev/null | sed "s/^/[all geometries] /" >> $O/splitk_probe.txt; stamp_txt $O/splitk_probe.txt
+  ( for a in 0 1; do SGX_GEPI_APPLY1=$a SGX_GEPI_BWD2S=$a python tools/gepi_probe.py --batch 32 4 --min-h 128 --reps 10 2>&1 | grep epilogue | sed "s/^/[short-lived apply passes $a] /"; done ) > $O/gepi_probe.txt; stamp_txt $O/gepi_probe.txt
 fi
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"
