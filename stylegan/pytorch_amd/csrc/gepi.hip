@@ -119,7 +119,7 @@ __device__ __forceinline__ void gepi_block_totals(const double* __restrict__ par
 // mode 0: (sum a, sum a^2)                       [forward statistics]
 // mode 1: (sum dy, sum dy*xh)                    [backward reduction]
 // mode 2: writes dx, (sum dp*noise, sum dp)      [backward apply]
-template <typename T, int MODE>
+template <typename T, int MODE, bool NT = false>
 __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                  const float* __restrict__ bias, const float* __restrict__ noise,
                                                  const float* __restrict__ nw, const float* __restrict__ style,
@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
                 const size_t off = (((size_t)b * HW + p) * cv + v) * VE;
                 const float nz = noise[(size_t)b * HW + p];
                 float xv[VE];
-                VecTraits<T>::load(x + off, xv);
+                if constexpr (NT) { const uint4 q = ld16(x + off, true); unpack16<T>(q, xv); }
+                else VecTraits<T>::load(x + off, xv);
                 if (MODE == 0) {
 #pragma unroll
                     for (int j = 0; j < VE; ++j) {
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
                     }
                 } else {
                     float gv[VE];
-                    VecTraits<T>::load(dy + off, gv);
+                    if constexpr (NT) { const uint4 q = ld16(dy + off, true); unpack16<T>(q, gv); }
+                    else VecTraits<T>::load(dy + off, gv);
                     if (MODE == 1) {
 #pragma unroll
                         for (int j = 0; j < VE; ++j) {
@@ -208,7 +210,8 @@ __global__ __launch_bounds__(256) void gepi_pass(const T* __restrict__ x, const 
                             ov[j] = dp;
                             s0[j] += dp * nz; s1[j] += dp;
                         }
-                        VecTraits<T>::store(dx + off, ov);
+                        if constexpr (NT) st16(dx + off, pack16<T>(ov), true);
+                        else VecTraits<T>::store(dx + off, ov);
                     }
                 }
             }
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(256) void gepi_apply1(const T* __restrict__ x, cons
     uint4 raw = make_uint4(0u, 0u, 0u, 0u);
     float nz = 0.f;
     if (live) {
-        raw = *reinterpret_cast<const uint4*>(x + off);
+        raw = ld16(x + off, true);                                 // (these launches are tensors of >= 192 MB: nontemporal both ways)
         nz = noise[(size_t)b * HW + p];
     }
     const float4* src = reinterpret_cast<const float4*>(ctab + (size_t)b * 6 * C);
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(256) void gepi_apply1(const T* __restrict__ x, cons
         const float xh = (a - km[j]) * kr[j];
         xv[j] = xh * ks[j] + k1[j];
     }
-    *reinterpret_cast<uint4*>(y + off) = pack16<T>(xv);
+    st16(y + off, pack16<T>(xv), true);
 }
 // ---- the backward apply pass as short-lived blocks (round 6; as gepi_apply1): two inputs, one output -- 4.0 TB/s through a capped grid-stride
 // loop, 6.0 as blocks that move a vector or four per thread and exit (tools/stream_probe.hip T0).  A thread owns U = 4 vectors of ONE channel vector
@@ -468,8 +471,8 @@ __global__ __launch_bounds__(256) void gepi_bwd2s(const T* __restrict__ x, const
         const unsigned i = i0 + u * 256u;
         rx[u] = make_uint4(0u, 0u, 0u, 0u); rg[u] = rx[u]; nz[u] = 0.f;
         if (i < nvi) {
-            rx[u] = *reinterpret_cast<const uint4*>(xb + (size_t)i * VE);
-            rg[u] = *reinterpret_cast<const uint4*>(gb + (size_t)i * VE);
+            rx[u] = ld16(xb + (size_t)i * VE, true);
+            rg[u] = ld16(gb + (size_t)i * VE, true);
             nz[u] = nzb[i >> lcv];
         }
     }
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(256) void gepi_bwd2s(const T* __restrict__ x, const
                 ov[j] = dp;
                 s0[j] += dp * nz[u]; s1[j] += dp;
             }
-            *reinterpret_cast<uint4*>(db + (size_t)i * VE) = pack16<T>(ov);
+            st16(db + (size_t)i * VE, pack16<T>(ov), true);
         }
     }
     // lanes of a 16-lane ROW with the same channel vector (lane % cv; cv a power of two <= 16): DPP row rotations -- one v_add per step and value
@@ -926,6 +929,11 @@ static int gepi_bwd_t(const void* dy, const void* x, const float* bias, const fl
     }
     if (fold) {          // gepi_fin_bwd1's work (dstyle, the statistics-gradient coefficients) in the prologue of the apply pass
         SGX_NOTE(0.0, 3.0 * nb, "gepi_bwd2 B%d HW%d C%d", B, HW, C);
+        if (sgx_nt_for(nb))
+            hipLaunchKernelGGL((gepi_pass<T, 2, true>), dim3(g.nchunk, B), dim3(256), shb + 2 * C * sizeof(float), st, (const T*)x, (const T*)dy, (T*)dx, bias,
+                               noise, nw, style, mean, rstd, (const float*)nullptr, partB, HW, C, g.cvt, g.rows, g.chunk, act,
+                               (const double*)partA, g.nchunk, norm, dstyle);
+        else
         hipLaunchKernelGGL((gepi_pass<T, 2>), dim3(g.nchunk, B), dim3(256), shb + 2 * C * sizeof(float), st, (const T*)x, (const T*)dy, (T*)dx, bias,
                            noise, nw, style, mean, rstd, (const float*)nullptr, partB, HW, C, g.cvt, g.rows, g.chunk, act,
                            (const double*)partA, g.nchunk, norm, dstyle);

@@ -511,7 +511,7 @@ __device__ __forceinline__ float mask_mul(float v, float v_slope, unsigned bits,
     const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)bits, j, 1);
     return __uint_as_float((__float_as_uint(v) & m) | (__float_as_uint(v_slope) & ~m));
 }
-template <typename T, int MODE, int ROWS, int PF>
+template <typename T, int MODE, int ROWS, int PF, bool NT = false>
 __global__ __launch_bounds__(256) void blur3x3s_kernel(const T* __restrict__ x, const T* __restrict__ z, T* __restrict__ y, int B, int H,
                                                        int W, int C) {
     static_assert(MODE != 3, "blur3x3s: mode 3 is not built");
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void blur3x3s_kernel(const T* __restrict__ x, 
             const int r = h0 - 1 + k, s = k % PF;
             if ((unsigned)r < (unsigned)H) {                                  // (wave-uniform)
                 const uint4* xr = reinterpret_cast<const uint4*>(x) + (img_row0 + r) * rowv;
-                rc[s] = xr[iv];
+                rc[s] = ld16(xr + iv, NT);
                 if (has_edge) re[s] = xr[ev];
                 if (MODE == 5) {
                     const unsigned char* zr = zb + (img_row0 + r) * rowv;
@@ -623,7 +623,9 @@ __global__ __launch_bounds__(256) void blur3x3s_kernel(const T* __restrict__ x, 
                     float o[VE];
 #pragma unroll
                     for (int j = 0; j < VP; ++j) { o[2 * j] = o2[j].x; o[2 * j + 1] = o2[j].y; }
-                    VecTraits<T>::store(yo, o);
+                    if constexpr (NT && sizeof(T) == 2) {
+                        st16(yo, make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4 % VE], o[5 % VE]), pack_bf16x2(o[6 % VE], o[7 % VE])), true);
+                    } else VecTraits<T>::store(yo, o);
                 }
             }
 #pragma unroll
@@ -643,6 +645,21 @@ static void blur_launch_shfl(const void* x, const void* z, void* y, int B, int H
     constexpr int VE = VecTraits<T>::VE;
     const dim3 grid(grid_all((size_t)B * ((H + ROWS - 1) / ROWS) * W * C / VE)), block(256);
     const T* xp = (const T*)x; const T* zp = (const T*)z; T* yp = (T*)y;
+    // nontemporal accesses for the tensors the caches cannot hold anyway (bf16, the default prefetch depths).  Measured alone at batch 32
+    // (tools/blur_rows_probe.py, SGX_NT_MIN_MB=0 vs default): 512^2 x 32 204.6 -> 194.8 us, 256^2 x 64 107.1 -> 98.9; 1024^2 x 16 406 -> 432
+    // (WORSE: the strips' halo rows are the neighbour block's L2 hits there) -- so from 32 channels up
+    if constexpr (sizeof(T) == 2 && (PF == 1 || PF == 3)) {
+        if (C >= 32 && sgx_nt_for((double)sizeof(T) * B * H * W * C)) {
+            switch (mode) {
+                case 0: hipLaunchKernelGGL((blur3x3s_kernel<T, 0, ROWS, PF, true>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+                case 1: hipLaunchKernelGGL((blur3x3s_kernel<T, 1, ROWS, PF, true>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+                case 2: hipLaunchKernelGGL((blur3x3s_kernel<T, 2, ROWS, PF, true>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+                case 4: hipLaunchKernelGGL((blur3x3s_kernel<T, 4, ROWS, PF, true>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+                default: hipLaunchKernelGGL((blur3x3s_kernel<T, 5, ROWS, PF, true>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
+            }
+            return;
+        }
+    }
     switch (mode) {
         case 0: hipLaunchKernelGGL((blur3x3s_kernel<T, 0, ROWS, PF>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
         case 1: hipLaunchKernelGGL((blur3x3s_kernel<T, 1, ROWS, PF>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;

@@ -214,6 +214,36 @@ __global__ __launch_bounds__(256) void k_r1w2(const uint4* __restrict__ x, uint4
     if (i < n) { const uint4 v = f(x[i]); y[i] = v; y2[i] = v; }
 }
 
+
+// NT: the loop forms with nontemporal loads / stores (do the library's long-lived kernels gain what the short-lived probe blocks gain from them?)
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+template <int NTL, int NTS>
+__global__ __launch_bounds__(256) void k_gridstride_nt(const uint4* __restrict__ x, uint4* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        v4u_t v = NTL ? __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(x) + i) : reinterpret_cast<const v4u_t*>(x)[i];
+        v.x ^= 0x00010001u; v.y += 1u;
+        if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<v4u_t*>(y) + i); else reinterpret_cast<v4u_t*>(y)[i] = v;
+    }
+}
+template <int NTL, int NTS>
+__global__ __launch_bounds__(256) void k_apply_lib_nt(const uint4* __restrict__ x, uint4* __restrict__ y, const float* __restrict__ nzp, const float* __restrict__ coef,
+                                                      int HW, int cv, int rpt) {
+    const int b = blockIdx.y, rows = 256 / cv, tc = threadIdx.x % cv, tr = threadIdx.x / cv;
+    const float* cb = coef + ((size_t)b * cv + tc) * 48;
+    float k[48];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { const float4 t = reinterpret_cast<const float4*>(cb)[j]; k[4 * j] = t.x; k[4 * j + 1] = t.y; k[4 * j + 2] = t.z; k[4 * j + 3] = t.w; }
+    const int p0 = blockIdx.x * rows * rpt, p1 = min(HW, p0 + rows * rpt);
+#pragma unroll 4
+    for (int p = p0 + tr; p < p1; p += rows) {
+        const size_t off = ((size_t)b * HW + p) * cv + tc;
+        const v4u_t r = NTL ? __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(x) + off) : reinterpret_cast<const v4u_t*>(x)[off];
+        const uint4 o = apply8(make_uint4(r.x, r.y, r.z, r.w), nzp[(size_t)b * HW + p], k, k + 8, k + 16, k + 24, k + 32, k + 40);
+        const v4u_t ov = {o.x, o.y, o.z, o.w};
+        if (NTS) __builtin_nontemporal_store(ov, reinterpret_cast<v4u_t*>(y) + off); else reinterpret_cast<v4u_t*>(y)[off] = ov;
+    }
+}
+
 int main(int argc, char** argv) {
     const size_t bytes = (size_t)32 * 512 * 512 * 32 * 2;      // 537 MB
     const size_t n = bytes / 16;
@@ -299,5 +329,19 @@ int main(int argc, char** argv) {
     bench("W0 write only, x1 chunk blocks (bytes x0.5)", [&](uint4* x, uint4* y) { hipLaunchKernelGGL(k_write_only<256>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, y, n); });
     bench("W0 write only, grid-stride 8192 (bytes x0.5)", [&](uint4* x, uint4* y) { hipLaunchKernelGGL(k_write_loop, dim3(8192), dim3(256), 0, 0, y, n); });
     bench("W1 read 1 : write 2, x1 chunk blocks (bytes x1.5)", [&](uint4* x, uint4* y) { hipLaunchKernelGGL(k_r1w2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, x, y, ys[(y == ys[0]) ? 1 : 0], n); });
+
+    bench("NT grid-stride 8192x256, nt load", [&](uint4* x, uint4* y) { hipLaunchKernelGGL((k_gridstride_nt<1, 0>), dim3(8192), dim3(256), 0, 0, x, y, n); });
+    bench("NT grid-stride 8192x256, nt store", [&](uint4* x, uint4* y) { hipLaunchKernelGGL((k_gridstride_nt<0, 1>), dim3(8192), dim3(256), 0, 0, x, y, n); });
+    bench("NT grid-stride 8192x256, nt load + store", [&](uint4* x, uint4* y) { hipLaunchKernelGGL((k_gridstride_nt<1, 1>), dim3(8192), dim3(256), 0, 0, x, y, n); });
+    {
+        const int C = 32, cv = C / 8, B = 32, HW = 512 * 512, rows = 256 / cv, rpt = 64;
+        float *nz, *coef;
+        CK(hipMalloc(&nz, (size_t)B * HW * 4)); CK(hipMemset(nz, 0, (size_t)B * HW * 4));
+        CK(hipMalloc(&coef, (size_t)B * cv * 48 * 4)); CK(hipMemset(coef, 0, (size_t)B * cv * 48 * 4));
+        bench("NT apply, library structure 64 rows, plain", [&](uint4* x, uint4* y) { hipLaunchKernelGGL((k_apply_lib_nt<0, 0>), dim3((HW + rows * rpt - 1) / (rows * rpt), B), dim3(256), 0, 0, x, y, nz, coef, HW, cv, rpt); });
+        bench("NT apply, library structure 64 rows, nt load", [&](uint4* x, uint4* y) { hipLaunchKernelGGL((k_apply_lib_nt<1, 0>), dim3((HW + rows * rpt - 1) / (rows * rpt), B), dim3(256), 0, 0, x, y, nz, coef, HW, cv, rpt); });
+        bench("NT apply, library structure 64 rows, nt store", [&](uint4* x, uint4* y) { hipLaunchKernelGGL((k_apply_lib_nt<0, 1>), dim3((HW + rows * rpt - 1) / (rows * rpt), B), dim3(256), 0, 0, x, y, nz, coef, HW, cv, rpt); });
+        bench("NT apply, library structure 64 rows, nt load + store", [&](uint4* x, uint4* y) { hipLaunchKernelGGL((k_apply_lib_nt<1, 1>), dim3((HW + rows * rpt - 1) / (rows * rpt), B), dim3(256), 0, 0, x, y, nz, coef, HW, cv, rpt); });
+    }
     return 0;
 }
