@@ -47,6 +47,12 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// the same with the nontemporal cache policy (aux = 2): the patch stream of a tensor far larger than the caches (Conv2Args.nt bit 1, probe)
+__device__ __forceinline__ void glds16_nt(const void* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+
 enum { C2_S = 0, C2_D = 1, C2_U = 2 };
 
 struct Conv2Args {
@@ -78,6 +84,7 @@ struct Conv2Args {
     const float* fade_pimg; const float* fade_wr; const float* fade_rb; float fade_ws, fade_bs1, fade_bs2;
     int part_slots;                           // EPI_STATS: the slot count `part` was sized for (launch_conv2 refuses any other nslots)
     const bf16_t* wcorr;                      // conv3_kernel<UB>: the 22 border-correction tiles [22][32][32] behind the 9 composite taps of the same pack
+    int nt;                                   // nontemporal hints (launch_conv2 / launch_conv3, SGX_CONV_NT, outputs of >= 192 MB): bit 0 the output stores, bit 1 the patch DMA
     int ureg;                                 // C2_U without the blur epilogue: 0 = the LDS-transposed store (default), 1 = the register epilogue (A/B: SGX_CONVU_REGSTORE=1, measured 0.5 % slower)
     int dbg;                                  // conv3_kernel, probe launches only (sgx_conv_variant + SGX_CONV3_DBG): DMA ablations, WRONG results by design
 };
@@ -252,7 +259,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                 // divergent branches around every DMA instruction)
                 const unsigned long long ok = ((pp >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W)) ? ~0ull : 0ull;
                 const unsigned long long pa = reinterpret_cast<unsigned long long>(base + prel[jj]);
-                glds16(reinterpret_cast<const void*>(zaddr + ((pa - zaddr) & ok)), buf + ii * 1024);
+                if (a.nt & 2) glds16_nt(reinterpret_cast<const void*>(zaddr + ((pa - zaddr) & ok)), buf + ii * 1024);
+                else glds16(reinterpret_cast<const void*>(zaddr + ((pa - zaddr) & ok)), buf + ii * 1024);
             }
         }
         // <= 2 K-steps per tile: step q's weights live in stage q for the whole launch (not with the blur epilogue: its row
@@ -566,7 +574,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                                                  __uint_as_float(rw[q] & 0xffff0000u);
                                 ow[q] = pack_bf16x2(h0 * lrelu_slope(__uint_as_float(mw[q] << 16)), h1 * lrelu_slope(__uint_as_float(mw[q] & 0xffff0000u)));
                             }
-                            *reinterpret_cast<uint4*>(a.y + doff) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                            st16(a.y + doff, make_uint4(ow[0], ow[1], ow[2], ow[3]), a.nt & 1);
                         }
                     }
                 }
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                                 const unsigned ux = pack_bf16x2(v[8 * k + 4], v[8 * k + 5]), uy = pack_bf16x2(v[8 * k + 6], v[8 * k + 7]);
                                 auto rx = __builtin_amdgcn_permlane32_swap(lx, ux, false, false);
                                 auto ry = __builtin_amdgcn_permlane32_swap(ly, uy, false, false);
-                                if (inimg) *reinterpret_cast<uint4*>(a.y + pix + 16 * k) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                                if (inimg) st16(a.y + pix + 16 * k, make_uint4(rx[0], ry[0], rx[1], ry[1]), a.nt & 1);
                             }
                         }
                     }
@@ -633,7 +641,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                             const uint4 val = make_uint4(swp ? raw.z : raw.x, swp ? raw.w : raw.y, swp ? raw.x : raw.z, swp ? raw.y : raw.w);
                             const int ox = 2 * tx0 + fpx;
                             if (oy < a.OH && ox < a.OW)
-                                *reinterpret_cast<uint4*>(a.y + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8) = val;
+                                st16(a.y + (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8, val, a.nt & 1);
                         }
                     }
                 }
@@ -701,7 +709,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                                                             fade_a * __uint_as_float(yv[q] & 0xffff0000u) + fade_b * __uint_as_float(rv[q] & 0xffff0000u));
                                     val = make_uint4(ov[0], ov[1], ov[2], ov[3]);
                                 }
-                                *reinterpret_cast<uint4*>(a.y + doff) = val;
+                                st16(a.y + doff, val, a.nt & 1);
                             }
                         }
                         if ((GEO == C2_S || GEO == C2_D) && a.signbits) {
@@ -762,7 +770,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv2_kernel(Conv2Args a) {
                         if (oy < a.OH && ox < a.OW) {
                             const size_t doff = (((size_t)b * a.OH + oy) * a.OW + ox) * a.Cout + co0 + v * 8;
                             if (GEO == C2_S && a.mask) val = lrelu_mask_bf16x8(val, *reinterpret_cast<const uint4*>(a.mask + doff));
-                            *reinterpret_cast<uint4*>(a.y + doff) = val;
+                            st16(a.y + doff, val, a.nt & 1);
                             if constexpr (EPI == EPI_STATS) {
                                 // (64 % VPR == 0: v = lane % VPR is the same channel vector in every iteration)
                                 const float nz = nzv[f][i];
@@ -961,7 +969,8 @@ __global__ __launch_bounds__(NW * 64, UB == 2 ? 2 * NW / 4 : NW / 4) void conv3_
                 const unsigned long long ok = ((pp >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W)) ? ~0ull : 0ull;
                 unsigned long long pa = reinterpret_cast<unsigned long long>(base + prel[j]);
                 if (a.dbg & 1) pa = reinterpret_cast<unsigned long long>(xg + (((long)ib * a.H + (ity0 > 0 ? ity0 : 0)) * a.W) * a.Cin + (ii * 64 + lane) * 8);
-                glds16(reinterpret_cast<const void*>(zaddr + ((pa - zaddr) & ok)), buf + ii * 1024);
+                if (a.nt & 2) glds16_nt(reinterpret_cast<const void*>(zaddr + ((pa - zaddr) & ok)), buf + ii * 1024);
+                else glds16(reinterpret_cast<const void*>(zaddr + ((pa - zaddr) & ok)), buf + ii * 1024);
             }
         } else {
             constexpr int jw = j - NPI;
@@ -1214,7 +1223,7 @@ __global__ __launch_bounds__(NW * 64, UB == 2 ? 2 * NW / 4 : NW / 4) void conv3_
                         uint2 lo = o2[2 * py], up = o2[2 * py + 1];
                         auto rx = __builtin_amdgcn_permlane32_swap(lo.x, up.x, false, false);
                         auto ry = __builtin_amdgcn_permlane32_swap(lo.y, up.y, false, false);
-                        if (inimg) *reinterpret_cast<uint4*>(a.y + ((((size_t)b * a.OH + 2 * i + py) * a.OW) + 2 * j + px) * 16 + 8 * hi) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                        if (inimg) st16(a.y + ((((size_t)b * a.OH + 2 * i + py) * a.OW) + 2 * j + px) * 16 + 8 * hi, make_uint4(rx[0], ry[0], rx[1], ry[1]), a.nt & 1);
                     }
                 }
             }
@@ -1286,7 +1295,7 @@ __global__ __launch_bounds__(NW * 64, UB == 2 ? 2 * NW / 4 : NW / 4) void conv3_
                                                         fade_a * __uint_as_float(yv[q] & 0xffff0000u) + fade_b * __uint_as_float(rv[q] & 0xffff0000u));
                                 val = make_uint4(ov[0], ov[1], ov[2], ov[3]);
                             }
-                            *reinterpret_cast<uint4*>(a.y + doff) = val;
+                            st16(a.y + doff, val, a.nt & 1);
                         }
                     }
                     if (a.signbits) {                 // (one aligned word per pixel and 32 channels: conv2_kernel's epilogue)
@@ -1312,6 +1321,10 @@ static int launch_conv3(Conv2Args& a, hipStream_t st) {
     a.tiles_x = (gw + 31) / 32; a.tiles_y = (gh + L::TH - 1) / L::TH;
     a.ntiles = a.B * a.tiles_y * a.tiles_x;
     a.ncb = a.Cout / L::BCO;
+    {
+        static const int cnt = [] { const char* e = getenv("SGX_CONV_NT"); return e ? atoi(e) : 0; }();      // probe: bit 0 stores, bit 1 patch loads
+        a.nt = sgx_nt_for(2.0 * a.B * a.OH * a.OW * (UB ? 16 : a.Cout)) ? cnt : 0;
+    }
     int per = sgx_ncu() * BPC / (8 * a.ncb);
     const int need = (a.ntiles + 7) / 8;
     if (per > need) per = need;
@@ -1339,6 +1352,10 @@ static int launch_conv2(Conv2Args& a, hipStream_t st) {
     }
     a.ntiles = a.B * a.tiles_y * a.tiles_x;
     a.ncb = CO16 ? 1 : a.Cout / L::BCO;
+    {
+        static const int cnt = [] { const char* e = getenv("SGX_CONV_NT"); return e ? atoi(e) : 0; }();      // probe: bit 0 stores, bit 1 patch loads
+        a.nt = sgx_nt_for(2.0 * a.B * a.OH * a.OW * (CO16 ? 16 : a.Cout)) ? cnt : 0;
+    }
     if constexpr (GEO == C2_U && EPI == EPI_NONE) {
         // A/B switch; measured on one box (round 6, default bench line, two interleaved rounds): register store 291.2 / 291.4 img/s at batch 4 and
         // 523.0 / 521.4 at batch 32, LDS-transposed store 292.8 / 293.9 and 525.0 / 525.4 -- whole 64-byte pixels per store instruction win
