@@ -105,15 +105,18 @@ extern "C" int sgx_lrelu_bwd(const void* dy, const void* y, void* dx, size_t n, 
 // the same with the activation given as SIGN BITS (bits[i] = the signs of the 8 channels of vector i, as sgx_conv3x3_signbits /
 // sgx_conv4x4s2_down_fade write them): the activation itself need not exist
 __global__ void lrelu_bwd_bits_kernel(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ bits, bf16_t* __restrict__ dx, size_t nvec, float slope,
-                                      float scale, const float* __restrict__ scale_dev) {
+                                      float scale, const float* __restrict__ scale_dev, int nt) {
     if (scale_dev) scale = scale_dev[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
         float g[8];
-        VecTraits<bf16_t>::load(dy + i * 8, g);
+        const uint4 raw = ld16(dy + i * 8, nt != 0);                // (nt: both streams of a >= 192 MB tensor with the nontemporal hint)
+        const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { g[2 * k] = __uint_as_float(w4[k] << 16); g[2 * k + 1] = __uint_as_float(w4[k] & 0xffff0000u); }
         const unsigned bb = bits[i];
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] = (scale * g[j]) * (((bb >> j) & 1u) ? 1.f : slope);
-        VecTraits<bf16_t>::store(dx + i * 8, g);
+        st16(dx + i * 8, make_uint4(pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]), pack_bf16x2(g[4], g[5]), pack_bf16x2(g[6], g[7])), nt != 0);
     }
 }
 extern "C" int sgx_lrelu_bwd_bits(const void* dy, const void* bits, void* dx, size_t n, float slope, float scale, const float* scale_dev, int dtype,
@@ -122,7 +125,7 @@ extern "C" int sgx_lrelu_bwd_bits(const void* dy, const void* bits, void* dx, si
     SGX_REQUIRE(dy && bits && dx, SGX_EINVAL, "lrelu_bwd_bits: null argument");
     SGX_NOTE(0.0, 4.125 * n, "lrelu_bwd_bits %zu", n);
     hipLaunchKernelGGL(lrelu_bwd_bits_kernel, dim3(grid_all(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const unsigned char*)bits, (bf16_t*)dx,
-                       n / 8, slope, scale, scale_dev);
+                       n / 8, slope, scale, scale_dev, sgx_nt_for(2.0 * (double)n) ? 1 : 0);
     SGX_LAUNCH_CHECK("lrelu_bwd_bits");
     return 0;
 }
@@ -139,7 +142,7 @@ extern "C" int sgx_lrelu_bwd_bits(const void* dy, const void* bits, void* dx, si
 template <int CV>
 __global__ __launch_bounds__(256) void fade_rgb_bwd_kernel(const bf16_t* __restrict__ g, const unsigned char* __restrict__ bits, const float* __restrict__ pimg,
                                                            const float* __restrict__ wr, float ws, float alpha, float beta, const float* __restrict__ ab_dev,
-                                                           bf16_t* __restrict__ gy, float* __restrict__ gpimg, double* __restrict__ part, size_t npix) {
+                                                           bf16_t* __restrict__ gy, float* __restrict__ gpimg, double* __restrict__ part, size_t npix, int nt) {
     constexpr int PPI = 256 / CV;                            // pixels per block iteration
     __shared__ double sh[4][CV][32];
     if (ab_dev) { alpha = ab_dev[0]; beta = ab_dev[1]; }
@@ -167,13 +170,18 @@ __global__ __launch_bounds__(256) void fade_rgb_bwd_kernel(const bf16_t* __restr
         float i0 = 0.f, i1 = 0.f, i2 = 0.f;
         unsigned bb = 0;
         if (ok) {
-            VecTraits<bf16_t>::load(g + (p * CV + v) * 8, gv);
+            {   // (nt: both streams of a >= 192 MB tensor with the nontemporal hint, see ld16 / st16)
+                const uint4 raw = ld16(g + (p * CV + v) * 8, nt != 0);
+                const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { gv[2 * i] = __uint_as_float(w4[i] << 16); gv[2 * i + 1] = __uint_as_float(w4[i] & 0xffff0000u); }
+            }
             bb = bits[p * CV + v];
             i0 = pimg[p * 3]; i1 = pimg[p * 3 + 1]; i2 = pimg[p * 3 + 2];
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (alpha * gv[j]) * (((bb >> j) & 1u) ? 1.f : SGX_LRELU);
-            VecTraits<bf16_t>::store(gy + (p * CV + v) * 8, o);
+            st16(gy + (p * CV + v) * 8, make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])), nt != 0);
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) gv[j] = 0.f;
@@ -252,9 +260,10 @@ extern "C" int sgx_fade_rgb_bwd(const void* g, const void* bits, const float* pi
     const unsigned char* bp = static_cast<const unsigned char*>(bits);
     bf16_t* yp = static_cast<bf16_t*>(gy);
     double* part = static_cast<double*>(wsbuf);
-    if (C == 32) hipLaunchKernelGGL(fade_rgb_bwd_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, st, gp, bp, pimg, wr, ws, alpha, beta, ab_dev, yp, gpimg, part, npix);
-    else if (C == 64) hipLaunchKernelGGL(fade_rgb_bwd_kernel<8>, dim3((unsigned)nblk), dim3(256), 0, st, gp, bp, pimg, wr, ws, alpha, beta, ab_dev, yp, gpimg, part, npix);
-    else hipLaunchKernelGGL(fade_rgb_bwd_kernel<16>, dim3((unsigned)nblk), dim3(256), 0, st, gp, bp, pimg, wr, ws, alpha, beta, ab_dev, yp, gpimg, part, npix);
+    const int nt = sgx_nt_for(2.0 * (double)npix * C) ? 1 : 0;
+    if (C == 32) hipLaunchKernelGGL(fade_rgb_bwd_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, st, gp, bp, pimg, wr, ws, alpha, beta, ab_dev, yp, gpimg, part, npix, nt);
+    else if (C == 64) hipLaunchKernelGGL(fade_rgb_bwd_kernel<8>, dim3((unsigned)nblk), dim3(256), 0, st, gp, bp, pimg, wr, ws, alpha, beta, ab_dev, yp, gpimg, part, npix, nt);
+    else hipLaunchKernelGGL(fade_rgb_bwd_kernel<16>, dim3((unsigned)nblk), dim3(256), 0, st, gp, bp, pimg, wr, ws, alpha, beta, ab_dev, yp, gpimg, part, npix, nt);
     SGX_LAUNCH_CHECK("fade_rgb_bwd_kernel");
     if (dwr || drb) {
         hipLaunchKernelGGL(fade_rgb_bwd_finish, dim3((unsigned)((4 * C + 3) / 4)), dim3(256), 0, st, part, dwr, drb, (int)nblk, C, ws, bs, beta, ab_dev, acc);
@@ -645,11 +654,14 @@ static void blur_launch_shfl(const void* x, const void* z, void* y, int B, int H
     constexpr int VE = VecTraits<T>::VE;
     const dim3 grid(grid_all((size_t)B * ((H + ROWS - 1) / ROWS) * W * C / VE)), block(256);
     const T* xp = (const T*)x; const T* zp = (const T*)z; T* yp = (T*)y;
-    // nontemporal accesses for the tensors the caches cannot hold anyway (bf16, the default prefetch depths).  Measured alone at batch 32
-    // (tools/blur_rows_probe.py, SGX_NT_MIN_MB=0 vs default): 512^2 x 32 204.6 -> 194.8 us, 256^2 x 64 107.1 -> 98.9; 1024^2 x 16 406 -> 432
-    // (WORSE: the strips' halo rows are the neighbour block's L2 hits there) -- so from 32 channels up
+    // nontemporal accesses (bf16, the default prefetch depths): a PROBE (SGX_BLUR_NT=1), off by default.  Alone at batch 32
+    // (tools/blur_rows_probe.py) they gain: 512^2 x 32 204.6 -> 194.8 us, 256^2 x 64 107.1 -> 98.9 (1024^2 x 16 406 -> 432: the strips' halo
+    // rows are the neighbour block's L2 hits there) -- but INSIDE the step they lose: blur1 512^2 209.7 -> 230.1 us, blur0 204.4 -> 213.5,
+    // 256^2 103 -> 110..113 (same box, single-stream layer tables): the blur's input was written by the launch before it and its output is
+    // read by the launch after it, and a good part of a 268-537 MB tensor is still in the 256 MB memory-side cache unless the hint evicts it
+    static const int blur_nt = [] { const char* e = getenv("SGX_BLUR_NT"); return e ? atoi(e) : 0; }();
     if constexpr (sizeof(T) == 2 && (PF == 1 || PF == 3)) {
-        if (C >= 32 && sgx_nt_for((double)sizeof(T) * B * H * W * C)) {
+        if (blur_nt && C >= 32 && sgx_nt_for((double)sizeof(T) * B * H * W * C)) {
             switch (mode) {
                 case 0: hipLaunchKernelGGL((blur3x3s_kernel<T, 0, ROWS, PF, true>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
                 case 1: hipLaunchKernelGGL((blur3x3s_kernel<T, 1, ROWS, PF, true>), grid, block, 0, st, xp, zp, yp, B, H, W, C); break;
