@@ -712,14 +712,15 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const float* __restric
 // How many ways a bf16 launch splits its reduction (0 = not at all): only launches that stay with this file's kernel, only when their grid
 // leaves most of the chip idle, a divisor of the K-chunk count, as many blocks as ~2 per CU, at most 8 (the finish pass reads ksplit partials).
 static int conv_splitk_plan(int geo, int B, int H, int W, int Cin, int Cout, int dtype) {
-    static const int on = [] { const char* e = getenv("SGX_CONV_SPLITK"); return e ? atoi(e) : 1; }();      // A/B switch (0 = off; n > 1 = at most n ways)
+    static const int on = [] { const char* e = getenv("SGX_CONV_SPLITK"); const int v = e ? atoi(e) : 1; return v < 0 ? 1 : v; }();      // A/B switch (0 = off; n > 1 = at most n ways)
     if (!on || dtype != SGX_BF16 || geo < 0 || geo > 2 || Cin % 16 || Cout % 16) return 0;
     // Measured alone on the MI355X (tools/splitk_probe.py, batch 4, 512 channels; both launches of the split form): stride-2 16^2 -> 8^2 23.1 ->
     // 17.0 us, 8^2 -> 4^2 21.2 -> 11.4 us; 3x3 at 4^2 / 8^2 11.3 -> 9.7 / 11.7 -> 10.8 us; transposed 4^2 -> 8^2 8.2 -> 9.1 us (worse).  The 3x3 and
     // transposed launches already run deep (128-channel) K-chunks -- 4 of them; the stride-2 geometry cannot (its patch x 4 planes does not
     // fit the LDS) and walks 16 chunks of 32 channels, each behind a global-load latency: that is the one split-K shortens enough to pay for
-    // the finishing launch.  SGX_CONV_SPLITK=-1 lifts the restriction (probes, tests of the other geometries).
-    if (geo != GDOWN && on >= 0) return 0;
+    // the finishing launch.  (The split-K forms of the other two geometries were built and measured -- profiles/r06_splitk_probe.txt, commit a6b45ff --
+    // and are no longer compiled: 84 instantiations and two minutes of build time for nothing.)
+    if (geo != GDOWN) return 0;
     if (sgx_conv2_takes(geo, B, H, W, Cin, Cout)) return 0;
     const int ohc = geo == GDOWN ? H / 2 : H, owc = geo == GDOWN ? W / 2 : W;
     // the instantiation dispatch_conv picks for this shape: deep K-chunks first, else (transposed) the all-class kernel
@@ -760,9 +761,8 @@ extern "C" int sgx_conv_splitk(int geo, const void* x, const void* w, const floa
     SGX_NOTE(2.0 * macs * Cin * Cout * opix, 2.0 * ((double)B * H * W * Cin + opix * Cout + taps * Cin * Cout) + 4.0 * ks * opix * Cout, "conv%c/k%d B%d %dx%d %d->%d",
              geo == G3X3 ? 'S' : (geo == GDOWN ? 'D' : 'U'), ks, B, H, W, Cin, Cout);
     int rc;
-    if (geo == G3X3) rc = dispatch_conv<G3X3, true>(a, dtype, st);
-    else if (geo == GDOWN) rc = dispatch_conv<GDOWN, true>(a, dtype, st);
-    else rc = dispatch_conv<GUP, true>(a, dtype, st);
+    SGX_REQUIRE(geo == GDOWN, SGX_EUNSUPPORTED, "conv_splitk: only the stride-2 geometry has split-K kernels");
+    rc = dispatch_conv<GDOWN, true>(a, dtype, st);
     if (rc) return rc;
     const size_t npix = (size_t)B * OH * OW, nvec = npix * Cout / 8;
     SGX_NOTE(0.0, 4.0 * ks * npix * Cout + 2.0 * npix * Cout, "conv_splitk_finish %zux%d", npix, Cout);

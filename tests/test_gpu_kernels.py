@@ -805,10 +805,8 @@ def test_conv3_configurations_write_conv2_bits(cfg, geo, cin, cout, B, H, W):
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), f"conv3 configuration {cfg} differs from conv2 on {geo} {cin}->{cout} B{B} {H}x{W}"
 
 
-SPLITK_SHAPES = [  # (geo, B, H, Cin, Cout): the 512-channel layers of the 1024 model at batch 4 (+ one narrower), input size H x H
-    ("S", 4, 16, 512, 512), ("S", 4, 8, 512, 512), ("S", 4, 4, 512, 512), ("S", 2, 16, 256, 256),
-    ("D", 4, 32, 512, 512), ("D", 4, 16, 512, 512), ("D", 4, 8, 512, 512), ("D", 8, 8, 512, 512), ("D", 4, 8, 544, 512), ("D", 2, 16, 256, 512),
-    ("U", 4, 16, 512, 512), ("U", 4, 8, 512, 512), ("U", 4, 4, 512, 512),
+SPLITK_SHAPES = [  # (geo, B, H, Cin, Cout): the 512-channel stride-2 layers of the 1024 model at a small batch (+ ragged K-chunk counts, a narrower one), input H x H
+    ("D", 4, 16, 512, 512), ("D", 4, 8, 512, 512), ("D", 8, 8, 512, 512), ("D", 4, 8, 544, 512), ("D", 2, 16, 256, 512), ("D", 1, 16, 512, 512), ("D", 4, 32, 512, 512),
 ]
 
 
@@ -825,9 +823,7 @@ def test_split_k_convolution_vs_fp32_reference_and_unsplit_kernel(geo, B, H, Cin
     k = 3 if geo == "S" else 4
     wsb = L.sgx_conv_splitk_ws_bytes(gi, B, H, H, Cin, Cout, N.BF16)
     if not wsb:
-        # (the default plan splits the stride-2 geometry only -- where it was measured to pay; SGX_CONV_SPLITK=-1 runs the others too:
-        # tests/test_gpu_kernels.py under that switch is part of tools/gpu_final6.sh)
-        pytest.skip("this shape does not split under the default plan")
+        pytest.skip("this shape does not split under the plan (enough blocks without it)")
     torch.manual_seed(H + Cin + gi)
     w = torch.randn(Cout, Cin, k, k, device=DEV)
     x = torch.randn(B, H, H, Cin, device=DEV).bfloat16()

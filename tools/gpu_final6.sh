@@ -45,12 +45,10 @@ d = json.loads(sys.stdin.read())
 print('[$v] b4', round(d['value'], 1), 'img/s', round(d['ms_per_step'], 3), 'ms graphs', d.get('hip_graphs'), 'launches', d.get('library_launches_per_step'), '| b32', round(d['b32']['value'], 1), 'img/s', round(d['b32']['ms_per_step'], 2), 'ms')"
   done; done | tee $O/ab_round6.txt
   stamp_txt $O/ab_round6.txt
-  echo "== the split-K tests of all three geometries (SGX_CONV_SPLITK=-1)"
-  SGX_CONV_SPLITK=-1 timeout 300 python -m pytest tests/test_gpu_kernels.py -q -k split_k 2>&1 | tail -2 | tee $O/splitk_all_geometries.txt
   echo "== probes of the second session"
   timeout 120 tools/stream_probe > $O/stream_probe.txt 2>&1; stamp_txt $O/stream_probe.txt; head -12 $O/stream_probe.txt
   timeout 200 python tools/overlap_probe.py 2>/dev/null > $O/overlap_probe.txt; stamp_txt $O/overlap_probe.txt; cat $O/overlap_probe.txt
-  timeout 200 python tools/splitk_probe.py --batch 4 8 2>/dev/null > $O/splitk_probe.txt; SGX_CONV_SPLITK=-1 timeout 200 python tools/splitk_probe.py --batch 4 2>/dev/null | sed "s/^/[all geometries] /" >> $O/splitk_probe.txt; stamp_txt $O/splitk_probe.txt
+  timeout 200 python tools/splitk_probe.py --batch 4 8 2>/dev/null > $O/splitk_probe.txt; stamp_txt $O/splitk_probe.txt
   ( for a in 0 1; do SGX_GEPI_APPLY1=$a SGX_GEPI_BWD2S=$a python tools/gepi_probe.py --batch 32 4 --min-h 128 --reps 10 2>&1 | grep epilogue | sed "s/^/[short-lived apply passes $a] /"; done ) > $O/gepi_probe.txt; stamp_txt $O/gepi_probe.txt
 fi
 cd /tmp && export TMPDIR=/tmp
