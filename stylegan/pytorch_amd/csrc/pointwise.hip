@@ -1270,6 +1270,67 @@ __global__ void rgb_in_kernel(const float* __restrict__ img, const float* __rest
         VecTraits<T>::store(y + i * VE, v);
     }
 }
+// The same as SHORT-LIVED blocks (round 6, tools/stream_probe.hip: a write stream runs at 4.6 TB/s through a capped grid-stride loop and at 6.8 as
+// blocks that store one 16-byte vector per thread and exit; this pass is a write stream -- 12 bytes in, 2 C bytes out per pixel).  The hoisted
+// weights that tied the kernel above to its loop (uncapped it lost 3x: 24 scalar loads per stored vector) go through LDS once per block: the
+// same products `wscale * w`, the same sum order: bit-identical output.
+template <typename T>
+__global__ __launch_bounds__(256) void rgb_in1_kernel(const float* __restrict__ img, const float* __restrict__ w, int sj, int sc, float wscale,
+                                                      const float* __restrict__ bias, T* __restrict__ y, unsigned nvec, int C, const T* __restrict__ add) {
+    constexpr int VE = VecTraits<T>::VE, U = 4;              // four vectors per thread: with one, the block's lifetime is the latency of its table
+                                                             // loads (1024^2 x 16 at batch 32: 294 -> 343 us; with four: see the launch function)
+    extern __shared__ float tw[];                            // [4][C]: wscale * W[0..2][c], bias[c]
+    for (int c = threadIdx.x; c < C; c += 256) {
+        tw[c] = wscale * w[c * sc]; tw[C + c] = wscale * w[sj + c * sc]; tw[2 * C + c] = wscale * w[2 * sj + c * sc];
+        tw[3 * C + c] = bias ? bias[c] : 0.f;
+    }
+    const unsigned i0 = blockIdx.x * (256u * U) + threadIdx.x, cv = (unsigned)(C / VE);
+    float r[U], g[U], b[U];
+    uint4 araw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned i = i0 + u * 256u;
+        r[u] = g[u] = b[u] = 0.f; araw[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (i < nvec) {
+            const size_t p = i / cv;
+            r[u] = img[p * 3]; g[u] = img[p * 3 + 1]; b[u] = img[p * 3 + 2];
+            if (add) araw[u] = *reinterpret_cast<const uint4*>(add + (size_t)i * VE);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned i = i0 + u * 256u;
+        if (i >= nvec) continue;
+        const int c0 = (int)(i % cv) * VE;
+        float v[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) v[j] = tw[3 * C + c0 + j] + (r[u] * tw[c0 + j] + g[u] * tw[C + c0 + j] + b[u] * tw[2 * C + c0 + j]);
+        if (add) {
+            const unsigned w4[4] = {araw[u].x, araw[u].y, araw[u].z, araw[u].w};
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[(2 * k) % VE] += __uint_as_float(w4[k] << 16); v[(2 * k + 1) % VE] += __uint_as_float(w4[k] & 0xffff0000u); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k % VE] += __uint_as_float(w4[k]);
+            }
+        }
+        VecTraits<T>::store(y + (size_t)i * VE, v);
+    }
+}
+template <typename T>
+static bool rgb_in1_launch(const float* img, const float* w, int sj, int sc, float wscale, const float* bias, T* y, size_t npix, int C, const T* add, hipStream_t st) {
+    static const int on = [] { const char* e = getenv("SGX_RGB_IN1"); return e ? atoi(e) : 1; }();           // A/B switch
+    const size_t nvec = npix * (C / VecTraits<T>::VE);
+    // measured inside the single-stream step (same box, SGX_RGB_IN1=0 vs 1): batch 32 rgb_in 1024^2 x 16 288 -> 275 us, rgb_in+add 512^2 x 32 221 -> 188;
+    // batch 4 52.5 -> 39.4 and 52.0 -> 30.0 us.  (Staging the block's pixels through LDS with 16-byte loads instead of three scalar loads per
+    // vector: no better -- 285 / 189 and 43 / 33 us.)
+    if (!on || nvec < 65536 || nvec >= 0x7fffffffull || C > 2048) return false;                               // small launches keep the loop kernel
+    hipLaunchKernelGGL(rgb_in1_kernel<T>, dim3((unsigned)((nvec + 1023) / 1024)), dim3(256), (size_t)4 * C * sizeof(float), st, img, w, sj, sc, wscale, bias, y,
+                       (unsigned)nvec, C, add);
+    return true;
+}
 // the kernel hoists its channel group's weights, so the grid stride (256 * blocks) must be a multiple of cv
 static inline unsigned rgb_in_grid(size_t nvec, int cv) {
     unsigned g = grid_for(nvec);
@@ -1281,9 +1342,11 @@ extern "C" int sgx_rgb_in(const float* img, const float* w, int sj, int sc, floa
     SGX_NOTE(6.0 * npix * C, npix * (12.0 + (dtype == SGX_F32 ? 4.0 : 2.0) * C), "rgb_in %zux%d", npix, C);
     if (dtype == SGX_F32) {
         SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "rgb_in: C %% 4");
+        if (!rgb_in1_launch<float>(img, w, sj, sc, wscale, bias, (float*)y, npix, C, (const float*)nullptr, st))
         hipLaunchKernelGGL(rgb_in_kernel<float>, dim3(rgb_in_grid(npix * C / 4, C / 4)), dim3(256), 0, st, img, w, sj, sc, wscale, bias, (float*)y, npix, C, (const float*)nullptr);
     } else {
         SGX_REQUIRE(C % 8 == 0, SGX_EUNSUPPORTED, "rgb_in: C %% 8");
+        if (!rgb_in1_launch<bf16_t>(img, w, sj, sc, wscale, bias, (bf16_t*)y, npix, C, (const bf16_t*)nullptr, st))
         hipLaunchKernelGGL(rgb_in_kernel<bf16_t>, dim3(rgb_in_grid(npix * C / 8, C / 8)), dim3(256), 0, st, img, w, sj, sc, wscale, bias, (bf16_t*)y, npix, C, (const bf16_t*)nullptr);
     }
     SGX_LAUNCH_CHECK("rgb_in");
@@ -1299,9 +1362,11 @@ extern "C" int sgx_rgb_in_add(const float* img, const float* w, int sj, int sc, 
     SGX_NOTE(6.0 * npix * C, npix * (12.0 + 2.0 * (dtype == SGX_F32 ? 4.0 : 2.0) * C), "rgb_in+add %zux%d", npix, C);
     if (dtype == SGX_F32) {
         SGX_REQUIRE(C % 4 == 0, SGX_EUNSUPPORTED, "rgb_in_add: C %% 4");
+        if (!rgb_in1_launch<float>(img, w, sj, sc, wscale, (const float*)nullptr, (float*)y, npix, C, (const float*)add, st))
         hipLaunchKernelGGL(rgb_in_kernel<float>, dim3(rgb_in_grid(npix * C / 4, C / 4)), dim3(256), 0, st, img, w, sj, sc, wscale, (const float*)nullptr, (float*)y, npix, C, (const float*)add);
     } else {
         SGX_REQUIRE(dtype == SGX_BF16 && C % 8 == 0, SGX_EUNSUPPORTED, "rgb_in_add: bf16 with C %% 8");
+        if (!rgb_in1_launch<bf16_t>(img, w, sj, sc, wscale, (const float*)nullptr, (bf16_t*)y, npix, C, (const bf16_t*)add, st))
         hipLaunchKernelGGL(rgb_in_kernel<bf16_t>, dim3(rgb_in_grid(npix * C / 8, C / 8)), dim3(256), 0, st, img, w, sj, sc, wscale, (const float*)nullptr, (bf16_t*)y, npix, C, (const bf16_t*)add);
     }
     SGX_LAUNCH_CHECK("rgb_in_add");
