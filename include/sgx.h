@@ -83,11 +83,12 @@ int sgx_conv4x4s2_up(const void* x, const void* w, void* y, int B, int H, int W,
  *   The three entry points above choose by themselves.                                                               */
 int sgx_conv_variant(int geo, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
                      int act, int dtype, int variant, void* stream);
-/* Round 6: split-K for the bf16 launches that leave most of the chip idle (the 512-channel layers at 4x4 .. 32x32 of a small batch: 32-128
- * blocks, each streaming its whole weight slice at one CU's load rate).  sgx_conv_splitk_ws_bytes: 0 = the shape does not split (call
- * sgx_conv3x3 / sgx_conv4x4s2_down / sgx_conv4x4s2_up), else the bytes of fp32 partials [ksplit][output pixel][Cout] sgx_conv_splitk needs.
- * sgx_conv_splitk: geo 0 / 1 / 2 = those three entry points' convolutions (models/CustomLayers.py:137-180; bias, act, mask as there; mask geo 0
- * only), the reduction over input channels split over ksplit blocks, the partials summed in a fixed order by a second launch. */
+/* Round 6: split-K for the bf16 stride-2 launches that leave most of the chip idle (the 512-channel conv1_down layers at 16x16 -> 8x8 and
+ * 8x8 -> 4x4 of a small batch: 32-128 blocks, each walking 16 K-chunks behind a global-load latency).  sgx_conv_splitk_ws_bytes: 0 = the shape
+ * does not split (call sgx_conv3x3 / sgx_conv4x4s2_down / sgx_conv4x4s2_up; always 0 for geo 0 and 2, whose split forms were measured no better
+ * and are not built), else the bytes of fp32 partials [ksplit][output pixel][Cout] sgx_conv_splitk needs.  sgx_conv_splitk: geo 1 =
+ * sgx_conv4x4s2_down's convolution (models/CustomLayers.py:160-171; bias and act as there, mask NULL), the reduction over input channels split
+ * over ksplit <= 8 blocks, the partials summed in a fixed order by a second launch.  Other geometries: SGX_EUNSUPPORTED. */
 size_t sgx_conv_splitk_ws_bytes(int geo, int B, int H, int W, int Cin, int Cout, int dtype);
 int sgx_conv_splitk(int geo, const void* x, const void* w, const float* bias, void* y, const void* mask, int B, int H, int W, int Cin, int Cout,
                     int act, int dtype, void* ws, size_t ws_bytes, void* stream);

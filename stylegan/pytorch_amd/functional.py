@@ -12,6 +12,7 @@ reference models/Losses.py:197-211) works through autograd composition.  Generat
 epilogue, PixelNorm) and parameter gradients are first order.
 """
 import contextlib
+import functools
 import os
 import weakref
 
@@ -327,6 +328,13 @@ def upblur_pack(weight, mode, scale, ipad, adjoint):
 
 
 # ---------------------------------------------------------------------------------------------------
+@functools.lru_cache(maxsize=None)
+def _splitk_ws_bytes(gi, B, H, W, Cin, Cout, dt):
+    """``sgx_conv_splitk_ws_bytes`` per shape, asked of the library once (the plan is a pure function of the shape and process-wide switches;
+    a ctypes call per convolution launch would be host time on the host-bound low-resolution depths)."""
+    return int(N.lib().sgx_conv_splitk_ws_bytes(gi, B, H, W, Cin, Cout, dt))
+
+
 def _conv_launch(geo, x, wq, bias, act, mask=None):
     B, H, W, Cin = x.shape
     taps, Cout, K = wq.shape
@@ -334,7 +342,7 @@ def _conv_launch(geo, x, wq, bias, act, mask=None):
         raise N.SgxError(f"conv: weight pack expects {K} input channels, activation has {Cin}")
     L = N.lib()
     gi = "SDU".index(geo)
-    wsb = L.sgx_conv_splitk_ws_bytes(gi, B, H, W, Cin, Cout, N.dt(x))
+    wsb = _splitk_ws_bytes(gi, B, H, W, Cin, Cout, N.dt(x))
     if wsb:
         # round 6: the launches that would leave most of the chip idle split their reduction over blocks (fp32 partials + a finishing launch)
         oh, ow = (H, W) if geo == "S" else ((H // 2, W // 2) if geo == "D" else (2 * H, 2 * W))
